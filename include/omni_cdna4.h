@@ -1,0 +1,254 @@
+/*
+ * omni_cdna4.h — C ABI of libomni_cdna4.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * Qwen-Image DiT denoising hot path of vllm-omni.
+ *
+ * The reference (vllm-project/vllm-omni) is 100 % Python and has NO FFI for this path; every GPU
+ * kernel it runs comes from PyTorch / vLLM / flash-attn / diffusers.  The entry points below are
+ * what a binding for its L0 plug-in points would call.  Each one cites the
+ * reference call site (path:line relative to the reference root) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, explicit sizes/strides, a hipStream_t passed as void*;
+ *     no torch / ATen types, no allocation inside any call (the caller owns every buffer).
+ *   - bf16 tensors are `uint16_t` bit patterns (storage bf16, all arithmetic fp32, one rounding).
+ *   - every function returns OMNI_OK (0) or a negative omni_status; it never throws or aborts.
+ *     Launch errors are reported through hipGetLastError() -> OMNI_ERR_LAUNCH.
+ *   - thread-safe for concurrent calls on different streams; no global mutable state.
+ *   - "rows" are tokens.  Batches are RAGGED: B items are concatenated along the row axis
+ *     and described by `cu_seqlens` (B+1 prefix sums) or per-row int32 maps, so step-batched
+ *     requests with different text lengths need no padding.
+ */
+#ifndef OMNI_CDNA4_H
+#define OMNI_CDNA4_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t omni_bf16;
+typedef void* omni_stream; /* hipStream_t */
+
+typedef enum {
+  OMNI_OK = 0,
+  OMNI_ERR_BAD_ARG = -1,     /* null pointer, non-positive size                       */
+  OMNI_ERR_UNSUPPORTED = -2, /* shape outside what the kernel is built for (see each) */
+  OMNI_ERR_LAUNCH = -3,      /* hipGetLastError() != hipSuccess after the launch      */
+  OMNI_ERR_ALIGN = -4        /* pointer / stride not 16-byte aligned where required   */
+} omni_status;
+
+/* Library identity: ABI version (bumped on any signature change) and the gfx target it was built for. */
+int omni_abi_version(void);
+const char* omni_build_arch(void);
+const char* omni_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------------
+ * Grouped GEMM with fused epilogue:  Y_g = epilogue(A_g · W_gᵀ + bias_g)  for g < ngroups (<= 2).
+ * Replaces the hipBLASLt GEMMs behind F.linear at
+ *   vllm_omni/diffusion/models/qwen_image/qwen_image_transformer.py:380,384 (to_qkv / add_kv_proj),
+ *   :452,456 (to_out[0] / to_add_out), :491,501,591,596 (FeedForward), :743,759,798 (img_in/txt_in/proj_out)
+ * plus the elementwise ops the reference runs after them (:586-587,592,597 gated residuals,
+ * GELU-tanh inside FeedForward, torch.cat at :414-416 for the QKV split-to-joint write).
+ * Both groups (image stream, text stream) share N, K and the epilogue and run in ONE launch.
+ *
+ * A_g  [M_g, K] bf16 row-major, row stride lda (elements); optional a_row_map[M_g] gathers rows.
+ * W_g  [N, K]   bf16 row-major ([out, in], the nn.Linear layout; fused QKV rows ordered q|k|v).
+ * K % 64 == 0 (else OMNI_ERR_UNSUPPORTED); M_g, N arbitrary (tails are predicated).
+ * ---------------------------------------------------------------------------------------------- */
+typedef enum {
+  OMNI_EPI_BIAS = 0,          /* y = acc + bias                                              */
+  OMNI_EPI_BIAS_GELU_TANH = 1,/* y = gelu_tanh(acc + bias)                                   */
+  OMNI_EPI_BIAS_GATE_RES = 2, /* y = res + gate[item(row)] * (acc + bias)   (res may alias y) */
+  OMNI_EPI_BIAS_SPLIT3 = 3    /* y = acc + bias, column block n/split_n selects out/out1/out2 */
+} omni_epilogue;
+
+typedef struct {
+  const omni_bf16* A;
+  int64_t lda;
+  const int32_t* a_row_map; /* nullable: source row of logical row r (gather)              */
+  int32_t M;
+  const omni_bf16* W;       /* [N, K], ld = K                                              */
+  const omni_bf16* bias;    /* [N], nullable                                               */
+  omni_bf16* out;           /* [*, ldo]                                                    */
+  omni_bf16* out1;          /* SPLIT3 only: columns [split_n, 2*split_n)                   */
+  omni_bf16* out2;          /* SPLIT3 only: columns [2*split_n, 3*split_n)                 */
+  int64_t ldo;
+  const int32_t* out_row_map; /* nullable: destination row of logical row r (scatter)      */
+  const omni_bf16* res;     /* GATE_RES: residual, same row indexing as out                */
+  int64_t ldres;
+  const omni_bf16* gate;    /* GATE_RES: gate[item * gate_item_stride + n]                 */
+  int64_t gate_item_stride;
+  const int32_t* row_item_map; /* nullable: item (batch element) of logical row r          */
+  int32_t rows_per_item;    /* used when row_item_map == NULL: item = r / rows_per_item    */
+} omni_gemm_group;
+
+typedef struct {
+  int32_t ngroups; /* 1 or 2 */
+  int32_t N, K;
+  int32_t epilogue; /* omni_epilogue */
+  int32_t split_n;  /* SPLIT3: width of each output (multiple of 32) */
+  omni_gemm_group g[2];
+} omni_gemm_params;
+
+int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * AdaLN-modulate:  y = LayerNorm(x; eps, no affine) * (1 + scale[item]) + shift[item]
+ * Replaces AdaLayerNorm.forward_hip -> forward_native, vllm_omni/diffusion/layers/adalayernorm.py:70-76,94-102
+ * (nn.LayerNorm + mul + add = 3 passes -> 1), and the LayerNorm half of diffusers
+ * AdaLayerNormContinuous (call site qwen_image_transformer.py:797).
+ * x,y [rows, D] bf16 (row strides ldx/ldy); scale/shift bf16 vectors of length D per item with
+ * stride mod_item_stride; item(row) = row_item_map ? row_item_map[row] : row / rows_per_item.
+ * D % 8 == 0 and D <= 8192.
+ * ---------------------------------------------------------------------------------------------- */
+int omni_adaln_modulate(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows, int32_t D,
+                        const omni_bf16* scale, const omni_bf16* shift, int64_t mod_item_stride,
+                        const int32_t* row_item_map, int32_t rows_per_item, float eps, omni_stream stream);
+
+/* RMSNorm over the last dim with learned weight: y = x * rsqrt(mean(x^2) + eps) * w.
+ * Replaces vllm RMSNorm at qwen_image_transformer.py:758 (txt_norm, D = 3584).  D % 8 == 0, D <= 8192. */
+int omni_rmsnorm(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows, int32_t D,
+                 const omni_bf16* weight, float eps, omni_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-head RMSNorm (head_dim 128, learned weight) + interleaved RoPE, in place on a [rows, H*128] tensor.
+ * Replaces qwen_image_transformer.py:397-400 (vllm RMSNorm on q,k) and :403-410
+ * (RotaryEmbedding(is_neox_style=False), vllm_omni/diffusion/layers/rope.py:12-36,108-127):
+ *   xn = x * rsqrt(mean_128(x^2) + eps) * w[stream(row)]
+ *   out[2i] = xn[2i]*cos[p,i] - xn[2i+1]*sin[p,i] ; out[2i+1] = xn[2i+1]*cos[p,i] + xn[2i]*sin[p,i]
+ * cos/sin: bf16 tables [npos, 64] (the reference casts them to the activation dtype first, :403-406).
+ * row_pos[row] (int32) = table row; weight = w_txt if row_pos[row] < txt_pos_end else w_img.
+ * ---------------------------------------------------------------------------------------------- */
+int omni_qk_norm_rope(omni_bf16* x, int64_t ldx, int32_t rows, int32_t num_heads,
+                      const omni_bf16* w_img, const omni_bf16* w_txt, const omni_bf16* cos_tab,
+                      const omni_bf16* sin_tab, const int32_t* row_pos, int32_t txt_pos_end, float eps,
+                      omni_stream stream);
+
+/* Standalone interleaved RoPE on [B, S, H, dh] (the RotaryEmbedding.forward_hip plug-in point,
+ * vllm_omni/diffusion/layers/rope.py:108-127).  cos/sin bf16 [S, dh/2]; x -> y (may alias). dh % 16 == 0. */
+int omni_rope_interleaved(const omni_bf16* x, omni_bf16* y, int32_t B, int32_t S, int32_t H, int32_t dh,
+                          const omni_bf16* cos_tab, const omni_bf16* sin_tab, omni_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flash attention forward, non-causal, no mask, head_dim 128, bf16 in/out, fp32 softmax/accumulate.
+ * Replaces F.scaled_dot_product_attention at vllm_omni/diffusion/attention/backends/sdpa.py:46-66
+ * (and flash_attn_func / sageattn in the sibling backends).
+ * q,k,v,out: [total_rows, H*128] with row strides ld* (the reference's [B,S,H,dh] "NHD" layout
+ * flattened over B,S); item b owns rows [cu_seqlens[b], cu_seqlens[b+1]).  cu_seqlens is a
+ * DEVICE int32 array of B+1 entries.  max_seqlen bounds the grid.
+ * ---------------------------------------------------------------------------------------------- */
+int omni_flash_attn_fwd(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
+                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,
+                        int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
+                        omni_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small-batch weight-streaming linear:  y[b, n] = act_out( sum_k act_in(x[b, k]) * W[n, k] + bias[n] ).
+ * Replaces the GEMVs at qwen_image_transformer.py:51-52 (TimestepEmbedding), :552,557
+ * (img_mod / txt_mod = SiLU -> Linear(D -> 6D), 13.6 GB of weights per forward) and the Linear inside
+ * AdaLayerNormContinuous (:797).  HBM-bound: W is read exactly once.  B <= 8, K % 8 == 0, K <= 4096.
+ * act codes: 0 none, 1 SiLU.
+ * ---------------------------------------------------------------------------------------------- */
+int omni_linear_smallbatch(const omni_bf16* x, int64_t ldx, int32_t B, const omni_bf16* W, const omni_bf16* bias,
+                           int64_t N, int32_t K, omni_bf16* y, int64_t ldy, int32_t act_in, int32_t act_out,
+                           omni_stream stream);
+
+/* Sinusoidal timestep projection, diffusers Timesteps(256, flip_sin_to_cos=True, shift 0, scale 1000)
+ * (qwen_image_transformer.py:44,51; body in-tree at pipeline_qwen_image.py:135-184): out[b] = [cos | sin]. */
+int omni_timestep_sinusoid(const float* t, int32_t B, int32_t dim, float scale, omni_bf16* out, omni_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Step epilogue: true-CFG combine + norm rescale + Flow-Match Euler update, fused.
+ * Replaces pipeline_qwen_image.py:580-583 and scheduler.step at :585:
+ *   comb = neg + s*(pos - neg); pred = comb * (||pos|| / ||comb||)   (norms over the last dim C)
+ *   latents <- bf16( float(latents) + dt * pred )            (neg == NULL: pred = pos)
+ * pos/neg/latents: [rows, C] bf16 contiguous, C == 64.  dt = sigma_next - sigma (per-row item via dt_item
+ * when dt_rows_per_item > 0: dt[row / dt_rows_per_item], else dt[0]).  dt is a DEVICE fp32 array.
+ * ---------------------------------------------------------------------------------------------- */
+int omni_cfg_euler_step(const omni_bf16* pos, const omni_bf16* neg, omni_bf16* latents, int32_t rows, int32_t C,
+                        float true_cfg_scale, const float* dt, int32_t dt_rows_per_item, omni_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * VAE decode kernels (AutoencoderKLQwenImage.decode for one frame,
+ * vllm_omni/diffusion/models/qwen_image/autoencoder_kl_qwenimage.py:839-863 / diffusers twin).
+ * Activations are NHWC bf16 ([B, H, W, C]); conv weights are pre-packed [Cout, 3, 3, Cin] bf16 from temporal
+ * slice [-1] of the causal Conv3d weights (:69-84: the two zero front frames make the other slices dead).
+ * ---------------------------------------------------------------------------------------------- */
+/* 3x3 (pad 1) or 1x1 convolution as implicit GEMM on MFMA.  Optional fused prologue
+ * RMS-norm(channels)*gamma -> SiLU on the input (QwenImageRMS_norm :108-109 + SiLU, :262-265),
+ * optional nearest-exact x2 upsample of the input (QwenImageUpsample :112-124), optional residual add. */
+typedef struct {
+  const omni_bf16* x;     /* [B, Hin, Win, Cin] */
+  const omni_bf16* w;     /* [Cout, ks, ks, Cin] */
+  const omni_bf16* bias;  /* [Cout], nullable */
+  const omni_bf16* gamma; /* [Cin], nullable -> no norm/SiLU prologue */
+  const omni_bf16* res;   /* [B, Hout, Wout, Cout], nullable */
+  omni_bf16* y;           /* [B, Hout, Wout, Cout] */
+  int32_t B, Hin, Win, Cin, Cout;
+  int32_t ksize;          /* 1 or 3 */
+  int32_t upsample2x;     /* 1: Hout = 2*Hin (input index = out/2), else Hout = Hin */
+  int32_t silu;           /* with gamma: apply SiLU after the norm */
+  float clamp_lo, clamp_hi; /* applied if clamp_lo < clamp_hi */
+} omni_conv_params;
+int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream);
+
+/* Channel RMS-norm (F.normalize(dim=C) * sqrt(C) * gamma) with optional SiLU: NHWC rows of C channels. */
+int omni_vae_rmsnorm_silu(const omni_bf16* x, omni_bf16* y, int64_t rows, int32_t C, const omni_bf16* gamma,
+                          int32_t silu, omni_stream stream);
+
+/* In-place row softmax p = softmax(scale * s) over rows of `cols` bf16 scores (row stride ld).  Used for the
+ * single-head mid-block attention of the VAE (F.scaled_dot_product_attention at
+ * autoencoder_kl_qwenimage.py:319), which runs as GEMM(QK^T) -> this -> GEMM(PV).  cols % 8 == 0. */
+int omni_softmax_rows(omni_bf16* s, int64_t ld, int64_t rows, int32_t cols, float scale, omni_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole DiT forward as one native call: enqueues every kernel of
+ * QwenImageTransformer2DModel.forward (qwen_image_transformer.py:692-802) on `stream` from a
+ * descriptor of device pointers.  No host synchronisation, no allocation; hipGraph-capturable.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const omni_bf16 *img_mod_w, *img_mod_b, *txt_mod_w, *txt_mod_b;   /* [6D, D], [6D] */
+  const omni_bf16 *to_qkv_w, *to_qkv_b, *add_qkv_w, *add_qkv_b;     /* [3D, D], [3D] */
+  const omni_bf16 *norm_q_w, *norm_k_w, *norm_added_q_w, *norm_added_k_w; /* [128] */
+  const omni_bf16 *to_out_w, *to_out_b, *to_add_out_w, *to_add_out_b; /* [D, D], [D] */
+  const omni_bf16 *img_mlp_w1, *img_mlp_b1, *img_mlp_w2, *img_mlp_b2; /* [4D, D],[4D],[D,4D],[D] */
+  const omni_bf16 *txt_mlp_w1, *txt_mlp_b1, *txt_mlp_w2, *txt_mlp_b2;
+} omni_dit_layer_weights;
+
+typedef struct {
+  int32_t num_layers, num_heads, head_dim, joint_dim, in_channels, out_channels_packed; /* 60,24,128,3584,64,64 */
+  const omni_bf16 *t_lin1_w, *t_lin1_b, *t_lin2_w, *t_lin2_b; /* TimestepEmbedding */
+  const omni_bf16 *txt_norm_w, *img_in_w, *img_in_b, *txt_in_w, *txt_in_b;
+  const omni_bf16 *norm_out_w, *norm_out_b, *proj_out_w, *proj_out_b;
+  const omni_dit_layer_weights* layers; /* HOST array [num_layers] of device pointers */
+} omni_dit_weights;
+
+typedef struct {
+  /* ragged batch of n_items sequences; item i: T_i text rows then S_img image rows in the joint order */
+  int32_t n_items, n_img_rows, n_txt_rows, n_joint_rows, n_temb, max_seqlen;
+  const omni_bf16* latents;       /* [n_img_rows, in_channels] packed latents           */
+  const omni_bf16* prompt_embeds; /* [n_txt_rows, joint_dim]                            */
+  const float* timestep;          /* [n_temb] sigma (the pipeline's t/1000)             */
+  const int32_t* cu_seqlens;      /* [n_items+1] joint-row prefix sums                  */
+  const int32_t* img_item;        /* [n_img_rows] -> temb row of that token             */
+  const int32_t* txt_item;        /* [n_txt_rows] -> temb row                            */
+  const int32_t* img_joint_row;   /* [n_img_rows] -> joint row                           */
+  const int32_t* txt_joint_row;   /* [n_txt_rows] -> joint row                           */
+  const int32_t* joint_pos;       /* [n_joint_rows] -> rope table row                    */
+  int32_t txt_pos_end;            /* rope rows < this are text positions                 */
+  const omni_bf16 *rope_cos, *rope_sin; /* [npos, 64] bf16                               */
+  omni_bf16* noise_pred;          /* [n_img_rows, out_channels_packed]                   */
+  /* workspace (caller-allocated, sizes from omni_dit_workspace_bytes) */
+  void* workspace;
+  size_t workspace_bytes;
+} omni_dit_batch;
+
+size_t omni_dit_workspace_bytes(const omni_dit_weights* w, int32_t n_img_rows, int32_t n_txt_rows, int32_t n_temb);
+int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch* b, omni_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNI_CDNA4_H */

@@ -1,0 +1,77 @@
+"""GPU parity of the whole native DiT forward against (a) the golden outputs the UNMODIFIED reference produced
+(tests/golden, generated through oracle/ref_shims.py) and (b) the fp32 oracle on bf16-rounded weights.
+
+Tolerance: single forward, <= 4 layers, bf16 kernels vs fp32 reference: rel_l2(noise_pred) <= 1e-2,
+cosine >= 0.9995.  For calibration, the reference itself run in bf16 on CPU differs from its own fp32 run by
+~4e-3..1e-2 on these cases (tests/test_oracle_golden.py)."""
+import pytest
+import torch
+
+import qwen_image_oracle as O
+from _util import bf16_round, cosine, golden_params, load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def build_model(case, P):
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+
+    m = QwenImageTransformer2DModel(num_layers=case["layers"], num_attention_heads=case["heads"],
+                                    joint_attention_dim=case["joint"], device="cuda:0")
+    loaded = m.load_weights((k, v) for k, v in P.items())
+    assert loaded == set(P.keys())
+    return m
+
+
+@pytest.mark.parametrize("name", ["dit_small_fp32", "dit_rect_b2_fp32", "dit_fullwidth_1layer_fp32", "dit_small_bf16"])
+def test_dit_forward_matches_reference_golden(name):
+    z, meta, c = load_golden(name)
+    P = golden_params(c)
+    m = build_model(c, P)
+    lat = torch.from_numpy(z["latents"]).to("cuda:0", BF16)
+    txt = torch.from_numpy(z["prompt_embeds"]).to("cuda:0", BF16)
+    sig = torch.from_numpy(z["sigma"])
+    gh, gw = c["grid"]
+    out = m(hidden_states=lat, encoder_hidden_states=txt, encoder_hidden_states_mask=None,
+            timestep=sig.to("cuda:0"), img_shapes=[[(1, gh, gw)]] * c["B"], txt_seq_lens=[c["T"]] * c["B"],
+            return_dict=False)[0]
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(z["noise_pred"])
+    # inputs/weights are rounded to bf16 on our side: compare against the oracle on the SAME rounded bits (tight),
+    # and against the reference's own output (looser: includes the input-rounding effect)
+    Pb = {k: bf16_round(v) for k, v in P.items()}
+    # the reference casts the timestep to the activation dtype (bf16) before the sinusoid (:746)
+    oracle = O.dit_forward(Pb, bf16_round(torch.from_numpy(z["latents"])), bf16_round(torch.from_numpy(z["prompt_embeds"])),
+                           bf16_round(sig), (1, gh, gw), num_heads=c["heads"])
+    r_or, r_ref = rel_l2(out, oracle), rel_l2(out, ref)
+    print(f"{name}: rel_l2 vs oracle(bf16-rounded inputs) {r_or:.3e}  vs reference golden {r_ref:.3e}  cos {cosine(out, oracle):.6f}")
+    assert r_or <= 1e-2 and cosine(out, oracle) >= 0.9995
+    assert r_ref <= 3e-2
+
+
+def test_ragged_batch_equals_per_request():
+    """Two requests with DIFFERENT text lengths in one forward == each request alone (B=1 semantics, no padding)."""
+    from vllm_omni_amd.diffusion.batch import build_ragged_batch
+
+    z, meta, c = load_golden("dit_small_fp32")
+    P = golden_params(c)
+    m = build_model(c, P)
+    grid = (1, 8, 8)
+    g = torch.Generator().manual_seed(5)
+    lens = [7, 19]
+    lat = [torch.randn(64, 64, generator=g).to("cuda:0", BF16) for _ in lens]
+    txt = [torch.randn(t, c["joint"], generator=g).to("cuda:0", BF16) for t in lens]
+    sig = torch.tensor([0.81, 0.33], dtype=torch.float32, device="cuda:0")
+    both = m.forward_ragged(m.prepare_batch(build_ragged_batch(lens, grid)), torch.cat(lat), torch.cat(txt), sig)
+    for i, t in enumerate(lens):
+        solo = m.forward_ragged(m.prepare_batch(build_ragged_batch([t], grid)), lat[i], txt[i], sig[i:i + 1].contiguous())
+        torch.cuda.synchronize()
+        assert rel_l2(both[i * 64:(i + 1) * 64], solo) <= 2e-3
+    # CFG pair sharing one temb row: same as two separate temb rows with equal sigma
+    sh = m.forward_ragged(m.prepare_batch(build_ragged_batch(lens, grid, temb_rows=[0, 0])), torch.cat(lat), torch.cat(txt),
+                          sig[:1].contiguous())
+    sp = m.forward_ragged(m.prepare_batch(build_ragged_batch(lens, grid)), torch.cat(lat), torch.cat(txt),
+                          sig[:1].repeat(2).contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(sh, sp)

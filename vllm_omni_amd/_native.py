@@ -1,0 +1,157 @@
+"""ctypes binding of libomni_cdna4.so — the C-ABI declared in include/omni_cdna4.h.
+
+The product path has NO CPU / PyTorch fallback: if the shared library is missing or a call returns a
+non-zero status, an exception is raised (the worker turns it into `DiffusionOutput.error`, mirroring
+the reference's error path at vllm_omni/diffusion/worker/gpu_worker.py:266-274).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libomni_cdna4.so")
+ABI_VERSION = 1
+
+c_bf16_p = C.c_void_p  # device pointer to uint16_t bf16 bits
+c_i32_p = C.c_void_p
+c_f32_p = C.c_void_p
+
+
+class OmniNativeError(RuntimeError):
+    pass
+
+
+class GemmGroup(C.Structure):
+    _fields_ = [
+        ("A", c_bf16_p), ("lda", C.c_int64), ("a_row_map", c_i32_p), ("M", C.c_int32),
+        ("W", c_bf16_p), ("bias", c_bf16_p),
+        ("out", c_bf16_p), ("out1", c_bf16_p), ("out2", c_bf16_p), ("ldo", C.c_int64),
+        ("out_row_map", c_i32_p),
+        ("res", c_bf16_p), ("ldres", C.c_int64),
+        ("gate", c_bf16_p), ("gate_item_stride", C.c_int64),
+        ("row_item_map", c_i32_p), ("rows_per_item", C.c_int32),
+    ]
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("ngroups", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("epilogue", C.c_int32),
+        ("split_n", C.c_int32), ("g", GemmGroup * 2),
+    ]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("x", c_bf16_p), ("w", c_bf16_p), ("bias", c_bf16_p), ("gamma", c_bf16_p), ("res", c_bf16_p), ("y", c_bf16_p),
+        ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("ksize", C.c_int32), ("upsample2x", C.c_int32), ("silu", C.c_int32),
+        ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
+    ]
+
+
+_LAYER_FIELDS = [
+    "img_mod_w", "img_mod_b", "txt_mod_w", "txt_mod_b",
+    "to_qkv_w", "to_qkv_b", "add_qkv_w", "add_qkv_b",
+    "norm_q_w", "norm_k_w", "norm_added_q_w", "norm_added_k_w",
+    "to_out_w", "to_out_b", "to_add_out_w", "to_add_out_b",
+    "img_mlp_w1", "img_mlp_b1", "img_mlp_w2", "img_mlp_b2",
+    "txt_mlp_w1", "txt_mlp_b1", "txt_mlp_w2", "txt_mlp_b2",
+]
+
+
+class DitLayerWeights(C.Structure):
+    _fields_ = [(n, c_bf16_p) for n in _LAYER_FIELDS]
+
+
+class DitWeights(C.Structure):
+    _fields_ = [
+        ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("head_dim", C.c_int32), ("joint_dim", C.c_int32),
+        ("in_channels", C.c_int32), ("out_channels_packed", C.c_int32),
+        ("t_lin1_w", c_bf16_p), ("t_lin1_b", c_bf16_p), ("t_lin2_w", c_bf16_p), ("t_lin2_b", c_bf16_p),
+        ("txt_norm_w", c_bf16_p), ("img_in_w", c_bf16_p), ("img_in_b", c_bf16_p), ("txt_in_w", c_bf16_p),
+        ("txt_in_b", c_bf16_p),
+        ("norm_out_w", c_bf16_p), ("norm_out_b", c_bf16_p), ("proj_out_w", c_bf16_p), ("proj_out_b", c_bf16_p),
+        ("layers", C.POINTER(DitLayerWeights)),
+    ]
+
+
+class DitBatch(C.Structure):
+    _fields_ = [
+        ("n_items", C.c_int32), ("n_img_rows", C.c_int32), ("n_txt_rows", C.c_int32), ("n_joint_rows", C.c_int32),
+        ("n_temb", C.c_int32), ("max_seqlen", C.c_int32),
+        ("latents", c_bf16_p), ("prompt_embeds", c_bf16_p), ("timestep", c_f32_p),
+        ("cu_seqlens", c_i32_p), ("img_item", c_i32_p), ("txt_item", c_i32_p),
+        ("img_joint_row", c_i32_p), ("txt_joint_row", c_i32_p), ("joint_pos", c_i32_p),
+        ("txt_pos_end", C.c_int32),
+        ("rope_cos", c_bf16_p), ("rope_sin", c_bf16_p),
+        ("noise_pred", c_bf16_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/omni_cdna4.h declares
+PROTOTYPES = {
+    "omni_abi_version": (C.c_int, []),
+    "omni_build_arch": (C.c_char_p, []),
+    "omni_status_string": (C.c_char_p, [C.c_int]),
+    "omni_gemm_bf16": (C.c_int, [C.POINTER(GemmParams), C.c_void_p]),
+    "omni_adaln_modulate": (C.c_int, [c_bf16_p, C.c_int64, c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p,
+                                      c_bf16_p, C.c_int64, c_i32_p, C.c_int32, C.c_float, C.c_void_p]),
+    "omni_rmsnorm": (C.c_int, [c_bf16_p, C.c_int64, c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, C.c_float,
+                               C.c_void_p]),
+    "omni_qk_norm_rope": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p,
+                                    c_i32_p, C.c_int32, C.c_float, C.c_void_p]),
+    "omni_rope_interleaved": (C.c_int, [c_bf16_p, c_bf16_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_bf16_p,
+                                        c_bf16_p, C.c_void_p]),
+    "omni_flash_attn_fwd": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p, C.c_int64, C.c_int64, C.c_int64,
+                                      C.c_int64, c_i32_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                      C.c_void_p]),
+    "omni_linear_smallbatch": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, c_bf16_p, c_bf16_p, C.c_int64, C.c_int32,
+                                         c_bf16_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "omni_timestep_sinusoid": (C.c_int, [c_f32_p, C.c_int32, C.c_int32, C.c_float, c_bf16_p, C.c_void_p]),
+    "omni_cfg_euler_step": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, C.c_int32, C.c_int32, C.c_float, c_f32_p,
+                                      C.c_int32, C.c_void_p]),
+    "omni_vae_conv2d": (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
+    "omni_vae_rmsnorm_silu": (C.c_int, [c_bf16_p, c_bf16_p, C.c_int64, C.c_int32, c_bf16_p, C.c_int32, C.c_void_p]),
+    "omni_softmax_rows": (C.c_int, [c_bf16_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "omni_dit_workspace_bytes": (C.c_size_t, [C.POINTER(DitWeights), C.c_int32, C.c_int32, C.c_int32]),
+    "omni_dit_forward": (C.c_int, [C.POINTER(DitWeights), C.POINTER(DitBatch), C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the native library; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise OmniNativeError(
+                f"{LIB_PATH} is missing: build it with `python vllm_omni_amd/csrc/build.py` "
+                "(or __graft_entry__.build()).  There is no CPU fallback for the DiT hot path.")
+        dll = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(dll, name)
+            except AttributeError as e:  # pragma: no cover
+                raise OmniNativeError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        got = dll.omni_abi_version()
+        if got != ABI_VERSION:
+            raise OmniNativeError(f"ABI mismatch: library {got}, binding {ABI_VERSION}")
+        _lib = dll
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().omni_status_string(status).decode()
+        raise OmniNativeError(f"{what} failed: status {status} ({msg})")

@@ -1,0 +1,56 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/omni_cdna4.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define OMNI_DEVINL __device__ __forceinline__
+
+OMNI_DEVINL float bf16_bits_to_f32(uint16_t b) { return __builtin_bit_cast(float, ((uint32_t)b) << 16); }
+OMNI_DEVINL float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+OMNI_DEVINL float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// round-to-nearest-even fp32 -> bf16 (the compiler lowers the __bf16 cast to v_cvt_pk_bf16_f32 on gfx950)
+OMNI_DEVINL uint16_t f32_to_bf16_bits(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+OMNI_DEVINL uint32_t pack_bf16x2(float lo, float hi) {
+  bf16x2_t v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+OMNI_DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// GELU tanh approximation: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  == x * sigmoid(2u)
+OMNI_DEVINL float gelu_tanh_f(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+}
+
+template <int W>
+OMNI_DEVINL float wave_sum(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int W>
+OMNI_DEVINL float wave_max(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+#define OMNI_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    if (hipGetLastError() != hipSuccess) return OMNI_ERR_LAUNCH; \
+  } while (0)
+
+static inline bool omni_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,0 +1,205 @@
+// Host-side runner: enqueues one full QwenImageTransformer2DModel.forward (reference
+// vllm_omni/diffusion/models/qwen_image/qwen_image_transformer.py:692-802) on a HIP stream from a descriptor of
+// device pointers.  No allocation, no host sync: the sequence is hipGraph-capturable.
+//
+// Batch layout (ragged, token-major): image rows [n_img_rows, D] and text rows [n_txt_rows, D] are separate
+// residual streams; q/k/v/attention live in the JOINT order ([text_i ; image_i] per item, cu_seqlens) so the
+// reference's three torch.cat (:414-416) and the split (:448-449) never materialise: the QKV GEMM scatters its
+// rows into the joint buffers and the out-projection GEMM gathers them back.
+#include <stdio.h>
+
+#include "common.h"
+
+namespace {
+
+struct Workspace {
+  omni_bf16 *tproj, *th, *temb, *mod_img, *mod_txt, *emb_out;
+  omni_bf16 *hidden_img, *hidden_txt, *xn, *txt_normed, *q, *k, *v, *attn, *mlp_h;
+  size_t total;
+};
+
+inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+Workspace carve(void* base, const omni_dit_weights* w, int64_t Ri, int64_t Rt, int64_t nT) {
+  const int64_t D = (int64_t)w->num_heads * w->head_dim;
+  const int64_t Rj = Ri + Rt;
+  size_t off = 0;
+  char* b = static_cast<char*>(base);
+  auto take = [&](int64_t elems) {
+    omni_bf16* p = reinterpret_cast<omni_bf16*>(b + off);
+    off += align_up((size_t)elems * sizeof(omni_bf16));
+    return p;
+  };
+  Workspace ws;
+  ws.tproj = take(nT * 256);
+  ws.th = take(nT * D);
+  ws.temb = take(nT * D);
+  ws.mod_img = take(nT * 6 * D);
+  ws.mod_txt = take(nT * 6 * D);
+  ws.emb_out = take(nT * 2 * D);
+  ws.hidden_img = take(Ri * D);
+  ws.hidden_txt = take(Rt * D);
+  ws.xn = take(Rj * D);
+  ws.txt_normed = take(Rt * w->joint_dim);
+  ws.q = take(Rj * D);
+  ws.k = take(Rj * D);
+  ws.v = take(Rj * D);
+  ws.attn = take(Rj * D);
+  ws.mlp_h = take(Rj * 4 * D);
+  ws.total = off;
+  return ws;
+}
+
+#define OMNI_TRY(expr)            \
+  do {                            \
+    const int _st = (expr);       \
+    if (_st != OMNI_OK) return _st; \
+  } while (0)
+
+}  // namespace
+
+extern "C" int omni_abi_version(void) { return 1; }
+extern "C" const char* omni_build_arch(void) { return "gfx950"; }
+extern "C" const char* omni_status_string(int status) {
+  switch (status) {
+    case OMNI_OK: return "ok";
+    case OMNI_ERR_BAD_ARG: return "bad argument (null pointer or non-positive size)";
+    case OMNI_ERR_UNSUPPORTED: return "unsupported shape for this kernel";
+    case OMNI_ERR_LAUNCH: return "HIP launch failed";
+    case OMNI_ERR_ALIGN: return "pointer or stride not sufficiently aligned";
+    default: return "unknown status";
+  }
+}
+
+extern "C" size_t omni_dit_workspace_bytes(const omni_dit_weights* w, int32_t n_img_rows, int32_t n_txt_rows,
+                                           int32_t n_temb) {
+  if (!w || n_img_rows <= 0 || n_txt_rows <= 0 || n_temb <= 0) return 0;
+  return carve(nullptr, w, n_img_rows, n_txt_rows, n_temb).total;
+}
+
+extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch* b, omni_stream stream) {
+  if (!w || !b || !w->layers || !b->workspace) return OMNI_ERR_BAD_ARG;
+  if (w->head_dim != 128 || w->in_channels % 64 != 0) return OMNI_ERR_UNSUPPORTED;
+  const int32_t Ri = b->n_img_rows, Rt = b->n_txt_rows, nT = b->n_temb;
+  const int32_t D = w->num_heads * w->head_dim;
+  if (Ri <= 0 || Rt <= 0 || nT <= 0 || b->n_joint_rows != Ri + Rt) return OMNI_ERR_BAD_ARG;
+  const Workspace ws = carve(b->workspace, w, Ri, Rt, nT);
+  if (ws.total > b->workspace_bytes) return OMNI_ERR_BAD_ARG;
+  const float eps = 1e-6f;
+
+  // --- conditioning: sinusoid -> Linear -> SiLU -> Linear   (reference :50-62) ---------------------------
+  OMNI_TRY(omni_timestep_sinusoid(b->timestep, nT, 256, 1000.0f, ws.tproj, stream));
+  OMNI_TRY(omni_linear_smallbatch(ws.tproj, 256, nT, w->t_lin1_w, w->t_lin1_b, D, 256, ws.th, D, 0, 1, stream));
+  OMNI_TRY(omni_linear_smallbatch(ws.th, D, nT, w->t_lin2_w, w->t_lin2_b, D, D, ws.temb, D, 0, 0, stream));
+
+  // --- input projections (reference :743, :758-759) -------------------------------------------------------
+  {
+    omni_gemm_params p = {};
+    p.ngroups = 1; p.N = D; p.K = w->in_channels; p.epilogue = OMNI_EPI_BIAS;
+    p.g[0].A = b->latents; p.g[0].lda = w->in_channels; p.g[0].M = Ri;
+    p.g[0].W = w->img_in_w; p.g[0].bias = w->img_in_b; p.g[0].out = ws.hidden_img; p.g[0].ldo = D;
+    OMNI_TRY(omni_gemm_bf16(&p, stream));
+  }
+  OMNI_TRY(omni_rmsnorm(b->prompt_embeds, w->joint_dim, ws.txt_normed, w->joint_dim, Rt, w->joint_dim,
+                        w->txt_norm_w, eps, stream));
+  {
+    omni_gemm_params p = {};
+    p.ngroups = 1; p.N = D; p.K = w->joint_dim; p.epilogue = OMNI_EPI_BIAS;
+    p.g[0].A = ws.txt_normed; p.g[0].lda = w->joint_dim; p.g[0].M = Rt;
+    p.g[0].W = w->txt_in_w; p.g[0].bias = w->txt_in_b; p.g[0].out = ws.hidden_txt; p.g[0].ldo = D;
+    OMNI_TRY(omni_gemm_bf16(&p, stream));
+  }
+
+  omni_bf16* xn_img = ws.xn;
+  omni_bf16* xn_txt = ws.xn + (int64_t)Ri * D;
+  omni_bf16* h_img = ws.mlp_h;
+  omni_bf16* h_txt = ws.mlp_h + (int64_t)Ri * 4 * D;
+  const float sm_scale = 1.0f / sqrtf((float)w->head_dim);
+
+  for (int l = 0; l < w->num_layers; ++l) {
+    const omni_dit_layer_weights& L = w->layers[l];
+    // modulation vectors [shift1|scale1|gate1|shift2|scale2|gate2]  (reference :552-561)
+    OMNI_TRY(omni_linear_smallbatch(ws.temb, D, nT, L.img_mod_w, L.img_mod_b, 6 * (int64_t)D, D, ws.mod_img, 6 * D, 1,
+                                    0, stream));
+    OMNI_TRY(omni_linear_smallbatch(ws.temb, D, nT, L.txt_mod_w, L.txt_mod_b, 6 * (int64_t)D, D, ws.mod_txt, 6 * D, 1,
+                                    0, stream));
+    // norm1 + modulate (reference :564-567)
+    OMNI_TRY(omni_adaln_modulate(ws.hidden_img, D, xn_img, D, Ri, D, ws.mod_img + D, ws.mod_img, 6 * D, b->img_item, 0,
+                                 eps, stream));
+    OMNI_TRY(omni_adaln_modulate(ws.hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + D, ws.mod_txt, 6 * D, b->txt_item, 0,
+                                 eps, stream));
+    // fused QKV projections of both streams, scattered into the joint q/k/v (reference :380-394, :414-416)
+    {
+      omni_gemm_params p = {};
+      p.ngroups = 2; p.N = 3 * D; p.K = D; p.epilogue = OMNI_EPI_BIAS_SPLIT3; p.split_n = D;
+      p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = L.to_qkv_w; p.g[0].bias = L.to_qkv_b;
+      p.g[0].out = ws.q; p.g[0].out1 = ws.k; p.g[0].out2 = ws.v; p.g[0].ldo = D; p.g[0].out_row_map = b->img_joint_row;
+      p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.add_qkv_w; p.g[1].bias = L.add_qkv_b;
+      p.g[1].out = ws.q; p.g[1].out1 = ws.k; p.g[1].out2 = ws.v; p.g[1].ldo = D; p.g[1].out_row_map = b->txt_joint_row;
+      OMNI_TRY(omni_gemm_bf16(&p, stream));
+    }
+    // per-head RMSNorm + RoPE on q and k (reference :397-410)
+    OMNI_TRY(omni_qk_norm_rope(ws.q, D, Ri + Rt, w->num_heads, L.norm_q_w, L.norm_added_q_w, b->rope_cos, b->rope_sin,
+                               b->joint_pos, b->txt_pos_end, eps, stream));
+    OMNI_TRY(omni_qk_norm_rope(ws.k, D, Ri + Rt, w->num_heads, L.norm_k_w, L.norm_added_k_w, b->rope_cos, b->rope_sin,
+                               b->joint_pos, b->txt_pos_end, eps, stream));
+    // joint attention (reference :437-443 -> attention/backends/sdpa.py:46-66)
+    OMNI_TRY(omni_flash_attn_fwd(ws.q, ws.k, ws.v, ws.attn, D, D, D, D, b->cu_seqlens, b->n_items, w->num_heads,
+                                 w->head_dim, b->max_seqlen, sm_scale, stream));
+    // output projections + gated residual (reference :448-456, :586-587)
+    {
+      omni_gemm_params p = {};
+      p.ngroups = 2; p.N = D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GATE_RES;
+      p.g[0].A = ws.attn; p.g[0].lda = D; p.g[0].a_row_map = b->img_joint_row; p.g[0].M = Ri;
+      p.g[0].W = L.to_out_w; p.g[0].bias = L.to_out_b; p.g[0].out = ws.hidden_img; p.g[0].ldo = D;
+      p.g[0].res = ws.hidden_img; p.g[0].ldres = D; p.g[0].gate = ws.mod_img + 2 * D; p.g[0].gate_item_stride = 6 * D;
+      p.g[0].row_item_map = b->img_item;
+      p.g[1].A = ws.attn; p.g[1].lda = D; p.g[1].a_row_map = b->txt_joint_row; p.g[1].M = Rt;
+      p.g[1].W = L.to_add_out_w; p.g[1].bias = L.to_add_out_b; p.g[1].out = ws.hidden_txt; p.g[1].ldo = D;
+      p.g[1].res = ws.hidden_txt; p.g[1].ldres = D; p.g[1].gate = ws.mod_txt + 2 * D; p.g[1].gate_item_stride = 6 * D;
+      p.g[1].row_item_map = b->txt_item;
+      OMNI_TRY(omni_gemm_bf16(&p, stream));
+    }
+    // norm2 + modulate (reference :590, :595)
+    OMNI_TRY(omni_adaln_modulate(ws.hidden_img, D, xn_img, D, Ri, D, ws.mod_img + 4 * D, ws.mod_img + 3 * D, 6 * D,
+                                 b->img_item, 0, eps, stream));
+    OMNI_TRY(omni_adaln_modulate(ws.hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + 4 * D, ws.mod_txt + 3 * D, 6 * D,
+                                 b->txt_item, 0, eps, stream));
+    // MLP up + GELU-tanh (reference :591, :596 -> diffusers FeedForward)
+    {
+      omni_gemm_params p = {};
+      p.ngroups = 2; p.N = 4 * D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GELU_TANH;
+      p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = L.img_mlp_w1; p.g[0].bias = L.img_mlp_b1;
+      p.g[0].out = h_img; p.g[0].ldo = 4 * D;
+      p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w1; p.g[1].bias = L.txt_mlp_b1;
+      p.g[1].out = h_txt; p.g[1].ldo = 4 * D;
+      OMNI_TRY(omni_gemm_bf16(&p, stream));
+    }
+    // MLP down + gated residual (reference :592, :597)
+    {
+      omni_gemm_params p = {};
+      p.ngroups = 2; p.N = D; p.K = 4 * D; p.epilogue = OMNI_EPI_BIAS_GATE_RES;
+      p.g[0].A = h_img; p.g[0].lda = 4 * D; p.g[0].M = Ri; p.g[0].W = L.img_mlp_w2; p.g[0].bias = L.img_mlp_b2;
+      p.g[0].out = ws.hidden_img; p.g[0].ldo = D; p.g[0].res = ws.hidden_img; p.g[0].ldres = D;
+      p.g[0].gate = ws.mod_img + 5 * D; p.g[0].gate_item_stride = 6 * D; p.g[0].row_item_map = b->img_item;
+      p.g[1].A = h_txt; p.g[1].lda = 4 * D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w2; p.g[1].bias = L.txt_mlp_b2;
+      p.g[1].out = ws.hidden_txt; p.g[1].ldo = D; p.g[1].res = ws.hidden_txt; p.g[1].ldres = D;
+      p.g[1].gate = ws.mod_txt + 5 * D; p.g[1].gate_item_stride = 6 * D; p.g[1].row_item_map = b->txt_item;
+      OMNI_TRY(omni_gemm_bf16(&p, stream));
+    }
+  }
+
+  // --- output head: AdaLayerNormContinuous (scale first, then shift) + proj_out (reference :797-798) -------
+  OMNI_TRY(omni_linear_smallbatch(ws.temb, D, nT, w->norm_out_w, w->norm_out_b, 2 * (int64_t)D, D, ws.emb_out, 2 * D, 1,
+                                  0, stream));
+  OMNI_TRY(omni_adaln_modulate(ws.hidden_img, D, xn_img, D, Ri, D, ws.emb_out, ws.emb_out + D, 2 * D, b->img_item, 0,
+                               eps, stream));
+  {
+    omni_gemm_params p = {};
+    p.ngroups = 1; p.N = w->out_channels_packed; p.K = D; p.epilogue = OMNI_EPI_BIAS;
+    p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = w->proj_out_w; p.g[0].bias = w->proj_out_b;
+    p.g[0].out = b->noise_pred; p.g[0].ldo = w->out_channels_packed;
+    OMNI_TRY(omni_gemm_bf16(&p, stream));
+  }
+  return OMNI_OK;
+}

@@ -1,0 +1,430 @@
+// HBM-bound kernels of the DiT path for gfx950: AdaLN-modulate, RMSNorm, per-head RMSNorm+RoPE, RoPE,
+// small-batch weight-streaming linear (modulation / timestep GEMVs), timestep sinusoid, CFG+Euler step.
+// All of them move 16 bytes per lane per access (8 bf16) and do their arithmetic in fp32 with one rounding.
+// Roofline: HBM.  Algorithmic bytes are stated per kernel.
+#include "common.h"
+
+namespace {
+
+OMNI_DEVINL void unpack8(const u32x4_t& w, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = bf16_lo(w[i]);
+    f[2 * i + 1] = bf16_hi(w[i]);
+  }
+}
+OMNI_DEVINL u32x4_t pack8(const float* f) {
+  u32x4_t w;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+  return w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdaLN-modulate / RMSNorm: one wave per row, the row lives in registers (NCH chunks of 512 elements).
+// bytes/row = 2*D (read) + 2*D (write) + modulation vectors (L2-resident).
+// MODE 0: y = LN(x)*(1+scale)+shift    MODE 1: y = x*rsqrt(mean(x^2)+eps)*w
+// ------------------------------------------------------------------------------------------------
+template <int NCH, int MODE>
+__global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                      uint16_t* __restrict__ y, int64_t ldy, int rows, int D,
+                                                      const uint16_t* __restrict__ scale_or_w,
+                                                      const uint16_t* __restrict__ shift, int64_t item_stride,
+                                                      const int32_t* __restrict__ row_item_map, int rows_per_item,
+                                                      float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint16_t* xr = x + (int64_t)row * ldx;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e = (c * 64 + lane) * 8;
+    if (e < D) {
+      unpack8(*reinterpret_cast<const u32x4_t*>(xr + e), v[c]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += (MODE == 0) ? v[c][i] : v[c][i] * v[c][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+    }
+  }
+  sum = wave_sum<64>(sum);
+  float mean = 0.f, rstd;
+  if (MODE == 0) {
+    mean = sum / D;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int e = (c * 64 + lane) * 8;
+      if (e < D) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float d = v[c][i] - mean;
+          var += d * d;
+        }
+      }
+    }
+    var = wave_sum<64>(var) / D;
+    rstd = rsqrtf(var + eps);
+  } else {
+    rstd = rsqrtf(sum / D + eps);
+  }
+  int64_t moff = 0;
+  if (MODE == 0) {
+    const int item = row_item_map ? row_item_map[row] : row / rows_per_item;
+    moff = (int64_t)item * item_stride;
+  }
+  uint16_t* yr = y + (int64_t)row * ldy;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e = (c * 64 + lane) * 8;
+    if (e < D) {
+      float sc[8], sh[8], o[8];
+      unpack8(*reinterpret_cast<const u32x4_t*>(scale_or_w + moff + e), sc);
+      if (MODE == 0) {
+        unpack8(*reinterpret_cast<const u32x4_t*>(shift + moff + e), sh);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mean) * rstd * (1.0f + sc[i]) + sh[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = v[c][i] * rstd * sc[i];
+      }
+      *reinterpret_cast<u32x4_t*>(yr + e) = pack8(o);
+    }
+  }
+}
+
+template <int MODE>
+int launch_rownorm(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int rows, int D, const omni_bf16* a,
+                   const omni_bf16* b, int64_t stride, const int32_t* map, int rpi, float eps, hipStream_t s) {
+  const int nch = (D + 511) / 512;
+  const dim3 grid((rows + 3) / 4), block(256);
+#define OMNI_RN(N)                                                                                            \
+  hipLaunchKernelGGL((rownorm_kernel<N, MODE>), grid, block, 0, s, x, ldx, y, ldy, rows, D, a, b, stride, map, \
+                     rpi, eps)
+  if (nch <= 1) OMNI_RN(1);
+  else if (nch <= 2) OMNI_RN(2);
+  else if (nch <= 4) OMNI_RN(4);
+  else if (nch <= 6) OMNI_RN(6);
+  else if (nch <= 8) OMNI_RN(8);
+  else if (nch <= 16) OMNI_RN(16);
+  else return OMNI_ERR_UNSUPPORTED;
+#undef OMNI_RN
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-head RMSNorm(128) + interleaved RoPE, in place.  16 lanes x 8 elements = one (row, head);
+// a wave handles 4 (row, head) pairs per instruction.  bytes = 2 * rows*H*128*2 (read + write).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict__ x, int64_t ldx, int rows, int H,
+                                                           const uint16_t* __restrict__ w_img,
+                                                           const uint16_t* __restrict__ w_txt,
+                                                           const uint16_t* __restrict__ cos_tab,
+                                                           const uint16_t* __restrict__ sin_tab,
+                                                           const int32_t* __restrict__ row_pos, int txt_pos_end,
+                                                           float eps) {
+  const int sub = threadIdx.x & 15;
+  const int64_t unit = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // (row, head) pair index
+  if (unit >= (int64_t)rows * H) return;
+  const int row = (int)(unit / H), head = (int)(unit - (int64_t)row * H);
+  uint16_t* p = x + (int64_t)row * ldx + head * 128 + sub * 8;
+  float f[8], w[8], o[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(p), f);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
+  ss = wave_sum<16>(ss);
+  const float rstd = rsqrtf(ss * (1.0f / 128.0f) + eps);
+  const int pos = row_pos[row];
+  unpack8(*reinterpret_cast<const u32x4_t*>((pos < txt_pos_end ? w_txt : w_img) + sub * 8), w);
+  const u32x2_t cw = *reinterpret_cast<const u32x2_t*>(cos_tab + (int64_t)pos * 64 + sub * 4);
+  const u32x2_t sw = *reinterpret_cast<const u32x2_t*>(sin_tab + (int64_t)pos * 64 + sub * 4);
+  const float c[4] = {bf16_lo(cw[0]), bf16_hi(cw[0]), bf16_lo(cw[1]), bf16_hi(cw[1])};
+  const float s[4] = {bf16_lo(sw[0]), bf16_hi(sw[0]), bf16_lo(sw[1]), bf16_hi(sw[1])};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = f[2 * i] * rstd * w[2 * i], b = f[2 * i + 1] * rstd * w[2 * i + 1];
+    o[2 * i] = a * c[i] - b * s[i];
+    o[2 * i + 1] = b * c[i] + a * s[i];
+  }
+  *reinterpret_cast<u32x4_t*>(p) = pack8(o);
+}
+
+// Standalone interleaved RoPE on [B,S,H,dh]; one lane per 8 elements.
+__global__ __launch_bounds__(256) void rope_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                   int64_t total_chunks, int S, int H, int dh,
+                                                   const uint16_t* __restrict__ cos_tab,
+                                                   const uint16_t* __restrict__ sin_tab) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= total_chunks) return;
+  const int cpr = dh / 8;  // chunks per head row
+  const int sub = (int)(id % cpr);
+  const int64_t tok_head = id / cpr;
+  const int s_idx = (int)((tok_head / H) % S);
+  float f[8], o[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(x + id * 8), f);
+  const u32x2_t cw = *reinterpret_cast<const u32x2_t*>(cos_tab + (int64_t)s_idx * (dh / 2) + sub * 4);
+  const u32x2_t sw = *reinterpret_cast<const u32x2_t*>(sin_tab + (int64_t)s_idx * (dh / 2) + sub * 4);
+  const float c[4] = {bf16_lo(cw[0]), bf16_hi(cw[0]), bf16_lo(cw[1]), bf16_hi(cw[1])};
+  const float s[4] = {bf16_lo(sw[0]), bf16_hi(sw[0]), bf16_lo(sw[1]), bf16_hi(sw[1])};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = f[2 * i] * c[i] - f[2 * i + 1] * s[i];
+    o[2 * i + 1] = f[2 * i + 1] * c[i] + f[2 * i] * s[i];
+  }
+  *reinterpret_cast<u32x4_t*>(y + id * 8) = pack8(o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small-batch linear (weight streaming):  y[b,n] = act_out(sum_k act_in(x[b,k]) W[n,k] + bias[n]).
+// act_in(x) is staged once per workgroup into LDS as fp32; each wave then streams whole weight rows
+// (16 B per lane per load, ROWS_PER_ITER rows in flight) and reduces across the wave.
+// bytes = N*K*2 (W, read once) — the 13.6 GB/forward modulation stream of the DiT.
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void linear_smallbatch_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                                const uint16_t* __restrict__ W,
+                                                                const uint16_t* __restrict__ bias, int64_t N, int K,
+                                                                uint16_t* __restrict__ y, int64_t ldy, int act_in,
+                                                                int act_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = reinterpret_cast<float*>(smem);  // [NB][K]
+  for (int i = threadIdx.x; i < NB * K; i += 256) {
+    const int b = i / K, kk = i - b * K;
+    float v = bf16_bits_to_f32(x[(int64_t)b * ldx + kk]);
+    if (act_in == 1) v = silu_f(v);
+    xs[i] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int nchunk = K / 8;  // 16-B chunks per row
+  constexpr int R = 2;       // weight rows in flight per wave
+  for (int64_t n0 = wave_global * R; n0 < N; n0 += nwaves * R) {
+    float acc[R][NB];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+      u32x4_t w[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t n = min(n0 + r, N - 1);
+        w[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(W + n * K + c * 8));
+      }
+      float xv[NB][8];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(xs + b * K + c * 8);
+        const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(xs + b * K + c * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xv[b][i] = a0[i];
+          xv[b][4 + i] = a1[i];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float wf[8];
+        unpack8(w[r], wf);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[r][b] += wf[i] * xv[b][i];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[r][b] = wave_sum<64>(acc[r][b]);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t n = n0 + r;
+        if (n < N) {
+          const float bv = bias ? bf16_bits_to_f32(bias[n]) : 0.f;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            float v = acc[r][b] + bv;
+            if (act_out == 1) v = silu_f(v);
+            y[(int64_t)b * ldy + n] = f32_to_bf16_bits(v);
+          }
+        }
+      }
+    }
+  }
+}
+
+// Timesteps(dim, flip_sin_to_cos=True, shift 0, scale): out[b] = [cos(t*scale*f_i) | sin(t*scale*f_i)]
+__global__ void timestep_sinusoid_kernel(const float* __restrict__ t, int B, int dim, float scale,
+                                         uint16_t* __restrict__ out) {
+  const int half = dim / 2;
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * half) return;
+  const int b = id / half, i = id - b * half;
+  const float freq = expf(-9.210340371976184f * (float)i / (float)half);  // ln(10000)
+  const float arg = scale * (t[b] * freq);
+  out[(int64_t)b * dim + i] = f32_to_bf16_bits(cosf(arg));
+  out[(int64_t)b * dim + half + i] = f32_to_bf16_bits(sinf(arg));
+}
+
+// ------------------------------------------------------------------------------------------------
+// CFG combine + norm rescale + Euler update on [rows, 64] bf16: 8 lanes per row.
+// bytes/row = 3 reads + 1 write of 128 B.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cfg_euler_kernel(const uint16_t* __restrict__ pos,
+                                                        const uint16_t* __restrict__ neg,
+                                                        uint16_t* __restrict__ lat, int rows, float cfg_scale,
+                                                        const float* __restrict__ dt, int dt_rows_per_item) {
+  const int sub = threadIdx.x & 7;
+  const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (row >= rows) return;
+  const int64_t off = (int64_t)row * 64 + sub * 8;
+  float p[8], x[8], pred[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(pos + off), p);
+  unpack8(*reinterpret_cast<const u32x4_t*>(lat + off), x);
+  if (neg) {
+    float n[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(neg + off), n);
+    float pp = 0.f, cc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      pred[i] = n[i] + cfg_scale * (p[i] - n[i]);
+      pp += p[i] * p[i];
+      cc += pred[i] * pred[i];
+    }
+    pp = wave_sum<8>(pp);
+    cc = wave_sum<8>(cc);
+    const float r = sqrtf(pp) / sqrtf(cc);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pred[i] *= r;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pred[i] = p[i];
+  }
+  const float d = dt_rows_per_item > 0 ? dt[row / dt_rows_per_item] : dt[0];
+  float o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = x[i] + d * pred[i];
+  *reinterpret_cast<u32x4_t*>(lat + off) = pack8(o);
+}
+
+}  // namespace
+
+extern "C" int omni_adaln_modulate(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows,
+                                   int32_t D, const omni_bf16* scale, const omni_bf16* shift,
+                                   int64_t mod_item_stride, const int32_t* row_item_map, int32_t rows_per_item,
+                                   float eps, omni_stream stream) {
+  if (!x || !y || !scale || !shift || rows <= 0 || D <= 0) return OMNI_ERR_BAD_ARG;
+  if (!row_item_map && rows_per_item <= 0) return OMNI_ERR_BAD_ARG;
+  if (D % 8 || D > 8192) return OMNI_ERR_UNSUPPORTED;
+  if (!omni_aligned16(x) || !omni_aligned16(y) || !omni_aligned16(scale) || !omni_aligned16(shift) || (ldx % 8) ||
+      (ldy % 8) || (mod_item_stride % 8))
+    return OMNI_ERR_ALIGN;
+  return launch_rownorm<0>(x, ldx, y, ldy, rows, D, scale, shift, mod_item_stride, row_item_map, rows_per_item, eps,
+                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int omni_rmsnorm(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows, int32_t D,
+                            const omni_bf16* weight, float eps, omni_stream stream) {
+  if (!x || !y || !weight || rows <= 0 || D <= 0) return OMNI_ERR_BAD_ARG;
+  if (D % 8 || D > 8192) return OMNI_ERR_UNSUPPORTED;
+  if (!omni_aligned16(x) || !omni_aligned16(y) || !omni_aligned16(weight) || (ldx % 8) || (ldy % 8))
+    return OMNI_ERR_ALIGN;
+  return launch_rownorm<1>(x, ldx, y, ldy, rows, D, weight, nullptr, 0, nullptr, 1, eps,
+                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int omni_qk_norm_rope(omni_bf16* x, int64_t ldx, int32_t rows, int32_t num_heads, const omni_bf16* w_img,
+                                 const omni_bf16* w_txt, const omni_bf16* cos_tab, const omni_bf16* sin_tab,
+                                 const int32_t* row_pos, int32_t txt_pos_end, float eps, omni_stream stream) {
+  if (!x || !w_img || !w_txt || !cos_tab || !sin_tab || !row_pos || rows <= 0 || num_heads <= 0)
+    return OMNI_ERR_BAD_ARG;
+  if (!omni_aligned16(x) || !omni_aligned16(w_img) || !omni_aligned16(w_txt) || (ldx % 8) ||
+      (reinterpret_cast<uintptr_t>(cos_tab) & 7) || (reinterpret_cast<uintptr_t>(sin_tab) & 7))
+    return OMNI_ERR_ALIGN;
+  const int64_t units = (int64_t)rows * num_heads;
+  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((units + 15) / 16)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, ldx, rows, num_heads, w_img, w_txt, cos_tab, sin_tab,
+                     row_pos, txt_pos_end, eps);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+extern "C" int omni_rope_interleaved(const omni_bf16* x, omni_bf16* y, int32_t B, int32_t S, int32_t H, int32_t dh,
+                                     const omni_bf16* cos_tab, const omni_bf16* sin_tab, omni_stream stream) {
+  if (!x || !y || !cos_tab || !sin_tab || B <= 0 || S <= 0 || H <= 0 || dh <= 0) return OMNI_ERR_BAD_ARG;
+  if (dh % 16) return OMNI_ERR_UNSUPPORTED;
+  if (!omni_aligned16(x) || !omni_aligned16(y) || (reinterpret_cast<uintptr_t>(cos_tab) & 7) ||
+      (reinterpret_cast<uintptr_t>(sin_tab) & 7))
+    return OMNI_ERR_ALIGN;
+  const int64_t chunks = (int64_t)B * S * H * (dh / 8);
+  hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, y, chunks, S, H, dh, cos_tab, sin_tab);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+extern "C" int omni_linear_smallbatch(const omni_bf16* x, int64_t ldx, int32_t B, const omni_bf16* W,
+                                      const omni_bf16* bias, int64_t N, int32_t K, omni_bf16* y, int64_t ldy,
+                                      int32_t act_in, int32_t act_out, omni_stream stream) {
+  if (!x || !W || !y || B <= 0 || N <= 0 || K <= 0) return OMNI_ERR_BAD_ARG;
+  if (B > 8 || K % 8 || K > 4096) return OMNI_ERR_UNSUPPORTED;
+  if (!omni_aligned16(W)) return OMNI_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // 2 weight rows per wave-iteration, 4 waves per block; cap the grid at 8 blocks/CU and grid-stride the rest
+  int64_t blocks = (N + 7) / 8;
+  if (blocks > 2048) blocks = 2048;
+  const dim3 grid((unsigned)blocks), block(256);
+#define OMNI_LSB(NB)                                                                                              \
+  do {                                                                                                            \
+    const size_t lds = (size_t)NB * K * sizeof(float);                                                            \
+    if (lds > 65536) {                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_smallbatch_kernel<NB>),                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
+        return OMNI_ERR_LAUNCH;                                                                                   \
+    }                                                                                                             \
+    hipLaunchKernelGGL(linear_smallbatch_kernel<NB>, grid, block, lds, s, x, ldx, W, bias, N, K, y, ldy, act_in,  \
+                       act_out);                                                                                  \
+  } while (0)
+  if (B == 1) OMNI_LSB(1);
+  else if (B == 2) OMNI_LSB(2);
+  else if (B <= 4) {
+    if (B == 3) OMNI_LSB(3); else OMNI_LSB(4);
+  } else if (B <= 6) {
+    if (B == 5) OMNI_LSB(5); else OMNI_LSB(6);
+  } else {
+    if (B == 7) OMNI_LSB(7); else OMNI_LSB(8);
+  }
+#undef OMNI_LSB
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+extern "C" int omni_timestep_sinusoid(const float* t, int32_t B, int32_t dim, float scale, omni_bf16* out,
+                                      omni_stream stream) {
+  if (!t || !out || B <= 0 || dim <= 0 || dim % 2) return OMNI_ERR_BAD_ARG;
+  const int n = B * (dim / 2);
+  hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3((n + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
+                     t, B, dim, scale, out);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+extern "C" int omni_cfg_euler_step(const omni_bf16* pos, const omni_bf16* neg, omni_bf16* latents, int32_t rows,
+                                   int32_t C, float true_cfg_scale, const float* dt, int32_t dt_rows_per_item,
+                                   omni_stream stream) {
+  if (!pos || !latents || !dt || rows <= 0) return OMNI_ERR_BAD_ARG;
+  if (C != 64) return OMNI_ERR_UNSUPPORTED;
+  if (!omni_aligned16(pos) || !omni_aligned16(latents) || (neg && !omni_aligned16(neg))) return OMNI_ERR_ALIGN;
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((rows + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream), pos,
+                     neg, latents, rows, true_cfg_scale, dt, dt_rows_per_item);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}

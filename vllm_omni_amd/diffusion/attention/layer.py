@@ -1,0 +1,30 @@
+"""Attention layer — mirror of vllm_omni/diffusion/attention/layer.py:17-70 (backend impl between the
+parallel strategy's pre/post hooks).  Data-parallel serving needs no resharding, so the strategy is the
+identity (`NoParallelAttention` in the reference); Ulysses is SURVEY.md §8f row N2."""
+import torch
+import torch.nn as nn
+
+from .backends.abstract import AttentionMetadata
+from .selector import get_attn_backend
+
+
+class Attention(nn.Module):
+    def __init__(self, num_heads: int, head_size: int, causal: bool, softmax_scale: float,
+                 num_kv_heads: int | None = None, prefix: str = "", scatter_idx: int = 2, gather_idx: int = 1,
+                 use_sync: bool = False):
+        super().__init__()
+        self.attn_backend = get_attn_backend(-1)
+        self.attention = self.attn_backend.get_impl_cls()(num_heads=num_heads, head_size=head_size,
+                                                          softmax_scale=softmax_scale, causal=causal,
+                                                          num_kv_heads=num_kv_heads)
+        self.softmax_scale = softmax_scale
+
+    def forward(self, query, key, value, attn_metadata: AttentionMetadata = None) -> torch.Tensor:
+        if attn_metadata is not None and attn_metadata.joint_query is not None:
+            # SP-style call: the replicated text q/k/v ride in the metadata (reference ulysses.py:83-121)
+            front = attn_metadata.joint_strategy == "front"
+            cat = (lambda j, x: torch.cat([j, x], 1)) if front else (lambda j, x: torch.cat([x, j], 1))
+            query, key, value = cat(attn_metadata.joint_query, query), cat(attn_metadata.joint_key, key), \
+                cat(attn_metadata.joint_value, value)
+        out = self.attention.forward(query, key, value, None)
+        return out[0] if isinstance(out, tuple) else out

@@ -1,0 +1,31 @@
+"""Backend selection — mirror of vllm_omni/diffusion/attention/selector.py:18-77.
+
+Same env var (DIFFUSION_ATTENTION_BACKEND) and the same `{name: {module, class}}` registry shape; the only
+registered (and default) backend here is CDNA4_FLASH.  Unknown names raise ValueError like the reference.
+"""
+import importlib
+import os
+from functools import cache
+
+from .backends.abstract import AttentionBackend
+
+_BACKEND_CONFIG = {
+    "CDNA4_FLASH": {"module": "vllm_omni_amd.diffusion.attention.backends.cdna4_flash", "class": "CDNA4FlashBackend"},
+}
+
+
+def load_backend(backend_name: str) -> type[AttentionBackend]:
+    cfg = _BACKEND_CONFIG[backend_name]
+    return getattr(importlib.import_module(cfg["module"]), cfg["class"])
+
+
+@cache
+def get_attn_backend(head_size: int) -> type[AttentionBackend]:
+    name = os.environ.get("DIFFUSION_ATTENTION_BACKEND")
+    if name is not None:
+        up = name.upper()
+        if up not in _BACKEND_CONFIG:
+            raise ValueError(f"Invalid attention backend for diffusion: '{name}'. Valid backends are: "
+                             f"{list(_BACKEND_CONFIG)}")
+        return load_backend(up)
+    return load_backend("CDNA4_FLASH")

@@ -1,0 +1,315 @@
+"""QwenImageTransformer2DModel on the CDNA4 kernels.
+
+Mirror of the reference model class (vllm_omni/diffusion/models/qwen_image/qwen_image_transformer.py:609-839):
+same constructor contract (`od_config`, widths as keyword defaults, only `num_layers` read from
+`od_config.tf_model_config`), same parameter names (so diffusers / reference checkpoints load unchanged through
+`load_weights`, including the q/k/v -> to_qkv and add_q/k/v -> add_kv_proj stacking of :805-815), same
+`forward(hidden_states, encoder_hidden_states, encoder_hidden_states_mask, timestep, img_shapes, txt_seq_lens, ...)`
+signature and `(sample,)` return.  The attributes TeaCache reaches for (`img_in, txt_norm, txt_in,
+time_text_embed, transformer_blocks[i].img_mod, norm_out, proj_out, do_true_cfg`) exist under the same names.
+
+What differs is HOW it computes: the module tree only owns parameters; `forward` hands raw device pointers to
+`omni_dit_forward` (csrc/dit_forward.hip), which enqueues the fused kernel sequence on the current HIP stream.
+There is no eager/PyTorch fallback: without libomni_cdna4.so or off-GPU, forward raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections.abc import Iterable
+
+import torch
+import torch.nn as nn
+
+from ...batch import RaggedBatch, build_ragged_batch
+from .... import _native as N
+from .rope import rope_table
+
+BF16 = torch.bfloat16
+
+
+class _Param(nn.Module):
+    """weight (+bias) holder; parameters are allocated uninitialised on `device` (no CPU staging of 20 B params)."""
+
+    def __init__(self, out_features: int, in_features: int | None, bias: bool, device, dtype):
+        super().__init__()
+        shape = (out_features,) if in_features is None else (out_features, in_features)
+        self.weight = nn.Parameter(torch.empty(shape, device=device, dtype=dtype), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_features, device=device, dtype=dtype), requires_grad=False) if bias else None
+
+
+def _linear(i, o, device, dtype):
+    return _Param(o, i, True, device, dtype)
+
+
+def _norm_w(n, device, dtype):
+    return _Param(n, None, False, device, dtype)
+
+
+class _TimestepEmbedder(nn.Module):
+    def __init__(self, D, device, dtype):
+        super().__init__()
+        self.linear_1 = _linear(256, D, device, dtype)
+        self.linear_2 = _linear(D, D, device, dtype)
+
+
+class QwenTimestepProjEmbeddings(nn.Module):
+    """reference :40-62 (no additional_t_cond)."""
+
+    def __init__(self, embedding_dim, device, dtype):
+        super().__init__()
+        self.timestep_embedder = _TimestepEmbedder(embedding_dim, device, dtype)
+
+
+class _GeluProj(nn.Module):
+    def __init__(self, D, device, dtype):
+        super().__init__()
+        self.proj = _linear(D, 4 * D, device, dtype)
+
+
+class _FeedForward(nn.Module):
+    """diffusers FeedForward('gelu-approximate') parameter layout: net.0.proj, net.2."""
+
+    def __init__(self, D, device, dtype):
+        super().__init__()
+        self.net = nn.ModuleList([_GeluProj(D, device, dtype), nn.Identity(), _linear(4 * D, D, device, dtype)])
+
+
+class QwenImageCrossAttention(nn.Module):
+    """Parameter holder for the joint attention of one block (reference :288-368)."""
+
+    def __init__(self, D, head_dim, device, dtype):
+        super().__init__()
+        self.to_qkv = _linear(D, 3 * D, device, dtype)
+        self.norm_q = _norm_w(head_dim, device, dtype)
+        self.norm_k = _norm_w(head_dim, device, dtype)
+        self.add_kv_proj = _linear(D, 3 * D, device, dtype)
+        self.to_add_out = _linear(D, D, device, dtype)
+        self.to_out = nn.ModuleList([_linear(D, D, device, dtype)])
+        self.norm_added_q = _norm_w(head_dim, device, dtype)
+        self.norm_added_k = _norm_w(head_dim, device, dtype)
+
+
+class QwenImageTransformerBlock(nn.Module):
+    """Parameter holder for one dual-stream MMDiT block (reference :461-503)."""
+
+    def __init__(self, D, head_dim, device, dtype):
+        super().__init__()
+        self.img_mod = nn.Sequential(nn.SiLU(), _linear(D, 6 * D, device, dtype))
+        self.attn = QwenImageCrossAttention(D, head_dim, device, dtype)
+        self.img_mlp = _FeedForward(D, device, dtype)
+        self.txt_mod = nn.Sequential(nn.SiLU(), _linear(D, 6 * D, device, dtype))
+        self.txt_mlp = _FeedForward(D, device, dtype)
+
+
+class _NormOut(nn.Module):
+    def __init__(self, D, device, dtype):
+        super().__init__()
+        self.linear = _linear(D, 2 * D, device, dtype)
+
+
+class Transformer2DModelOutput(tuple):
+    """`(sample,)` with a `.sample` attribute (diffusers Transformer2DModelOutput look-alike)."""
+
+    def __new__(cls, sample):
+        return super().__new__(cls, (sample,))
+
+    @property
+    def sample(self):
+        return self[0]
+
+
+class QwenImageTransformer2DModel(nn.Module):
+    def __init__(self, od_config=None, patch_size: int = 2, in_channels: int = 64, out_channels: int | None = 16,
+                 num_layers: int = 60, attention_head_dim: int = 128, num_attention_heads: int = 24,
+                 joint_attention_dim: int = 3584, guidance_embeds: bool = False,
+                 axes_dims_rope: tuple[int, int, int] = (16, 56, 56), device=None, dtype=BF16):
+        super().__init__()
+        if od_config is not None and getattr(od_config, "tf_model_config", None) is not None:
+            nl = od_config.tf_model_config.get("num_layers", None)
+            num_layers = nl if nl is not None else num_layers
+            dtype = getattr(od_config, "dtype", dtype)
+        if attention_head_dim != 128 or tuple(axes_dims_rope) != (16, 56, 56):
+            raise ValueError("the CDNA4 attention / RoPE kernels are built for head_dim 128, axes (16, 56, 56)")
+        if dtype != BF16:
+            raise ValueError("the CDNA4 DiT path computes in bf16 storage / fp32 accumulate only")
+        device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.in_channels = in_channels
+        self.out_channels = out_channels or in_channels
+        self.patch_size = patch_size
+        self.num_heads = num_attention_heads
+        self.head_dim = attention_head_dim
+        self.inner_dim = num_attention_heads * attention_head_dim
+        self.joint_attention_dim = joint_attention_dim
+        self.guidance_embeds = guidance_embeds
+        self.do_true_cfg = False
+        D = self.inner_dim
+        self.time_text_embed = QwenTimestepProjEmbeddings(D, device, dtype)
+        self.txt_norm = _norm_w(joint_attention_dim, device, dtype)
+        self.img_in = _linear(in_channels, D, device, dtype)
+        self.txt_in = _linear(joint_attention_dim, D, device, dtype)
+        self.transformer_blocks = nn.ModuleList(
+            [QwenImageTransformerBlock(D, attention_head_dim, device, dtype) for _ in range(num_layers)])
+        self.norm_out = _NormOut(D, device, dtype)
+        self.proj_out = _linear(D, patch_size * patch_size * self.out_channels, device, dtype)
+        self._native = None        # (DitWeights struct, keep-alive list)
+        self._workspace = None
+        self._batch_cache: dict = {}
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def device(self):
+        return self.proj_out.weight.device
+
+    def init_random_(self, seed: int = 1234, std: float = 0.02) -> "QwenImageTransformer2DModel":
+        """Synthetic weights ON DEVICE (bench only): >=2-D ~ N(0, std^2), biases 0, norm weights 1."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for name, p in self.named_parameters():
+            if p.dim() >= 2:
+                p.data.normal_(0.0, std, generator=g)
+            elif "norm" in name:
+                p.data.fill_(1.0)
+            else:
+                p.data.zero_()
+        self._native = None
+        return self
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]) -> set[str]:
+        """Same contract as the reference loader (:804-839): HF names with split q/k/v are stacked into
+        to_qkv / add_kv_proj (row order q|k|v); fused names are accepted as they are."""
+        stacked = [(".to_qkv", ".to_q", 0), (".to_qkv", ".to_k", 1), (".to_qkv", ".to_v", 2),
+                   (".add_kv_proj", ".add_q_proj", 0), (".add_kv_proj", ".add_k_proj", 1),
+                   (".add_kv_proj", ".add_v_proj", 2)]
+        params = dict(self.named_parameters())
+        loaded: set[str] = set()
+        D = self.inner_dim
+        for name, w in weights:
+            for fused, split, idx in stacked:
+                # match ".to_q." exactly (".to_q" is a prefix of ".to_qkv": the reference's substring test would
+                # mangle already-fused names)
+                if (split + ".") in name:
+                    name = name.replace(split + ".", fused + ".")
+                    params[name].data[idx * D:(idx + 1) * D].copy_(w)
+                    break
+            else:
+                if name not in params:
+                    raise KeyError(f"unexpected weight {name}")
+                if params[name].shape != w.shape:
+                    raise ValueError(f"{name}: expected {tuple(params[name].shape)}, got {tuple(w.shape)}")
+                params[name].data.copy_(w)
+            loaded.add(name)
+        self._native = None  # derived pointer tables must be rebuilt after loading (SURVEY.md §8b Ownership)
+        return loaded
+
+    def _native_weights(self) -> N.DitWeights:
+        if self._native is not None:
+            return self._native[0]
+        for n, p in self.named_parameters():
+            if not p.is_cuda or p.dtype != BF16 or not p.is_contiguous():
+                raise N.OmniNativeError(f"parameter {n} must be a contiguous bf16 GPU tensor (got {p.device}, {p.dtype})")
+        L = len(self.transformer_blocks)
+        layers = (N.DitLayerWeights * L)()
+        for i, blk in enumerate(self.transformer_blocks):
+            a = blk.attn
+            vals = dict(
+                img_mod_w=blk.img_mod[1].weight, img_mod_b=blk.img_mod[1].bias,
+                txt_mod_w=blk.txt_mod[1].weight, txt_mod_b=blk.txt_mod[1].bias,
+                to_qkv_w=a.to_qkv.weight, to_qkv_b=a.to_qkv.bias, add_qkv_w=a.add_kv_proj.weight,
+                add_qkv_b=a.add_kv_proj.bias, norm_q_w=a.norm_q.weight, norm_k_w=a.norm_k.weight,
+                norm_added_q_w=a.norm_added_q.weight, norm_added_k_w=a.norm_added_k.weight,
+                to_out_w=a.to_out[0].weight, to_out_b=a.to_out[0].bias, to_add_out_w=a.to_add_out.weight,
+                to_add_out_b=a.to_add_out.bias,
+                img_mlp_w1=blk.img_mlp.net[0].proj.weight, img_mlp_b1=blk.img_mlp.net[0].proj.bias,
+                img_mlp_w2=blk.img_mlp.net[2].weight, img_mlp_b2=blk.img_mlp.net[2].bias,
+                txt_mlp_w1=blk.txt_mlp.net[0].proj.weight, txt_mlp_b1=blk.txt_mlp.net[0].proj.bias,
+                txt_mlp_w2=blk.txt_mlp.net[2].weight, txt_mlp_b2=blk.txt_mlp.net[2].bias)
+            for k, v in vals.items():
+                setattr(layers[i], k, v.data_ptr())
+        w = N.DitWeights()
+        w.num_layers, w.num_heads, w.head_dim = L, self.num_heads, self.head_dim
+        w.joint_dim, w.in_channels = self.joint_attention_dim, self.in_channels
+        w.out_channels_packed = self.proj_out.weight.shape[0]
+        te = self.time_text_embed.timestep_embedder
+        w.t_lin1_w, w.t_lin1_b = te.linear_1.weight.data_ptr(), te.linear_1.bias.data_ptr()
+        w.t_lin2_w, w.t_lin2_b = te.linear_2.weight.data_ptr(), te.linear_2.bias.data_ptr()
+        w.txt_norm_w = self.txt_norm.weight.data_ptr()
+        w.img_in_w, w.img_in_b = self.img_in.weight.data_ptr(), self.img_in.bias.data_ptr()
+        w.txt_in_w, w.txt_in_b = self.txt_in.weight.data_ptr(), self.txt_in.bias.data_ptr()
+        w.norm_out_w, w.norm_out_b = self.norm_out.linear.weight.data_ptr(), self.norm_out.linear.bias.data_ptr()
+        w.proj_out_w, w.proj_out_b = self.proj_out.weight.data_ptr(), self.proj_out.bias.data_ptr()
+        w.layers = C.cast(layers, C.POINTER(N.DitLayerWeights))
+        self._native = (w, layers)
+        return w
+
+    # ------------------------------------------------------------------ batches
+    def prepare_batch(self, batch: RaggedBatch) -> dict:
+        """Upload the int32 maps and the bf16 RoPE table of a RaggedBatch (cache by content)."""
+        key = (tuple(batch.txt_lens), tuple(batch.temb_rows), batch.grid, batch.txt_pos_end)
+        hit = self._batch_cache.get(key)
+        if hit is not None:
+            return hit
+        dev = self.device
+        cos, sin = rope_table(batch.grid, batch.txt_pos_end)
+        ent = dict(batch=batch, maps=batch.device_maps(dev), cos=cos.to(dev, BF16).contiguous(),
+                   sin=sin.to(dev, BF16).contiguous())
+        if len(self._batch_cache) > 32:
+            self._batch_cache.clear()
+        self._batch_cache[key] = ent
+        return ent
+
+    def forward_ragged(self, prepared: dict, latents: torch.Tensor, prompt_embeds: torch.Tensor,
+                       timestep: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """latents [n_img_rows, 64] bf16, prompt_embeds [n_txt_rows, joint_dim] bf16, timestep [n_temb] fp32
+        (sigma = t/1000 exactly as the pipeline passes it) -> noise_pred [n_img_rows, 64] bf16."""
+        rb: RaggedBatch = prepared["batch"]
+        lib = N.lib()
+        w = self._native_weights()
+        if latents.shape != (rb.n_img_rows, self.in_channels) or prompt_embeds.shape != (rb.n_txt_rows, self.joint_attention_dim):
+            raise ValueError(f"row counts do not match the batch descriptor: {tuple(latents.shape)}, {tuple(prompt_embeds.shape)}")
+        for t, dt, nm in ((latents, BF16, "latents"), (prompt_embeds, BF16, "prompt_embeds"), (timestep, torch.float32, "timestep")):
+            if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+                raise N.OmniNativeError(f"{nm} must be a contiguous {dt} GPU tensor")
+        if timestep.numel() != rb.n_temb:
+            raise ValueError("timestep must have one entry per temb row")
+        need = lib.omni_dit_workspace_bytes(C.byref(w), rb.n_img_rows, rb.n_txt_rows, rb.n_temb)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty(rb.n_img_rows, w.out_channels_packed, dtype=BF16, device=self.device)
+        m = prepared["maps"]
+        b = N.DitBatch()
+        b.n_items, b.n_img_rows, b.n_txt_rows = rb.n_items, rb.n_img_rows, rb.n_txt_rows
+        b.n_joint_rows, b.n_temb, b.max_seqlen = rb.n_joint_rows, rb.n_temb, rb.max_seqlen
+        b.latents, b.prompt_embeds, b.timestep = latents.data_ptr(), prompt_embeds.data_ptr(), timestep.data_ptr()
+        b.cu_seqlens, b.img_item, b.txt_item = m["cu_seqlens"].data_ptr(), m["img_item"].data_ptr(), m["txt_item"].data_ptr()
+        b.img_joint_row, b.txt_joint_row = m["img_joint_row"].data_ptr(), m["txt_joint_row"].data_ptr()
+        b.joint_pos, b.txt_pos_end = m["joint_pos"].data_ptr(), rb.txt_pos_end
+        b.rope_cos, b.rope_sin = prepared["cos"].data_ptr(), prepared["sin"].data_ptr()
+        b.noise_pred = out.data_ptr()
+        b.workspace, b.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
+        N.check(lib.omni_dit_forward(C.byref(w), C.byref(b), torch.cuda.current_stream().cuda_stream), "omni_dit_forward")
+        return out
+
+    # ------------------------------------------------------------------ reference-shaped forward
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
+                encoder_hidden_states_mask: torch.Tensor = None, timestep: torch.Tensor = None,
+                img_shapes=None, txt_seq_lens=None, guidance=None, attention_kwargs=None,
+                additional_t_cond=None, return_dict: bool = True):
+        """Reference signature (:692-802).  B items of equal text length T (as the reference batches them)."""
+        if guidance is not None or additional_t_cond is not None:
+            raise NotImplementedError("guidance / additional_t_cond variants are outside the Qwen-Image T2I path")
+        B, S_img, _ = hidden_states.shape
+        T = encoder_hidden_states.shape[1]
+        shp = img_shapes[0]
+        if isinstance(shp, (list, tuple)) and isinstance(shp[0], (list, tuple)):
+            shp = shp[0]  # reference reads img_shapes[0] only (:231-232)
+        grid = tuple(int(v) for v in shp)
+        if grid[0] * grid[1] * grid[2] != S_img:
+            raise ValueError(f"img_shapes {grid} does not match {S_img} image tokens")
+        prepared = self.prepare_batch(build_ragged_batch([T] * B, grid))
+        # the reference casts timestep to the activation dtype before the sinusoid (:746)
+        ts = timestep.to(device=self.device, dtype=hidden_states.dtype).to(torch.float32).contiguous()
+        out = self.forward_ragged(prepared, hidden_states.reshape(B * S_img, -1).contiguous(),
+                                  encoder_hidden_states.reshape(B * T, -1).contiguous(), ts)
+        out = out.view(B, S_img, -1)
+        return Transformer2DModelOutput(out) if return_dict else (out,)

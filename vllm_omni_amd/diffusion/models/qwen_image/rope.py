@@ -1,0 +1,43 @@
+"""3-axis rotary position tables for Qwen-Image (host side; computed once per (grid, text length), cached).
+
+Semantics follow QwenEmbedRope with scale_rope=True (reference
+vllm_omni/diffusion/models/qwen_image/qwen_image_transformer.py:179-285): head_dim 128 = 64 rotation pairs split
+(8, 28, 28) over the (frame, height, width) axes, theta 10000; height/width indices are centred
+([-(n - n//2) .. n//2 - 1]); text tokens sit on the diagonal (same index on all three axes) starting at
+max(h//2, w//2).  The reference keeps a complex64 table and casts cos/sin to the activation dtype before
+rotating (:403-406); we store the bf16 cos/sin directly, [text rows | image rows] in one table so that a single
+int32 per joint row (`joint_pos`) addresses it.
+"""
+from __future__ import annotations
+
+import functools
+
+import torch
+
+AXES_DIM = (16, 56, 56)
+THETA = 10000.0
+
+
+def _axis_angles(index: torch.Tensor, dim: int) -> torch.Tensor:
+    inv_freq = 1.0 / torch.pow(torch.tensor(THETA, dtype=torch.float32),
+                               torch.arange(0, dim, 2, dtype=torch.float32) / dim)
+    return index.to(torch.float32)[:, None] * inv_freq[None, :]
+
+
+@functools.lru_cache(maxsize=64)
+def rope_table(grid: tuple[int, int, int], n_txt_pos: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """(cos, sin) fp32 CPU tensors of shape [n_txt_pos + f*h*w, 64]; rows [0, n_txt_pos) are text positions."""
+    f, h, w = grid
+    fi = torch.arange(f)
+    hi = torch.arange(h) - (h - h // 2)
+    wi = torch.arange(w) - (w - w // 2)
+    af, ah, aw = (_axis_angles(i, d) for i, d in zip((fi, hi, wi), AXES_DIM))
+    ang_img = torch.cat([
+        af[:, None, None, :].expand(f, h, w, -1),
+        ah[None, :, None, :].expand(f, h, w, -1),
+        aw[None, None, :, :].expand(f, h, w, -1)], dim=-1).reshape(f * h * w, -1)
+    start = max(h // 2, w // 2)
+    ti = torch.arange(start, start + n_txt_pos)
+    ang_txt = torch.cat([_axis_angles(ti, d) for d in AXES_DIM], dim=-1)
+    ang = torch.cat([ang_txt, ang_img], dim=0)
+    return torch.cos(ang), torch.sin(ang)

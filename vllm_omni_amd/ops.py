@@ -1,0 +1,198 @@
+"""Tensor-level wrappers over the C-ABI (raw device pointers + the current HIP stream).
+
+PyTorch is plumbing here (device memory, streams); all arithmetic happens in libomni_cdna4.so.
+Every wrapper raises if a tensor is not a bf16/int32/fp32 CUDA(HIP) tensor of the expected layout —
+there is no eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+BF16 = torch.bfloat16
+
+EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RES, EPI_BIAS_SPLIT3 = 0, 1, 2, 3
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: torch.Tensor | None, dtype=BF16, name: str = "tensor") -> int | None:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise N.OmniNativeError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise N.OmniNativeError(f"{name} must be {dtype}, got {t.dtype}")
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise N.OmniNativeError(f"{name} must be contiguous in its last dimension")
+    return t.data_ptr()
+
+
+def _rows2d(t: torch.Tensor, name: str) -> tuple[int, int, int]:
+    """(rows, cols, row_stride) of a 2-D row-major view."""
+    if t.dim() != 2:
+        raise N.OmniNativeError(f"{name} must be 2-D, got shape {tuple(t.shape)}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+class GemmGroupArgs:
+    """Python-side mirror of omni_gemm_group (one stream of a grouped GEMM)."""
+
+    def __init__(self, a, w, bias=None, out=None, *, a_row_map=None, out_row_map=None, out1=None, out2=None,
+                 res=None, gate=None, gate_item_stride=0, row_item_map=None, rows_per_item=0):
+        self.a, self.w, self.bias, self.out = a, w, bias, out
+        self.a_row_map, self.out_row_map, self.out1, self.out2 = a_row_map, out_row_map, out1, out2
+        self.res, self.gate, self.gate_item_stride = res, gate, gate_item_stride
+        self.row_item_map, self.rows_per_item = row_item_map, rows_per_item
+
+
+def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0, m_override: list[int] | None = None):
+    """Y_g = epilogue(A_g @ W_g.T + bias_g) for up to two groups sharing N, K (omni_gemm_bf16)."""
+    p = N.GemmParams()
+    p.ngroups = len(groups)
+    p.epilogue = epilogue
+    p.split_n = split_n
+    N_, K_ = groups[0].w.shape
+    p.N, p.K = N_, K_
+    for i, g in enumerate(groups):
+        G = p.g[i]
+        m, k, lda = _rows2d(g.a, "A")
+        if g.w.shape != (N_, K_) or not g.w.is_contiguous():
+            raise N.OmniNativeError("all groups must share a contiguous [N, K] weight shape")
+        G.A, G.lda = _p(g.a, name="A"), lda
+        G.M = m_override[i] if m_override else (g.a_row_map.numel() if g.a_row_map is not None else m)
+        if g.a_row_map is None and k != K_:
+            raise N.OmniNativeError(f"A has K={k}, W has K={K_}")
+        G.a_row_map = _p(g.a_row_map, torch.int32, "a_row_map")
+        G.W, G.bias = _p(g.w, name="W"), _p(g.bias, name="bias")
+        G.out, G.ldo = _p(g.out, name="out"), g.out.stride(0)
+        G.out1, G.out2 = _p(g.out1, name="out1"), _p(g.out2, name="out2")
+        G.out_row_map = _p(g.out_row_map, torch.int32, "out_row_map")
+        if g.res is not None:
+            G.res, G.ldres = _p(g.res, name="res"), g.res.stride(0)
+        G.gate, G.gate_item_stride = _p(g.gate, name="gate"), g.gate_item_stride
+        G.row_item_map = _p(g.row_item_map, torch.int32, "row_item_map")
+        G.rows_per_item = g.rows_per_item
+    N.check(N.lib().omni_gemm_bf16(C.byref(p), _stream()), "omni_gemm_bf16")
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, *, gelu: bool = False) -> torch.Tensor:
+    """Single-group convenience: x [M,K] @ w[N,K].T + bias (optionally GELU-tanh)."""
+    out = torch.empty(x.shape[0], w.shape[0], dtype=BF16, device=x.device)
+    gemm([GemmGroupArgs(x, w, bias, out)], EPI_BIAS_GELU_TANH if gelu else EPI_BIAS)
+    return out
+
+
+def adaln_modulate(x, scale, shift, *, mod_item_stride: int, row_item_map=None, rows_per_item: int = 0,
+                   eps: float = 1e-6, out=None):
+    rows, D, ldx = _rows2d(x, "x")
+    y = torch.empty_like(x) if out is None else out
+    N.check(N.lib().omni_adaln_modulate(_p(x, name="x"), ldx, _p(y, name="y"), y.stride(0), rows, D,
+                                        _p(scale, name="scale"), _p(shift, name="shift"), mod_item_stride,
+                                        _p(row_item_map, torch.int32, "row_item_map"), rows_per_item, eps, _stream()),
+            "omni_adaln_modulate")
+    return y
+
+
+def rmsnorm(x, weight, eps: float = 1e-6, out=None):
+    rows, D, ldx = _rows2d(x, "x")
+    y = torch.empty_like(x) if out is None else out
+    N.check(N.lib().omni_rmsnorm(_p(x, name="x"), ldx, _p(y, name="y"), y.stride(0), rows, D, _p(weight, name="w"),
+                                 eps, _stream()), "omni_rmsnorm")
+    return y
+
+
+def qk_norm_rope_(x, num_heads, w_img, w_txt, cos_tab, sin_tab, row_pos, txt_pos_end, eps: float = 1e-6):
+    rows, _, ldx = _rows2d(x, "x")
+    N.check(N.lib().omni_qk_norm_rope(_p(x, name="x"), ldx, rows, num_heads, _p(w_img, name="w_img"),
+                                      _p(w_txt, name="w_txt"), _p(cos_tab, name="cos"), _p(sin_tab, name="sin"),
+                                      _p(row_pos, torch.int32, "row_pos"), txt_pos_end, eps, _stream()),
+            "omni_qk_norm_rope")
+    return x
+
+
+def rope_interleaved(x, cos_tab, sin_tab, out=None):
+    """x [B,S,H,dh] contiguous bf16; cos/sin [S, dh/2] bf16."""
+    if x.dim() != 4 or not x.is_contiguous():
+        raise N.OmniNativeError("rope_interleaved expects a contiguous [B,S,H,dh] tensor")
+    B, S, H, dh = x.shape
+    y = torch.empty_like(x) if out is None else out
+    N.check(N.lib().omni_rope_interleaved(_p(x, name="x"), _p(y, name="y"), B, S, H, dh,
+                                          _p(cos_tab.contiguous(), name="cos"), _p(sin_tab.contiguous(), name="sin"),
+                                          _stream()), "omni_rope_interleaved")
+    return y
+
+
+def flash_attn_varlen(q, k, v, cu_seqlens, num_heads: int, max_seqlen: int, softmax_scale: float, out=None):
+    """q,k,v [rows, H*128] (row strides free), cu_seqlens int32 [B+1] on device."""
+    rows, HD, ldq = _rows2d(q, "q")
+    o = torch.empty(rows, HD, dtype=BF16, device=q.device) if out is None else out
+    N.check(N.lib().omni_flash_attn_fwd(_p(q, name="q"), _p(k, name="k"), _p(v, name="v"), _p(o, name="out"), ldq,
+                                        k.stride(0), v.stride(0), o.stride(0),
+                                        _p(cu_seqlens, torch.int32, "cu_seqlens"), cu_seqlens.numel() - 1, num_heads,
+                                        HD // num_heads, max_seqlen, softmax_scale, _stream()),
+            "omni_flash_attn_fwd")
+    return o
+
+
+def linear_smallbatch(x, w, bias=None, act_in: int = 0, act_out: int = 0, out=None):
+    B, K, ldx = _rows2d(x, "x")
+    Nn = w.shape[0]
+    y = torch.empty(B, Nn, dtype=BF16, device=x.device) if out is None else out
+    N.check(N.lib().omni_linear_smallbatch(_p(x, name="x"), ldx, B, _p(w, name="W"), _p(bias, name="bias"), Nn, K,
+                                           _p(y, name="y"), y.stride(0), act_in, act_out, _stream()),
+            "omni_linear_smallbatch")
+    return y
+
+
+def timestep_sinusoid(t: torch.Tensor, dim: int = 256, scale: float = 1000.0):
+    out = torch.empty(t.numel(), dim, dtype=BF16, device=t.device)
+    N.check(N.lib().omni_timestep_sinusoid(_p(t, torch.float32, "t"), t.numel(), dim, scale, _p(out), _stream()),
+            "omni_timestep_sinusoid")
+    return out
+
+
+def cfg_euler_step_(latents, pos, neg, true_cfg_scale: float, dt: torch.Tensor, dt_rows_per_item: int = 0):
+    """latents [rows,64] bf16 updated in place; dt fp32 device tensor."""
+    rows, Cc, _ = _rows2d(latents, "latents")
+    if not (latents.is_contiguous() and pos.is_contiguous() and (neg is None or neg.is_contiguous())):
+        raise N.OmniNativeError("cfg_euler_step_ needs contiguous [rows, 64] tensors")
+    N.check(N.lib().omni_cfg_euler_step(_p(pos, name="pos"), _p(neg, name="neg"), _p(latents, name="latents"), rows,
+                                        Cc, true_cfg_scale, _p(dt, torch.float32, "dt"), dt_rows_per_item, _stream()),
+            "omni_cfg_euler_step")
+    return latents
+
+
+def vae_conv2d(x, w, bias=None, *, gamma=None, silu=True, res=None, upsample2x=False, clamp=None, out=None):
+    """NHWC bf16 conv (3x3 pad 1 or 1x1): x [B,H,W,Cin], w [Cout,ks,ks,Cin]."""
+    B, Hin, Win, Cin = x.shape
+    Cout, ks = w.shape[0], w.shape[1]
+    Hout, Wout = (2 * Hin, 2 * Win) if upsample2x else (Hin, Win)
+    y = torch.empty(B, Hout, Wout, Cout, dtype=BF16, device=x.device) if out is None else out
+    p = N.ConvParams()
+    p.x, p.w, p.bias, p.gamma = _p(x.contiguous(), name="x"), _p(w, name="w"), _p(bias, name="bias"), _p(gamma)
+    p.res, p.y = _p(res, name="res"), _p(y, name="y")
+    p.B, p.Hin, p.Win, p.Cin, p.Cout, p.ksize = B, Hin, Win, Cin, Cout, ks
+    p.upsample2x, p.silu = int(upsample2x), int(silu)
+    p.clamp_lo, p.clamp_hi = clamp if clamp else (0.0, 0.0)
+    N.check(N.lib().omni_vae_conv2d(C.byref(p), _stream()), "omni_vae_conv2d")
+    return y
+
+
+def vae_rmsnorm_silu(x, gamma, silu: bool = True):
+    y = torch.empty_like(x)
+    Cc = x.shape[-1]
+    N.check(N.lib().omni_vae_rmsnorm_silu(_p(x.contiguous(), name="x"), _p(y), x.numel() // Cc, Cc, _p(gamma),
+                                          int(silu), _stream()), "omni_vae_rmsnorm_silu")
+    return y
+
+
+def softmax_rows_(s: torch.Tensor, scale: float):
+    rows, cols, ld = _rows2d(s, "scores")
+    N.check(N.lib().omni_softmax_rows(_p(s, name="scores"), ld, rows, cols, scale, _stream()), "omni_softmax_rows")
+    return s
