@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the Qwen-Image DiT denoising path on N MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = every rank produces ONE 1024x1024 image end to end on the hot path: 20 denoising steps with
+true-CFG (2 DiT forwards of the 60-layer Qwen-Image transformer per step, run as one ragged CFG-pair forward),
+fused CFG+Euler updates, VAE decode, and (N > 1) the RCCL all-gather of the finished latents.  Inputs
+(seeded noise, synthetic prompt embeddings T=64, random-init bf16 weights of the real architecture) are resident
+in HBM before the timed region.  value = N*K images / max-over-ranks seconds.  Data-parallel by request
+(weak scaling): no collective inside the denoise loop.
+
+Also printed in the same JSON line:
+  roofline     — dominant kernel = gemm_bf16_kernel<GELU> (MLP up-projection, 27 % of the DiT FLOPs, one shape
+                 per launch so rocprofv3's per-kernel average is shape-pure): algorithmic 2*M*N*K flop per launch
+                 / average launch duration measured here with HIP events on the launch stream.
+  cpu_baseline — the fp32 CPU oracle (kind "port") timed on this box's host cores on a bounded sample and
+                 extrapolated linearly in layers/forwards (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HEIGHT = WIDTH = 1024
+STEPS_DENOISE = 20
+T_TXT = 64
+LAYERS = 60
+TRUE_CFG = 4.0
+PFLOP_PER_IMAGE = 2.777e15          # 40 x 69.310 TF (DiT) + 4.71 TF (VAE)
+PEAK_BF16 = 2.5e15                  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(layers_sample: int = 1) -> dict:
+    """Oracle DiT blocks at full width on the host cores; extrapolated to images/sec."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import qwen_image_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    D, S_img = 3072, (HEIGHT // 16) * (WIDTH // 16)
+    P = O.make_dit_params(layers_sample, seed=1234)
+    g = torch.Generator().manual_seed(0)
+    hidden, enc, temb = torch.randn(1, S_img, D, generator=g), torch.randn(1, T_TXT, D, generator=g), torch.randn(1, D, generator=g)
+    vid, txt = O.rope_tables(1, HEIGHT // 16, WIDTH // 16, T_TXT)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        for i in range(layers_sample):
+            enc, hidden = O.dit_block(P, i, hidden, enc, temb, vid, txt, 24)
+        dt = (time.perf_counter() - t0) / layers_sample
+    sec_per_image = dt * LAYERS * STEPS_DENOISE * 2          # 2 forwards per step (true-CFG), blocks dominate
+    return {"value": 1.0 / sec_per_image, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{layers_sample} full-width DiT block(s) (S_img=4096, T=64, fp32) = {dt:.2f} s/block, "
+                      f"extrapolated x{LAYERS} layers x{STEPS_DENOISE * 2} forwards"}
+
+
+def measure_roofline(dev) -> dict:
+    from vllm_omni_amd import ops
+
+    D, Mi, Mt = 3072, 2 * 4096, 2 * T_TXT
+    N, K = 4 * D, D
+    g = torch.Generator(device=dev).manual_seed(7)
+    xi = torch.randn(Mi, K, device=dev, generator=g).to(torch.bfloat16)
+    xt = torch.randn(Mt, K, device=dev, generator=g).to(torch.bfloat16)
+    wi = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    wt = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    b = torch.zeros(N, device=dev, dtype=torch.bfloat16)
+    oi = torch.empty(Mi, N, device=dev, dtype=torch.bfloat16)
+    ot = torch.empty(Mt, N, device=dev, dtype=torch.bfloat16)
+
+    def launch():
+        ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi), ops.GemmGroupArgs(xt, wt, b, ot)], ops.EPI_BIAS_GELU_TANH)
+
+    for _ in range(3):
+        launch()
+    s = torch.cuda.current_stream()
+    iters = 30
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(iters):
+        launch()
+    e1.record(s)
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    flops = 2.0 * (Mi + Mt) * N * K
+    ach = flops / sec / 1e12
+    return {"bound": "mfma", "kernel": "gemm_bf16_kernel<OMNI_EPI_BIAS_GELU_TANH> M=8192+128 N=12288 K=3072",
+            "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
+            "flop_per_launch": flops, "avg_launch_us": sec * 1e6, "traffic": None}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=LAYERS, help=argparse.SUPPRESS)      # dev only; default = real model
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig, TransformerConfig
+    from vllm_omni_amd.diffusion.distributed import data_parallel as dp
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    rank, world, local = dp.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product kernels")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = OmniDiffusionConfig(model="Qwen/Qwen-Image(random-init)", tf_model_config=TransformerConfig.from_dict({"num_layers": args.layers}))
+    pipe = QwenImagePipeline(od_config=cfg, device=dev)
+    pipe.transformer.init_random_(seed=1234)
+    pipe.vae.init_random_(seed=4321)
+
+    S_img = (HEIGHT // 16) * (WIDTH // 16)
+    g = torch.Generator().manual_seed(1)
+    pos = torch.randn(1, T_TXT, 3584, generator=g).to(dev, torch.bfloat16)
+    neg = torch.randn(1, T_TXT, 3584, generator=g).to(dev, torch.bfloat16)
+
+    def one_image(seed: int):
+        lat = torch.randn(1, S_img, 64, generator=torch.Generator().manual_seed(seed)).to(dev, torch.bfloat16)
+        req = OmniDiffusionRequest(height=HEIGHT, width=WIDTH, num_inference_steps=STEPS_DENOISE, true_cfg_scale=TRUE_CFG,
+                                   latents=lat, prompt_embeds=pos, negative_prompt_embeds=neg, output_type="latent")
+        out = pipe.generate([req], output_type="latent")[0].output           # [1, S_img, 64]
+        gathered = dp.gather_latents(out.contiguous(), [1] * world)           # RCCL all-gather of finished latents
+        img = pipe.decode_latents(out, HEIGHT, WIDTH)                         # each rank decodes its own image
+        return gathered, img
+
+    for i in range(args.warmup):
+        one_image(100 + i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        gathered, img = one_image(42 + rank * 1000 + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ok = bool(torch.isfinite(img.float()).all()) and bool(torch.isfinite(gathered.float()).all())
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        line = {
+            "metric": "images/sec (whole node) @1024^2, 20-step Qwen-Image DiT", "value": value, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Qwen-Image DiT 1024x1024, 20 steps, true-CFG 4.0 (2 forwards/step), bf16, "
+                                   f"{args.layers} layers, T=64 synthetic prompt embeds, + VAE decode; DP={world}",
+                       "global_batch": world, "parallelism": f"dp{world}", "images_per_step": world},
+            "finite_outputs": ok,
+            "dit_mfma_roofline_frac": (value / world) * PFLOP_PER_IMAGE * (args.layers / LAYERS) / PEAK_BF16,
+            "roofline": measure_roofline(dev),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+"""CPU: C-ABI exports, ragged-batch maps, schedule, weight loading, request sharding, gloo DP gather."""
+import ctypes
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import qwen_image_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vllm_omni_amd import _native
+
+    assert os.path.exists(_native.LIB_PATH), "run __graft_entry__.build() first"
+    dll = ctypes.CDLL(_native.LIB_PATH)   # loads without a GPU; no compute call is made here
+    header = open(os.path.join(ROOT, "include", "omni_cdna4.h")).read()
+    declared = set(re.findall(r"\b(omni_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no prototypes parsed from the header"
+    for name in declared:
+        assert hasattr(dll, name), f"{name} declared in include/omni_cdna4.h but not exported"
+    assert declared == set(_native.PROTOTYPES), "ctypes binding and header disagree"
+    dll.omni_abi_version.restype = ctypes.c_int
+    assert dll.omni_abi_version() == _native.ABI_VERSION
+
+
+def test_ctypes_struct_layout_matches_c():
+    # sizes the C compiler produces for the ABI structs (computed with the same alignment rules)
+    from vllm_omni_amd import _native as N
+
+    assert ctypes.sizeof(N.GemmGroup) == 136 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 136
+    assert ctypes.sizeof(N.DitLayerWeights) == 24 * 8
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from vllm_omni_amd import ops
+    from vllm_omni_amd._native import OmniNativeError
+
+    x = torch.zeros(4, 64, dtype=torch.bfloat16)
+    with pytest.raises(OmniNativeError):
+        ops.linear(x, x)          # CPU tensors must raise, never fall back
+
+
+def test_ragged_batch_maps():
+    from vllm_omni_amd.diffusion.batch import build_ragged_batch
+
+    rb = build_ragged_batch([3, 5], (1, 2, 2), temb_rows=[0, 0])
+    assert rb.n_img_rows == 8 and rb.n_txt_rows == 8 and rb.n_joint_rows == 16 and rb.max_seqlen == 9
+    assert rb.cu_seqlens.tolist() == [0, 7, 16]
+    assert rb.txt_joint_row.tolist() == [0, 1, 2, 7, 8, 9, 10, 11]
+    assert rb.img_joint_row.tolist() == [3, 4, 5, 6, 12, 13, 14, 15]
+    assert rb.txt_pos_end == 5
+    assert rb.joint_pos.tolist() == [0, 1, 2, 5, 6, 7, 8, 0, 1, 2, 3, 4, 5, 6, 7, 8]
+    assert rb.img_item.tolist() == [0] * 8 and rb.n_temb == 1
+    # every joint row is hit exactly once
+    assert sorted(rb.txt_joint_row.tolist() + rb.img_joint_row.tolist()) == list(range(16))
+    with pytest.raises(ValueError):
+        build_ragged_batch([0, 2], (1, 2, 2))
+
+
+def test_schedule_matches_oracle():
+    from vllm_omni_amd.diffusion.models.qwen_image.scheduling_flow_match import FlowMatchEulerSchedule
+
+    for steps, seq in ((4, 256), (20, 4096), (50, 16384)):
+        s = FlowMatchEulerSchedule()
+        ts = s.set_timesteps(steps, seq)
+        ots, osig = O.flow_match_sigmas(steps, seq)
+        assert torch.equal(ts, ots) and torch.equal(s.sigmas, osig)
+        assert torch.equal(s.dt(), osig[1:] - osig[:-1])
+    t = torch.tensor([731.23, 20.0])
+    got = FlowMatchEulerSchedule.model_timestep(t)
+    assert torch.equal(got, (t.bfloat16() / 1000).bfloat16().float())
+
+
+def test_pack_unpack_match_oracle():
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline as Pn
+
+    x = torch.randn(2, 16, 8, 12)
+    assert torch.equal(Pn._pack_latents(x, 2, 16, 8, 12), O.pack_latents(x))
+    p = O.pack_latents(x)
+    assert torch.equal(Pn._unpack_latents(p, 64, 96, 8), O.unpack_latents(p, 64, 96))
+
+
+def test_transformer_param_names_and_loader_on_cpu():
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+
+    m = QwenImageTransformer2DModel(num_layers=2, num_attention_heads=2, joint_attention_dim=128, device="cpu")
+    shapes = O.dit_param_shapes(2, num_heads=2, joint_dim=128)
+    assert {n: tuple(p.shape) for n, p in m.named_parameters()} == shapes
+    P = O.make_dit_params(2, num_heads=2, joint_dim=128)
+    D = 256
+    split = []
+    for k, v in P.items():          # HF-style split q/k/v names, as the reference loader receives them
+        if ".to_qkv." in k:
+            split += [(k.replace("to_qkv", s), v[j * D:(j + 1) * D]) for j, s in enumerate(("to_q", "to_k", "to_v"))]
+        elif ".add_kv_proj." in k:
+            split += [(k.replace("add_kv_proj", s), v[j * D:(j + 1) * D])
+                      for j, s in enumerate(("add_q_proj", "add_k_proj", "add_v_proj"))]
+        else:
+            split.append((k, v))
+    loaded = m.load_weights(split)
+    assert loaded == set(P)
+    for n, p in m.named_parameters():
+        assert torch.equal(p.data.float(), P[n].bfloat16().float()), n
+    with pytest.raises(Exception):
+        m(hidden_states=torch.zeros(1, 4, 64, dtype=torch.bfloat16), encoder_hidden_states=torch.zeros(1, 2, 128, dtype=torch.bfloat16),
+          timestep=torch.tensor([0.5]), img_shapes=[[(1, 2, 2)]], txt_seq_lens=[2])   # no GPU -> loud failure
+
+
+def test_vae_param_names_match_oracle():
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import _VaeConfig, decoder_param_shapes
+
+    ours = decoder_param_shapes(_VaeConfig())
+    theirs = {k: v for k, v in O.vae_decoder_param_shapes().items() if "time_conv" not in k}
+    assert ours == theirs
+
+
+def test_shard_requests_balanced_and_deterministic():
+    from vllm_omni_amd.diffusion.distributed.data_parallel import shard_requests, unshard
+
+    costs = [20, 50, 20, 20, 50, 20, 20, 20, 4]
+    a = shard_requests(costs, 4)
+    assert sorted(i for lst in a for i in lst) == list(range(9))
+    loads = [sum(costs[i] for i in lst) for lst in a]
+    assert max(loads) - min(loads) <= 50 and a == shard_requests(costs, 4)
+    flat = torch.arange(9)
+    gathered = torch.stack([flat[i] for lst in a for i in lst])
+    assert [int(t) for t in unshard(gathered, a)] == list(range(9))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from vllm_omni_amd.diffusion.data import DiffusionOutput, OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+    from vllm_omni_amd.diffusion.worker.gpu_worker import GPUWorker
+
+    class FakePipeline:
+        """Stands in for the GPU pipeline: 'denoised latent' = seed-filled tensor, so routing is checkable."""
+        device = torch.device("cpu")
+
+        def generate(self, reqs, output_type="latent"):
+            return [DiffusionOutput(output=torch.full((1, 16, 64), float(r.seed), dtype=torch.bfloat16)) for r in reqs]
+
+        def decode_latents(self, lat, h, w):
+            return lat
+
+    w = GPUWorker(rank, rank, OmniDiffusionConfig(dist_timeout=60), pipeline=FakePipeline())
+    w.init_device_and_model()
+    reqs = [OmniDiffusionRequest(height=64, width=64, num_inference_steps=s, seed=i, prompt_embeds=torch.zeros(1, 1, 8))
+            for i, s in enumerate([4, 20, 4, 4, 20])]
+    out = w.execute_model(reqs, decode=False)
+    q.put((rank, out.error, None if out.output is None else out.output[:, 0, 0].float().tolist()))
+    torch.distributed.destroy_process_group()
+
+
+def test_dp_worker_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(2):
+        rank, err, vals = q.get(timeout=120)
+        res[rank] = (err, vals)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == (None, [0.0, 1.0, 2.0, 3.0, 4.0])     # request order restored on the output rank
+    assert res[1] == (None, None)

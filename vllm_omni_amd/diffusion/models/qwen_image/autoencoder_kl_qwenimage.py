@@ -1,0 +1,207 @@
+"""AutoencoderKLQwenImage — DECODE side, single frame, on the CDNA4 conv kernels.
+
+Mirror of the decoder half of the vendored VAE (reference
+vllm_omni/diffusion/models/qwen_image/autoencoder_kl_qwenimage.py:549-664 QwenImageDecoder3d, :839-863 _decode;
+the T2I pipeline imports the diffusers original with the same arithmetic).  Parameter names and shapes are the
+checkpoint's ([O, I, kt, kh, kw] causal-Conv3d weights, `gamma` norms, `resample.1` upsample convs), so a
+diffusers state dict loads unchanged; `load_weights` then derives the kernels' layout once:
+
+  * for one frame the causal temporal padding puts two ZERO frames in front (:69-84), so only temporal slice
+    [-1] of every 3x3x3 kernel touches data -> each conv is a 2-D conv with weight[:, :, -1] (1/3 of the MACs the
+    reference executes);
+  * activations run NHWC bf16; weights are packed [O, kh, kw, I];
+  * nearest-exact x2 upsample (:112-124, fp32 round trip in the reference) is fused into the following conv's
+    gather (source = dst >> 1), the residual add into the conv epilogue, the final clamp(-1, 1) into conv_out;
+  * the first-chunk "Rep" path skips `time_conv` (:170-176), so upsample3d == upsample2d here.
+  * the single-head mid-block attention (:305-330, 16384 tokens x 384 ch at 1024^2) runs as
+    GEMM(q k^T) -> row softmax -> GEMM(P v) on the MFMA GEMM kernel.
+"""
+from __future__ import annotations
+
+import math
+from collections.abc import Iterable
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+
+BF16 = torch.bfloat16
+
+LATENTS_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+                0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+LATENTS_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+               3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+
+
+class _VaeConfig:
+    def __init__(self, base_dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2,
+                 temperal_downsample=(False, True, True)):
+        self.base_dim, self.z_dim, self.dim_mult, self.num_res_blocks = base_dim, z_dim, tuple(dim_mult), num_res_blocks
+        self.temporal_upsample = tuple(temperal_downsample[::-1])
+        self.latents_mean, self.latents_std = list(LATENTS_MEAN), list(LATENTS_STD)
+
+
+def decoder_param_shapes(cfg: _VaeConfig) -> dict[str, tuple]:
+    """Decoder-side checkpoint names -> shapes (the subset of the state dict this module owns)."""
+    s: dict[str, tuple] = {}
+    dims = [cfg.base_dim * u for u in [cfg.dim_mult[-1]] + list(cfg.dim_mult[::-1])]
+
+    def conv(n, i, o, k):
+        s[n + ".weight"], s[n + ".bias"] = (o, i, k, k, k), (o,)
+
+    def res(n, i, o):
+        s[n + ".norm1.gamma"] = (i, 1, 1, 1)
+        conv(n + ".conv1", i, o, 3)
+        s[n + ".norm2.gamma"] = (o, 1, 1, 1)
+        conv(n + ".conv2", o, o, 3)
+        if i != o:
+            conv(n + ".conv_shortcut", i, o, 1)
+
+    conv("post_quant_conv", cfg.z_dim, cfg.z_dim, 1)
+    conv("decoder.conv_in", cfg.z_dim, dims[0], 3)
+    res("decoder.mid_block.resnets.0", dims[0], dims[0])
+    a = "decoder.mid_block.attentions.0"
+    s[a + ".norm.gamma"] = (dims[0], 1, 1)
+    s[a + ".to_qkv.weight"], s[a + ".to_qkv.bias"] = (dims[0] * 3, dims[0], 1, 1), (dims[0] * 3,)
+    s[a + ".proj.weight"], s[a + ".proj.bias"] = (dims[0], dims[0], 1, 1), (dims[0],)
+    res("decoder.mid_block.resnets.1", dims[0], dims[0])
+    for i, (i_dim, o_dim) in enumerate(zip(dims[:-1], dims[1:])):
+        if i > 0:
+            i_dim //= 2
+        cur = i_dim
+        for j in range(cfg.num_res_blocks + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", cur, o_dim)
+            cur = o_dim
+        if i != len(cfg.dim_mult) - 1:
+            u = f"decoder.up_blocks.{i}.upsamplers.0"
+            s[u + ".resample.1.weight"], s[u + ".resample.1.bias"] = (o_dim // 2, o_dim, 3, 3), (o_dim // 2,)
+    s["decoder.norm_out.gamma"] = (dims[-1], 1, 1, 1)
+    conv("decoder.conv_out", dims[-1], 3, 3)
+    return s
+
+
+class AutoencoderKLQwenImage(nn.Module):
+    """Decoder-only VAE.  `decode(z)` takes de-normalised latents [B, 16, 1, h, w] -> image [B, 3, 1, 8h, 8w]."""
+
+    def __init__(self, device=None, dtype=BF16, **cfg_kw):
+        super().__init__()
+        self.config = _VaeConfig(**cfg_kw)
+        self.dtype_ = dtype
+        dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self._shapes = decoder_param_shapes(self.config)
+        self.params = nn.ParameterDict()
+        self._names = {}
+        for name, shape in self._shapes.items():
+            key = name.replace(".", "__")
+            self._names[name] = key
+            self.params[key] = nn.Parameter(torch.empty(shape, device=dev, dtype=dtype), requires_grad=False)
+        self._packed: dict[str, torch.Tensor] | None = None
+
+    @property
+    def dtype(self):
+        return self.dtype_
+
+    @property
+    def device(self):
+        return next(iter(self.params.values())).device
+
+    def state_names(self) -> list[str]:
+        return list(self._shapes.keys())
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]) -> set[str]:
+        loaded = set()
+        for name, w in weights:
+            if name not in self._names:
+                continue  # encoder / quant_conv / time_conv: not on the decode path
+            p = self.params[self._names[name]]
+            if p.shape != w.shape:
+                raise ValueError(f"{name}: expected {tuple(p.shape)}, got {tuple(w.shape)}")
+            p.data.copy_(w)
+            loaded.add(name)
+        self._packed = None
+        return loaded
+
+    def init_random_(self, seed: int = 4321):
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for name, shape in self._shapes.items():
+            p = self.params[self._names[name]]
+            if name.endswith(".weight"):
+                fan = math.prod(shape[1:]) // (shape[2] if len(shape) == 5 else 1)
+                p.data.copy_(torch.randn(shape, device=self.device, generator=g) / math.sqrt(fan))
+            elif name.endswith(".gamma"):
+                p.data.fill_(1.0)
+            else:
+                p.data.zero_()
+        self._packed = None
+        return self
+
+    # ------------------------------------------------------------------ derived kernel layout
+    def _pack(self) -> dict[str, torch.Tensor]:
+        if self._packed is not None:
+            return self._packed
+        out: dict[str, torch.Tensor] = {}
+        for name in self._shapes:
+            p = self.params[self._names[name]].data
+            if name.endswith(".weight"):
+                if p.dim() == 5:
+                    p = p[:, :, -1]                       # only the last temporal slice sees the single frame
+                out[name] = p.permute(0, 2, 3, 1).contiguous()   # [O, kh, kw, I]
+            else:
+                out[name] = p.reshape(-1).contiguous()
+        self._packed = out
+        return out
+
+    # ------------------------------------------------------------------ blocks (NHWC bf16)
+    def _res_block(self, W, pre, x):
+        h = ops.vae_conv2d(x, W[pre + ".conv_shortcut.weight"], W[pre + ".conv_shortcut.bias"]) \
+            if (pre + ".conv_shortcut.weight") in W else x
+        y = ops.vae_rmsnorm_silu(x, W[pre + ".norm1.gamma"])
+        y = ops.vae_conv2d(y, W[pre + ".conv1.weight"], W[pre + ".conv1.bias"])
+        y = ops.vae_rmsnorm_silu(y, W[pre + ".norm2.gamma"])
+        return ops.vae_conv2d(y, W[pre + ".conv2.weight"], W[pre + ".conv2.bias"], res=h)
+
+    def _attn_block(self, W, pre, x):
+        B, H, Wd, Cc = x.shape
+        tok = H * Wd
+        if tok % 64 or Cc % 64:
+            raise NotImplementedError("mid-block attention needs h*w and channels to be multiples of 64")
+        xn = ops.vae_rmsnorm_silu(x, W[pre + ".norm.gamma"], silu=False)
+        wqkv = W[pre + ".to_qkv.weight"].reshape(3 * Cc, Cc)
+        bqkv = W[pre + ".to_qkv.bias"]
+        outs = []
+        for b in range(B):
+            t = xn[b].reshape(tok, Cc)
+            q = ops.linear(t, wqkv[:Cc], bqkv[:Cc])
+            k = ops.linear(t, wqkv[Cc:2 * Cc], bqkv[Cc:2 * Cc])
+            vt = ops.linear(wqkv[2 * Cc:].contiguous(), t)              # V^T [C, tok] (bias folded below)
+            s = ops.linear(q, k)                                        # [tok, tok] scores
+            ops.softmax_rows_(s, 1.0 / math.sqrt(Cc))
+            outs.append(ops.linear(s, vt, bqkv[2 * Cc:]))               # P V + b_v  (rows of P sum to 1)
+        o = torch.stack(outs).view(B, H, Wd, Cc)
+        return ops.vae_conv2d(o, W[pre + ".proj.weight"], W[pre + ".proj.bias"], res=x)
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = False):
+        """z [B, z_dim, 1, h, w] -> [B, 3, 1, 8h, 8w] in [-1, 1] (reference _decode :839-863, one frame)."""
+        if z.dim() != 5 or z.shape[2] != 1:
+            raise NotImplementedError("single-frame (image) decode only")
+        W = self._pack()
+        c = self.config
+        x = z[:, :, 0].permute(0, 2, 3, 1).contiguous().to(BF16)      # NHWC
+        x = ops.vae_conv2d(x, W["post_quant_conv.weight"], W["post_quant_conv.bias"])
+        x = ops.vae_conv2d(x, W["decoder.conv_in.weight"], W["decoder.conv_in.bias"])
+        x = self._res_block(W, "decoder.mid_block.resnets.0", x)
+        x = self._attn_block(W, "decoder.mid_block.attentions.0", x)
+        x = self._res_block(W, "decoder.mid_block.resnets.1", x)
+        n_up = len(c.dim_mult)
+        for i in range(n_up):
+            for j in range(c.num_res_blocks + 1):
+                x = self._res_block(W, f"decoder.up_blocks.{i}.resnets.{j}", x)
+            if i != n_up - 1:
+                u = f"decoder.up_blocks.{i}.upsamplers.0.resample.1"
+                x = ops.vae_conv2d(x, W[u + ".weight"], W[u + ".bias"], upsample2x=True)
+        x = ops.vae_rmsnorm_silu(x, W["decoder.norm_out.gamma"])
+        x = ops.vae_conv2d(x, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], clamp=(-1.0, 1.0))
+        img = x.permute(0, 3, 1, 2).unsqueeze(2)                       # [B, 3, 1, H, W]
+        return (img,)

@@ -1,0 +1,217 @@
+"""QwenImagePipeline on the CDNA4 kernels: latents -> timesteps -> diffuse() -> VAE decode.
+
+Mirror of the reference pipeline (vllm_omni/diffusion/models/qwen_image/pipeline_qwen_image.py:235-754): same class
+contract (`__init__(*, od_config, prefix="")`, `forward(req) -> DiffusionOutput`, attributes `.transformer`, `.vae`,
+`load_weights`), same helpers (`_pack_latents`, `_unpack_latents`, `prepare_latents`, `prepare_timesteps`, `diffuse`).
+
+What is new relative to the reference (SURVEY.md F6/F7 — neither exists there):
+  * the two true-CFG branches of a step run as ONE ragged DiT forward (two items sharing a timestep row) instead
+    of two sequential forwards (:556-579);
+  * `generate(requests)` step-batches several requests that share (H, W, steps): every denoising step is one DiT
+    forward over all their items, with per-request B=1 semantics (no padding, no cross-request attention);
+  * CFG combine + norm rescale + Euler update (:580-585) are one fused kernel.
+
+The text encoder (Qwen2.5-VL, :357-433) is SURVEY.md §8f row N1: requests must carry `prompt_embeds`.
+"""
+from __future__ import annotations
+
+from collections.abc import Iterable
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ...batch import build_ragged_batch
+from ...data import DiffusionOutput, OmniDiffusionConfig
+from ...request import OmniDiffusionRequest
+from .autoencoder_kl_qwenimage import AutoencoderKLQwenImage
+from .qwen_image_transformer import QwenImageTransformer2DModel
+from .scheduling_flow_match import FlowMatchEulerSchedule
+
+BF16 = torch.bfloat16
+
+
+def get_qwen_image_post_process_func(od_config: OmniDiffusionConfig):
+    """VaeImageProcessor.postprocess equivalent: [-1,1] float image -> uint8 HWC (reference :41-60)."""
+
+    def post_process_func(images: torch.Tensor):
+        x = (images.float() / 2 + 0.5).clamp(0, 1)
+        return (x.permute(0, 2, 3, 1) * 255).round().to(torch.uint8).cpu().numpy()
+
+    return post_process_func
+
+
+class QwenImagePipeline(nn.Module):
+    def __init__(self, *, od_config: OmniDiffusionConfig | None = None, prefix: str = "", device=None,
+                 transformer: QwenImageTransformer2DModel | None = None, vae: AutoencoderKLQwenImage | None = None,
+                 transformer_kwargs: dict | None = None):
+        super().__init__()
+        self.od_config = od_config or OmniDiffusionConfig()
+        dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.device = dev
+        self.transformer = transformer if transformer is not None else QwenImageTransformer2DModel(
+            od_config=self.od_config, device=dev, **(transformer_kwargs or {}))
+        self.vae = vae if vae is not None else AutoencoderKLQwenImage(device=dev)
+        self.scheduler = FlowMatchEulerSchedule()
+        self.vae_scale_factor = 8
+        self.default_sample_size = 128
+        self._latents_mean = torch.tensor(self.vae.config.latents_mean).view(1, -1, 1, 1, 1)
+        self._latents_std = torch.tensor(self.vae.config.latents_std).view(1, -1, 1, 1, 1)
+        self.weights_sources: list = []
+
+    # ------------------------------------------------------------------ helpers with the reference's semantics
+    @staticmethod
+    def _pack_latents(latents, batch_size, num_channels_latents, height, width):
+        """[B, C, H, W] -> [B, (H/2)(W/2), 4C]: row-major over (h/2, w/2), channel-major inside the 2x2 patch (:436-441)."""
+        x = latents.view(batch_size, num_channels_latents, height // 2, 2, width // 2, 2).permute(0, 2, 4, 1, 3, 5)
+        return x.reshape(batch_size, (height // 2) * (width // 2), num_channels_latents * 4)
+
+    @staticmethod
+    def _unpack_latents(latents, height, width, vae_scale_factor):
+        """[B, S, 4C] -> [B, C, 1, H/8, W/8] (:444-457)."""
+        B, _, ch = latents.shape
+        h = 2 * (int(height) // (vae_scale_factor * 2))
+        w = 2 * (int(width) // (vae_scale_factor * 2))
+        x = latents.view(B, h // 2, w // 2, ch // 4, 2, 2).permute(0, 3, 1, 4, 2, 5)
+        return x.reshape(B, ch // 4, 1, h, w)
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        """(:459-490).  Noise is drawn with the caller's generator; parity runs inject `latents` instead."""
+        h = 2 * (int(height) // (self.vae_scale_factor * 2))
+        w = 2 * (int(width) // (self.vae_scale_factor * 2))
+        if latents is not None:
+            return latents.to(device=device, dtype=dtype)
+        gdev = generator.device if generator is not None else device
+        x = torch.randn((batch_size, 1, num_channels_latents, h, w), generator=generator, device=gdev, dtype=dtype).to(device)
+        return self._pack_latents(x, batch_size, num_channels_latents, h, w)
+
+    def prepare_timesteps(self, num_inference_steps, sigmas, image_seq_len):
+        """(:492-508) -> (timesteps fp32 [N], N)."""
+        ts = self.scheduler.set_timesteps(num_inference_steps, image_seq_len, sigmas)
+        return ts, len(ts)
+
+    # ------------------------------------------------------------------ the hot loop
+    @torch.no_grad()
+    def diffuse(self, prompt_embeds, prompt_embeds_mask, negative_prompt_embeds, negative_prompt_embeds_mask, latents,
+                img_shapes, txt_seq_lens, negative_txt_seq_lens, timesteps, do_true_cfg, guidance, true_cfg_scale):
+        """Reference signature (:530-586) for ONE request batch of B items with equal T; delegates to the
+        step-batched core with one 'request' per batch item."""
+        B = latents.shape[0]
+        shp = img_shapes[0][0] if isinstance(img_shapes[0], (list, tuple)) and isinstance(img_shapes[0][0], (list, tuple)) else img_shapes[0]
+        grid = tuple(int(v) for v in shp)
+        pos = [prompt_embeds[i, : int(txt_seq_lens[i])] if txt_seq_lens else prompt_embeds[i] for i in range(B)]
+        neg = None
+        if do_true_cfg:
+            neg = [negative_prompt_embeds[i, : int(negative_txt_seq_lens[i])] if negative_txt_seq_lens
+                   else negative_prompt_embeds[i] for i in range(B)]
+        out = self._denoise(list(latents.unbind(0)), pos, neg, grid, timesteps, self.scheduler.dt(),
+                            [float(true_cfg_scale)] * B)
+        return torch.stack(out)
+
+    @torch.no_grad()
+    def _denoise(self, latents: list[torch.Tensor], pos: list[torch.Tensor], neg: list[torch.Tensor] | None,
+                 grid, timesteps: torch.Tensor, dts: torch.Tensor, cfg_scales: list[float]) -> list[torch.Tensor]:
+        """Step-batched denoising of R requests sharing (grid, schedule).  latents[r] [S_img, 64];
+        pos[r]/neg[r] [T, joint_dim] (ragged T).  Item order: pos_0..pos_{R-1}, then neg_0..neg_{R-1}."""
+        tr, dev = self.transformer, self.device
+        R = len(latents)
+        S = latents[0].shape[0]
+        do_cfg = neg is not None
+        if do_cfg and len(set(cfg_scales)) != 1:
+            raise NotImplementedError("step-batched requests must share true_cfg_scale")
+        txt = [p.to(dev, BF16) for p in pos] + ([n.to(dev, BF16) for n in neg] if do_cfg else [])
+        lens = [int(t.shape[0]) for t in txt]
+        # all requests are at the same timestep: ONE temb row, shared by every item (both CFG branches included)
+        rb = build_ragged_batch(lens, grid, temb_rows=[0] * len(lens))
+        prepared = tr.prepare_batch(rb)
+        prompt_rows = torch.cat(txt).contiguous()
+        lat = torch.cat([x.to(dev, BF16) for x in latents]).contiguous()            # [R*S, 64]
+        lat_in = torch.empty((2 if do_cfg else 1) * R * S, lat.shape[1], dtype=BF16, device=dev)
+        pred = torch.empty_like(lat_in)
+        sig_in = self.scheduler.model_timestep(timesteps).to(dev)                   # bf16-rounded t/1000, fp32 [N]
+        dt_dev = dts.to(dev, torch.float32).contiguous()
+        for i in range(len(timesteps)):
+            lat_in[: R * S].copy_(lat)
+            if do_cfg:
+                lat_in[R * S:].copy_(lat)
+            tr.do_true_cfg = do_cfg
+            tr.forward_ragged(prepared, lat_in, prompt_rows, sig_in[i:i + 1], out=pred)
+            ops.cfg_euler_step_(lat, pred[: R * S], pred[R * S:] if do_cfg else None, cfg_scales[0], dt_dev[i:i + 1])
+        return list(lat.view(R, S, -1).unbind(0))
+
+    # ------------------------------------------------------------------ decode
+    @torch.no_grad()
+    def decode_latents(self, latents: torch.Tensor, height: int, width: int) -> torch.Tensor:
+        """packed latents [B, S, 64] -> image [B, 3, H, W] in [-1, 1]  (:736-747)."""
+        z = self._unpack_latents(latents, height, width, self.vae_scale_factor).to(self.vae.dtype)
+        mean = self._latents_mean.to(z.device, z.dtype)
+        inv_std = 1.0 / self._latents_std.to(z.device, z.dtype)
+        z = z / inv_std + mean
+        return self.vae.decode(z, return_dict=False)[0][:, :, 0]
+
+    # ------------------------------------------------------------------ request level
+    def _req_params(self, req: OmniDiffusionRequest):
+        height = req.height or self.default_sample_size * self.vae_scale_factor
+        width = req.width or self.default_sample_size * self.vae_scale_factor
+        steps = req.num_inference_steps or 50
+        cfg = req.true_cfg_scale or 4.0
+        if req.prompt_embeds is None:
+            raise NotImplementedError("text encoding is not built (SURVEY.md §8f N1): pass prompt_embeds")
+        has_neg = req.negative_prompt_embeds is not None
+        return height, width, steps, cfg, (cfg > 1 and has_neg)
+
+    @torch.no_grad()
+    def generate(self, requests: list[OmniDiffusionRequest], output_type: str = "pt") -> list[DiffusionOutput]:
+        """Run requests, step-batching those that share (height, width, steps, cfg on/off, cfg scale)."""
+        groups: dict[tuple, list[int]] = {}
+        for i, r in enumerate(requests):
+            groups.setdefault(self._req_params(r), []).append(i)
+        outs: list[DiffusionOutput | None] = [None] * len(requests)
+        cap = max(1, int(getattr(self.od_config, "max_step_batch", 4)))
+        for (height, width, steps, cfg, do_cfg), idxs in groups.items():
+            gh, gw = height // self.vae_scale_factor // 2, width // self.vae_scale_factor // 2
+            for s0 in range(0, len(idxs), cap):
+                chunk = idxs[s0:s0 + cap]
+                lats, pos, neg = [], [], []
+                for i in chunk:
+                    r = requests[i]
+                    gen = r.generator
+                    if gen is None and r.seed is not None:
+                        gen = torch.Generator(device="cpu").manual_seed(r.seed)
+                    lat = self.prepare_latents(1, self.transformer.in_channels // 4, height, width, BF16, self.device,
+                                               gen, r.latents)
+                    lats.append(lat.reshape(-1, lat.shape[-1]))
+                    pe = r.prompt_embeds.reshape(-1, r.prompt_embeds.shape[-1])
+                    if r.prompt_embeds_mask is not None:
+                        pe = pe[: int(r.prompt_embeds_mask.sum())]
+                    pos.append(pe)
+                    if do_cfg:
+                        ne = r.negative_prompt_embeds.reshape(-1, r.negative_prompt_embeds.shape[-1])
+                        if r.negative_prompt_embeds_mask is not None:
+                            ne = ne[: int(r.negative_prompt_embeds_mask.sum())]
+                        neg.append(ne)
+                timesteps, _ = self.prepare_timesteps(steps, None, lats[0].shape[0])
+                final = self._denoise(lats, pos, neg if do_cfg else None, (1, gh, gw), timesteps, self.scheduler.dt(),
+                                      [cfg] * len(chunk))
+                for i, lat in zip(chunk, final):
+                    if output_type == "latent" or requests[i].output_type == "latent":
+                        outs[i] = DiffusionOutput(output=lat.unsqueeze(0))
+                    else:
+                        outs[i] = DiffusionOutput(output=self.decode_latents(lat.unsqueeze(0), height, width))
+        return outs  # type: ignore[return-value]
+
+    def forward(self, req: OmniDiffusionRequest, **_kw) -> DiffusionOutput:
+        """Reference entry point (:588-750): one request in, DiffusionOutput out."""
+        return self.generate([req])[0]
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]) -> set[str]:
+        """Names prefixed `transformer.` / `vae.` are routed to the sub-models (AutoWeightsLoader role, :752-754)."""
+        tw, vw = [], []
+        for n, w in weights:
+            if n.startswith("transformer."):
+                tw.append((n[len("transformer."):], w))
+            elif n.startswith("vae."):
+                vw.append((n[len("vae."):], w))
+        loaded = {"transformer." + n for n in self.transformer.load_weights(tw)}
+        loaded |= {"vae." + n for n in self.vae.load_weights(vw)}
+        return loaded
