@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Launch ONE hot kernel a few times (for rocprofv3 --kernel-trace / --pmc passes).
+   python tools/run_kernel.py gemm_mlp_up|gemm_mlp_down|gemm_qkv|gemm_out|attention|forward [iters]"""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vllm_omni_amd import ops  # noqa: E402
+
+BF16 = torch.bfloat16
+dev = torch.device("cuda:0")
+which = sys.argv[1] if len(sys.argv) > 1 else "gemm_mlp_up"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+g = torch.Generator(device=dev).manual_seed(0)
+D, Mi, Mt = 3072, 8192, 128
+
+
+def rn(*shape, s=1.0):
+    return (torch.randn(*shape, device=dev, generator=g) * s).to(BF16)
+
+
+if which.startswith("gemm"):
+    N, K, epi = {"gemm_mlp_up": (4 * D, D, ops.EPI_BIAS_GELU_TANH), "gemm_mlp_down": (D, 4 * D, ops.EPI_BIAS),
+                 "gemm_qkv": (3 * D, D, ops.EPI_BIAS), "gemm_out": (D, D, ops.EPI_BIAS)}[which]
+    xi, xt, wi, wt, b = rn(Mi, K), rn(Mt, K), rn(N, K, s=0.02), rn(N, K, s=0.02), rn(N)
+    oi, ot = torch.empty(Mi, N, dtype=BF16, device=dev), torch.empty(Mt, N, dtype=BF16, device=dev)
+    fn = lambda: ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi), ops.GemmGroupArgs(xt, wt, b, ot)], epi)  # noqa: E731
+elif which == "attention":
+    B, H, S = 2, 24, 4160
+    q, k, v = rn(B * S, H * 128), rn(B * S, H * 128), rn(B * S, H * 128)
+    cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
+    fn = lambda: ops.flash_attn_varlen(q, k, v, cu, H, S, 1 / math.sqrt(128))  # noqa: E731
+else:
+    raise SystemExit("unknown kernel")
+for _ in range(iters):
+    fn()
+torch.cuda.synchronize()
+print("done", which, iters)
