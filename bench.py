@@ -5,15 +5,18 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = every rank produces ONE 1024x1024 image end to end on the hot path: 20 denoising steps with
-true-CFG (2 DiT forwards of the 60-layer Qwen-Image transformer per step, run as one ragged CFG-pair forward),
-fused CFG+Euler updates, VAE decode, and (N > 1) the RCCL all-gather of the finished latents.  Inputs
+One "step" = every rank serves one STEP-BATCH of R (default 3) independent 1024x1024 requests end to end on the
+hot path: 20 denoising steps with true-CFG (2 DiT forwards of the 60-layer Qwen-Image transformer per request per
+step; all 2R items of the step-batch share ONE ragged DiT forward, per-request B=1 semantics), fused CFG+Euler
+updates, VAE decode of every image, and (N > 1) the RCCL all-gather of the finished latents.  R=3 is chosen for
+tile quantisation: 6 items = 98 row-tiles of 256, which fills the 256 CUs to 92-98 % in all four GEMM shapes
+(R=1: 77-93 %).  Inputs
 (seeded noise, synthetic prompt embeddings T=64, random-init bf16 weights of the real architecture) are resident
-in HBM before the timed region.  value = N*K images / max-over-ranks seconds.  Data-parallel by request
+in HBM before the timed region.  value = N*K*R images / max-over-ranks seconds.  Data-parallel by request
 (weak scaling): no collective inside the denoise loop.
 
 Also printed in the same JSON line:
-  roofline     — dominant kernel = gemm_bf16_kernel<GELU> (MLP up-projection, 27 % of the DiT FLOPs, one shape
+  roofline     — dominant kernel = gemm_bf16_ring_kernel<GELU> (MLP up-projection, 27 % of the DiT FLOPs, one shape
                  per launch so rocprofv3's per-kernel average is shape-pure): algorithmic 2*M*N*K flop per launch
                  / average launch duration measured here with HIP events on the launch stream.
   cpu_baseline — the fp32 CPU oracle (kind "port") timed on this box's host cores on a bounded sample and
@@ -64,10 +67,10 @@ def cpu_baseline(layers_sample: int = 1) -> dict:
                       f"extrapolated x{LAYERS} layers x{STEPS_DENOISE * 2} forwards"}
 
 
-def measure_roofline(dev) -> dict:
+def measure_roofline(dev, R: int = 3) -> dict:
     from vllm_omni_amd import ops
 
-    D, Mi, Mt = 3072, 2 * 4096, 2 * T_TXT
+    D, Mi, Mt = 3072, 2 * R * 4096, 2 * R * T_TXT
     N, K = 4 * D, D
     g = torch.Generator(device=dev).manual_seed(7)
     xi = torch.randn(Mi, K, device=dev, generator=g).to(torch.bfloat16)
@@ -94,7 +97,7 @@ def measure_roofline(dev) -> dict:
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 2.0 * (Mi + Mt) * N * K
     ach = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": "gemm_bf16_kernel<OMNI_EPI_BIAS_GELU_TANH> M=8192+128 N=12288 K=3072",
+    return {"bound": "mfma", "kernel": f"gemm_bf16_ring_kernel<OMNI_EPI_BIAS_GELU_TANH> M={Mi}+{Mt} N=12288 K=3072",
             "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
             "flop_per_launch": flops, "avg_launch_us": sec * 1e6, "traffic": None}
 
@@ -105,6 +108,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--layers", type=int, default=LAYERS, help=argparse.SUPPRESS)      # dev only; default = real model
+    ap.add_argument("--requests", type=int, default=3, help="requests step-batched per rank per step (R)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,33 +125,39 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    cfg = OmniDiffusionConfig(model="Qwen/Qwen-Image(random-init)", tf_model_config=TransformerConfig.from_dict({"num_layers": args.layers}))
+    R = args.requests
+    cfg = OmniDiffusionConfig(model="Qwen/Qwen-Image(random-init)", max_step_batch=R,
+                              tf_model_config=TransformerConfig.from_dict({"num_layers": args.layers}))
     pipe = QwenImagePipeline(od_config=cfg, device=dev)
     pipe.transformer.init_random_(seed=1234)
     pipe.vae.init_random_(seed=4321)
 
     S_img = (HEIGHT // 16) * (WIDTH // 16)
     g = torch.Generator().manual_seed(1)
-    pos = torch.randn(1, T_TXT, 3584, generator=g).to(dev, torch.bfloat16)
-    neg = torch.randn(1, T_TXT, 3584, generator=g).to(dev, torch.bfloat16)
+    pos = [torch.randn(1, T_TXT, 3584, generator=g).to(dev, torch.bfloat16) for _ in range(R)]   # one prompt per request
+    neg = [torch.randn(1, T_TXT, 3584, generator=g).to(dev, torch.bfloat16) for _ in range(R)]
 
-    def one_image(seed: int):
-        lat = torch.randn(1, S_img, 64, generator=torch.Generator().manual_seed(seed)).to(dev, torch.bfloat16)
-        req = OmniDiffusionRequest(height=HEIGHT, width=WIDTH, num_inference_steps=STEPS_DENOISE, true_cfg_scale=TRUE_CFG,
-                                   latents=lat, prompt_embeds=pos, negative_prompt_embeds=neg, output_type="latent")
-        out = pipe.generate([req], output_type="latent")[0].output           # [1, S_img, 64]
-        gathered = dp.gather_latents(out.contiguous(), [1] * world)           # RCCL all-gather of finished latents
-        img = pipe.decode_latents(out, HEIGHT, WIDTH)                         # each rank decodes its own image
-        return gathered, img
+    def one_step(seed: int):
+        reqs = []
+        for r in range(R):
+            lat = torch.randn(1, S_img, 64, generator=torch.Generator().manual_seed(seed * 97 + r)).to(dev, torch.bfloat16)
+            reqs.append(OmniDiffusionRequest(height=HEIGHT, width=WIDTH, num_inference_steps=STEPS_DENOISE,
+                                             true_cfg_scale=TRUE_CFG, latents=lat, prompt_embeds=pos[r],
+                                             negative_prompt_embeds=neg[r], output_type="latent"))
+        outs = pipe.generate(reqs, output_type="latent")                      # one step-batched denoise loop
+        lat = torch.cat([o.output for o in outs]).contiguous()                # [R, S_img, 64]
+        gathered = dp.gather_latents(lat, [R] * world)                        # RCCL all-gather of finished latents
+        imgs = [pipe.decode_latents(lat[r:r + 1], HEIGHT, WIDTH) for r in range(R)]   # each rank decodes its own
+        return gathered, imgs[-1]
 
     for i in range(args.warmup):
-        one_image(100 + i)
+        one_step(100 + i)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        gathered, img = one_image(42 + rank * 1000 + i)
+        gathered, img = one_step(42 + rank * 1000 + i)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -159,17 +169,18 @@ def main():
     ok = bool(torch.isfinite(img.float()).all()) and bool(torch.isfinite(gathered.float()).all())
 
     if rank == 0:
-        value = world * args.steps / elapsed
+        value = world * args.steps * R / elapsed
         line = {
             "metric": "images/sec (whole node) @1024^2, 20-step Qwen-Image DiT", "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Qwen-Image DiT 1024x1024, 20 steps, true-CFG 4.0 (2 forwards/step), bf16, "
-                                   f"{args.layers} layers, T=64 synthetic prompt embeds, + VAE decode; DP={world}",
-                       "global_batch": world, "parallelism": f"dp{world}", "images_per_step": world},
+                                   f"{args.layers} layers, T=64 synthetic prompt embeds, + VAE decode; DP={world}, "
+                                   f"{R} requests step-batched per rank",
+                       "global_batch": world * R, "parallelism": f"dp{world}", "images_per_step": world * R},
             "finite_outputs": ok,
             "dit_mfma_roofline_frac": (value / world) * PFLOP_PER_IMAGE * (args.layers / LAYERS) / PEAK_BF16,
-            "roofline": measure_roofline(dev),
+            "roofline": measure_roofline(dev, R),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -39,6 +39,85 @@ OMNI_DEVINL void glds16(const void* gsrc, uint32_t lds_byte_addr) {
   __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)(uintptr_t)lds_byte_addr, 16, 0, 0);
 }
 
+// ---- hand-pipelined fragment reads -------------------------------------------------------------------------
+// hipcc always retires a group of ds_reads with lgkmcnt(0) and refuses to keep the NEXT k-step's reads in flight
+// behind the current k-step's MFMAs (it sinks them back or waits for all of them).  With 8 waves leaving the
+// barrier together that makes every k-step "burst-read 48 KiB, wait, then MFMA": the matrix pipe idles ~50 %.
+// So the reads are issued from inline asm (invisible to the compiler's waitcnt pass) and retired with COUNTED
+// waits: two k-steps of fragments (12 x ds_read_b128) are in flight while 8 MFMAs run.
+// Rules followed (cdna_hip_programming.md §5.7 form iii, rule 18): every asm load is "=v", the wait is its own
+// statement, and a sched_barrier(0) fences the consuming MFMAs below the wait.
+template <int OFF>
+OMNI_DEVINL bf16x8_t lds_read16(uint32_t addr) {
+  bf16x8_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+
+// One LDS stage of NKS k-steps (16 k each) for a wave tile of 128 (4 x 32 rows of A) x 64 (2 x 32 rows of W).
+// a_base[ks] / w_base[ks]: per-lane byte offsets of the fragment rows for k-step ks (swizzle folded in);
+// MB_STRIDE = bytes between 32-row blocks, W_BASE = byte offset of the W image inside a stage.
+// ABL (dev-only ablation, tools/bench_ablate.py): 0 normal, 2 no MFMA, 3/5 no fragment reads
+template <int NKS, int MB_STRIDE, int W_BASE, int ABL, typename Hook>
+OMNI_DEVINL void mma_stage(f32x16_t (&acc)[2][4], const uint32_t (&a_base)[NKS], const uint32_t (&w_base)[NKS],
+                           uint32_t stage_addr, Hook&& after_kstep) {
+  bf16x8_t wf[2][2], af[2][4];
+  if (ABL == 3 || ABL == 5) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) asm volatile("" : "=v"(wf[b][i]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(af[b][i]));
+    }
+  }
+#define OMNI_READ_KS(buf, ks)                                        \
+  do {                                                               \
+    if (ABL == 3 || ABL == 5) break;                                 \
+    const uint32_t aa_ = a_base[ks] + stage_addr;                    \
+    const uint32_t wa_ = w_base[ks] + stage_addr;                    \
+    wf[buf][0] = lds_read16<W_BASE>(wa_);                            \
+    wf[buf][1] = lds_read16<W_BASE + MB_STRIDE>(wa_);                \
+    af[buf][0] = lds_read16<0>(aa_);                                 \
+    af[buf][1] = lds_read16<MB_STRIDE>(aa_);                         \
+    af[buf][2] = lds_read16<2 * MB_STRIDE>(aa_);                     \
+    af[buf][3] = lds_read16<3 * MB_STRIDE>(aa_);                     \
+  } while (0)
+  OMNI_READ_KS(0, 0);
+  if (NKS > 1) OMNI_READ_KS(1, 1);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (ks + 1 < NKS) {
+      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL == 2) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) asm volatile("" ::"v"(wf[ks & 1][nb]));
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) asm volatile("" ::"v"(af[ks & 1][mb]));
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+          acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nb], af[ks & 1][mb], acc[nb][mb], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 2 < NKS) {
+      if ((ks & 1) == 0) OMNI_READ_KS(0, (ks + 2 < NKS ? ks + 2 : 0));
+      else OMNI_READ_KS(1, (ks + 2 < NKS ? ks + 2 : 0));
+    }
+    // DMA issue for a later stage is SPREAD over the k-steps (each global_load_lds costs the issuing wave
+    // 60-185 issue cycles: a burst of 8 right after the barrier stalls every wave while the matrix pipe idles)
+    after_kstep(ks);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef OMNI_READ_KS
+}
+
 template <int EPI>
 OMNI_DEVINL void gemm_epilogue(const omni_gemm_params& P, const omni_gemm_group& G, f32x16_t (&acc)[2][4], int m0,
                                int n0, int wm, int wn, int l31, int hi) {
@@ -93,7 +172,7 @@ OMNI_DEVINL void gemm_epilogue(const omni_gemm_params& P, const omni_gemm_group&
   }
 }
 
-template <int EPI>
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
                                                                   int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -131,30 +210,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const omni_gemm_
     w_src[j] = G.W + (int64_t)wr * K + c * 8;
   }
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;  // LDS byte address of the dynamic region
-  auto issue_stage = [&](int stage, int kt) {
+  auto issue_part = [&](int stage, int kt, int part) {   // part 0..3: one A piece + one W piece (1 KiB each)
     const uint32_t base = lds0 + stage * STAGE_BYTES + (wave * 4) * 1024;
     const int koff = kt * BK;
+    glds16(a_src[part] + koff, base + part * 1024);
+    glds16(w_src[part] + koff, base + TILE_BYTES + part * 1024);
+  };
+  auto issue_stage = [&](int stage, int kt) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(a_src[j] + koff, base + j * 1024);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(w_src[j] + koff, base + TILE_BYTES + j * 1024);
+    for (int j = 0; j < 4; ++j) issue_part(stage, kt, j);
   };
 
   // ---- per-lane fragment read offsets ---------------------------------------------------------
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, hi = lane >> 5;
-  uint32_t a_row_off[4], a_swz[4], w_row_off[2], w_swz[2];
+  // per-lane fragment byte offsets per k-step: row*128 + ((ks*2+hi) ^ swz)*16, swz = (row>>1)&7 = (l31>>1)&7
+  uint32_t a_base[4], w_base[4];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    const int r = wm * 128 + mb * 32 + l31;
-    a_row_off[mb] = r * 128;
-    a_swz[mb] = (r >> 1) & 7;
-  }
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int r = wn * 64 + nb * 32 + l31;
-    w_row_off[nb] = TILE_BYTES + r * 128;
-    w_swz[nb] = (r >> 1) & 7;
+  for (int ks = 0; ks < 4; ++ks) {
+    const uint32_t chunk = ((uint32_t)(ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    a_base[ks] = (wm * 128 + l31) * 128 + chunk;
+    w_base[ks] = (wn * 64 + l31) * 128 + chunk;
   }
 
   f32x16_t acc[2][4];
@@ -169,26 +245,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const omni_gemm_
   issue_stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nkt) issue_stage(cur ^ 1, kt + 1);
-    const char* sb = smem + cur * STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const uint32_t ch = ks * 2 + hi;
-      bf16x8_t wf[2], af[4];
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-        wf[nb] = *reinterpret_cast<const bf16x8_t*>(sb + w_row_off[nb] + ((ch ^ w_swz[nb]) << 4));
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
-        af[mb] = *reinterpret_cast<const bf16x8_t*>(sb + a_row_off[mb] + ((ch ^ a_swz[mb]) << 4));
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-          acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], af[mb], acc[nb][mb], 0, 0, 0);
+    if (ABL != 4 && ABL != 5) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
+    if (ABL != 1 && ABL != 5 && kt + 1 < nkt) issue_stage(cur ^ 1, kt + 1);
+    mma_stage<4, 32 * 128, TILE_BYTES, ABL>(acc, a_base, w_base, lds0 + cur * STAGE_BYTES, [](int) {});
   }
 
   gemm_epilogue<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi);
@@ -243,29 +305,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
     w_src[j] = G.W + (int64_t)wr * K + c * 8;
   }
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  auto issue_stage = [&](int slot, int st) {
+  auto issue_piece = [&](int slot, int st, int piece) {   // piece 0..3 = A0, W0, A1, W1 (1 KiB each)
     const uint32_t base = lds0 + slot * RSTAGE_BYTES + (wave * 2) * 1024;
-    const int koff = st * RBK;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) glds16(a_src[j] + koff, base + j * 1024);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) glds16(w_src[j] + koff, base + ROP_BYTES + j * 1024);
+    const int koff = st * RBK, part = piece >> 1;
+    if (piece & 1) glds16(w_src[part] + koff, base + ROP_BYTES + part * 1024);
+    else glds16(a_src[part] + koff, base + part * 1024);
+  };
+  auto issue_part = [&](int slot, int st, int part) {   // part 0..1
+    issue_piece(slot, st, 2 * part);
+    issue_piece(slot, st, 2 * part + 1);
+  };
+  auto issue_stage = [&](int slot, int st) {
+    issue_part(slot, st, 0);
+    issue_part(slot, st, 1);
   };
 
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, hi = lane >> 5;
-  uint32_t a_row_off[4], a_swz[4], w_row_off[2], w_swz[2];
+  // per-lane fragment byte offsets per k-step: row*64 + ((ks*2+hi) ^ swz)*16, swz = (row>>2)&3 = (l31>>2)&3
+  uint32_t a_base[2], w_base[2];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    const int r = wm * 128 + mb * 32 + l31;
-    a_row_off[mb] = r * 64;
-    a_swz[mb] = (r >> 2) & 3;
-  }
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int r = wn * 64 + nb * 32 + l31;
-    w_row_off[nb] = ROP_BYTES + r * 64;
-    w_swz[nb] = (r >> 2) & 3;
+  for (int ks = 0; ks < 2; ++ks) {
+    const uint32_t chunk = ((uint32_t)(ks * 2 + hi) ^ ((l31 >> 2) & 3)) << 4;
+    a_base[ks] = (wm * 128 + l31) * 64 + chunk;
+    w_base[ks] = (wn * 64 + l31) * 64 + chunk;
   }
 
   f32x16_t acc[2][4];
@@ -276,40 +339,111 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.0f;
 
+  // ---- continuous pipeline ---------------------------------------------------------------------------------
+  // global k-step g = 2*stage + ks.  Fragment reads run TWO k-steps ahead of the MFMAs and cross stage boundaries:
+  // at barrier B_t every wave has already waited for its DMA pieces of stages <= t+1, so stage t+1 is visible
+  // one barrier early and its first fragments are fetched while stage t's last MFMAs run.  B_t also frees the
+  // slot of stage t-1 (all its reads were consumed by MFMAs issued before B_t), which is refilled with stage
+  // t+4.  DMA lead = 3 stage-times (~1.5 BK64 tiles); only stages t+2, t+3 (8 DMAs per wave) stay in flight
+  // across B_t (counted vmcnt(8)); the matrix pipe never waits for an LDS read burst after a barrier.
   const int nst = K / RBK;
+  constexpr int LEAD = RSTAGES - 1;
 #pragma unroll
-  for (int s = 0; s < RSTAGES - 1; ++s)
-    if (s < nst) issue_stage(s, s);
-  int slot = 0, islot = RSTAGES - 1;
-  for (int s = 0; s < nst; ++s) {
-    if (s + (RSTAGES - 2) < nst) {
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // stages s+1..s+3 (3 x 4 DMAs per wave) may stay in flight
+  for (int st = 0; st < LEAD; ++st)
+    if (st < nst) issue_stage(st, st);
+  bf16x8_t wf[2][2], af[2][4];
+#define OMNI_RING_ADDR(slot_, ks)                                            \
+  const uint32_t sa_ = lds0 + (slot_) * RSTAGE_BYTES;                       \
+  const uint32_t aa_ = a_base[ks] + sa_, wa_ = w_base[ks] + sa_;
+#define OMNI_RING_READ(buf, slot_, ks)                                      \
+  do {                                                                      \
+    OMNI_RING_ADDR(slot_, ks)                                               \
+    wf[buf][0] = lds_read16<ROP_BYTES>(wa_);                                \
+    wf[buf][1] = lds_read16<ROP_BYTES + 32 * 64>(wa_);                      \
+    af[buf][0] = lds_read16<0>(aa_);                                        \
+    af[buf][1] = lds_read16<32 * 64>(aa_);                                  \
+    af[buf][2] = lds_read16<2 * 32 * 64>(aa_);                              \
+    af[buf][3] = lds_read16<3 * 32 * 64>(aa_);                              \
+  } while (0)
+// 8 MFMAs of one k-step (A-fragment-major order) with, interleaved in their issue shadows:
+//   * the reads of k-step g+2 into the SAME buffer: af[mb] is dead after its two MFMAs, wf[] after the last pair;
+//   * two single-piece DMA issues (DMA_A after MFMA 1, DMA_B after MFMA 5).
+#define OMNI_RING_PAIR(buf, mb)                                                                            \
+  acc[0][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][0], af[buf][mb], acc[0][mb], 0, 0, 0);        \
+  acc[1][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][1], af[buf][mb], acc[1][mb], 0, 0, 0);        \
+  __builtin_amdgcn_sched_barrier(0);
+#define OMNI_RING_MMA(buf, PREFETCH, nslot_, ks, DMA_A, DMA_B)                                               \
+  do {                                                                                                       \
+    OMNI_RING_ADDR(nslot_, ks)                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    OMNI_RING_PAIR(buf, 0)                                                                                   \
+    if (PREFETCH) af[buf][0] = lds_read16<0>(aa_);                                                           \
+    DMA_A;                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    OMNI_RING_PAIR(buf, 1)                                                                                   \
+    if (PREFETCH) af[buf][1] = lds_read16<32 * 64>(aa_);                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    OMNI_RING_PAIR(buf, 2)                                                                                   \
+    if (PREFETCH) af[buf][2] = lds_read16<2 * 32 * 64>(aa_);                                                 \
+    DMA_B;                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    OMNI_RING_PAIR(buf, 3)                                                                                   \
+    if (PREFETCH) {                                                                                          \
+      af[buf][3] = lds_read16<3 * 32 * 64>(aa_);                                                             \
+      wf[buf][0] = lds_read16<ROP_BYTES>(wa_);                                                               \
+      wf[buf][1] = lds_read16<ROP_BYTES + 32 * 64>(wa_);                                                     \
+    }                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+  } while (0)
+  // B_0
+  if (LEAD - 1 < nst) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (LEAD < nst) issue_stage(LEAD, LEAD);
+  OMNI_RING_READ(0, 0, 0);
+  OMNI_RING_READ(1, 0, 1);
+  // DMA for stage st+LEAD goes into the slot of stage st-1 (free since B_st) and is issued ONE PIECE AT A TIME
+  // between the MFMAs of iteration st: a global_load_lds costs its wave 60-185 issue cycles, which the partner
+  // wave on the SIMD covers with its own MFMAs; a burst of 4-8 right after the barrier stalls all waves at once.
+  int slot = 0;                       // slot of stage st
+  int pslot = RSTAGES - 1;            // slot of stage st-1 (stage LEAD was issued into slot LEAD at B_0)
+  for (int st = 0; st + 1 < nst; ++st) {               // every stage but the last: stage st+1 exists
+    const int nslot = (slot + 1 == RSTAGES) ? 0 : slot + 1;
+    const bool dma = st > 0 && st + LEAD < nst;
+    const int dst = st + LEAD;
+    // k-step 2*st   (prefetches stage st+1 / k-step 0: visible since B_st)
+    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    OMNI_RING_MMA(0, true, nslot, 0, if (dma) issue_piece(pslot, dst, 0), if (dma) issue_piece(pslot, dst, 1));
+    // k-step 2*st+1 (prefetches stage st+1 / k-step 1)
+    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    OMNI_RING_MMA(1, true, nslot, 1, if (dma) issue_piece(pslot, dst, 2), if (dma) issue_piece(pslot, dst, 3));
+    // ---- B_{st+1}: own pieces of stages <= st+2 landed; afterwards the slot of stage st is free
+    if (st + LEAD < nst) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (s + (RSTAGES - 1) < nst) issue_stage(islot, s + (RSTAGES - 1));
-    const char* sb = smem + slot * RSTAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const uint32_t ch = ks * 2 + hi;
-      bf16x8_t wf[2], af[4];
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-        wf[nb] = *reinterpret_cast<const bf16x8_t*>(sb + w_row_off[nb] + ((ch ^ w_swz[nb]) << 4));
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
-        af[mb] = *reinterpret_cast<const bf16x8_t*>(sb + a_row_off[mb] + ((ch ^ a_swz[mb]) << 4));
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-          acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], af[mb], acc[nb][mb], 0, 0, 0);
-    }
-    slot = (slot + 1 == RSTAGES) ? 0 : slot + 1;
-    islot = (islot + 1 == RSTAGES) ? 0 : islot + 1;
+    pslot = slot;
+    slot = nslot;
   }
+  // last stage: nothing left to prefetch
+  asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+  OMNI_RING_MMA(0, false, 0, 0, (void)0, (void)0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  OMNI_RING_MMA(1, false, 0, 1, (void)0, (void)0);
+#undef OMNI_RING_READ
+#undef OMNI_RING_ADDR
+#undef OMNI_RING_MMA
+#undef OMNI_RING_PAIR
+
   gemm_epilogue<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi);
 }
 
@@ -349,6 +483,28 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
 }
 
 }  // namespace
+
+// dev-only (NOT part of the C-ABI in include/omni_cdna4.h): time the 2-stage kernel with parts removed.
+extern "C" int omni_dev_gemm_ablate(const omni_gemm_params* p, int mode, omni_stream stream) {
+  const int mt0 = (p->g[0].M + BM - 1) / BM;
+  const int mt1 = p->ngroups > 1 ? (p->g[1].M + BM - 1) / BM : 0;
+  const int tiles_m = mt0 + mt1, tiles_n = (p->N + BN - 1) / BN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define OMNI_ABL(A)                                                                                                \
+  case A:                                                                                                          \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<OMNI_EPI_BIAS, A>),                         \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                                    \
+    hipLaunchKernelGGL((gemm_bf16_kernel<OMNI_EPI_BIAS, A>), dim3(tiles_m * tiles_n), dim3(NTHREADS), LDS_BYTES, s, \
+                       *p, mt0, tiles_m, tiles_n);                                                                 \
+    break;
+  switch (mode) {
+    OMNI_ABL(0) OMNI_ABL(1) OMNI_ABL(2) OMNI_ABL(3) OMNI_ABL(4) OMNI_ABL(5)
+    default: return OMNI_ERR_BAD_ARG;
+  }
+#undef OMNI_ABL
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
 
 extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
   if (!p || p->ngroups < 1 || p->ngroups > 2 || p->N <= 0 || p->K <= 0) return OMNI_ERR_BAD_ARG;
