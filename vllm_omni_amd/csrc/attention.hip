@@ -32,6 +32,20 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES;    // 64 KiB
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
 
+template <int OFF>
+OMNI_DEVINL bf16x8_t lds_read16(uint32_t addr) {   // invisible to hipcc's waitcnt pass: waits are counted by hand
+  bf16x8_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+
+template <int OFF>
+OMNI_DEVINL u32x2_t lds_tr_read8(uint32_t addr) {   // ds_read_b64_tr_b16: hardware 4x4 transpose read
+  u32x2_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+
 OMNI_DEVINL bf16x8_t tr_read_pair(uint32_t lds_addr_a, uint32_t lds_addr_b) {
   // two hardware-transposed 4x(16 lanes) reads -> the 8 k-elements of one MFMA A fragment
   s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)lds_addr_a);
@@ -69,25 +83,40 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
     const uint16_t* qp = q + (int64_t)(seq_start + qrow) * ldq + h * DH + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+    // make the fragments opaque: otherwise hipcc REMATERIALISES these global loads inside the KV loop (to save 32
+    // VGPRs) and every QK^T MFMA then waits on an L2 round trip (seen as vmcnt(7..0) waits in the loop)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
   }
 
-  // ---- staging maps: thread t moves 16-B chunks id = t + 256*i; key = id>>4, c = id&15 ---------
+  // ---- staging: thread t moves 16-B chunks id = t + 256*i; key = id>>4, c = id&15 -----------------------
+  // Loads go through buffer descriptors: the per-thread byte offset is loop-invariant (voffset), the tile
+  // offset is an SGPR (soffset) -> ZERO per-tile address VALU (the flat-address form cost ~90 VALU per tile,
+  // much of it quarter-rate 64-bit multiplies), and rows past the sequence end are out of the descriptor's range
+  // and read as 0 (no clamp; those keys are masked to -inf anyway).
   u32x4_t kreg[4], vreg[4];
-  uint32_t k_wr_off[4], v_wr_off[4];
+  uint32_t k_wr_off[4], v_wr_off[4], k_ld_off[4], v_ld_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int id = tid + 256 * i;
     const int key = id >> 4, c = id & 15;
     k_wr_off[i] = key * 256 + ((c ^ (key & 15)) << 4);
     v_wr_off[i] = K_TILE_BYTES + (c >> 2) * 4096 + (key >> 2) * 256 + (key & 3) * 64 + (c & 3) * 16;
+    k_ld_off[i] = (uint32_t)(key * ldk * 2 + c * 16);
+    v_ld_off[i] = (uint32_t)(key * ldv * 2 + c * 16);
   }
-  auto load_tile = [&](int kv0) {
+  const uint32_t k_bytes = (uint32_t)((int64_t)(seq_len - 1) * ldk * 2 + DH * 2);
+  const uint32_t v_bytes = (uint32_t)((int64_t)(seq_len - 1) * ldv * 2 + DH * 2);
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, v_bytes, 0x00020000);
+  const uint32_t k_tile_stride = (uint32_t)(KVBLK * ldk * 2), v_tile_stride = (uint32_t)(KVBLK * ldv * 2);
+  auto load_tile = [&](int t) {
+    const uint32_t ks_ = __builtin_amdgcn_readfirstlane(t * k_tile_stride);
+    const uint32_t vs_ = __builtin_amdgcn_readfirstlane(t * v_tile_stride);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int id = tid + 256 * i;
-      const int key = min(kv0 + (id >> 4), seq_len - 1), c = id & 15;
-      kreg[i] = *reinterpret_cast<const u32x4_t*>(kbase + (int64_t)key * ldk + c * 8);
-      vreg[i] = *reinterpret_cast<const u32x4_t*>(vbase + (int64_t)key * ldv + c * 8);
+      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_ld_off[i], ks_, 0);
+      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_ld_off[i], vs_, 0);
     }
   };
   auto store_tile = [&](int stage) {
@@ -102,8 +131,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
   // ---- fragment read addresses ------------------------------------------------------------------
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   // K: row key = j*32 + l31, chunk (ks*2+hi) ^ (key&15)      (j*32 keeps key&15 = l31&15)
-  const uint32_t k_row_off = l31 * 256;
-  const uint32_t k_swz = l31 & 15;
+  uint32_t k_addr[8];   // per k-step: key-row offset + swizzled 16-B chunk (sub-block j adds 32*256 as an immediate)
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_addr[ks] = l31 * 256 + ((((uint32_t)(ks * 2 + hi)) ^ (l31 & 15)) << 4);
   // V (tr read): g = lane>>4, m = lane&15:  base = (m>>2)*64 + (g&1)*32 + (m&3)*8 + hi*256
   const uint32_t v_lane_off = K_TILE_BYTES + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + hi * 256;
 
@@ -122,21 +152,36 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     const int kv0 = t * KVBLK;
-    if (t + 1 < ntiles) load_tile(kv0 + KVBLK);  // in flight under this tile's MFMAs
+    if (t + 1 < ntiles) load_tile(t + 1);  // in flight under this tile's MFMAs
     const char* sb = smem + cur * STAGE_BYTES;
 
-    // ---- Sᵀ = K Qᵀ : two 32-key sub-blocks ----------------------------------------------------
+    // ---- Sᵀ = K Qᵀ : two 32-key sub-blocks = 16 MFMAs; K fragments are read 4 deep ahead of their MFMA
+    // (hand-issued ds_read_b128 + counted lgkmcnt: hipcc otherwise waits lgkmcnt(0) before every single MFMA).
     f32x16_t s[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[j][i] = 0.0f;
+    {
+      const uint32_t kst = lds0 + cur * STAGE_BYTES;
+      bf16x8_t kf[4];
+#define OMNI_KREAD(i) \
+  kf[(i) & 3] = (((i) >> 3) ? lds_read16<32 * 256>(k_addr[(i) & 7] + kst) : lds_read16<0>(k_addr[(i) & 7] + kst))
+      OMNI_KREAD(0); OMNI_KREAD(1); OMNI_KREAD(2); OMNI_KREAD(3);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const uint32_t ch = (ks * 2 + hi) ^ k_swz;
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sb + j * 32 * 256 + k_row_off + (ch << 4));
-        s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
+      for (int i = 0; i < 16; ++i) {
+        if (i <= 12) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else if (i == 13) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if (i == 14) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        s[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 3], qf[i & 7], s[i >> 3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 4 < 16) OMNI_KREAD(i + 4);
       }
+      __builtin_amdgcn_s_setprio(0);
+#undef OMNI_KREAD
     }
     // ---- mask the ragged tail (last tile only; wave-uniform branch) ---------------------------
     if (kv0 + KVBLK > seq_len) {
@@ -155,10 +200,22 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-    const float mneg = -m_new * scale_log2e;
-    m_run = m_new;
+    // defer-max (cdna guide T13): while the row max grows by less than 2^DEFER (in the exponent's log2 units) keep
+    // the OLD reference max — P is then bounded by 2^DEFER instead of 1 (harmless in bf16/fp32) and the 64-register
+    // rescale of O is skipped.  The decision is taken AFTER the previous tile's P·V is complete and BEFORE this
+    // tile's P is exponentiated, so O, l and P always share one reference max.
+    constexpr float DEFER = 6.0f;
+    if (!__all((mx - m_run) * scale_log2e <= DEFER)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    }
+    const float mneg = -m_run * scale_log2e;
     float psum = 0.0f;
     bf16x8_t pf[2][2];
 #pragma unroll
@@ -171,24 +228,46 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
           psum += p;
           pf[j][ss][e] = (__bf16)p;
         }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    l_run += psum;
 
     // ---- Oᵀ += Vᵀ Pᵀ ----------------------------------------------------------------------------
-    const uint32_t vb = lds0 + cur * STAGE_BYTES + v_lane_off;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const uint32_t a0 = vb + d * 4096 + (j * 8 + ss * 4) * 256;
-          const bf16x8_t vf = tr_read_pair(a0, a0 + 512);
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[j][ss], o[d], 0, 0, 0);
-        }
+    // 16 MFMAs, i -> (j = i>>3, ss = (i>>2)&1, d = i&3); each needs one Vᵀ fragment = two transposed reads.
+    // Fragments are fetched THREE MFMAs ahead (hand-issued + counted lgkmcnt; hipcc keeps only one ahead and
+    // every MFMA then eats an LDS round trip).
+    {
+      const uint32_t vb = lds0 + cur * STAGE_BYTES + v_lane_off;
+      u32x2_t vlo[4], vhi[4];
+#define OMNI_VOFF(i) (((i) & 3) * 4096 + ((((i) >> 3) * 8 + (((i) >> 2) & 1) * 4) * 256))
+#define OMNI_VREAD(i)                                   \
+  do {                                                  \
+    vlo[(i) & 3] = lds_tr_read8<OMNI_VOFF(i)>(vb);      \
+    vhi[(i) & 3] = lds_tr_read8<OMNI_VOFF(i) + 512>(vb); \
+  } while (0)
+#define OMNI_PV(i)                                                                                             \
+  do {                                                                                                         \
+    if ((i) <= 13) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                          \
+    else if ((i) == 14) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                                     \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    {                                                                                                          \
+      typedef __attribute__((ext_vector_type(4))) uint32_t u4_;                                                \
+      const u4_ w_ = {vlo[(i) & 3][0], vlo[(i) & 3][1], vhi[(i) & 3][0], vhi[(i) & 3][1]};                     \
+      o[(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w_),                   \
+                                                         pf[(i) >> 3][((i) >> 2) & 1], o[(i) & 3], 0, 0, 0);   \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+      OMNI_VREAD(0); OMNI_VREAD(1); OMNI_VREAD(2);
+      __builtin_amdgcn_s_setprio(1);
+      OMNI_PV(0);  OMNI_VREAD(3);  OMNI_PV(1);  OMNI_VREAD(4);  OMNI_PV(2);  OMNI_VREAD(5);  OMNI_PV(3);  OMNI_VREAD(6);
+      OMNI_PV(4);  OMNI_VREAD(7);  OMNI_PV(5);  OMNI_VREAD(8);  OMNI_PV(6);  OMNI_VREAD(9);  OMNI_PV(7);  OMNI_VREAD(10);
+      OMNI_PV(8);  OMNI_VREAD(11); OMNI_PV(9);  OMNI_VREAD(12); OMNI_PV(10); OMNI_VREAD(13); OMNI_PV(11); OMNI_VREAD(14);
+      OMNI_PV(12); OMNI_VREAD(15); OMNI_PV(13); OMNI_PV(14); OMNI_PV(15);
+      __builtin_amdgcn_s_setprio(0);
+#undef OMNI_PV
+#undef OMNI_VREAD
+#undef OMNI_VOFF
+    }
 
     if (t + 1 < ntiles) store_tile(cur ^ 1);
     __syncthreads();
