@@ -64,3 +64,25 @@ for mode in (0, 2, 5):
     print(f"  mode {mode} {names[mode]:24s}: {t*1e3:8.3f} ms   ({fl/t/1e12:7.1f} TF/s-equivalent)")
 # same shape through the product entry point with the ring variant for comparison
 os.environ["OMNI_GEMM_VARIANT"] = "1"
+
+# ---- product (ring) kernel: real data vs cache-resident operands
+lib.omni_gemm_bf16.restype = C.c_int
+for label, (M, Nn, K, lda0) in {"ring real 8192^3": (8192, 8192, 8192, False), "ring cache-resident": (262144, 256, 8192, True)}.items():
+    a = torch.randn(256 if lda0 else M, K, device=dev).to(BF16)
+    w = (torch.randn(Nn, K, device=dev) * 0.02).to(BF16)
+    o = torch.empty(M, Nn, device=dev, dtype=BF16)
+    p = N.GemmParams()
+    p.ngroups, p.N, p.K, p.epilogue = 1, Nn, K, 0
+    g = p.g[0]
+    g.A, g.lda, g.M, g.W, g.out, g.ldo = a.data_ptr(), (0 if lda0 else K), M, w.data_ptr(), o.data_ptr(), Nn
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        assert lib.omni_gemm_bf16(C.byref(p), st) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        lib.omni_gemm_bf16(C.byref(p), st)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / 10 * 1e-3
+    print(f"--- {label}: {t*1e3:8.3f} ms  {2.0*M*Nn*K/t/1e12:7.1f} TF/s")
