@@ -1,0 +1,92 @@
+"""GPU: the reference's L0 plug-in classes (mirrored names/signatures) dispatch to the HIP kernels and agree with their
+own forward_native, plus the worker entry point on one rank."""
+import math
+
+import pytest
+import torch
+
+import qwen_image_oracle as O
+from _util import bf16_round, rel_l2
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+DEV = "cuda:0"
+
+
+def test_adalayernorm_customop_dispatches_to_hip():
+    from vllm_omni_amd.diffusion.layers.adalayernorm import AdaLayerNorm
+
+    op = AdaLayerNorm(512).to(DEV)
+    assert op._forward_method.__name__ == "forward_hip"          # CustomOp.dispatch_forward picks the ROCm path
+    g = torch.Generator().manual_seed(0)
+    x, mod = bf16_round(torch.randn(2, 77, 512, generator=g) * 2), bf16_round(torch.randn(2, 3 * 512, generator=g) * 0.3)
+    y, gate = op(x.to(DEV, BF16), mod.to(DEV, BF16))
+    ry, rgate = O.ada_layer_norm(x, mod)
+    assert y.shape == (2, 77, 512) and gate.shape == (2, 1, 512)
+    assert rel_l2(y, ry) <= 4e-3 and torch.equal(gate.float().cpu(), rgate)
+    # Layered-variant `index` path: per-token choice between two modulation sets
+    mod2 = bf16_round(torch.randn(4, 3 * 512, generator=g) * 0.3)
+    idx = (torch.arange(77) % 3 == 0).int()[None].repeat(2, 1)
+    y2, gate2 = op(x.to(DEV, BF16), mod2.to(DEV, BF16), idx.to(DEV))
+    ny, ngate = op.forward_native(x, mod2, idx)
+    assert rel_l2(y2, ny) <= 4e-3 and torch.equal(gate2.float().cpu(), ngate)
+
+
+def test_rotary_embedding_customop_matches_native():
+    from vllm_omni_amd.diffusion.layers.rope import RotaryEmbedding
+
+    op = RotaryEmbedding(is_neox_style=False)
+    g = torch.Generator().manual_seed(1)
+    x = bf16_round(torch.randn(2, 50, 4, 128, generator=g))
+    ang = torch.randn(50, 64, generator=g)
+    cos, sin = bf16_round(torch.cos(ang)), bf16_round(torch.sin(ang))
+    got = op(x.to(DEV, BF16), cos.to(DEV, BF16), sin.to(DEV, BF16))
+    assert rel_l2(got, op.forward_native(x, cos, sin)) <= 4e-3
+
+
+def test_attention_layer_joint_metadata_front():
+    """Attention(q,k,v, AttentionMetadata(joint_*, 'front')) == attention over [joint ; x] (reference layer.py + ulysses)."""
+    from vllm_omni_amd.diffusion.attention.backends.abstract import AttentionMetadata
+    from vllm_omni_amd.diffusion.attention.layer import Attention
+
+    attn = Attention(num_heads=2, head_size=128, causal=False, softmax_scale=1 / math.sqrt(128))
+    g = torch.Generator().manual_seed(2)
+    mk = lambda s: bf16_round(torch.randn(1, s, 2, 128, generator=g))  # noqa: E731
+    q, k, v, jq, jk, jv = mk(100), mk(100), mk(100), mk(9), mk(9), mk(9)
+    d = lambda t: t.to(DEV, BF16)  # noqa: E731
+    out = attn(d(q), d(k), d(v), AttentionMetadata(joint_query=d(jq), joint_key=d(jk), joint_value=d(jv), joint_strategy="front"))
+    ref = O.sdpa_nhd(torch.cat([jq, q], 1), torch.cat([jk, k], 1), torch.cat([jv, v], 1), 1 / math.sqrt(128))
+    assert out.shape == (1, 109, 2, 128) and rel_l2(out, ref) <= 4e-3
+
+
+def test_selector_rejects_unknown_backend(monkeypatch):
+    from vllm_omni_amd.diffusion.attention import selector
+
+    selector.get_attn_backend.cache_clear()
+    monkeypatch.setenv("DIFFUSION_ATTENTION_BACKEND", "FLASH_ATTN")   # a reference backend that is not built here
+    with pytest.raises(ValueError):
+        selector.get_attn_backend(128)
+    selector.get_attn_backend.cache_clear()
+    monkeypatch.setenv("DIFFUSION_ATTENTION_BACKEND", "cdna4_flash")
+    assert selector.get_attn_backend(128).get_name() == "CDNA4_FLASH"
+    selector.get_attn_backend.cache_clear()
+
+
+def test_worker_execute_model_single_rank_uses_all_requests():
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+    from vllm_omni_amd.diffusion.worker.gpu_worker import GPUWorker
+
+    m = QwenImageTransformer2DModel(num_layers=1, num_attention_heads=2, joint_attention_dim=128, device=DEV).init_random_()
+    pipe = QwenImagePipeline(device=DEV, transformer=m)
+    pipe.vae.init_random_()
+    w = GPUWorker(0, 0, OmniDiffusionConfig(), pipeline=pipe)
+    g = torch.Generator().manual_seed(0)
+    reqs = [OmniDiffusionRequest(height=128, width=128, num_inference_steps=2, seed=i,
+                                 prompt_embeds=torch.randn(1, 5 + i, 128, generator=g).to(BF16)) for i in range(3)]
+    out = w.execute_model(reqs)
+    assert out.error is None and out.output.shape == (3, 3, 128, 128)     # the reference would return 1 image (reqs[0])
+    bad = w.execute_model([OmniDiffusionRequest(height=128, width=128, num_inference_steps=2)])   # no prompt_embeds
+    assert bad.output is None and "NotImplementedError" in bad.error      # errors are reported, not raised (gpu_worker.py:266-274)

@@ -29,7 +29,7 @@ constexpr int NTHREADS = 512;
 constexpr int TILE_BYTES = BM * BK * 2;      // 32 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + W
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // 128 KiB
-constexpr int GROUP_M = 4;
+constexpr int GROUP_M_DEFAULT = 4;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -47,10 +47,11 @@ OMNI_DEVINL void glds16(const void* gsrc, uint32_t lds_byte_addr) {
 // waits: two k-steps of fragments (12 x ds_read_b128) are in flight while 8 MFMAs run.
 // Rules followed (cdna_hip_programming.md §5.7 form iii, rule 18): every asm load is "=v", the wait is its own
 // statement, and a sched_barrier(0) fences the consuming MFMAs below the wait.
-template <int OFF>
+template <int OFF, bool SKIP = false>
 OMNI_DEVINL bf16x8_t lds_read16(uint32_t addr) {
   bf16x8_t v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  if (SKIP) asm volatile("" : "=v"(v) : "v"(addr));
+  else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
   return v;
 }
 
@@ -118,23 +119,24 @@ OMNI_DEVINL void mma_stage(f32x16_t (&acc)[2][4], const uint32_t (&a_base)[NKS],
 #undef OMNI_READ_KS
 }
 
-template <int EPI>
-OMNI_DEVINL void gemm_epilogue(const omni_gemm_params& P, const omni_gemm_group& G, f32x16_t (&acc)[2][4], int m0,
-                               int n0, int wm, int wn, int l31, int hi) {
+// acc[nb][mb][4q+j] = C[m][n],  m = mrow0 + mb*32 + l31,  n = ncol0 + nb*32 + 8q + 4hi + j
+template <int EPI, int NB, int MB>
+OMNI_DEVINL void gemm_epilogue_t(const omni_gemm_params& P, const omni_gemm_group& G, f32x16_t (&acc)[NB][MB],
+                                 int mrow0, int ncol0, int l31, int hi) {
   const int M = G.M, N = P.N;
   // ---- epilogue: acc[nb][mb][4q+j] = C[m][n],  m = m0+wm*128+mb*32+l31,  n = n0+wn*64+nb*32+8q+4hi+j
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    const int m = m0 + wm * 128 + mb * 32 + l31;
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = mrow0 + mb * 32 + l31;
     if (m >= M) continue;
     const int64_t orow = G.out_row_map ? G.out_row_map[m] : m;
     int item = 0;
     if (EPI == OMNI_EPI_BIAS_GATE_RES) item = G.row_item_map ? G.row_item_map[m] : m / G.rows_per_item;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + nb * 32 + q * 8 + hi * 4;
+        const int n = ncol0 + nb * 32 + q * 8 + hi * 4;
         if (n >= N) continue;
         float v[4];
 #pragma unroll
@@ -172,9 +174,15 @@ OMNI_DEVINL void gemm_epilogue(const omni_gemm_params& P, const omni_gemm_group&
   }
 }
 
+template <int EPI>
+OMNI_DEVINL void gemm_epilogue(const omni_gemm_params& P, const omni_gemm_group& G, f32x16_t (&acc)[2][4], int m0,
+                               int n0, int wm, int wn, int l31, int hi) {
+  gemm_epilogue_t<EPI, 2, 4>(P, G, acc, m0 + wm * 128, n0 + wn * 64, l31, hi);
+}
+
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
-                                                                  int tiles_n) {
+                                                                  int tiles_n, int GROUP_M) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -270,9 +278,9 @@ constexpr int ROP_BYTES = BM * RBK * 2;        // 16 KiB per operand per stage
 constexpr int RSTAGE_BYTES = 2 * ROP_BYTES;    // 32 KiB
 constexpr int RLDS_BYTES = RSTAGES * RSTAGE_BYTES;  // 160 KiB
 
-template <int EPI>
+template <int EPI, int ABL = 0>   // ABL: dev-only ablation (1 no DMA in loop, 3 no fragment reads, 4 no vmcnt/barrier)
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_gemm_params P, int mtiles0,
-                                                                       int tiles_m, int tiles_n) {
+                                                                       int tiles_m, int tiles_n, int GROUP_M) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -358,12 +366,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
 #define OMNI_RING_READ(buf, slot_, ks)                                      \
   do {                                                                      \
     OMNI_RING_ADDR(slot_, ks)                                               \
-    wf[buf][0] = lds_read16<ROP_BYTES>(wa_);                                \
-    wf[buf][1] = lds_read16<ROP_BYTES + 32 * 64>(wa_);                      \
-    af[buf][0] = lds_read16<0>(aa_);                                        \
-    af[buf][1] = lds_read16<32 * 64>(aa_);                                  \
-    af[buf][2] = lds_read16<2 * 32 * 64>(aa_);                              \
-    af[buf][3] = lds_read16<3 * 32 * 64>(aa_);                              \
+    wf[buf][0] = lds_read16<ROP_BYTES, ABL == 3>(wa_);                                \
+    wf[buf][1] = lds_read16<ROP_BYTES + 32 * 64, ABL == 3>(wa_);                      \
+    af[buf][0] = lds_read16<0, ABL == 3>(aa_);                                        \
+    af[buf][1] = lds_read16<32 * 64, ABL == 3>(aa_);                                  \
+    af[buf][2] = lds_read16<2 * 32 * 64, ABL == 3>(aa_);                              \
+    af[buf][3] = lds_read16<3 * 32 * 64, ABL == 3>(aa_);                              \
   } while (0)
 // 8 MFMAs of one k-step (A-fragment-major order) with, interleaved in their issue shadows:
 //   * the reads of k-step g+2 into the SAME buffer: af[mb] is dead after its two MFMAs, wf[] after the last pair;
@@ -378,21 +386,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
     __builtin_amdgcn_s_setprio(1);                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     OMNI_RING_PAIR(buf, 0)                                                                                   \
-    if (PREFETCH) af[buf][0] = lds_read16<0>(aa_);                                                           \
+    if (PREFETCH) af[buf][0] = lds_read16<0, ABL == 3>(aa_);                                                           \
     DMA_A;                                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     OMNI_RING_PAIR(buf, 1)                                                                                   \
-    if (PREFETCH) af[buf][1] = lds_read16<32 * 64>(aa_);                                                     \
+    if (PREFETCH) af[buf][1] = lds_read16<32 * 64, ABL == 3>(aa_);                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     OMNI_RING_PAIR(buf, 2)                                                                                   \
-    if (PREFETCH) af[buf][2] = lds_read16<2 * 32 * 64>(aa_);                                                 \
+    if (PREFETCH) af[buf][2] = lds_read16<2 * 32 * 64, ABL == 3>(aa_);                                                 \
     DMA_B;                                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     OMNI_RING_PAIR(buf, 3)                                                                                   \
     if (PREFETCH) {                                                                                          \
-      af[buf][3] = lds_read16<3 * 32 * 64>(aa_);                                                             \
-      wf[buf][0] = lds_read16<ROP_BYTES>(wa_);                                                               \
-      wf[buf][1] = lds_read16<ROP_BYTES + 32 * 64>(wa_);                                                     \
+      af[buf][3] = lds_read16<3 * 32 * 64, ABL == 3>(aa_);                                                             \
+      wf[buf][0] = lds_read16<ROP_BYTES, ABL == 3>(wa_);                                                               \
+      wf[buf][1] = lds_read16<ROP_BYTES + 32 * 64, ABL == 3>(wa_);                                                     \
     }                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                                           \
@@ -419,17 +427,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
     const int dst = st + LEAD;
     // k-step 2*st   (prefetches stage st+1 / k-step 0: visible since B_st)
     asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-    OMNI_RING_MMA(0, true, nslot, 0, if (dma) issue_piece(pslot, dst, 0), if (dma) issue_piece(pslot, dst, 1));
+    OMNI_RING_MMA(0, true, nslot, 0, if (dma && ABL != 1) issue_piece(pslot, dst, 0), if (dma && ABL != 1) issue_piece(pslot, dst, 1));
     // k-step 2*st+1 (prefetches stage st+1 / k-step 1)
     asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-    OMNI_RING_MMA(1, true, nslot, 1, if (dma) issue_piece(pslot, dst, 2), if (dma) issue_piece(pslot, dst, 3));
+    OMNI_RING_MMA(1, true, nslot, 1, if (dma && ABL != 1) issue_piece(pslot, dst, 2), if (dma && ABL != 1) issue_piece(pslot, dst, 3));
     // ---- B_{st+1}: own pieces of stages <= st+2 landed; afterwards the slot of stage st is free
-    if (st + LEAD < nst) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ABL != 4) {
+      if (st + LEAD < nst && ABL != 1) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
     }
-    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     pslot = slot;
     slot = nslot;
@@ -447,6 +457,192 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
   gemm_epilogue<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// W4 variant: 4 waves x (128 x 128), ONE wave per SIMD owning the whole 512-entry register file (256 accumulator
+// registers + double-buffered fragments).  Same 5-stage BK=32 LDS ring and continuous pipeline as the ring kernel.
+// Why: the ablation (tools/bench_ablate_ring.py) shows DMA landings and fragment reads fighting for LDS bandwidth on
+// real data; a 128x128 wave tile needs 8 fragment reads per 16 MFMAs instead of 6 per 8 (-33 % LDS read bytes) and
+// the barrier only joins 4 waves.  All latency hiding is intra-wave: reads run two k-steps ahead, one DMA piece and
+// one or two reads ride in the issue shadow of every group of 4 MFMAs.
+// ------------------------------------------------------------------------------------------------
+constexpr int W4_THREADS = 256;
+
+template <int EPI>
+__global__ __launch_bounds__(W4_THREADS, 1) void gemm_bf16_w4_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
+                                                                      int tiles_n, int GROUP_M) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int band_sz = GROUP_M * tiles_n;
+  const int band = lid / band_sz, in_band = lid - band * band_sz;
+  const int first_m = band * GROUP_M;
+  const int gm = min(GROUP_M, tiles_m - first_m);
+  const int mt = first_m + in_band % gm;
+  const int nt = in_band / gm;
+  const int gi = (mt >= mtiles0) ? 1 : 0;
+  const omni_gemm_group& G = P.g[gi];
+  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
+  const int n0 = nt * BN;
+  const int M = G.M, N = P.N, K = P.K;
+
+  // DMA sources: a stage is 16 A pieces + 16 W pieces of (16 rows x 64 B); wave w moves pieces w*4 .. w*4+3 of each
+  const uint16_t* a_src[4];
+  const uint16_t* w_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave * 4 + j) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((r >> 2) & 3);
+    int ar = min(m0 + r, M - 1);
+    if (G.a_row_map) ar = G.a_row_map[ar];
+    a_src[j] = G.A + (int64_t)ar * G.lda + c * 8;
+    const int wr = min(n0 + r, N - 1);
+    w_src[j] = G.W + (int64_t)wr * K + c * 8;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  auto issue_piece = [&](int slot, int st, int piece) {   // piece 0..7 = A0, W0, A1, W1, ...
+    const uint32_t base = lds0 + slot * RSTAGE_BYTES + (wave * 4) * 1024;
+    const int koff = st * RBK, part = piece >> 1;
+    if (piece & 1) glds16(w_src[part] + koff, base + ROP_BYTES + part * 1024);
+    else glds16(a_src[part] + koff, base + part * 1024);
+  };
+  auto issue_stage = [&](int slot, int st) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) issue_piece(slot, st, p);
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  uint32_t a_base[2], w_base[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const uint32_t chunk = ((uint32_t)(ks * 2 + hi) ^ ((l31 >> 2) & 3)) << 4;
+    a_base[ks] = (wm * 128 + l31) * 64 + chunk;
+    w_base[ks] = ROP_BYTES + (wn * 128 + l31) * 64 + chunk;
+  }
+
+  f32x16_t acc[4][4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.0f;
+
+  const int nst = K / RBK;
+  constexpr int LEAD = RSTAGES - 1;
+#pragma unroll
+  for (int st = 0; st < LEAD; ++st)
+    if (st < nst) issue_stage(st, st);
+  bf16x8_t wf[2][4], af[2][4];
+  constexpr int BS = 32 * 64;   // bytes between 32-row blocks
+#define W4_ADDR(slot_, ks)                                  \
+  const uint32_t sa_ = lds0 + (slot_) * RSTAGE_BYTES;       \
+  const uint32_t aa_ = a_base[ks] + sa_, wa_ = w_base[ks] + sa_;
+#define W4_READ_ALL(buf, slot_, ks)                         \
+  do {                                                      \
+    W4_ADDR(slot_, ks)                                      \
+    wf[buf][0] = lds_read16<0>(wa_);                        \
+    wf[buf][1] = lds_read16<BS>(wa_);                       \
+    wf[buf][2] = lds_read16<2 * BS>(wa_);                   \
+    wf[buf][3] = lds_read16<3 * BS>(wa_);                   \
+    af[buf][0] = lds_read16<0>(aa_);                        \
+    af[buf][1] = lds_read16<BS>(aa_);                       \
+    af[buf][2] = lds_read16<2 * BS>(aa_);                   \
+    af[buf][3] = lds_read16<3 * BS>(aa_);                   \
+  } while (0)
+#define W4_GROUP(buf, mb)                                                                                     \
+  acc[0][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][0], af[buf][mb], acc[0][mb], 0, 0, 0);         \
+  acc[1][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][1], af[buf][mb], acc[1][mb], 0, 0, 0);         \
+  acc[2][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][2], af[buf][mb], acc[2][mb], 0, 0, 0);         \
+  acc[3][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][3], af[buf][mb], acc[3][mb], 0, 0, 0);         \
+  __builtin_amdgcn_sched_barrier(0);
+// 16 MFMAs of one k-step; in their issue shadows: the 8 reads of k-step g+2 (same buffer) and 4 DMA pieces
+#define W4_MMA(buf, PREFETCH, nslot_, ks, D0, D1, D2, D3)          \
+  do {                                                             \
+    W4_ADDR(nslot_, ks)                                            \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    W4_GROUP(buf, 0)                                               \
+    if (PREFETCH) af[buf][0] = lds_read16<0>(aa_);                 \
+    D0;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    W4_GROUP(buf, 1)                                               \
+    if (PREFETCH) af[buf][1] = lds_read16<BS>(aa_);                \
+    D1;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    W4_GROUP(buf, 2)                                               \
+    if (PREFETCH) af[buf][2] = lds_read16<2 * BS>(aa_);            \
+    D2;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    W4_GROUP(buf, 3)                                               \
+    if (PREFETCH) {                                                \
+      af[buf][3] = lds_read16<3 * BS>(aa_);                        \
+      wf[buf][0] = lds_read16<0>(wa_);                             \
+      wf[buf][1] = lds_read16<BS>(wa_);                            \
+      wf[buf][2] = lds_read16<2 * BS>(wa_);                        \
+      wf[buf][3] = lds_read16<3 * BS>(wa_);                        \
+    }                                                              \
+    D3;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+  // B_0: own pieces of stages 0,1 landed (stages 2,3 = 16 DMAs may stay in flight)
+  if (LEAD - 1 < nst) {
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (LEAD < nst) issue_stage(LEAD, LEAD);
+  W4_READ_ALL(0, 0, 0);
+  W4_READ_ALL(1, 0, 1);
+  int slot = 0, pslot = RSTAGES - 1;
+  for (int st = 0; st + 1 < nst; ++st) {
+    const int nslot = (slot + 1 == RSTAGES) ? 0 : slot + 1;
+    const bool dma = st > 0 && st + LEAD < nst;
+    const int dst = st + LEAD;
+#define W4_D(p) if (dma) issue_piece(pslot, dst, p)
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    W4_MMA(0, true, nslot, 0, W4_D(0), W4_D(1), W4_D(2), W4_D(3));
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    W4_MMA(1, true, nslot, 1, W4_D(4), W4_D(5), W4_D(6), W4_D(7));
+#undef W4_D
+    if (st + LEAD < nst) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    pslot = slot;
+    slot = nslot;
+  }
+  asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+  W4_MMA(0, false, 0, 0, (void)0, (void)0, (void)0, (void)0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  W4_MMA(1, false, 0, 1, (void)0, (void)0, (void)0, (void)0);
+#undef W4_MMA
+#undef W4_GROUP
+#undef W4_READ_ALL
+#undef W4_ADDR
+  gemm_epilogue_t<EPI, 4, 4>(P, G, acc, m0 + wm * 128, n0 + wn * 128, l31, hi);
+}
+
+
+int gemm_group_m() {
+  // dev knob: OMNI_GEMM_GROUP_M = row-tiles per L2 band
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OMNI_GEMM_GROUP_M");
+    v = e ? atoi(e) : GROUP_M_DEFAULT;
+    if (v < 1) v = 1;
+  }
+  return v;
+}
 
 int gemm_variant() {
   // dev knob: OMNI_GEMM_VARIANT=0 -> 2-stage BK=64 pipeline, 1 (default) -> 5-stage BK=32 ring
@@ -468,16 +664,21 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_w4_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
     attr_set = true;
   }
   if (gemm_variant() == 0 && p->K % BK == 0)
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(NTHREADS), LDS_BYTES, s, *p, mt0, tiles_m,
-                       tiles_n);
+                       tiles_n, gemm_group_m());
+  else if (gemm_variant() == 2)
+    hipLaunchKernelGGL(gemm_bf16_w4_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(W4_THREADS), RLDS_BYTES, s, *p, mt0,
+                       tiles_m, tiles_n, gemm_group_m());
   else
     hipLaunchKernelGGL(gemm_bf16_ring_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
-                       tiles_m, tiles_n);
+                       tiles_m, tiles_n, gemm_group_m());
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }
@@ -495,10 +696,30 @@ extern "C" int omni_dev_gemm_ablate(const omni_gemm_params* p, int mode, omni_st
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<OMNI_EPI_BIAS, A>),                         \
                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                                    \
     hipLaunchKernelGGL((gemm_bf16_kernel<OMNI_EPI_BIAS, A>), dim3(tiles_m * tiles_n), dim3(NTHREADS), LDS_BYTES, s, \
-                       *p, mt0, tiles_m, tiles_n);                                                                 \
+                       *p, mt0, tiles_m, tiles_n, GROUP_M_DEFAULT);                                                                 \
     break;
   switch (mode) {
     OMNI_ABL(0) OMNI_ABL(1) OMNI_ABL(2) OMNI_ABL(3) OMNI_ABL(4) OMNI_ABL(5)
+    default: return OMNI_ERR_BAD_ARG;
+  }
+#undef OMNI_ABL
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+extern "C" int omni_dev_gemm_ring_ablate(const omni_gemm_params* p, int mode, omni_stream stream) {
+  const int mt0 = (p->g[0].M + BM - 1) / BM;
+  const int tiles_m = mt0, tiles_n = (p->N + BN - 1) / BN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define OMNI_ABL(A)                                                                                                  \
+  case A:                                                                                                            \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<OMNI_EPI_BIAS, A>),                      \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES);                                     \
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<OMNI_EPI_BIAS, A>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, \
+                       s, *p, mt0, tiles_m, tiles_n, GROUP_M_DEFAULT);                                               \
+    break;
+  switch (mode) {
+    OMNI_ABL(0) OMNI_ABL(1) OMNI_ABL(3) OMNI_ABL(4)
     default: return OMNI_ERR_BAD_ARG;
   }
 #undef OMNI_ABL
