@@ -34,9 +34,12 @@ constexpr int GROUP_M_DEFAULT = 4;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+#ifndef OMNI_GLDS_AUX
+#define OMNI_GLDS_AUX 0   // cache-policy bits of the DMA loads: 1 = sc0, 2 = nt, 16 = sc1
+#endif
 OMNI_DEVINL void glds16(const void* gsrc, uint32_t lds_byte_addr) {
   // wave-uniform LDS base (goes to M0); the hardware adds lane*16.
-  __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)(uintptr_t)lds_byte_addr, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)(uintptr_t)lds_byte_addr, 16, 0, OMNI_GLDS_AUX);
 }
 
 // ---- hand-pipelined fragment reads -------------------------------------------------------------------------
@@ -273,7 +276,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const omni_gemm_
 // LDS image per operand per stage: row-major [256][32] bf16 (64-B rows), 16-B chunk index XOR (row>>2)&3.
 // One DMA wave-instruction = 16 rows x 64 B.
 // ------------------------------------------------------------------------------------------------
-constexpr int RBK = 32, RSTAGES = 5;
+#ifndef OMNI_RING_STAGES
+#define OMNI_RING_STAGES 5
+#endif
+#ifndef OMNI_RING_SETPRIO
+#define OMNI_RING_SETPRIO 1
+#endif
+#if OMNI_RING_STAGES == 5
+#define OMNI_RING_VMCNT "s_waitcnt vmcnt(8)"   // (LEAD - 2) stages x 4 DMA pieces per wave stay in flight across a barrier
+#elif OMNI_RING_STAGES == 4
+#define OMNI_RING_VMCNT "s_waitcnt vmcnt(4)"
+#else
+#error "OMNI_RING_STAGES must be 4 or 5"
+#endif
+constexpr int RBK = 32, RSTAGES = OMNI_RING_STAGES;
 constexpr int ROP_BYTES = BM * RBK * 2;        // 16 KiB per operand per stage
 constexpr int RSTAGE_BYTES = 2 * ROP_BYTES;    // 32 KiB
 constexpr int RLDS_BYTES = RSTAGES * RSTAGE_BYTES;  // 160 KiB
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
 #define OMNI_RING_MMA(buf, PREFETCH, nslot_, ks, DMA_A, DMA_B)                                               \
   do {                                                                                                       \
     OMNI_RING_ADDR(nslot_, ks)                                                                               \
-    __builtin_amdgcn_s_setprio(1);                                                                           \
+    if (OMNI_RING_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     OMNI_RING_PAIR(buf, 0)                                                                                   \
     if (PREFETCH) af[buf][0] = lds_read16<0, ABL == 3>(aa_);                                                           \
@@ -403,11 +419,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
       wf[buf][1] = lds_read16<ROP_BYTES + 32 * 64, ABL == 3>(wa_);                                                     \
     }                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
-    __builtin_amdgcn_s_setprio(0);                                                                           \
+    if (OMNI_RING_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
   // B_0
   if (LEAD - 1 < nst) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile(OMNI_RING_VMCNT ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -434,7 +450,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
     // ---- B_{st+1}: own pieces of stages <= st+2 landed; afterwards the slot of stage st is free
     if (ABL != 4) {
       if (st + LEAD < nst && ABL != 1) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile(OMNI_RING_VMCNT ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
