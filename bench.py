@@ -49,7 +49,11 @@ def cpu_baseline(layers_sample: int = 1) -> dict:
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import qwen_image_oracle as O
 
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))        # cores this process may actually use (cgroup / affinity aware)
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))                  # torch CPU GEMM stops scaling (and oversubscribes) beyond this
     torch.set_num_threads(cores)
     D, S_img = 3072, (HEIGHT // 16) * (WIDTH // 16)
     P = O.make_dit_params(layers_sample, seed=1234)
