@@ -68,15 +68,17 @@ def main():
         del a, w, o
 
     # ---------------- attention ----------------
-    B, H, S = 2, 24, 4096 + 64
-    q, k, v = rn(B * S, H * 128), rn(B * S, H * 128), rn(B * S, H * 128)
-    cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
-    t = timeit(lambda: ops.flash_attn_varlen(q, k, v, cu, H, S, 1 / math.sqrt(128)), iters=10)
-    fl = 4.0 * B * H * S * S * 128
-    q4, k4, v4 = (x.view(B, S, H, 128).permute(0, 2, 1, 3) for x in (q, k, v))
-    t_ref = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(q4, k4, v4), iters=10)
-    res["attention"] = dict(ms=t * 1e3, tflops=fl / t / 1e12, sdpa_ms=t_ref * 1e3, sdpa_tflops=fl / t_ref / 1e12)
-    print(f"attention B={B} H={H} S={S}: {t*1e3:8.3f} ms {fl/t/1e12:7.1f} TF/s | torch SDPA {t_ref*1e3:8.3f} ms {fl/t_ref/1e12:7.1f} TF/s", flush=True)
+    H, S = 24, 4096 + 64
+    for B in (2, 6):
+        q, k, v = rn(B * S, H * 128), rn(B * S, H * 128), rn(B * S, H * 128)
+        cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
+        t = timeit(lambda: ops.flash_attn_varlen(q, k, v, cu, H, S, 1 / math.sqrt(128)), iters=10)
+        fl = 4.0 * B * H * S * S * 128
+        q4, k4, v4 = (x.view(B, S, H, 128).permute(0, 2, 1, 3) for x in (q, k, v))
+        t_ref = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(q4, k4, v4), iters=5)
+        res[f"attention_B{B}"] = dict(ms=t * 1e3, tflops=fl / t / 1e12, sdpa_ms=t_ref * 1e3, sdpa_tflops=fl / t_ref / 1e12)
+        print(f"attention B={B} H={H} S={S}: {t*1e3:8.3f} ms {fl/t/1e12:7.1f} TF/s | torch SDPA {t_ref*1e3:8.3f} ms {fl/t_ref/1e12:7.1f} TF/s", flush=True)
+    B = 2
 
     # ---------------- HBM-bound ----------------
     x, mod = rn(Mi, D), rn(2, 6 * D)

@@ -17,13 +17,14 @@
 //
 // Layout contract: q/k/v/out are [total_rows, H*128] (the reference's [B,S,H,dh] flattened), item b owns rows
 // [cu_seqlens[b], cu_seqlens[b+1]).  Roofline: MFMA-bound, 4*S^2*128 flop per (item, head).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 constexpr int DH = 128;
 constexpr int NWAVES = 4;
-constexpr int QBLK = 32 * NWAVES;  // 128 queries / workgroup
 constexpr int KVBLK = 64;
 constexpr int K_TILE_BYTES = KVBLK * DH * 2;  // 16 KiB
 constexpr int STAGE_BYTES = 2 * K_TILE_BYTES; // K + V
@@ -55,7 +56,12 @@ OMNI_DEVINL bf16x8_t tr_read_pair(uint32_t lds_addr_a, uint32_t lds_addr_b) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-__global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
+// NQ = 32-query blocks per wave.  NQ = 1: 4 waves x 32 queries, 2 workgroups / CU (two waves per SIMD overlap each other).
+// NQ = 2: 4 waves x 64 queries, ONE wave per SIMD with ~400 registers: every K / V^T fragment read from LDS feeds TWO
+// MFMAs, and staging traffic + barriers per query halve (the NQ = 1 loop is LDS-traffic-bound: each wave re-reads all
+// of K and V for only 32 queries).
+template <int NQ>
+__global__ __launch_bounds__(NWAVES * 64, (NQ == 1 ? 2 : 1)) void flash_attn_fwd_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
     const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e) {
@@ -71,22 +77,24 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
   const int b = hb / H, h = hb - b * H;
   const int seq_start = cu_seqlens[b];
   const int seq_len = cu_seqlens[b + 1] - seq_start;
+  constexpr int QBLK = 32 * NWAVES * NQ;   // queries per workgroup
   if (qb * QBLK >= seq_len) return;
 
   const uint16_t* kbase = k + (int64_t)seq_start * ldk + h * DH;
   const uint16_t* vbase = v + (int64_t)seq_start * ldv + h * DH;
 
   // ---- Q fragments (B operand): lane holds q = l31, d = ks*16 + hi*8 .. +8 ---------------------
-  bf16x8_t qf[8];
-  {
-    const int qrow = min(qb * QBLK + wave * 32 + l31, seq_len - 1);
+  bf16x8_t qf[NQ][8];
+#pragma unroll
+  for (int bq = 0; bq < NQ; ++bq) {
+    const int qrow = min(qb * QBLK + (wave * NQ + bq) * 32 + l31, seq_len - 1);
     const uint16_t* qp = q + (int64_t)(seq_start + qrow) * ldq + h * DH + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
-    // make the fragments opaque: otherwise hipcc REMATERIALISES these global loads inside the KV loop (to save 32
+    for (int ks = 0; ks < 8; ++ks) qf[bq][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+    // make the fragments opaque: otherwise hipcc REMATERIALISES these global loads inside the KV loop (to save
     // VGPRs) and every QK^T MFMA then waits on an L2 round trip (seen as vmcnt(7..0) waits in the loop)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[bq][ks]));
   }
 
   // ---- staging: thread t moves 16-B chunks id = t + 256*i; key = id>>4, c = id&15 -----------------------
@@ -137,12 +145,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
   // V (tr read): g = lane>>4, m = lane&15:  base = (m>>2)*64 + (g&1)*32 + (m&3)*8 + hi*256
   const uint32_t v_lane_off = K_TILE_BYTES + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + hi * 256;
 
-  f32x16_t o[4];
+  f32x16_t o[NQ][4];
+  float m_run[NQ], l_run[NQ];
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int bq = 0; bq < NQ; ++bq) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[d][i] = 0.0f;
-  float m_run = -INFINITY, l_run = 0.0f;
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[bq][d][i] = 0.0f;
+    m_run[bq] = -INFINITY;
+    l_run[bq] = 0.0f;
+  }
 
   const int ntiles = (seq_len + KVBLK - 1) / KVBLK;
   load_tile(0);
@@ -157,11 +170,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
 
     // ---- Sᵀ = K Qᵀ : two 32-key sub-blocks = 16 MFMAs; K fragments are read 4 deep ahead of their MFMA
     // (hand-issued ds_read_b128 + counted lgkmcnt: hipcc otherwise waits lgkmcnt(0) before every single MFMA).
-    f32x16_t s[2];
+    f32x16_t s[NQ][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int bq = 0; bq < NQ; ++bq)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[j][i] = 0.0f;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[bq][j][i] = 0.0f;
     {
       const uint32_t kst = lds0 + cur * STAGE_BYTES;
       bf16x8_t kf[4];
@@ -176,7 +191,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
         else if (i == 14) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        s[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 3], qf[i & 7], s[i >> 3], 0, 0, 0);
+#pragma unroll
+        for (int bq = 0; bq < NQ; ++bq)
+          s[bq][i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 3], qf[bq][i & 7], s[bq][i >> 3], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (i + 4 < 16) OMNI_KREAD(i + 4);
       }
@@ -190,47 +207,52 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= seq_len) s[j][r] = -INFINITY;
+          if (key >= seq_len) {
+#pragma unroll
+            for (int bq = 0; bq < NQ; ++bq) s[bq][j][r] = -INFINITY;
+          }
         }
     }
-    // ---- online softmax (lane-local; one cross-half exchange for the max) ---------------------
-    float mx = s[0][0];
+    // ---- online softmax (lane-local; one cross-half exchange for the max), per 32-query block -----------
+    bf16x8_t pf[NQ][2][2];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+    for (int bq = 0; bq < NQ; ++bq) {
+      float mx = s[bq][0][0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // defer-max (cdna guide T13): while the row max grows by less than 2^DEFER (in the exponent's log2 units) keep
-    // the OLD reference max — P is then bounded by 2^DEFER instead of 1 (harmless in bf16/fp32) and the 64-register
-    // rescale of O is skipped.  The decision is taken AFTER the previous tile's P·V is complete and BEFORE this
-    // tile's P is exponentiated, so O, l and P always share one reference max.
-    constexpr float DEFER = 6.0f;
-    if (!__all((mx - m_run) * scale_log2e <= DEFER)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-      m_run = m_new;
-      l_run *= alpha;
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[bq][0][r]);
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[bq][1][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // defer-max (cdna guide T13): while the row max grows by less than 2^DEFER (in the exponent's log2 units) keep
+      // the OLD reference max — P is then bounded by 2^DEFER instead of 1 (harmless in bf16/fp32) and the 64-register
+      // rescale of O is skipped.  The decision is taken AFTER the previous tile's P·V is complete and BEFORE this
+      // tile's P is exponentiated, so O, l and P always share one reference max.
+      constexpr float DEFER = 6.0f;
+      if (!__all((mx - m_run[bq]) * scale_log2e <= DEFER)) {
+        const float m_new = fmaxf(m_run[bq], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[bq] - m_new) * scale_log2e);
+        m_run[bq] = m_new;
+        l_run[bq] *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[bq][d][i] *= alpha;
+      }
+      const float mneg = -m_run[bq] * scale_log2e;
+      float psum = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[bq][j][ss * 8 + e], scale_log2e, mneg));
+            psum += p;
+            pf[bq][j][ss][e] = (__bf16)p;
+          }
+      l_run[bq] += psum;
     }
-    const float mneg = -m_run * scale_log2e;
-    float psum = 0.0f;
-    bf16x8_t pf[2][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][ss * 8 + e], scale_log2e, mneg));
-          psum += p;
-          pf[j][ss][e] = (__bf16)p;
-        }
-    l_run += psum;
 
-    // ---- Oᵀ += Vᵀ Pᵀ ----------------------------------------------------------------------------
     // 16 MFMAs, i -> (j = i>>3, ss = (i>>2)&1, d = i&3); each needs one Vᵀ fragment = two transposed reads.
     // Fragments are fetched THREE MFMAs ahead (hand-issued + counted lgkmcnt; hipcc keeps only one ahead and
     // every MFMA then eats an LDS round trip).
@@ -252,8 +274,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
     {                                                                                                          \
       typedef __attribute__((ext_vector_type(4))) uint32_t u4_;                                                \
       const u4_ w_ = {vlo[(i) & 3][0], vlo[(i) & 3][1], vhi[(i) & 3][0], vhi[(i) & 3][1]};                     \
-      o[(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w_),                   \
-                                                         pf[(i) >> 3][((i) >> 2) & 1], o[(i) & 3], 0, 0, 0);   \
+      _Pragma("unroll") for (int bq = 0; bq < NQ; ++bq)                                                         \
+        o[bq][(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w_),             \
+                                                  pf[bq][(i) >> 3][((i) >> 2) & 1], o[bq][(i) & 3], 0, 0, 0);  \
     }                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
@@ -274,23 +297,60 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void flash_attn_fwd_kernel(
   }
 
   // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31, d = dblk*32 + 8*qd + 4*hi + {0..3} -------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int qrow = qb * QBLK + wave * 32 + l31;
-  if (qrow < seq_len) {
-    uint16_t* op = out + (int64_t)(seq_start + qrow) * ldo + h * DH + hi * 4;
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+  for (int bq = 0; bq < NQ; ++bq) {
+    const float l_tot = l_run[bq] + __shfl_xor(l_run[bq], 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qrow = qb * QBLK + (wave * NQ + bq) * 32 + l31;
+    if (qrow < seq_len) {
+      uint16_t* op = out + (int64_t)(seq_start + qrow) * ldo + h * DH + hi * 4;
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        u32x2_t w;
-        w[0] = pack_bf16x2(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv);
-        w[1] = pack_bf16x2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
-        *reinterpret_cast<u32x2_t*>(op + d * 32 + qd * 8) = w;
-      }
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          u32x2_t w;
+          w[0] = pack_bf16x2(o[bq][d][qd * 4 + 0] * inv, o[bq][d][qd * 4 + 1] * inv);
+          w[1] = pack_bf16x2(o[bq][d][qd * 4 + 2] * inv, o[bq][d][qd * 4 + 3] * inv);
+          *reinterpret_cast<u32x2_t*>(op + d * 32 + qd * 8) = w;
+        }
+    }
   }
 }
 
+}  // namespace
+
+namespace {
+int attn_variant() {
+  // dev knob: OMNI_ATTN_NQ = 1 (default; 32 queries / wave, 839-875 TF/s) or 2 (64 queries / wave).  NQ = 2 is correct
+  // but measures 346 TF/s as compiled by hipcc: with ~400 live registers it shuffles ~250 values between the AGPR
+  // and VGPR halves every tile and spills 19 — it needs hand-placed registers before it can pay off.
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OMNI_ATTN_NQ");
+    v = e ? atoi(e) : 1;
+    if (v != 1 && v != 2) v = 1;
+  }
+  return v;
+}
+template <int NQ>
+int launch_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
+                int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
+                float softmax_scale, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel<NQ>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return OMNI_ERR_LAUNCH;
+    attr_set = true;
+  }
+  constexpr int QBLK = 32 * NWAVES * NQ;
+  const int qblocks = (max_seqlen + QBLK - 1) / QBLK;
+  const int nh = B * H;
+  hipLaunchKernelGGL(flash_attn_fwd_kernel<NQ>, dim3(nh * qblocks), dim3(NWAVES * 64), LDS_BYTES, s, q, k, v, out, ldq,
+                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
 }  // namespace
 
 extern "C" int omni_flash_attn_fwd(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
@@ -302,18 +362,8 @@ extern "C" int omni_flash_attn_fwd(const omni_bf16* q, const omni_bf16* k, const
   if (!omni_aligned16(q) || !omni_aligned16(k) || !omni_aligned16(v) || (reinterpret_cast<uintptr_t>(out) & 7) ||
       (ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 4))
     return OMNI_ERR_ALIGN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return OMNI_ERR_LAUNCH;
-    attr_set = true;
-  }
-  const int qblocks = (max_seqlen + QBLK - 1) / QBLK;
-  const int nh = B * H;
-  hipLaunchKernelGGL(flash_attn_fwd_kernel, dim3(nh * qblocks), dim3(NWAVES * 64), LDS_BYTES,
-                     static_cast<hipStream_t>(stream), q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, nh, H,
-                     softmax_scale * 1.4426950408889634f);
-  OMNI_CHECK_LAUNCH();
-  return OMNI_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (attn_variant() == 1)
+    return launch_attn<1>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
+  return launch_attn<2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
 }
