@@ -14,21 +14,20 @@ from .abstract import AttentionBackend, AttentionImpl, AttentionMetadata
 class CDNA4FlashImpl(AttentionImpl):
     def __init__(self, num_heads: int, head_size: int, softmax_scale: float, causal: bool = False,
                  num_kv_heads: int | None = None, prefix: str = "", **extra_impl_args) -> None:
+        super().__init__(num_heads, head_size, softmax_scale, causal, num_kv_heads, prefix)
         if causal:
             raise NotImplementedError("the diffusion path is non-causal")
         if head_size != 128:
             raise NotImplementedError("CDNA4_FLASH is built for head_size 128")
-        if num_kv_heads not in (None, num_heads):
+        if self.num_kv_heads != num_heads:
             raise NotImplementedError("GQA is not on the Qwen-Image path")
-        self.num_heads, self.softmax_scale = num_heads, softmax_scale
         self._cu = {}
 
     def forward(self, query, key, value, attn_metadata: AttentionMetadata = None) -> torch.Tensor:
         if attn_metadata is not None and attn_metadata.attn_mask is not None:
             raise NotImplementedError("attention masks are not on the Qwen-Image path")
         B, S, H, dh = query.shape
-        Sk = key.shape[1]
-        if Sk != S:
+        if key.shape[1] != S:
             raise NotImplementedError("q and k/v sequence lengths must match (joint self-attention)")
         cu = self._cu.get((B, S, query.device))
         if cu is None:
@@ -41,15 +40,6 @@ class CDNA4FlashImpl(AttentionImpl):
 
 class CDNA4FlashBackend(AttentionBackend):
     accept_output_buffer = True
-
-    @staticmethod
-    def get_name() -> str:
-        return "CDNA4_FLASH"
-
-    @staticmethod
-    def get_impl_cls():
-        return CDNA4FlashImpl
-
-    @staticmethod
-    def get_supported_head_sizes() -> list[int]:
-        return [128]
+    NAME = "CDNA4_FLASH"
+    IMPL = CDNA4FlashImpl
+    HEAD_SIZES = (128,)

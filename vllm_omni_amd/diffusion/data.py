@@ -11,27 +11,36 @@ from typing import Any
 import torch
 
 
+_PARALLEL_AXES = ("pipeline_parallel_size", "data_parallel_size", "tensor_parallel_size", "ulysses_degree",
+                  "ring_degree", "cfg_parallel_size")
+
+
 @dataclass
 class DiffusionParallelConfig:
+    """Degrees of every parallel axis the reference's config knows (same field names as
+    vllm_omni/diffusion/data.py:26-91).  This build shards by REQUEST only: `data_parallel_size` is
+    the world size and every other axis must stay 1."""
     pipeline_parallel_size: int = 1
     data_parallel_size: int = 1
     tensor_parallel_size: int = 1
-    sequence_parallel_size: int | None = None
+    sequence_parallel_size: int | None = None      # = ulysses_degree * ring_degree
     ulysses_degree: int = 1
     ring_degree: int = 1
     cfg_parallel_size: int = 1
 
     def __post_init__(self) -> None:
+        sp = self.ulysses_degree * self.ring_degree
         if self.sequence_parallel_size is None:
-            self.sequence_parallel_size = self.ulysses_degree * self.ring_degree
-        for n in ("pipeline_parallel_size", "data_parallel_size", "tensor_parallel_size", "sequence_parallel_size",
-                  "ulysses_degree", "ring_degree", "cfg_parallel_size"):
-            assert getattr(self, n) > 0, f"{n} must be > 0"
-        assert self.sequence_parallel_size == self.ulysses_degree * self.ring_degree
-        # this build shards by REQUEST (data parallel): everything else must stay 1
-        for n in ("pipeline_parallel_size", "tensor_parallel_size", "sequence_parallel_size", "cfg_parallel_size"):
-            if getattr(self, n) != 1:
-                raise NotImplementedError(f"{n} > 1 is not built; the MI355X path is data-parallel over requests")
+            self.sequence_parallel_size = sp
+        bad = [ax for ax in _PARALLEL_AXES if int(getattr(self, ax)) <= 0]
+        if bad:
+            raise AssertionError(f"parallel degrees must be positive: {bad}")
+        if self.sequence_parallel_size != sp:
+            raise AssertionError(f"sequence_parallel_size {self.sequence_parallel_size} != ulysses {self.ulysses_degree}"
+                                 f" * ring {self.ring_degree}")
+        unsupported = [ax for ax in _PARALLEL_AXES if ax != "data_parallel_size" and getattr(self, ax) != 1]
+        if unsupported:
+            raise NotImplementedError(f"{unsupported} > 1 is not built; the MI355X path is data-parallel over requests")
         self.world_size = self.data_parallel_size
 
     @classmethod
