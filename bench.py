@@ -101,7 +101,7 @@ def measure_roofline(dev, R: int = 3) -> dict:
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 2.0 * (Mi + Mt) * N * K
     ach = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": f"gemm_bf16_ring_kernel<OMNI_EPI_BIAS_GELU_TANH> M={Mi}+{Mt} N=12288 K=3072",
+    return {"bound": "mfma", "kernel": f"gemm_bf16_ring_kernel<OMNI_EPI_BIAS_GELU_TANH, 0, true> M={Mi}+{Mt} N=12288 K=3072",
             "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
             "flop_per_launch": flops, "avg_launch_us": sec * 1e6, "traffic": None}
 

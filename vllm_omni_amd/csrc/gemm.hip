@@ -123,6 +123,19 @@ OMNI_DEVINL void mma_stage(f32x16_t (&acc)[2][4], const uint32_t (&a_base)[NKS],
 }
 
 // acc[nb][mb][4q+j] = C[m][n],  m = mrow0 + mb*32 + l31,  n = ncol0 + nb*32 + 8q + 4hi + j
+// Group selection with STATIC kernarg indexing.  `P.g[gi]` with a runtime gi makes the compiler copy the whole
+// by-value kernarg struct to scratch and re-load its fields from there (scratch_load in the epilogue loops); a
+// field-wise uniform select keeps everything in SGPRs.
+OMNI_DEVINL omni_gemm_group pick_group(const omni_gemm_params& P, int gi) {
+  omni_gemm_group G;
+#define OMNI_PICK(f) G.f = gi ? P.g[1].f : P.g[0].f
+  OMNI_PICK(A); OMNI_PICK(lda); OMNI_PICK(a_row_map); OMNI_PICK(M); OMNI_PICK(W); OMNI_PICK(bias); OMNI_PICK(out);
+  OMNI_PICK(out1); OMNI_PICK(out2); OMNI_PICK(ldo); OMNI_PICK(out_row_map); OMNI_PICK(res); OMNI_PICK(ldres);
+  OMNI_PICK(gate); OMNI_PICK(gate_item_stride); OMNI_PICK(row_item_map); OMNI_PICK(rows_per_item);
+#undef OMNI_PICK
+  return G;
+}
+
 template <int EPI, int NB, int MB>
 OMNI_DEVINL void gemm_epilogue_t(const omni_gemm_params& P, const omni_gemm_group& G, f32x16_t (&acc)[NB][MB],
                                  int mrow0, int ncol0, int l31, int hi) {
@@ -183,6 +196,148 @@ OMNI_DEVINL void gemm_epilogue(const omni_gemm_params& P, const omni_gemm_group&
   gemm_epilogue_t<EPI, 2, 4>(P, G, acc, m0 + wm * 128, n0 + wn * 64, l31, hi);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-coalesced epilogue for the 8-wave (2M x 4N) kernels.  The MFMA C layout gives a lane 4 consecutive columns of
+// 32 DIFFERENT rows, so a direct store instruction touches 32 cache lines with 16 B each; tools/bench_ksweep.py puts
+// that at ~10 us per 256x256 tile (8192 partial-line writes; another ~10 us for the residual reads of GATE_RES) —
+// 10-20 % of a K=3072 tile.  Here the tile is first written to LDS (free once the operand ring is drained) as bf16
+// [256][256] with a 16-B row pad (ds_write_b64, 2-way = optimal bank use), then every thread moves 16 B of one row:
+// a wave instruction covers 2 rows x 512 contiguous bytes (8 full lines) for the stores AND the residual/gate loads.
+// GATE_RES note: acc+bias is rounded to bf16 in LDS before res + gate*x — exactly the rounding point of the
+// reference's bf16 nn.Linear output (qwen_image_transformer.py: `hidden_states + gate * attn_output`).
+// ------------------------------------------------------------------------------------------------
+constexpr int EPI_LDS_STRIDE = BN * 2 + 16;              // 528 B per C row in LDS
+constexpr int EPI_LDS_BYTES = BM * EPI_LDS_STRIDE;       // 132 KiB
+
+template <int EPI>
+OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_group& G, f32x16_t (&acc)[2][4], int m0,
+                                   int n0, int wm, int wn, int l31, int hi, char* smem, int tid) {
+  const int M = G.M, N = P.N;
+  // Phase 2 moves rows in batches of 4 per thread: batch b = tile rows (4b+j)*16 + rsub.  Its pipeline is
+  //   row-map loads (b+2)  |  residual/gate/LDS loads (b+1)  |  math + stores (b)
+  // in a ROLLED loop: fully unrolled, hipcc hoists all 16 rows' 64-bit addresses and predicates above phase 1, where
+  // they are live together with the 128 accumulator registers and spill.
+  constexpr int BATCH = 4, NBATCH = BM / 16 / BATCH;
+  struct RowIdx { int ro[BATCH], im[BATCH]; };
+  struct RowData { u32x4_t c[BATCH], g[BATCH], r[BATCH]; int ro[BATCH]; };
+  const int rsub = tid >> 5;
+  const float inv_rpi = 1.0f / (float)max(G.rows_per_item, 1);
+  auto load_maps = [&](int b, RowIdx& x) {
+    int mc[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      mc[j] = min(m0 + (b * BATCH + j) * 16 + rsub, M - 1);     // rows past M: clamped here, masked at the store
+      x.ro[j] = mc[j];
+    }
+    if (G.out_row_map) {                 // uniform branches around whole groups of loads, none between the loads
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) x.ro[j] = G.out_row_map[mc[j]];
+    }
+    if (EPI == OMNI_EPI_BIAS_GATE_RES) {
+      if (G.row_item_map) {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) x.im[j] = G.row_item_map[mc[j]];
+      } else {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {        // exact m / rows_per_item from a float estimate + one fix-up (the
+          int q = (int)((float)mc[j] * inv_rpi);   // generic integer division needs ~10 temporaries per row)
+          const int rem = mc[j] - q * G.rows_per_item;
+          q += (rem >= G.rows_per_item) - (rem < 0);
+          x.im[j] = q;
+        }
+      }
+    }
+  };
+  RowIdx x0, x1;
+  load_maps(0, x0);                      // in flight under phase 1
+  load_maps(1, x1);
+
+  __builtin_amdgcn_s_barrier();          // every wave has finished reading the operand ring
+  {
+    const int ncol = wn * 64 + hi * 4;   // tile-local column of this lane's first value
+    u32x2_t bvp[2][4];                   // bias stays PACKED (8 VGPRs, not 32 floats) next to the 128 accumulators
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + ncol + nb * 32 + q * 8;
+        u32x2_t b = {0u, 0u};
+        if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
+        bvp[nb][q] = b;
+      }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      char* rowp = smem + (wm * 128 + mb * 32 + l31) * EPI_LDS_STRIDE + ncol * 2;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u32x2_t b = bvp[nb][q];
+          asm volatile("" : "+v"(b));    // unpack here, every time: hoisted, the 32 floats would be live across mb
+          const float bf[4] = {bf16_lo(b[0]), bf16_hi(b[0]), bf16_lo(b[1]), bf16_hi(b[1])};
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = acc[nb][mb][q * 4 + j] + bf[j];
+            if (EPI == OMNI_EPI_BIAS_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
+          }
+          u32x2_t o;
+          o[0] = pack_bf16x2(v[0], v[1]);
+          o[1] = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<u32x2_t*>(rowp + (nb * 32 + q * 8) * 2) = o;
+        }
+    }
+  }
+  __syncthreads();
+  const int chunk = tid & 31;
+  const int n = n0 + chunk * 8;
+  if (n >= N) return;
+  uint16_t* obase = G.out;
+  int ncol_out = n;
+  if (EPI == OMNI_EPI_BIAS_SPLIT3) {
+    const int which = n / P.split_n;
+    const uintptr_t o0 = (uintptr_t)G.out, o1 = (uintptr_t)G.out1, o2 = (uintptr_t)G.out2;   // integer selects: a
+    uintptr_t ob = which == 1 ? o1 : o0;                    // pointer select chain is turned into an indexed
+    ob = which == 2 ? o2 : ob;                              // load from a scratch copy of G
+    obase = reinterpret_cast<uint16_t*>(ob);
+    ncol_out = n - which * P.split_n;
+  }
+  const char* lds_row = smem + rsub * EPI_LDS_STRIDE + chunk * 16;
+  auto load_data = [&](int b, const RowIdx& x, RowData& d) {
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      d.ro[j] = x.ro[j];
+      if (EPI == OMNI_EPI_BIAS_GATE_RES) {
+        d.g[j] = *reinterpret_cast<const u32x4_t*>(G.gate + (int64_t)x.im[j] * G.gate_item_stride + n);
+        d.r[j] = *reinterpret_cast<const u32x4_t*>(G.res + (int64_t)x.ro[j] * G.ldres + n);
+      }
+      d.c[j] = *reinterpret_cast<const u32x4_t*>(lds_row + (b * BATCH + j) * 16 * EPI_LDS_STRIDE);
+    }
+  };
+  RowData d0, d1;
+  load_data(0, x0, d0);
+#pragma unroll 1
+  for (int b = 0; b < NBATCH; ++b) {
+    if (b + 1 < NBATCH) load_data(b + 1, x1, d1);
+    if (b + 2 < NBATCH) load_maps(b + 2, x1);
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      u32x4_t o = d0.c[j];
+      if (EPI == OMNI_EPI_BIAS_GATE_RES) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack_bf16x2(bf16_lo(d0.r[j][e]) + bf16_lo(d0.g[j][e]) * bf16_lo(d0.c[j][e]),
+                             bf16_hi(d0.r[j][e]) + bf16_hi(d0.g[j][e]) * bf16_hi(d0.c[j][e]));
+      }
+      uint16_t* dst = obase + (int64_t)d0.ro[j] * G.ldo + ncol_out;
+      // The store is issued from inline asm: `res` may alias `out` (in-place residual), and for a compiler-visible
+      // store hipcc drains vmcnt(0) before the next loads although a thread never re-reads a row it has written.
+      if (m0 + (b * BATCH + j) * 16 + rsub < M) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(o));
+    }
+    d0 = d1;
+  }
+}
+
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
                                                                   int tiles_n, int GROUP_M) {
@@ -202,7 +357,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const omni_gemm_
   const int mt = first_m + in_band % gm;
   const int nt = in_band / gm;
   const int gi = (mt >= mtiles0) ? 1 : 0;
-  const omni_gemm_group& G = P.g[gi];
+  const omni_gemm_group G = pick_group(P, gi);
   const int m0 = (gi ? mt - mtiles0 : mt) * BM;
   const int n0 = nt * BN;
   const int M = G.M, N = P.N, K = P.K;
@@ -294,7 +449,9 @@ constexpr int ROP_BYTES = BM * RBK * 2;        // 16 KiB per operand per stage
 constexpr int RSTAGE_BYTES = 2 * ROP_BYTES;    // 32 KiB
 constexpr int RLDS_BYTES = RSTAGES * RSTAGE_BYTES;  // 160 KiB
 
-template <int EPI, int ABL = 0>   // ABL: dev-only ablation (1 no DMA in loop, 3 no fragment reads, 4 no vmcnt/barrier)
+// ABL: dev-only ablation (1 no DMA in loop, 3 no fragment reads, 4 no vmcnt/barrier).  COALESCED selects the epilogue at
+// compile time: with both in one kernel their hoisted set-up code overlaps the live accumulators and spills.
+template <int EPI, int ABL = 0, bool COALESCED = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_gemm_params P, int mtiles0,
                                                                        int tiles_m, int tiles_n, int GROUP_M) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -311,7 +468,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
   const int mt = first_m + in_band % gm;
   const int nt = in_band / gm;
   const int gi = (mt >= mtiles0) ? 1 : 0;
-  const omni_gemm_group& G = P.g[gi];
+  const omni_gemm_group G = pick_group(P, gi);
   const int m0 = (gi ? mt - mtiles0 : mt) * BM;
   const int n0 = nt * BN;
   const int M = G.M, N = P.N, K = P.K;
@@ -470,7 +627,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
 #undef OMNI_RING_MMA
 #undef OMNI_RING_PAIR
 
-  gemm_epilogue<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi);
+  if (COALESCED) gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi, smem, tid);
+  else gemm_epilogue<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi);
 }
 
 
@@ -501,7 +659,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_bf16_w4_kernel(const omni_
   const int mt = first_m + in_band % gm;
   const int nt = in_band / gm;
   const int gi = (mt >= mtiles0) ? 1 : 0;
-  const omni_gemm_group& G = P.g[gi];
+  const omni_gemm_group G = pick_group(P, gi);
   const int m0 = (gi ? mt - mtiles0 : mt) * BM;
   const int n0 = nt * BN;
   const int M = G.M, N = P.N, K = P.K;
@@ -670,6 +828,28 @@ int gemm_variant() {
   return v;
 }
 
+// The row-coalesced epilogue moves 16 B per thread: every output / residual / gate pointer and stride must allow it.
+// (OMNI_GEMM_EPI_LDS=0 forces the direct epilogue: dev knob.)
+bool epilogue_rows_coalescable(const omni_gemm_params* p) {
+  static int knob = -1;
+  if (knob < 0) {
+    const char* e = getenv("OMNI_GEMM_EPI_LDS");
+    knob = e ? atoi(e) : 1;
+  }
+  if (!knob) return false;
+  static_assert(EPI_LDS_BYTES <= RLDS_BYTES, "C tile must fit the operand ring's LDS");
+  for (int g = 0; g < p->ngroups; ++g) {
+    const omni_gemm_group& G = p->g[g];
+    if (!omni_aligned16(G.out) || (G.ldo % 8) != 0) return false;
+    if (G.bias && !omni_aligned16(G.bias)) return false;
+    if (p->epilogue == OMNI_EPI_BIAS_GATE_RES &&
+        (!omni_aligned16(G.res) || !omni_aligned16(G.gate) || (G.ldres % 8) != 0 || (G.gate_item_stride % 8) != 0))
+      return false;
+    if (p->epilogue == OMNI_EPI_BIAS_SPLIT3 && (!omni_aligned16(G.out1) || !omni_aligned16(G.out2))) return false;
+  }
+  return true;
+}
+
 template <int EPI>
 int launch(const omni_gemm_params* p, hipStream_t s) {
   const int mt0 = (p->g[0].M + BM - 1) / BM;
@@ -680,6 +860,8 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI, 0, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_w4_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
@@ -692,6 +874,9 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
   else if (gemm_variant() == 2)
     hipLaunchKernelGGL(gemm_bf16_w4_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(W4_THREADS), RLDS_BYTES, s, *p, mt0,
                        tiles_m, tiles_n, gemm_group_m());
+  else if (epilogue_rows_coalescable(p))
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI, 0, true>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p,
+                       mt0, tiles_m, tiles_n, gemm_group_m());
   else
     hipLaunchKernelGGL(gemm_bf16_ring_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
                        tiles_m, tiles_n, gemm_group_m());
