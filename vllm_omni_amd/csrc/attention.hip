@@ -19,6 +19,8 @@
 // [cu_seqlens[b], cu_seqlens[b+1]).  Roofline: MFMA-bound, 4*S^2*128 flop per (item, head).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -317,6 +319,381 @@ __global__ __launch_bounds__(NWAVES * 64, (NQ == 1 ? 2 : 1)) void flash_attn_fwd
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined variant (default).  Same tiling and LDS images as flash_attn_fwd_kernel<1>, but
+//   * K/V tiles are staged by LDS-DMA (global_load_lds_dwordx4; the XOR swizzle / the V block layout are applied to the
+//     per-lane SOURCE address) instead of global -> 32 staging VGPRs -> ds_write: the registers pay for a second S tile;
+//   * the loop is skewed by one tile: iteration t runs  QK^T(t+1) || exp-half of softmax(t)  and then
+//     P.V(t) || max-half of softmax(t+1).  An MFMA occupies the matrix pipe for 32 cycles but its wave only for the
+//     issue, so the VALU work of the *same wave* placed between two MFMAs runs under them; in the unskewed loop a wave's
+//     softmax can only be hidden by the OTHER wave of the SIMD happening to be in an MFMA phase (measured: matrix pipe
+//     busy ~40 %, with VALU ~= MFMA cycles per tile).
+// Tile j lives in LDS stage j&1.  K(t+2) is fetched into stage t&1 at the top of iteration t (K(t) was consumed one
+// iteration earlier), V(t+1) into stage (t+1)&1 (V(t-1) was consumed at the end of iteration t-1); both land before the
+// single barrier that ends the iteration.
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA in the SADDR form (uniform 64-bit tile base in SGPRs + one 32-bit per-lane byte offset): the builtin keeps a
+// zero-extended 64-bit VGPR pair per source (16 registers for the 8 sources, and 64-bit VALU adds per tile).  Issued from
+// inline asm, so the loads are invisible to hipcc's waitcnt pass: the loop retires them with its own vmcnt(0).  M0 (the
+// wave-uniform LDS byte address; the hardware adds lane*16) is written here and used by nothing else in the kernel.
+OMNI_DEVINL void attn_glds16(const char* tile_base, uint32_t lane_byte_off, uint32_t lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(lds_byte_addr), "v"(lane_byte_off), "s"(tile_base) : "memory");
+}
+// max over the two half-waves WITHOUT touching LDS (a ds_bpermute would break the counted lgkmcnt waits of the
+// fragment pipeline): v_permlane32_swap exchanges a[32..63] with b[0..31].  Inline asm with two distinct registers —
+// the builtin called with the same value for both operands is folded to one register by hipcc.
+OMNI_DEVINL float xhalf_max(float x) {
+  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+OMNI_DEVINL float xhalf_sum(float x) {
+  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+
+#ifndef OMNI_ATTN_DMA_BURST
+#define OMNI_ATTN_DMA_BURST 1   // 1: a tile's DMA pieces in one burst at the top of the iteration (measured 881 / 913 TF/s
+                                // at 4 / 8 waves); 0: one piece per P.V MFMA slot (840 / 865: the issue stalls land on the
+                                // MFMA-bound phase)
+#endif
+#ifndef OMNI_ATTN_SETPRIO
+#define OMNI_ATTN_SETPRIO 1
+#endif
+#ifndef OMNI_ATTN_PKFMA
+#define OMNI_ATTN_PKFMA 0   // 1: v_pk_fma_f32 from inline asm for the exponent argument (measured -3 %: pair set-up moves)
+#endif
+#ifndef OMNI_ATTN_ABL
+#define OMNI_ATTN_ABL 0   // dev-only timing ablations (wrong results): 1 no DMA wait, 2 no barrier, 4 no DMA, 8 no exp, 16 no LDS reads
+#endif
+// NW = waves per workgroup sharing one K/V tile stream: 4 (128 queries, 2 workgroups per CU) or 8 (256 queries, one
+// workgroup per CU: half the LDS-DMA write traffic per query; the LDS write port is shared with the fragment reads).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pipe_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+    const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const int hb = blockIdx.x % n_heads_total;
+  const int qb = blockIdx.x / n_heads_total;
+  const int b = hb / H, h = hb - b * H;
+  const int seq_start = cu_seqlens[b];
+  const int seq_len = cu_seqlens[b + 1] - seq_start;
+  constexpr int QBLK = 32 * NW;
+  constexpr int NPIECE = 16 / NW;   // DMA pieces (1 KiB) per wave per operand per tile
+  if (qb * QBLK >= seq_len) return;
+
+  const char* kbase = reinterpret_cast<const char*>(k + (int64_t)seq_start * ldk + h * DH);
+  const char* vbase = reinterpret_cast<const char*>(v + (int64_t)seq_start * ldv + h * DH);
+
+  bf16x8_t qf[8];
+  {
+    const int qrow = min(qb * QBLK + wave * 32 + l31, seq_len - 1);
+    const uint16_t* qp = q + (int64_t)(seq_start + qrow) * ldq + h * DH + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));   // see flash_attn_fwd_kernel: no rematerialisation
+  }
+
+  // ---- DMA sources.  One wave-instruction = 1 KiB of the LDS image, lane L -> byte 16*L of the piece.
+  //  K piece p = wave + 4i (keys 4p .. 4p+3):   key = 4p + (L>>4), LDS chunk L&15 holds logical chunk (L&15)^(key&15)
+  //  V piece (dblk = i, key group = wave):       key = 16*wave + 4*(L>>4) + ((L>>2)&3), logical chunk 4i + (L&3)
+  //    (the four dblk pieces of one key group are issued back to back: together they cover whole 256-B V rows)
+  // Only the 8 per-lane byte offsets stay live across the loop; the ragged-tail variant recomputes key / column.
+  // piece P = wave + NW*i of each operand image (16 pieces of 1 KiB); V piece P = (dblk = P>>2, key group = P&3)
+  auto k_key_of = [&](int i) { return 4 * (wave + NW * i) + (lane >> 4); };
+  auto k_col_of = [&](int i) { return (uint32_t)(((lane & 15) ^ (k_key_of(i) & 15)) * 16); };
+  auto v_key_of = [&](int i) { return 16 * ((wave + NW * i) & 3) + 4 * (lane >> 4) + ((lane >> 2) & 3); };
+  auto v_col_of = [&](int i) { return (uint32_t)((4 * ((wave + NW * i) >> 2) + (lane & 3)) * 16); };
+  uint32_t k_src[NPIECE], v_src[NPIECE];
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) {
+    k_src[i] = (uint32_t)(k_key_of(i) * ldk * 2) + k_col_of(i);
+    v_src[i] = (uint32_t)(v_key_of(i) * ldv * 2) + v_col_of(i);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int ntiles = (seq_len + KVBLK - 1) / KVBLK;
+  const int last_valid = seq_len - (ntiles - 1) * KVBLK;          // keys in the last tile (1..64)
+  // one DMA piece (a global_load_lds costs its wave 60-185 issue cycles: they are spread over the P.V MFMAs, not burst)
+  auto issue_K_piece = [&](int t, int stage, int i) {
+    const char* tb = kbase + (int64_t)t * KVBLK * ldk * 2;          // uniform
+    const uint32_t dst = lds0 + stage * STAGE_BYTES + (wave + NW * i) * 1024;
+    if (t == ntiles - 1 && last_valid < KVBLK)                      // ragged tail: re-read the last valid row
+      attn_glds16(tb, (uint32_t)(min(k_key_of(i), last_valid - 1) * ldk * 2) + k_col_of(i), dst);
+    else
+      attn_glds16(tb, k_src[i], dst);
+  };
+  auto issue_V_piece = [&](int t, int stage, int i) {
+    const char* tb = vbase + (int64_t)t * KVBLK * ldv * 2;
+    const uint32_t dst = lds0 + stage * STAGE_BYTES + K_TILE_BYTES + (wave + NW * i) * 1024;
+    if (t == ntiles - 1 && last_valid < KVBLK)
+      attn_glds16(tb, (uint32_t)(min(v_key_of(i), last_valid - 1) * ldv * 2) + v_col_of(i), dst);
+    else
+      attn_glds16(tb, v_src[i], dst);
+  };
+  auto issue_K = [&](int t, int stage) {
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) issue_K_piece(t, stage, i);
+  };
+  auto issue_V = [&](int t, int stage) {
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) issue_V_piece(t, stage, i);
+  };
+
+  uint32_t k_addr[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_addr[ks] = l31 * 256 + ((((uint32_t)(ks * 2 + hi)) ^ (l31 & 15)) << 4);
+  const uint32_t v_lane_off = K_TILE_BYTES + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + hi * 256;
+
+  f32x16_t o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+
+  bf16x8_t kf[4];
+#define OMNI_KREAD(i, kst)                                                                                          \
+  do {                                                                                                              \
+    if (OMNI_ATTN_ABL & 16) asm volatile("" : "=v"(kf[(i) & 3]) : "v"(k_addr[(i) & 7] + (kst)));                     \
+    else kf[(i) & 3] = (((i) >> 3) ? lds_read16<32 * 256>(k_addr[(i) & 7] + (kst)) : lds_read16<0>(k_addr[(i) & 7] + (kst))); \
+  } while (0)
+#define OMNI_QK_STEP(i, SN, kst, CHUNK)                                                          \
+  do {                                                                                           \
+    if ((i) <= 12) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                            \
+    else if ((i) == 13) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                       \
+    else if ((i) == 14) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");                       \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    SN[(i) >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[(i) & 3], qf[(i) & 7], SN[(i) >> 3], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    if ((i) + 4 < 16) OMNI_KREAD((i) + 4, kst);                                                  \
+    CHUNK;                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
+#define OMNI_QK_ALL(SN, kst, CH)                                                                                     \
+  do {                                                                                                               \
+    OMNI_KREAD(0, kst); OMNI_KREAD(1, kst); OMNI_KREAD(2, kst); OMNI_KREAD(3, kst);                                  \
+    OMNI_QK_STEP(0, SN, kst, CH(0));   OMNI_QK_STEP(1, SN, kst, CH(1));   OMNI_QK_STEP(2, SN, kst, CH(2));           \
+    OMNI_QK_STEP(3, SN, kst, CH(3));   OMNI_QK_STEP(4, SN, kst, CH(4));   OMNI_QK_STEP(5, SN, kst, CH(5));           \
+    OMNI_QK_STEP(6, SN, kst, CH(6));   OMNI_QK_STEP(7, SN, kst, CH(7));   OMNI_QK_STEP(8, SN, kst, CH(8));           \
+    OMNI_QK_STEP(9, SN, kst, CH(9));   OMNI_QK_STEP(10, SN, kst, CH(10)); OMNI_QK_STEP(11, SN, kst, CH(11));         \
+    OMNI_QK_STEP(12, SN, kst, CH(12)); OMNI_QK_STEP(13, SN, kst, CH(13)); OMNI_QK_STEP(14, SN, kst, CH(14));         \
+    OMNI_QK_STEP(15, SN, kst, CH(15));                                                                               \
+  } while (0)
+#define OMNI_NOCHUNK(i) (void)0
+
+  auto mask_tail = [&](f32x16_t (&S)[2], int kv0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (key >= seq_len) S[j][r] = -INFINITY;
+      }
+  };
+  auto zero_s = [&](f32x16_t (&S)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) S[j][i] = 0.0f;
+  };
+
+  // ---- prologue: tiles 0 (K, V) and 1 (K) in flight, S(0) and its row max -------------------------------------
+  issue_K(0, 0);
+  issue_V(0, 0);
+  if (ntiles > 1) issue_K(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16_t sA[2], sB[2];
+  float mxA, mxB = 0.0f;
+  zero_s(sA);
+  OMNI_QK_ALL(sA, lds0, OMNI_NOCHUNK);
+  if (KVBLK > seq_len) mask_tail(sA, 0);
+  {
+    float mx = sA[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sA[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sA[1][r]);
+    mxA = xhalf_max(mx);
+  }
+
+  // One iteration; SC = S(t) (complete, row max mxc known), SN receives S(t+1).
+  // has_next is a compile-time constant: a run-time flag puts a branch between every two MFMAs of the P.V phase.
+  auto iteration = [&](auto has_next_c, int t, f32x16_t (&SC)[2], f32x16_t (&SN)[2], float mxc, float& mxn) {
+    constexpr bool has_next = decltype(has_next_c)::value;
+    const bool dma_k = !(OMNI_ATTN_ABL & 4) && t + 2 < ntiles, dma_v = !(OMNI_ATTN_ABL & 4) && has_next;
+    if (OMNI_ATTN_DMA_BURST) {
+      if (dma_k) issue_K(t + 2, t & 1);
+      if (dma_v) issue_V(t + 1, (t + 1) & 1);
+    }
+
+    // defer-max decision (see flash_attn_fwd_kernel); the rescale is rare after the first tiles
+    constexpr float DEFER = 6.0f;
+    if (!__all((mxc - m_run) * scale_log2e <= DEFER)) {
+      const float m_new = fmaxf(m_run, mxc);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    }
+    const float mneg = -m_run * scale_log2e;
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t scale2 = {scale_log2e, scale_log2e}, mneg2 = {mneg, mneg};
+    f32x2_t psum2 = {0.0f, 0.0f};
+    uint32_t pfu[2][2][4];
+    // exp chunk i: S elements (flat index over j, r) 2i and 2i+1 -> one packed bf16 pair of P
+#define OMNI_EXP_CHUNK(i)                                                                                        \
+  do {                                                                                                           \
+    if (OMNI_ATTN_ABL & 8) { pfu[(i) >> 3][((i) >> 2) & 1][(i) & 3] = 0x3c003c00u; break; }                        \
+    /* packed fp32 (v_pk_fma_f32 / v_pk_add_f32): S elements 2i, 2i+1 are an aligned register pair */          \
+    const f32x2_t x_ = {SC[(i) >> 3][(2 * (i)) & 15], SC[(i) >> 3][((2 * (i)) & 15) + 1]};                         \
+    f32x2_t y_;                                                                                                  \
+    if (OMNI_ATTN_PKFMA) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y_) : "v"(x_), "v"(scale2), "v"(mneg2)); /* hipcc scalarises the builtin */ \
+    else y_ = __builtin_elementwise_fma(x_, scale2, mneg2);                                                      \
+    const float p0_ = __builtin_amdgcn_exp2f(y_[0]), p1_ = __builtin_amdgcn_exp2f(y_[1]);                         \
+    const f32x2_t pp_ = {p0_, p1_};                                                                              \
+    psum2 += pp_;                                                                                                \
+    uint32_t pk_ = pack_bf16x2(p0_, p1_);                                                                        \
+    asm volatile("" : "+v"(pk_), "+v"(psum2)); /* pin: pure arithmetic is otherwise sunk below the whole MFMA run */ \
+    pfu[(i) >> 3][((i) >> 2) & 1][(i) & 3] = pk_;                                                                \
+  } while (0)
+    if (has_next) {
+      const uint32_t kst = lds0 + ((t + 1) & 1) * STAGE_BYTES;
+      zero_s(SN);
+      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(1);
+      OMNI_QK_ALL(SN, kst, OMNI_EXP_CHUNK);
+      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) OMNI_EXP_CHUNK(i);
+    }
+#undef OMNI_EXP_CHUNK
+    l_run += psum2[0] + psum2[1];
+    if (has_next && (t + 2) * KVBLK > seq_len) mask_tail(SN, (t + 1) * KVBLK);
+
+    // ---- O^T += V^T P^T (tile t), with the row max of S(t+1) in the MFMA shadows
+    float mx = has_next ? SN[0][0] : 0.0f;
+    {
+      const uint32_t vb = lds0 + (t & 1) * STAGE_BYTES + v_lane_off;
+      u32x2_t vlo[4], vhi[4];
+#define OMNI_VOFF(i) (((i) & 3) * 4096 + ((((i) >> 3) * 8 + (((i) >> 2) & 1) * 4) * 256))
+#define OMNI_VREAD(i)                                                                      \
+  do {                                                                                     \
+    if (OMNI_ATTN_ABL & 16) {                                                              \
+      asm volatile("" : "=v"(vlo[(i) & 3]) : "v"(vb));                                     \
+      asm volatile("" : "=v"(vhi[(i) & 3]) : "v"(vb));                                     \
+    } else {                                                                               \
+      vlo[(i) & 3] = lds_tr_read8<OMNI_VOFF(i)>(vb);                                       \
+      vhi[(i) & 3] = lds_tr_read8<OMNI_VOFF(i) + 512>(vb);                                 \
+    }                                                                                      \
+  } while (0)
+#define OMNI_PV(i)                                                                                             \
+  do {                                                                                                         \
+    if ((i) <= 13) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                          \
+    else if ((i) == 14) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                                     \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    {                                                                                                          \
+      const u32x4_t w_ = {vlo[(i) & 3][0], vlo[(i) & 3][1], vhi[(i) & 3][0], vhi[(i) & 3][1]};                 \
+      const u32x4_t p_ = {pfu[(i) >> 3][((i) >> 2) & 1][0], pfu[(i) >> 3][((i) >> 2) & 1][1],                  \
+                          pfu[(i) >> 3][((i) >> 2) & 1][2], pfu[(i) >> 3][((i) >> 2) & 1][3]};                 \
+      o[(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w_),                   \
+                                                           __builtin_bit_cast(bf16x8_t, p_), o[(i) & 3], 0, 0, 0); \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+#define OMNI_MAX_CHUNK(c)                                                                                       \
+  do {                                                                                                          \
+    if (has_next) {                                                                                             \
+      mx = fmaxf(fmaxf(mx, SN[(c) >> 2][((c) & 3) * 4 + 0]), SN[(c) >> 2][((c) & 3) * 4 + 1]);                   \
+      mx = fmaxf(fmaxf(mx, SN[(c) >> 2][((c) & 3) * 4 + 2]), SN[(c) >> 2][((c) & 3) * 4 + 3]);                   \
+      asm volatile("" : "+v"(mx));                                                                              \
+    }                                                                                                           \
+  } while (0)
+// DMA slot j (0 .. 2*NPIECE-1): K(t+2) pieces first (needed one iteration from now), then V(t+1) pieces
+#define OMNI_DMA_SLOT(j)                                                                  \
+  do {                                                                                    \
+    if (!OMNI_ATTN_DMA_BURST && (j) < 2 * NPIECE) {                                       \
+      if ((j) < NPIECE) { if (dma_k) issue_K_piece(t + 2, t & 1, (j) % NPIECE); }         \
+      else { if (dma_v) issue_V_piece(t + 1, (t + 1) & 1, (j) % NPIECE); }                \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+    }                                                                                     \
+  } while (0)
+      OMNI_VREAD(0); OMNI_VREAD(1); OMNI_VREAD(2);
+      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(1);
+      OMNI_PV(0);  OMNI_VREAD(3);  OMNI_DMA_SLOT(0); OMNI_PV(1);  OMNI_VREAD(4);  OMNI_DMA_SLOT(1);
+      OMNI_PV(2);  OMNI_VREAD(5);  OMNI_DMA_SLOT(2); OMNI_PV(3);  OMNI_VREAD(6);  OMNI_DMA_SLOT(3);
+      OMNI_PV(4);  OMNI_VREAD(7);  OMNI_MAX_CHUNK(0); OMNI_PV(5);  OMNI_VREAD(8);  OMNI_MAX_CHUNK(1);
+      OMNI_PV(6);  OMNI_VREAD(9);  OMNI_MAX_CHUNK(2); OMNI_PV(7);  OMNI_VREAD(10); OMNI_MAX_CHUNK(3);
+      OMNI_PV(8);  OMNI_VREAD(11); OMNI_MAX_CHUNK(4); OMNI_PV(9);  OMNI_VREAD(12); OMNI_MAX_CHUNK(5);
+      OMNI_PV(10); OMNI_VREAD(13); OMNI_MAX_CHUNK(6); OMNI_PV(11); OMNI_VREAD(14); OMNI_MAX_CHUNK(7);
+      OMNI_PV(12); OMNI_VREAD(15); OMNI_DMA_SLOT(4); OMNI_PV(13); OMNI_DMA_SLOT(5); OMNI_PV(14); OMNI_DMA_SLOT(6);
+      OMNI_PV(15); OMNI_DMA_SLOT(7);
+      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(0);
+#undef OMNI_DMA_SLOT
+#undef OMNI_MAX_CHUNK
+#undef OMNI_PV
+#undef OMNI_VREAD
+#undef OMNI_VOFF
+    }
+    if (has_next) mxn = xhalf_max(mx);
+    if (!(OMNI_ATTN_ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this iteration's DMA has landed
+    if (!(OMNI_ATTN_ABL & 2)) __syncthreads();          // ... for every wave; and every wave is done with K(t+1), V(t)
+  };
+
+  {
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    int t = 0;
+    for (; t + 2 < ntiles; t += 2) {
+      iteration(yes{}, t, sA, sB, mxA, mxB);
+      iteration(yes{}, t + 1, sB, sA, mxB, mxA);
+    }
+    if (t + 1 < ntiles) {
+      iteration(yes{}, t, sA, sB, mxA, mxB);
+      iteration(no{}, t + 1, sB, sA, mxB, mxA);
+    } else {
+      iteration(no{}, t, sA, sB, mxA, mxB);
+    }
+  }
+#undef OMNI_QK_ALL
+#undef OMNI_QK_STEP
+#undef OMNI_KREAD
+#undef OMNI_NOCHUNK
+
+  // ---- epilogue -------------------------------------------------------------------------------------------------
+  {
+    const float inv = 1.0f / xhalf_sum(l_run);
+    const int qrow = qb * QBLK + wave * 32 + l31;
+    if (qrow < seq_len) {
+      uint16_t* op = out + (int64_t)(seq_start + qrow) * ldo + h * DH + hi * 4;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          u32x2_t w;
+          w[0] = pack_bf16x2(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv);
+          w[1] = pack_bf16x2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
+          *reinterpret_cast<u32x2_t*>(op + d * 32 + qd * 8) = w;
+        }
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -331,6 +708,46 @@ int attn_variant() {
     if (v != 1 && v != 2) v = 1;
   }
   return v;
+}
+bool attn_pipelined() {
+  // dev knob: OMNI_ATTN_PIPE=0 selects the unskewed register-staged kernels (then OMNI_ATTN_NQ picks 32/64 queries per wave)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OMNI_ATTN_PIPE");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
+}
+int attn_pipe_waves(int n_heads_total, int max_seqlen) {
+  // 8 waves per workgroup (256 queries, half the DMA per query: +3.7 % at B=6) once the grid is at least 6 rounds of 256
+  // CUs deep; 4 waves (128 queries, finer tail) below that (+3.7 % at B=2).  dev knob: OMNI_ATTN_WAVES = 4 | 8.
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OMNI_ATTN_WAVES");
+    v = e ? atoi(e) : 0;
+    if (v != 4 && v != 8) v = 0;
+  }
+  if (v) return v;
+  const long wgs8 = (long)n_heads_total * ((max_seqlen + 255) / 256);
+  return wgs8 >= 6 * 256 ? 8 : 4;
+}
+template <int NW>
+int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
+                int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
+                float softmax_scale, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe_kernel<NW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return OMNI_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int qblocks = (max_seqlen + 32 * NW - 1) / (32 * NW);
+  const int nh = B * H;
+  hipLaunchKernelGGL(flash_attn_fwd_pipe_kernel<NW>, dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
+                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
 }
 template <int NQ>
 int launch_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
@@ -363,6 +780,11 @@ extern "C" int omni_flash_attn_fwd(const omni_bf16* q, const omni_bf16* k, const
       (ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 4))
     return OMNI_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (attn_pipelined()) {
+    if (attn_pipe_waves(B * H, max_seqlen) == 8)
+      return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
+    return launch_pipe<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
+  }
   if (attn_variant() == 1)
     return launch_attn<1>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
   return launch_attn<2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
