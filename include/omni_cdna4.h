@@ -89,6 +89,11 @@ typedef struct {
   int32_t N, K;
   int32_t epilogue; /* omni_epilogue */
   int32_t split_n;  /* SPLIT3: width of each output (multiple of 32) */
+  int32_t w_k32_blocked; /* 0: W is [N, K] row-major (the reference's nn.Linear.weight).  1: W is the SAME values in
+                          * K32-blocked order [K/32][N][32] (element (n,k) at ((k/32)*N + n)*32 + k%32): a 32-wide k-slab of
+                          * 16 consecutive rows is then 1 KiB contiguous, so every LDS-DMA piece of the weight operand
+                          * fetches whole 128-B lines instead of 16 half lines (the L1 request-slot limit).
+                          * A one-time re-layout at weight-load time; occupies the struct's former padding. */
   omni_gemm_group g[2];
 } omni_gemm_params;
 
@@ -219,6 +224,9 @@ typedef struct {
 
 typedef struct {
   int32_t num_layers, num_heads, head_dim, joint_dim, in_channels, out_channels_packed; /* 60,24,128,3584,64,64 */
+  int32_t gemm_w_k32_blocked; /* 1: the eight [out,in] matrices of every layer (to_qkv, add_qkv, to_out, to_add_out,
+                               * img/txt mlp w1, w2) are stored K32-blocked (omni_gemm_params.w_k32_blocked); all other
+                               * weights are always row-major.  ABI v2. */
   const omni_bf16 *t_lin1_w, *t_lin1_b, *t_lin2_w, *t_lin2_b; /* TimestepEmbedding */
   const omni_bf16 *txt_norm_w, *img_in_w, *img_in_b, *txt_in_w, *txt_in_b;
   const omni_bf16 *norm_out_w, *norm_out_b, *proj_out_w, *proj_out_b;

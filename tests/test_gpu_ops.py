@@ -63,6 +63,21 @@ def test_gemm_bias_and_gelu(M, N, K, gelu):
     assert rel_l2(got, ref) <= 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 264, 128), (77, 72, 3072), (4096 + 64, 1024, 512)])
+def test_gemm_k32_blocked_weight_layout_is_bit_identical(M, N, K):
+    """w_k32_blocked=1 only changes WHERE the weight bytes are fetched from: same MFMA order -> identical bits."""
+    from vllm_omni_amd import ops
+
+    a, w, b = rnd((M, K), 11), rnd((N, K), 12, 0.05), rnd((N,), 13, 0.5)
+    wb = ops.w_to_k32_blocked(g_(w))
+    assert torch.equal(wb.view(K // 32, N, 32)[3 % (K // 32), 5, 7].cpu(), g_(w)[5, (3 % (K // 32)) * 32 + 7].cpu())
+    y0 = ops.linear(g_(a), g_(w), g_(b), gelu=True)
+    y1 = ops.linear(g_(a), wb, g_(b), gelu=True, w_k32_blocked=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert rel_l2(y1, torch.nn.functional.gelu(a @ w.t() + b, approximate="tanh")) <= 4e-3
+
+
 def test_gemm_transpose_detecting_identity():
     # A = I (asymmetric W): catches swapped row/col in the MFMA accumulator write (cdna guide rule 16)
     from vllm_omni_amd import ops

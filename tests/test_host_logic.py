@@ -36,6 +36,7 @@ def test_ctypes_struct_layout_matches_c():
 
     assert ctypes.sizeof(N.GemmGroup) == 136 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 136
     assert ctypes.sizeof(N.DitLayerWeights) == 24 * 8
+    assert N.GemmParams.g.offset == 24 and N.DitWeights.t_lin1_w.offset == 32   # w_k32_blocked flags live in padding / ABI v2
 
 
 def test_product_path_fails_loudly_without_gpu():

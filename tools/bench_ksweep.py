@@ -19,16 +19,19 @@ def rn(*shape, s=1.0):
     return (torch.randn(*shape, device=dev, generator=g) * s).to(BF16)
 
 
-def run(M, N, Ks, epi, name):
+def run(M, N, Ks, epi, name, blocked=False):
     pts = []
+    name = name + ("/blk" if blocked else "")
     for K in Ks:
         x, w, b = rn(M, K), rn(N, K, s=0.02), rn(N)
+        if blocked:
+            w = ops.w_to_k32_blocked(w)
         o = torch.empty(M, N, dtype=BF16, device=dev)
         grp = ops.GemmGroupArgs(x, w, b, o)
         if epi == ops.EPI_BIAS_GATE_RES:
             res, gate = rn(M, N), rn(1, N)
             grp = ops.GemmGroupArgs(x, w, b, o, res=res, gate=gate, gate_item_stride=N, rows_per_item=M)
-        t = timeit(lambda: ops.gemm([grp], epi), iters=20)
+        t = timeit(lambda: ops.gemm([grp], epi, w_k32_blocked=blocked), iters=20)
         tiles = (M // 256) * (N // 256)
         rounds = -(-tiles // 256)
         us_tile = t * 1e6 / rounds
@@ -41,6 +44,12 @@ def run(M, N, Ks, epi, name):
 
 
 if __name__ == "__main__":
+    if "--blocked" in sys.argv:      # same-box A/B of the K32-blocked weight layout
+        Ks = (1024, 3072, 12288)
+        for blk in (False, True, False, True):
+            run(4096, 12288, Ks, ops.EPI_BIAS_GELU_TANH, "gelu", blk)
+            run(16384, 3072, Ks, ops.EPI_BIAS_GATE_RES, "gate_res", blk)
+        sys.exit(0)
     Ks = (512, 1024, 2048, 3072, 6144, 12288)
     run(4096, 12288, Ks, ops.EPI_BIAS, "bias")
     run(4096, 12288, Ks, ops.EPI_BIAS_GELU_TANH, "gelu")

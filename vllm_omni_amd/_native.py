@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OMNI_CDNA4_LIB", os.path.join(_HERE, "libomni_cdna4.so"))   # env override: dev sweeps
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_bf16_p = C.c_void_p  # device pointer to uint16_t bf16 bits
 c_i32_p = C.c_void_p
@@ -38,7 +38,7 @@ class GemmGroup(C.Structure):
 class GemmParams(C.Structure):
     _fields_ = [
         ("ngroups", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("epilogue", C.c_int32),
-        ("split_n", C.c_int32), ("g", GemmGroup * 2),
+        ("split_n", C.c_int32), ("w_k32_blocked", C.c_int32), ("g", GemmGroup * 2),
     ]
 
 
@@ -68,7 +68,7 @@ class DitLayerWeights(C.Structure):
 class DitWeights(C.Structure):
     _fields_ = [
         ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("head_dim", C.c_int32), ("joint_dim", C.c_int32),
-        ("in_channels", C.c_int32), ("out_channels_packed", C.c_int32),
+        ("in_channels", C.c_int32), ("out_channels_packed", C.c_int32), ("gemm_w_k32_blocked", C.c_int32),
         ("t_lin1_w", c_bf16_p), ("t_lin1_b", c_bf16_p), ("t_lin2_w", c_bf16_p), ("t_lin2_b", c_bf16_p),
         ("txt_norm_w", c_bf16_p), ("img_in_w", c_bf16_p), ("img_in_b", c_bf16_p), ("txt_in_w", c_bf16_p),
         ("txt_in_b", c_bf16_p),

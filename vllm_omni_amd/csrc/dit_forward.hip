@@ -58,7 +58,7 @@ Workspace carve(void* base, const omni_dit_weights* w, int64_t Ri, int64_t Rt, i
 
 }  // namespace
 
-extern "C" int omni_abi_version(void) { return 1; }
+extern "C" int omni_abi_version(void) { return 2; }
 extern "C" const char* omni_build_arch(void) { return "gfx950"; }
 extern "C" const char* omni_status_string(int status) {
   switch (status) {
@@ -131,7 +131,7 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     // fused QKV projections of both streams, scattered into the joint q/k/v (reference :380-394, :414-416)
     {
       omni_gemm_params p = {};
-      p.ngroups = 2; p.N = 3 * D; p.K = D; p.epilogue = OMNI_EPI_BIAS_SPLIT3; p.split_n = D;
+      p.ngroups = 2; p.N = 3 * D; p.K = D; p.epilogue = OMNI_EPI_BIAS_SPLIT3; p.split_n = D; p.w_k32_blocked = w->gemm_w_k32_blocked;
       p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = L.to_qkv_w; p.g[0].bias = L.to_qkv_b;
       p.g[0].out = ws.q; p.g[0].out1 = ws.k; p.g[0].out2 = ws.v; p.g[0].ldo = D; p.g[0].out_row_map = b->img_joint_row;
       p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.add_qkv_w; p.g[1].bias = L.add_qkv_b;
@@ -149,7 +149,7 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     // output projections + gated residual (reference :448-456, :586-587)
     {
       omni_gemm_params p = {};
-      p.ngroups = 2; p.N = D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GATE_RES;
+      p.ngroups = 2; p.N = D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GATE_RES; p.w_k32_blocked = w->gemm_w_k32_blocked;
       p.g[0].A = ws.attn; p.g[0].lda = D; p.g[0].a_row_map = b->img_joint_row; p.g[0].M = Ri;
       p.g[0].W = L.to_out_w; p.g[0].bias = L.to_out_b; p.g[0].out = ws.hidden_img; p.g[0].ldo = D;
       p.g[0].res = ws.hidden_img; p.g[0].ldres = D; p.g[0].gate = ws.mod_img + 2 * D; p.g[0].gate_item_stride = 6 * D;
@@ -168,7 +168,7 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     // MLP up + GELU-tanh (reference :591, :596 -> diffusers FeedForward)
     {
       omni_gemm_params p = {};
-      p.ngroups = 2; p.N = 4 * D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GELU_TANH;
+      p.ngroups = 2; p.N = 4 * D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GELU_TANH; p.w_k32_blocked = w->gemm_w_k32_blocked;
       p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = L.img_mlp_w1; p.g[0].bias = L.img_mlp_b1;
       p.g[0].out = h_img; p.g[0].ldo = 4 * D;
       p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w1; p.g[1].bias = L.txt_mlp_b1;
@@ -178,7 +178,7 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     // MLP down + gated residual (reference :592, :597)
     {
       omni_gemm_params p = {};
-      p.ngroups = 2; p.N = D; p.K = 4 * D; p.epilogue = OMNI_EPI_BIAS_GATE_RES;
+      p.ngroups = 2; p.N = D; p.K = 4 * D; p.epilogue = OMNI_EPI_BIAS_GATE_RES; p.w_k32_blocked = w->gemm_w_k32_blocked;
       p.g[0].A = h_img; p.g[0].lda = 4 * D; p.g[0].M = Ri; p.g[0].W = L.img_mlp_w2; p.g[0].bias = L.img_mlp_b2;
       p.g[0].out = ws.hidden_img; p.g[0].ldo = D; p.g[0].res = ws.hidden_img; p.g[0].ldres = D;
       p.g[0].gate = ws.mod_img + 5 * D; p.g[0].gate_item_stride = 6 * D; p.g[0].row_item_map = b->img_item;

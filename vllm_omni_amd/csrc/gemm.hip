@@ -483,14 +483,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
     if (G.a_row_map) ar = G.a_row_map[ar];
     a_src[j] = G.A + (int64_t)ar * G.lda + c * 8;
     const int wr = min(n0 + r, N - 1);
-    w_src[j] = G.W + (int64_t)wr * K + c * 8;
+    w_src[j] = G.W + (P.w_k32_blocked ? (int64_t)wr * RBK : (int64_t)wr * K) + c * 8;
   }
+  // elements between two k-stages of one W row: 32 in row-major, a whole [N][32] slab in the K32-blocked layout (where
+  // the 16 rows of a DMA piece are 1 KiB contiguous -> 8 full-line requests per piece instead of 16 half-line ones)
+  const int64_t wstep = P.w_k32_blocked ? (int64_t)N * RBK : RBK;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   auto issue_piece = [&](int slot, int st, int piece) {   // piece 0..3 = A0, W0, A1, W1 (1 KiB each)
     const uint32_t base = lds0 + slot * RSTAGE_BYTES + (wave * 2) * 1024;
-    const int koff = st * RBK, part = piece >> 1;
-    if (piece & 1) glds16(w_src[part] + koff, base + ROP_BYTES + part * 1024);
-    else glds16(a_src[part] + koff, base + part * 1024);
+    const int part = piece >> 1;
+    if (piece & 1) glds16(w_src[part] + st * wstep, base + ROP_BYTES + part * 1024);
+    else glds16(a_src[part] + st * RBK, base + part * 1024);
   };
   auto issue_part = [&](int slot, int st, int part) {   // part 0..1
     issue_piece(slot, st, 2 * part);
@@ -946,6 +949,8 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
   }
   if (p->epilogue == OMNI_EPI_BIAS_SPLIT3 && (p->split_n <= 0 || p->split_n % 32 != 0 || p->N != 3 * p->split_n))
     return OMNI_ERR_UNSUPPORTED;
+  if (p->w_k32_blocked != 0 && p->w_k32_blocked != 1) return OMNI_ERR_BAD_ARG;
+  if (p->w_k32_blocked && gemm_variant() != 1) return OMNI_ERR_UNSUPPORTED;   // only the ring kernel reads that layout
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (p->epilogue) {
     case OMNI_EPI_BIAS: return launch<OMNI_EPI_BIAS>(p, s);

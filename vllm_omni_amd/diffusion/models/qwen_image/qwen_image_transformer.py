@@ -15,6 +15,7 @@ There is no eager/PyTorch fallback: without libomni_cdna4.so or off-GPU, forward
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections.abc import Iterable
 
 import torch
@@ -22,6 +23,7 @@ import torch.nn as nn
 
 from ...batch import RaggedBatch, build_ragged_batch
 from .... import _native as N
+from .... import ops
 from .rope import rope_table
 
 BF16 = torch.bfloat16
@@ -152,6 +154,7 @@ class QwenImageTransformer2DModel(nn.Module):
         self.norm_out = _NormOut(D, device, dtype)
         self.proj_out = _linear(D, patch_size * patch_size * self.out_channels, device, dtype)
         self._native = None        # (DitWeights struct, keep-alive list)
+        self._w_blocked = False    # the 8 big matrices per layer currently hold the K32-blocked re-layout
         self._workspace = None
         self._batch_cache: dict = {}
 
@@ -160,8 +163,33 @@ class QwenImageTransformer2DModel(nn.Module):
     def device(self):
         return self.proj_out.weight.device
 
+    def _gemm_weight_params(self):
+        """The eight [out, in] matrices per layer that the grouped GEMMs read (omni_dit_weights.gemm_w_k32_blocked)."""
+        for blk in self.transformer_blocks:
+            a = blk.attn
+            yield from (a.to_qkv.weight, a.add_kv_proj.weight, a.to_out[0].weight, a.to_add_out.weight,
+                        blk.img_mlp.net[0].proj.weight, blk.img_mlp.net[2].weight,
+                        blk.txt_mlp.net[0].proj.weight, blk.txt_mlp.net[2].weight)
+
+    def _set_weight_layout(self, blocked: bool) -> None:
+        """In-place (one matrix of scratch) switch between the reference's row-major [out, in] and the K32-blocked order
+        [in/32][out][32] the ring GEMM's LDS-DMA reads in whole cache lines (include/omni_cdna4.h).  Parameters are in
+        row-major order whenever Python code can see them being written (init / load_weights); they are re-laid-out once,
+        lazily, when the native pointer table is built."""
+        if blocked == self._w_blocked:
+            return
+        for p in self._gemm_weight_params():
+            n, k = p.shape
+            if blocked:
+                p.data = ops.w_to_k32_blocked(p.data)
+            else:
+                p.data = p.data.view(k // 32, n, 32).transpose(0, 1).contiguous().view(n, k)
+        self._w_blocked = blocked
+        self._native = None
+
     def init_random_(self, seed: int = 1234, std: float = 0.02) -> "QwenImageTransformer2DModel":
         """Synthetic weights ON DEVICE (bench only): >=2-D ~ N(0, std^2), biases 0, norm weights 1."""
+        self._set_weight_layout(False)
         g = torch.Generator(device=self.device).manual_seed(seed)
         for name, p in self.named_parameters():
             if p.dim() >= 2:
@@ -179,6 +207,7 @@ class QwenImageTransformer2DModel(nn.Module):
         stacked = [(".to_qkv", ".to_q", 0), (".to_qkv", ".to_k", 1), (".to_qkv", ".to_v", 2),
                    (".add_kv_proj", ".add_q_proj", 0), (".add_kv_proj", ".add_k_proj", 1),
                    (".add_kv_proj", ".add_v_proj", 2)]
+        self._set_weight_layout(False)
         params = dict(self.named_parameters())
         loaded: set[str] = set()
         D = self.inner_dim
@@ -203,6 +232,7 @@ class QwenImageTransformer2DModel(nn.Module):
     def _native_weights(self) -> N.DitWeights:
         if self._native is not None:
             return self._native[0]
+        self._set_weight_layout(os.environ.get("OMNI_GEMM_W_BLOCKED", "1") != "0")
         for n, p in self.named_parameters():
             if not p.is_cuda or p.dtype != BF16 or not p.is_contiguous():
                 raise N.OmniNativeError(f"parameter {n} must be a contiguous bf16 GPU tensor (got {p.device}, {p.dtype})")
@@ -228,6 +258,7 @@ class QwenImageTransformer2DModel(nn.Module):
         w.num_layers, w.num_heads, w.head_dim = L, self.num_heads, self.head_dim
         w.joint_dim, w.in_channels = self.joint_attention_dim, self.in_channels
         w.out_channels_packed = self.proj_out.weight.shape[0]
+        w.gemm_w_k32_blocked = 1 if self._w_blocked else 0
         te = self.time_text_embed.timestep_embedder
         w.t_lin1_w, w.t_lin1_b = te.linear_1.weight.data_ptr(), te.linear_1.bias.data_ptr()
         w.t_lin2_w, w.t_lin2_b = te.linear_2.weight.data_ptr(), te.linear_2.bias.data_ptr()

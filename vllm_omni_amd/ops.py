@@ -51,12 +51,23 @@ class GemmGroupArgs:
         self.row_item_map, self.rows_per_item = row_item_map, rows_per_item
 
 
-def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0, m_override: list[int] | None = None):
+def w_to_k32_blocked(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] row-major -> the same values in K32-blocked order [K/32][N][32] (omni_gemm_params.w_k32_blocked = 1),
+    returned as an [N, K]-shaped contiguous tensor so that shape checks and pointer plumbing stay unchanged."""
+    n, k = w.shape
+    if k % 32:
+        raise ValueError("K must be a multiple of 32")
+    return w.view(n, k // 32, 32).transpose(0, 1).contiguous().view(n, k)
+
+
+def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0, m_override: list[int] | None = None,
+         w_k32_blocked: bool = False):
     """Y_g = epilogue(A_g @ W_g.T + bias_g) for up to two groups sharing N, K (omni_gemm_bf16)."""
     p = N.GemmParams()
     p.ngroups = len(groups)
     p.epilogue = epilogue
     p.split_n = split_n
+    p.w_k32_blocked = 1 if w_k32_blocked else 0
     N_, K_ = groups[0].w.shape
     p.N, p.K = N_, K_
     for i, g in enumerate(groups):
@@ -81,10 +92,11 @@ def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0
     N.check(N.lib().omni_gemm_bf16(C.byref(p), _stream()), "omni_gemm_bf16")
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, *, gelu: bool = False) -> torch.Tensor:
+def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, *, gelu: bool = False,
+           w_k32_blocked: bool = False) -> torch.Tensor:
     """Single-group convenience: x [M,K] @ w[N,K].T + bias (optionally GELU-tanh)."""
     out = torch.empty(x.shape[0], w.shape[0], dtype=BF16, device=x.device)
-    gemm([GemmGroupArgs(x, w, bias, out)], EPI_BIAS_GELU_TANH if gelu else EPI_BIAS)
+    gemm([GemmGroupArgs(x, w, bias, out)], EPI_BIAS_GELU_TANH if gelu else EPI_BIAS, w_k32_blocked=w_k32_blocked)
     return out
 
 
