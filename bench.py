@@ -82,14 +82,18 @@ def measure_roofline(dev, R: int = 3) -> dict:
     blocked = os.environ.get("OMNI_GEMM_W_BLOCKED", "1") != "0"       # the layout the DiT layers run with
     wi = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
     wt = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    ablk = blocked and os.environ.get("OMNI_DIT_ACT_BLOCKED", "1") != "0"   # A and the GELU output K32-blocked, as in the layers
     if blocked:
         wi, wt = ops.w_to_k32_blocked(wi), ops.w_to_k32_blocked(wt)
+    if ablk:
+        xi, xt = ops.w_to_k32_blocked(xi), ops.w_to_k32_blocked(xt)
     b = torch.zeros(N, device=dev, dtype=torch.bfloat16)
     oi = torch.empty(Mi, N, device=dev, dtype=torch.bfloat16)
     ot = torch.empty(Mt, N, device=dev, dtype=torch.bfloat16)
 
     def launch():
-        ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi), ops.GemmGroupArgs(xt, wt, b, ot)], ops.EPI_BIAS_GELU_TANH,
+        ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi, a_k32_blocked=ablk, out_k32_blocked=ablk),
+                  ops.GemmGroupArgs(xt, wt, b, ot, a_k32_blocked=ablk, out_k32_blocked=ablk)], ops.EPI_BIAS_GELU_TANH,
                  w_k32_blocked=blocked)
 
     for _ in range(3):
@@ -106,7 +110,7 @@ def measure_roofline(dev, R: int = 3) -> dict:
     flops = 2.0 * (Mi + Mt) * N * K
     ach = flops / sec / 1e12
     return {"bound": "mfma", "kernel": f"gemm_bf16_ring_kernel<OMNI_EPI_BIAS_GELU_TANH, 0, true> M={Mi}+{Mt} N=12288 K=3072"
-                                      + (" (W K32-blocked)" if blocked else ""),
+                                      + (" (W" + (", A, out" if ablk else "") + " K32-blocked)" if blocked else ""),
             "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
             "flop_per_launch": flops, "avg_launch_us": sec * 1e6, "traffic": None}
 

@@ -82,6 +82,11 @@ typedef struct {
   int64_t gate_item_stride;
   const int32_t* row_item_map; /* nullable: item (batch element) of logical row r          */
   int32_t rows_per_item;    /* used when row_item_map == NULL: item = r / rows_per_item    */
+  int32_t a_k32_rows;       /* 0: A is row-major [*, lda].  R > 0: A is K32-blocked [K/32][R][32] (element (r,k) at
+                             * ((k/32)*R + r)*32 + k%32; lda ignored; a_row_map still picks r).  Same idea as
+                             * omni_gemm_params.w_k32_blocked, for activations produced by this library's own kernels */
+  int32_t out_k32_rows;     /* 0: out is row-major [*, ldo].  R > 0: out is written K32-blocked [N/32][R][32] (ldo
+                             * ignored; BIAS / BIAS_GELU_TANH epilogues only) so that the next GEMM can read it blocked */
 } omni_gemm_group;
 
 typedef struct {
@@ -111,6 +116,12 @@ int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream);
 int omni_adaln_modulate(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows, int32_t D,
                         const omni_bf16* scale, const omni_bf16* shift, int64_t mod_item_stride,
                         const int32_t* row_item_map, int32_t rows_per_item, float eps, omni_stream stream);
+/* Same, with the output optionally K32-blocked: y_k32_rows = 0 -> row-major (ldy); R > 0 -> y is [D/32][R][32]
+ * (omni_gemm_group.a_k32_rows of the GEMM that consumes it; D % 32 == 0; ldy ignored). */
+int omni_adaln_modulate_ex(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows, int32_t D,
+                           const omni_bf16* scale, const omni_bf16* shift, int64_t mod_item_stride,
+                           const int32_t* row_item_map, int32_t rows_per_item, float eps, int32_t y_k32_rows,
+                           omni_stream stream);
 
 /* RMSNorm over the last dim with learned weight: y = x * rsqrt(mean(x^2) + eps) * w.
  * Replaces vllm RMSNorm at qwen_image_transformer.py:758 (txt_norm, D = 3584).  D % 8 == 0, D <= 8192. */
@@ -148,6 +159,12 @@ int omni_flash_attn_fwd(const omni_bf16* q, const omni_bf16* k, const omni_bf16*
                         int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,
                         int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
                         omni_stream stream);
+/* Same, with the output optionally K32-blocked: out_k32_rows = R > 0 -> out is [H*128/32][R][32] over the R rows of the
+ * whole buffer (ldo ignored); 0 -> row-major. */
+int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
+                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,
+                        int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
+                        int32_t out_k32_rows, omni_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small-batch weight-streaming linear:  y[b, n] = act_out( sum_k act_in(x[b, k]) * W[n, k] + bias[n] ).

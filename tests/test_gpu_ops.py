@@ -78,6 +78,53 @@ def test_gemm_k32_blocked_weight_layout_is_bit_identical(M, N, K):
     assert rel_l2(y1, torch.nn.functional.gelu(a @ w.t() + b, approximate="tanh")) <= 4e-3
 
 
+def test_gemm_k32_blocked_activations_are_bit_identical():
+    """a_k32_rows / out_k32_rows (grouped, ragged M, gathered A rows): same bits as the row-major run, re-laid-out."""
+    from vllm_omni_amd import ops
+
+    Mi, Mt, N, K, R = 700, 130, 512, 256, 1000          # A buffers have more rows (R) than the groups use
+    a = rnd((R, K), 21)
+    wi, wt, b = rnd((N, K), 22, 0.05), rnd((N, K), 23, 0.05), rnd((N,), 24, 0.5)
+    gi = torch.Generator().manual_seed(5)
+    map_i = torch.randperm(R, generator=gi)[:Mi].to(torch.int32)
+    map_t = torch.randperm(R, generator=gi)[:Mt].to(torch.int32)
+    a_rm, a_blk = g_(a), ops.w_to_k32_blocked(g_(a))
+    outs = []
+    for blocked in (False, True):
+        oi = torch.zeros(Mi, N, dtype=BF16, device=dev())
+        ot = torch.zeros(Mt, N, dtype=BF16, device=dev())
+        A = a_blk if blocked else a_rm
+        ops.gemm([ops.GemmGroupArgs(A, g_(wi), g_(b), oi, a_row_map=map_i.to(dev()), a_k32_blocked=blocked,
+                                    out_k32_blocked=blocked),
+                  ops.GemmGroupArgs(A, g_(wt), g_(b), ot, a_row_map=map_t.to(dev()), a_k32_blocked=blocked,
+                                    out_k32_blocked=blocked)], ops.EPI_BIAS_GELU_TANH)
+        torch.cuda.synchronize()
+        outs.append((ops.k32_blocked_to_rows(oi), ops.k32_blocked_to_rows(ot)) if blocked else (oi, ot))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.nn.functional.gelu(a[map_i.long()] @ wi.t() + b, approximate="tanh")
+    assert rel_l2(outs[1][0], ref) <= 4e-3
+
+
+def test_adaln_and_attention_k32_blocked_outputs_are_bit_identical():
+    from vllm_omni_amd import ops
+
+    rows, D = 333, 3072
+    x, mod = rnd((rows, D), 31), rnd((2, 6 * D), 32, 0.3)
+    item = (torch.arange(rows) % 2).to(torch.int32).to(dev())
+    kw = dict(mod_item_stride=6 * D, row_item_map=item)
+    y0 = ops.adaln_modulate(g_(x), g_(mod)[:, D:], g_(mod), **kw)
+    y1 = ops.adaln_modulate(g_(x), g_(mod)[:, D:], g_(mod), out_k32_blocked=True, **kw)
+    H, lens = 3, [200, 77]
+    tot = sum(lens)
+    q, k, v = (g_(rnd((tot, H * 128), 40 + i)) for i in range(3))
+    cu = torch.tensor([0, lens[0], tot], dtype=torch.int32, device=dev())
+    o0 = ops.flash_attn_varlen(q, k, v, cu, H, max(lens), 1 / math.sqrt(128))
+    o1 = ops.flash_attn_varlen(q, k, v, cu, H, max(lens), 1 / math.sqrt(128), out_k32_blocked=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, ops.k32_blocked_to_rows(y1))
+    assert torch.equal(o0, ops.k32_blocked_to_rows(o1))
+
+
 def test_gemm_transpose_detecting_identity():
     # A = I (asymmetric W): catches swapped row/col in the MFMA accumulator write (cdna guide rule 16)
     from vllm_omni_amd import ops

@@ -32,6 +32,7 @@ class GemmGroup(C.Structure):
         ("res", c_bf16_p), ("ldres", C.c_int64),
         ("gate", c_bf16_p), ("gate_item_stride", C.c_int64),
         ("row_item_map", c_i32_p), ("rows_per_item", C.c_int32),
+        ("a_k32_rows", C.c_int32), ("out_k32_rows", C.c_int32),
     ]
 
 
@@ -99,6 +100,8 @@ PROTOTYPES = {
     "omni_gemm_bf16": (C.c_int, [C.POINTER(GemmParams), C.c_void_p]),
     "omni_adaln_modulate": (C.c_int, [c_bf16_p, C.c_int64, c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p,
                                       c_bf16_p, C.c_int64, c_i32_p, C.c_int32, C.c_float, C.c_void_p]),
+    "omni_adaln_modulate_ex": (C.c_int, [c_bf16_p, C.c_int64, c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p,
+                                         c_bf16_p, C.c_int64, c_i32_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "omni_rmsnorm": (C.c_int, [c_bf16_p, C.c_int64, c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, C.c_float,
                                C.c_void_p]),
     "omni_qk_norm_rope": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p,
@@ -108,6 +111,9 @@ PROTOTYPES = {
     "omni_flash_attn_fwd": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p, C.c_int64, C.c_int64, C.c_int64,
                                       C.c_int64, c_i32_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                       C.c_void_p]),
+    "omni_flash_attn_fwd_ex": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p, C.c_int64, C.c_int64, C.c_int64,
+                                         C.c_int64, c_i32_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                         C.c_int32, C.c_void_p]),
     "omni_linear_smallbatch": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, c_bf16_p, c_bf16_p, C.c_int64, C.c_int32,
                                          c_bf16_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "omni_timestep_sinusoid": (C.c_int, [c_f32_p, C.c_int32, C.c_int32, C.c_float, c_bf16_p, C.c_void_p]),

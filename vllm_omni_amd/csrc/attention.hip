@@ -375,7 +375,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pipe_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-    const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e) {
+    const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e, int out_k32_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -680,7 +680,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
     const float inv = 1.0f / xhalf_sum(l_run);
     const int qrow = qb * QBLK + wave * 32 + l31;
     if (qrow < seq_len) {
-      uint16_t* op = out + (int64_t)(seq_start + qrow) * ldo + h * DH + hi * 4;
+      // row-major: out[row][h*128 + d*32 + qd*8 + hi*4 ..];  K32-blocked: slab h*4 + d, [slab][row][qd*8 + hi*4 ..]
+      uint16_t* op = out_k32_rows ? out + ((int64_t)(h * 4) * out_k32_rows + seq_start + qrow) * 32 + hi * 4
+                                  : out + (int64_t)(seq_start + qrow) * ldo + h * DH + hi * 4;
+      const int64_t dstep = out_k32_rows ? (int64_t)out_k32_rows * 32 : 32;
 #pragma unroll
       for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
           u32x2_t w;
           w[0] = pack_bf16x2(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv);
           w[1] = pack_bf16x2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
-          *reinterpret_cast<u32x2_t*>(op + d * 32 + qd * 8) = w;
+          *reinterpret_cast<u32x2_t*>(op + d * dstep + qd * 8) = w;
         }
     }
   }
@@ -734,7 +737,7 @@ int attn_pipe_waves(int n_heads_total, int max_seqlen) {
 template <int NW>
 int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
                 int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
-                float softmax_scale, hipStream_t s) {
+                float softmax_scale, int out_k32_rows, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe_kernel<NW>),
@@ -745,7 +748,7 @@ int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
   const int qblocks = (max_seqlen + 32 * NW - 1) / (32 * NW);
   const int nh = B * H;
   hipLaunchKernelGGL(flash_attn_fwd_pipe_kernel<NW>, dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
-                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f);
+                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows);
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }
@@ -770,22 +773,32 @@ int launch_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
 }
 }  // namespace
 
-extern "C" int omni_flash_attn_fwd(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
-                                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,
-                                   int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
-                                   omni_stream stream) {
-  if (!q || !k || !v || !out || !cu_seqlens || B <= 0 || H <= 0 || max_seqlen <= 0) return OMNI_ERR_BAD_ARG;
+extern "C" int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
+                                      int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,
+                                      int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
+                                      int32_t out_k32_rows, omni_stream stream) {
+  if (!q || !k || !v || !out || !cu_seqlens || B <= 0 || H <= 0 || max_seqlen <= 0 || out_k32_rows < 0)
+    return OMNI_ERR_BAD_ARG;
   if (head_dim != DH) return OMNI_ERR_UNSUPPORTED;
   if (!omni_aligned16(q) || !omni_aligned16(k) || !omni_aligned16(v) || (reinterpret_cast<uintptr_t>(out) & 7) ||
-      (ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 4))
+      (ldq % 8) || (ldk % 8) || (ldv % 8) || (!out_k32_rows && (ldo % 4)))
     return OMNI_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (attn_pipelined()) {
     if (attn_pipe_waves(B * H, max_seqlen) == 8)
-      return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
-    return launch_pipe<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
+      return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s);
+    return launch_pipe<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s);
   }
+  if (out_k32_rows) return OMNI_ERR_UNSUPPORTED;   // only the pipelined kernel writes the blocked layout
   if (attn_variant() == 1)
     return launch_attn<1>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
   return launch_attn<2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
+}
+
+extern "C" int omni_flash_attn_fwd(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
+                                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,
+                                   int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
+                                   omni_stream stream) {
+  return omni_flash_attn_fwd_ex(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, head_dim, max_seqlen,
+                                softmax_scale, 0, stream);
 }

@@ -8,6 +8,8 @@
 // rows into the joint buffers and the out-projection GEMM gathers them back.
 #include <stdio.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -115,6 +117,16 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
   omni_bf16* h_img = ws.mlp_h;
   omni_bf16* h_txt = ws.mlp_h + (int64_t)Ri * 4 * D;
   const float sm_scale = 1.0f / sqrtf((float)w->head_dim);
+  // Activations that only travel from one of this library's kernels into a GEMM A operand (AdaLN output, attention
+  // output, GELU output) are kept K32-blocked ([K/32][rows][32], same bytes) so that the GEMM's LDS-DMA pieces fetch
+  // whole cache lines (include/omni_cdna4.h: omni_gemm_group.a_k32_rows).  The residual stream, q/k/v and everything
+  // the caller sees stay row-major.  dev knob: OMNI_DIT_ACT_BLOCKED=0.
+  static const bool act_blocked = [] {
+    const char* e = getenv("OMNI_DIT_ACT_BLOCKED");
+    return e ? atoi(e) != 0 : true;
+  }();
+  const bool blk = act_blocked && (D % 32 == 0);
+  const int32_t bRi = blk ? Ri : 0, bRt = blk ? Rt : 0, bRj = blk ? Ri + Rt : 0;
 
   for (int l = 0; l < w->num_layers; ++l) {
     const omni_dit_layer_weights& L = w->layers[l];
@@ -124,14 +136,15 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     OMNI_TRY(omni_linear_smallbatch(ws.temb, D, nT, L.txt_mod_w, L.txt_mod_b, 6 * (int64_t)D, D, ws.mod_txt, 6 * D, 1,
                                     0, stream));
     // norm1 + modulate (reference :564-567)
-    OMNI_TRY(omni_adaln_modulate(ws.hidden_img, D, xn_img, D, Ri, D, ws.mod_img + D, ws.mod_img, 6 * D, b->img_item, 0,
-                                 eps, stream));
-    OMNI_TRY(omni_adaln_modulate(ws.hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + D, ws.mod_txt, 6 * D, b->txt_item, 0,
-                                 eps, stream));
+    OMNI_TRY(omni_adaln_modulate_ex(ws.hidden_img, D, xn_img, D, Ri, D, ws.mod_img + D, ws.mod_img, 6 * D, b->img_item,
+                                    0, eps, bRi, stream));
+    OMNI_TRY(omni_adaln_modulate_ex(ws.hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + D, ws.mod_txt, 6 * D, b->txt_item,
+                                    0, eps, bRt, stream));
     // fused QKV projections of both streams, scattered into the joint q/k/v (reference :380-394, :414-416)
     {
       omni_gemm_params p = {};
       p.ngroups = 2; p.N = 3 * D; p.K = D; p.epilogue = OMNI_EPI_BIAS_SPLIT3; p.split_n = D; p.w_k32_blocked = w->gemm_w_k32_blocked;
+      p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt;
       p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = L.to_qkv_w; p.g[0].bias = L.to_qkv_b;
       p.g[0].out = ws.q; p.g[0].out1 = ws.k; p.g[0].out2 = ws.v; p.g[0].ldo = D; p.g[0].out_row_map = b->img_joint_row;
       p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.add_qkv_w; p.g[1].bias = L.add_qkv_b;
@@ -144,12 +157,13 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     OMNI_TRY(omni_qk_norm_rope(ws.k, D, Ri + Rt, w->num_heads, L.norm_k_w, L.norm_added_k_w, b->rope_cos, b->rope_sin,
                                b->joint_pos, b->txt_pos_end, eps, stream));
     // joint attention (reference :437-443 -> attention/backends/sdpa.py:46-66)
-    OMNI_TRY(omni_flash_attn_fwd(ws.q, ws.k, ws.v, ws.attn, D, D, D, D, b->cu_seqlens, b->n_items, w->num_heads,
-                                 w->head_dim, b->max_seqlen, sm_scale, stream));
+    OMNI_TRY(omni_flash_attn_fwd_ex(ws.q, ws.k, ws.v, ws.attn, D, D, D, D, b->cu_seqlens, b->n_items, w->num_heads,
+                                    w->head_dim, b->max_seqlen, sm_scale, bRj, stream));
     // output projections + gated residual (reference :448-456, :586-587)
     {
       omni_gemm_params p = {};
       p.ngroups = 2; p.N = D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GATE_RES; p.w_k32_blocked = w->gemm_w_k32_blocked;
+      p.g[0].a_k32_rows = bRj; p.g[1].a_k32_rows = bRj;
       p.g[0].A = ws.attn; p.g[0].lda = D; p.g[0].a_row_map = b->img_joint_row; p.g[0].M = Ri;
       p.g[0].W = L.to_out_w; p.g[0].bias = L.to_out_b; p.g[0].out = ws.hidden_img; p.g[0].ldo = D;
       p.g[0].res = ws.hidden_img; p.g[0].ldres = D; p.g[0].gate = ws.mod_img + 2 * D; p.g[0].gate_item_stride = 6 * D;
@@ -161,14 +175,15 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
       OMNI_TRY(omni_gemm_bf16(&p, stream));
     }
     // norm2 + modulate (reference :590, :595)
-    OMNI_TRY(omni_adaln_modulate(ws.hidden_img, D, xn_img, D, Ri, D, ws.mod_img + 4 * D, ws.mod_img + 3 * D, 6 * D,
-                                 b->img_item, 0, eps, stream));
-    OMNI_TRY(omni_adaln_modulate(ws.hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + 4 * D, ws.mod_txt + 3 * D, 6 * D,
-                                 b->txt_item, 0, eps, stream));
+    OMNI_TRY(omni_adaln_modulate_ex(ws.hidden_img, D, xn_img, D, Ri, D, ws.mod_img + 4 * D, ws.mod_img + 3 * D, 6 * D,
+                                    b->img_item, 0, eps, bRi, stream));
+    OMNI_TRY(omni_adaln_modulate_ex(ws.hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + 4 * D, ws.mod_txt + 3 * D, 6 * D,
+                                    b->txt_item, 0, eps, bRt, stream));
     // MLP up + GELU-tanh (reference :591, :596 -> diffusers FeedForward)
     {
       omni_gemm_params p = {};
       p.ngroups = 2; p.N = 4 * D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GELU_TANH; p.w_k32_blocked = w->gemm_w_k32_blocked;
+      p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt; p.g[0].out_k32_rows = bRi; p.g[1].out_k32_rows = bRt;
       p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = L.img_mlp_w1; p.g[0].bias = L.img_mlp_b1;
       p.g[0].out = h_img; p.g[0].ldo = 4 * D;
       p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w1; p.g[1].bias = L.txt_mlp_b1;
@@ -179,6 +194,7 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     {
       omni_gemm_params p = {};
       p.ngroups = 2; p.N = D; p.K = 4 * D; p.epilogue = OMNI_EPI_BIAS_GATE_RES; p.w_k32_blocked = w->gemm_w_k32_blocked;
+      p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt;
       p.g[0].A = h_img; p.g[0].lda = 4 * D; p.g[0].M = Ri; p.g[0].W = L.img_mlp_w2; p.g[0].bias = L.img_mlp_b2;
       p.g[0].out = ws.hidden_img; p.g[0].ldo = D; p.g[0].res = ws.hidden_img; p.g[0].ldres = D;
       p.g[0].gate = ws.mod_img + 5 * D; p.g[0].gate_item_stride = 6 * D; p.g[0].row_item_map = b->img_item;

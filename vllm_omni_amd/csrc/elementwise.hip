@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
                                                       const uint16_t* __restrict__ scale_or_w,
                                                       const uint16_t* __restrict__ shift, int64_t item_stride,
                                                       const int32_t* __restrict__ row_item_map, int rows_per_item,
-                                                      float eps) {
+                                                      float eps, int y_k32_rows) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -91,19 +91,22 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = v[c][i] * rstd * sc[i];
       }
-      *reinterpret_cast<u32x4_t*>(yr + e) = pack8(o);
+      // K32-blocked output: the 8 elements stay one 16-B granule, at ((e/32) * R + row) * 32 + e%32
+      uint16_t* dst = y_k32_rows ? y + ((int64_t)(e >> 5) * y_k32_rows + row) * 32 + (e & 31) : yr + e;
+      *reinterpret_cast<u32x4_t*>(dst) = pack8(o);
     }
   }
 }
 
 template <int MODE>
 int launch_rownorm(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int rows, int D, const omni_bf16* a,
-                   const omni_bf16* b, int64_t stride, const int32_t* map, int rpi, float eps, hipStream_t s) {
+                   const omni_bf16* b, int64_t stride, const int32_t* map, int rpi, float eps, hipStream_t s,
+                   int y_k32_rows = 0) {
   const int nch = (D + 511) / 512;
   const dim3 grid((rows + 3) / 4), block(256);
 #define OMNI_RN(N)                                                                                            \
   hipLaunchKernelGGL((rownorm_kernel<N, MODE>), grid, block, 0, s, x, ldx, y, ldy, rows, D, a, b, stride, map, \
-                     rpi, eps)
+                     rpi, eps, y_k32_rows)
   if (nch <= 1) OMNI_RN(1);
   else if (nch <= 2) OMNI_RN(2);
   else if (nch <= 4) OMNI_RN(4);
@@ -317,18 +320,27 @@ __global__ __launch_bounds__(256) void cfg_euler_kernel(const uint16_t* __restri
 
 }  // namespace
 
+extern "C" int omni_adaln_modulate_ex(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows,
+                                      int32_t D, const omni_bf16* scale, const omni_bf16* shift,
+                                      int64_t mod_item_stride, const int32_t* row_item_map, int32_t rows_per_item,
+                                      float eps, int32_t y_k32_rows, omni_stream stream) {
+  if (!x || !y || !scale || !shift || rows <= 0 || D <= 0) return OMNI_ERR_BAD_ARG;
+  if (!row_item_map && rows_per_item <= 0) return OMNI_ERR_BAD_ARG;
+  if (y_k32_rows < 0 || (y_k32_rows > 0 && y_k32_rows < rows)) return OMNI_ERR_BAD_ARG;
+  if (D % 8 || D > 8192 || (y_k32_rows && D % 32)) return OMNI_ERR_UNSUPPORTED;
+  if (!omni_aligned16(x) || !omni_aligned16(y) || !omni_aligned16(scale) || !omni_aligned16(shift) || (ldx % 8) ||
+      (!y_k32_rows && (ldy % 8)) || (mod_item_stride % 8))
+    return OMNI_ERR_ALIGN;
+  return launch_rownorm<0>(x, ldx, y, ldy, rows, D, scale, shift, mod_item_stride, row_item_map, rows_per_item, eps,
+                           static_cast<hipStream_t>(stream), y_k32_rows);
+}
+
 extern "C" int omni_adaln_modulate(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows,
                                    int32_t D, const omni_bf16* scale, const omni_bf16* shift,
                                    int64_t mod_item_stride, const int32_t* row_item_map, int32_t rows_per_item,
                                    float eps, omni_stream stream) {
-  if (!x || !y || !scale || !shift || rows <= 0 || D <= 0) return OMNI_ERR_BAD_ARG;
-  if (!row_item_map && rows_per_item <= 0) return OMNI_ERR_BAD_ARG;
-  if (D % 8 || D > 8192) return OMNI_ERR_UNSUPPORTED;
-  if (!omni_aligned16(x) || !omni_aligned16(y) || !omni_aligned16(scale) || !omni_aligned16(shift) || (ldx % 8) ||
-      (ldy % 8) || (mod_item_stride % 8))
-    return OMNI_ERR_ALIGN;
-  return launch_rownorm<0>(x, ldx, y, ldy, rows, D, scale, shift, mod_item_stride, row_item_map, rows_per_item, eps,
-                           static_cast<hipStream_t>(stream));
+  return omni_adaln_modulate_ex(x, ldx, y, ldy, rows, D, scale, shift, mod_item_stride, row_item_map, rows_per_item,
+                                eps, 0, stream);
 }
 
 extern "C" int omni_rmsnorm(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows, int32_t D,

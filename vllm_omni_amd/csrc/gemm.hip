@@ -132,6 +132,7 @@ OMNI_DEVINL omni_gemm_group pick_group(const omni_gemm_params& P, int gi) {
   OMNI_PICK(A); OMNI_PICK(lda); OMNI_PICK(a_row_map); OMNI_PICK(M); OMNI_PICK(W); OMNI_PICK(bias); OMNI_PICK(out);
   OMNI_PICK(out1); OMNI_PICK(out2); OMNI_PICK(ldo); OMNI_PICK(out_row_map); OMNI_PICK(res); OMNI_PICK(ldres);
   OMNI_PICK(gate); OMNI_PICK(gate_item_stride); OMNI_PICK(row_item_map); OMNI_PICK(rows_per_item);
+  OMNI_PICK(a_k32_rows); OMNI_PICK(out_k32_rows);
 #undef OMNI_PICK
   return G;
 }
@@ -329,7 +330,9 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
           o[e] = pack_bf16x2(bf16_lo(d0.r[j][e]) + bf16_lo(d0.g[j][e]) * bf16_lo(d0.c[j][e]),
                              bf16_hi(d0.r[j][e]) + bf16_hi(d0.g[j][e]) * bf16_hi(d0.c[j][e]));
       }
-      uint16_t* dst = obase + (int64_t)d0.ro[j] * G.ldo + ncol_out;
+      uint16_t* dst = G.out_k32_rows
+                          ? obase + ((int64_t)(ncol_out >> 5) * G.out_k32_rows + d0.ro[j]) * 32 + (ncol_out & 31)
+                          : obase + (int64_t)d0.ro[j] * G.ldo + ncol_out;
       // The store is issued from inline asm: `res` may alias `out` (in-place residual), and for a compiler-visible
       // store hipcc drains vmcnt(0) before the next loads although a thread never re-reads a row it has written.
       if (m0 + (b * BATCH + j) * 16 + rsub < M) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(o));
@@ -481,19 +484,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
     const int c = (lane & 3) ^ ((r >> 2) & 3);
     int ar = min(m0 + r, M - 1);
     if (G.a_row_map) ar = G.a_row_map[ar];
-    a_src[j] = G.A + (int64_t)ar * G.lda + c * 8;
+    a_src[j] = G.A + (G.a_k32_rows ? (int64_t)ar * RBK : (int64_t)ar * G.lda) + c * 8;
     const int wr = min(n0 + r, N - 1);
     w_src[j] = G.W + (P.w_k32_blocked ? (int64_t)wr * RBK : (int64_t)wr * K) + c * 8;
   }
   // elements between two k-stages of one W row: 32 in row-major, a whole [N][32] slab in the K32-blocked layout (where
   // the 16 rows of a DMA piece are 1 KiB contiguous -> 8 full-line requests per piece instead of 16 half-line ones)
   const int64_t wstep = P.w_k32_blocked ? (int64_t)N * RBK : RBK;
+  const int64_t astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * RBK : RBK;   // same for a K32-blocked A operand
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   auto issue_piece = [&](int slot, int st, int piece) {   // piece 0..3 = A0, W0, A1, W1 (1 KiB each)
     const uint32_t base = lds0 + slot * RSTAGE_BYTES + (wave * 2) * 1024;
     const int part = piece >> 1;
     if (piece & 1) glds16(w_src[part] + st * wstep, base + ROP_BYTES + part * 1024);
-    else glds16(a_src[part] + st * RBK, base + part * 1024);
+    else glds16(a_src[part] + st * astep, base + part * 1024);
   };
   auto issue_part = [&](int slot, int st, int part) {   // part 0..1
     issue_piece(slot, st, 2 * part);
@@ -843,7 +847,7 @@ bool epilogue_rows_coalescable(const omni_gemm_params* p) {
   static_assert(EPI_LDS_BYTES <= RLDS_BYTES, "C tile must fit the operand ring's LDS");
   for (int g = 0; g < p->ngroups; ++g) {
     const omni_gemm_group& G = p->g[g];
-    if (!omni_aligned16(G.out) || (G.ldo % 8) != 0) return false;
+    if (!omni_aligned16(G.out) || (!G.out_k32_rows && (G.ldo % 8) != 0)) return false;
     if (G.bias && !omni_aligned16(G.bias)) return false;
     if (p->epilogue == OMNI_EPI_BIAS_GATE_RES &&
         (!omni_aligned16(G.res) || !omni_aligned16(G.gate) || (G.ldres % 8) != 0 || (G.gate_item_stride % 8) != 0))
@@ -937,8 +941,8 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
   for (int g = 0; g < p->ngroups; ++g) {
     const omni_gemm_group& G = p->g[g];
     if (!G.A || !G.W || !G.out || G.M <= 0) return OMNI_ERR_BAD_ARG;
-    if (!omni_aligned16(G.A) || !omni_aligned16(G.W) || (G.lda % 8) != 0) return OMNI_ERR_ALIGN;
-    if ((reinterpret_cast<uintptr_t>(G.out) & 7) || (G.ldo % 4) != 0) return OMNI_ERR_ALIGN;
+    if (!omni_aligned16(G.A) || !omni_aligned16(G.W) || (!G.a_k32_rows && (G.lda % 8) != 0)) return OMNI_ERR_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(G.out) & 7) || (!G.out_k32_rows && (G.ldo % 4) != 0)) return OMNI_ERR_ALIGN;
     if (p->epilogue == OMNI_EPI_BIAS_GATE_RES) {
       if (!G.res || !G.gate || (!G.row_item_map && G.rows_per_item <= 0)) return OMNI_ERR_BAD_ARG;
       if ((G.ldres % 4) != 0 || (G.gate_item_stride % 4) != 0) return OMNI_ERR_ALIGN;
@@ -949,6 +953,17 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
   }
   if (p->epilogue == OMNI_EPI_BIAS_SPLIT3 && (p->split_n <= 0 || p->split_n % 32 != 0 || p->N != 3 * p->split_n))
     return OMNI_ERR_UNSUPPORTED;
+  for (int g = 0; g < p->ngroups; ++g) {
+    const omni_gemm_group& G = p->g[g];
+    if (G.a_k32_rows < 0 || G.out_k32_rows < 0) return OMNI_ERR_BAD_ARG;
+    if (G.a_k32_rows && !G.a_row_map && G.a_k32_rows < G.M) return OMNI_ERR_BAD_ARG;
+    if (G.out_k32_rows) {
+      if (p->epilogue != OMNI_EPI_BIAS && p->epilogue != OMNI_EPI_BIAS_GELU_TANH) return OMNI_ERR_UNSUPPORTED;
+      if (p->N % 32 != 0 || (!G.out_row_map && G.out_k32_rows < G.M)) return OMNI_ERR_BAD_ARG;
+    }
+    if ((G.a_k32_rows || G.out_k32_rows) && gemm_variant() != 1) return OMNI_ERR_UNSUPPORTED;
+    if (G.out_k32_rows && !epilogue_rows_coalescable(p)) return OMNI_ERR_ALIGN;
+  }
   if (p->w_k32_blocked != 0 && p->w_k32_blocked != 1) return OMNI_ERR_BAD_ARG;
   if (p->w_k32_blocked && gemm_variant() != 1) return OMNI_ERR_UNSUPPORTED;   // only the ring kernel reads that layout
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -44,7 +44,9 @@ class GemmGroupArgs:
     """Python-side mirror of omni_gemm_group (one stream of a grouped GEMM)."""
 
     def __init__(self, a, w, bias=None, out=None, *, a_row_map=None, out_row_map=None, out1=None, out2=None,
-                 res=None, gate=None, gate_item_stride=0, row_item_map=None, rows_per_item=0):
+                 res=None, gate=None, gate_item_stride=0, row_item_map=None, rows_per_item=0,
+                 a_k32_blocked=False, out_k32_blocked=False):
+        self.a_k32_blocked, self.out_k32_blocked = a_k32_blocked, out_k32_blocked
         self.a, self.w, self.bias, self.out = a, w, bias, out
         self.a_row_map, self.out_row_map, self.out1, self.out2 = a_row_map, out_row_map, out1, out2
         self.res, self.gate, self.gate_item_stride = res, gate, gate_item_stride
@@ -89,6 +91,8 @@ def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0
         G.gate, G.gate_item_stride = _p(g.gate, name="gate"), g.gate_item_stride
         G.row_item_map = _p(g.row_item_map, torch.int32, "row_item_map")
         G.rows_per_item = g.rows_per_item
+        G.a_k32_rows = g.a.shape[0] if g.a_k32_blocked else 0       # blocked tensors keep their [rows, K] shape
+        G.out_k32_rows = g.out.shape[0] if g.out_k32_blocked else 0
     N.check(N.lib().omni_gemm_bf16(C.byref(p), _stream()), "omni_gemm_bf16")
 
 
@@ -100,14 +104,22 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, *
     return out
 
 
+def k32_blocked_to_rows(t: torch.Tensor) -> torch.Tensor:
+    """Inverse of the K32-blocked activation / weight layout: an [R, K]-shaped tensor holding [K/32][R][32] -> row-major."""
+    r, k = t.shape
+    return t.view(k // 32, r, 32).transpose(0, 1).contiguous().view(r, k)
+
+
 def adaln_modulate(x, scale, shift, *, mod_item_stride: int, row_item_map=None, rows_per_item: int = 0,
-                   eps: float = 1e-6, out=None):
+                   eps: float = 1e-6, out=None, out_k32_blocked: bool = False):
+    """out_k32_blocked: y (same [rows, D] shape) holds the K32-blocked order [D/32][rows][32] (omni_adaln_modulate_ex)."""
     rows, D, ldx = _rows2d(x, "x")
-    y = torch.empty_like(x) if out is None else out
-    N.check(N.lib().omni_adaln_modulate(_p(x, name="x"), ldx, _p(y, name="y"), y.stride(0), rows, D,
-                                        _p(scale, name="scale"), _p(shift, name="shift"), mod_item_stride,
-                                        _p(row_item_map, torch.int32, "row_item_map"), rows_per_item, eps, _stream()),
-            "omni_adaln_modulate")
+    y = torch.empty(rows, D, dtype=BF16, device=x.device) if out is None else out
+    N.check(N.lib().omni_adaln_modulate_ex(_p(x, name="x"), ldx, _p(y, name="y"), y.stride(0), rows, D,
+                                           _p(scale, name="scale"), _p(shift, name="shift"), mod_item_stride,
+                                           _p(row_item_map, torch.int32, "row_item_map"), rows_per_item, eps,
+                                           y.shape[0] if out_k32_blocked else 0, _stream()),
+            "omni_adaln_modulate_ex")
     return y
 
 
@@ -140,15 +152,18 @@ def rope_interleaved(x, cos_tab, sin_tab, out=None):
     return y
 
 
-def flash_attn_varlen(q, k, v, cu_seqlens, num_heads: int, max_seqlen: int, softmax_scale: float, out=None):
-    """q,k,v [rows, H*128] (row strides free), cu_seqlens int32 [B+1] on device."""
+def flash_attn_varlen(q, k, v, cu_seqlens, num_heads: int, max_seqlen: int, softmax_scale: float, out=None,
+                      out_k32_blocked: bool = False):
+    """q,k,v [rows, H*128] (row strides free), cu_seqlens int32 [B+1] on device.  out_k32_blocked: out (same shape)
+    holds the K32-blocked order [H*128/32][rows][32] (omni_flash_attn_fwd_ex)."""
     rows, HD, ldq = _rows2d(q, "q")
     o = torch.empty(rows, HD, dtype=BF16, device=q.device) if out is None else out
-    N.check(N.lib().omni_flash_attn_fwd(_p(q, name="q"), _p(k, name="k"), _p(v, name="v"), _p(o, name="out"), ldq,
-                                        k.stride(0), v.stride(0), o.stride(0),
-                                        _p(cu_seqlens, torch.int32, "cu_seqlens"), cu_seqlens.numel() - 1, num_heads,
-                                        HD // num_heads, max_seqlen, softmax_scale, _stream()),
-            "omni_flash_attn_fwd")
+    N.check(N.lib().omni_flash_attn_fwd_ex(_p(q, name="q"), _p(k, name="k"), _p(v, name="v"), _p(o, name="out"), ldq,
+                                           k.stride(0), v.stride(0), o.stride(0),
+                                           _p(cu_seqlens, torch.int32, "cu_seqlens"), cu_seqlens.numel() - 1, num_heads,
+                                           HD // num_heads, max_seqlen, softmax_scale,
+                                           o.shape[0] if out_k32_blocked else 0, _stream()),
+            "omni_flash_attn_fwd_ex")
     return o
 
 
