@@ -109,10 +109,19 @@ def measure_roofline(dev, R: int = 3) -> dict:
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 2.0 * (Mi + Mt) * N * K
     ach = flops / sec / 1e12
+    # HBM/fabric bytes per launch of this very kernel + shape: bench.py cannot run rocprofv3 on itself, so it reports the
+    # committed PMC measurement (tools/profile_round.sh -> tools/summarize_prof.py; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_roofline_traffic_pmc.json")) as fh:
+            traffic, traffic_src = json.load(fh)["traffic_bytes"], "profiles/r01_roofline_traffic_pmc.json (rocprofv3 --pmc)"
+    except (OSError, KeyError, ValueError):
+        pass
     return {"bound": "mfma", "kernel": f"gemm_bf16_ring_kernel<OMNI_EPI_BIAS_GELU_TANH, 0, true> M={Mi}+{Mt} N=12288 K=3072"
                                       + (" (W" + (", A, out" if ablk else "") + " K32-blocked)" if blocked else ""),
             "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
-            "flop_per_launch": flops, "avg_launch_us": sec * 1e6, "traffic": None}
+            "flop_per_launch": flops, "avg_launch_us": sec * 1e6, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes": 2.0 * ((Mi + Mt) * K + 2 * N * K + (Mi + Mt) * N)}
 
 
 def main():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch ONE hot kernel a few times (for rocprofv3 --kernel-trace / --pmc passes).
-   python tools/run_kernel.py gemm_mlp_up|gemm_mlp_down|gemm_qkv|gemm_out|attention|forward [iters]"""
+   python tools/run_kernel.py roofline|gemm_mlp_up|gemm_mlp_down|gemm_qkv|gemm_out|attention|attention6 [iters]"""
 import math
 import os
 import sys
@@ -28,8 +28,18 @@ if which.startswith("gemm"):
     xi, xt, wi, wt, b = rn(Mi, K), rn(Mt, K), rn(N, K, s=0.02), rn(N, K, s=0.02), rn(N)
     oi, ot = torch.empty(Mi, N, dtype=BF16, device=dev), torch.empty(Mt, N, dtype=BF16, device=dev)
     fn = lambda: ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi), ops.GemmGroupArgs(xt, wt, b, ot)], epi)  # noqa: E731
-elif which == "attention":
-    B, H, S = 2, 24, 4160
+elif which == "roofline":
+    # exactly bench.py's roofline launch: MLP-up + GELU at the step-batch shape (R=3), production layouts
+    R = 3
+    Mi, Mt, N, K = 2 * R * 4096, 2 * R * 64, 4 * D, D
+    xi, xt = ops.w_to_k32_blocked(rn(Mi, K)), ops.w_to_k32_blocked(rn(Mt, K))
+    wi, wt, b = ops.w_to_k32_blocked(rn(N, K, s=0.02)), ops.w_to_k32_blocked(rn(N, K, s=0.02)), rn(N)
+    oi, ot = torch.empty(Mi, N, dtype=BF16, device=dev), torch.empty(Mt, N, dtype=BF16, device=dev)
+    fn = lambda: ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi, a_k32_blocked=True, out_k32_blocked=True),  # noqa: E731
+                           ops.GemmGroupArgs(xt, wt, b, ot, a_k32_blocked=True, out_k32_blocked=True)],
+                          ops.EPI_BIAS_GELU_TANH, w_k32_blocked=True)
+elif which in ("attention", "attention6"):
+    B, H, S = (6 if which == "attention6" else 2), 24, 4160
     q, k, v = rn(B * S, H * 128), rn(B * S, H * 128), rn(B * S, H * 128)
     cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
     fn = lambda: ops.flash_attn_varlen(q, k, v, cu, H, S, 1 / math.sqrt(128))  # noqa: E731

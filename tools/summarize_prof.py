@@ -39,3 +39,26 @@ for f in sorted(glob.glob(f"{root}/pmc_{tag}_*/*.db")):
     for k, c, n, v, d in rows:
         if "gemm" in k or "attn" in k:
             print(f"   {short(k)[:70]:70s} {c:28s} n={n:3d} mean {v:18.1f}  avg_dur_us {d/1e3 if d else 0:9.2f}")
+
+# roofline-kernel fabric traffic per launch -> JSON that bench.py reports as roofline.traffic
+# (MI355X_MICROARCH.md "HBM": FETCH_SIZE is in KB and counts 128-B requests at 64 B on gfx950 -> x2; WRITE_SIZE in KB, uncalibrated)
+import json
+vals = {}
+for f in sorted(glob.glob(f"{root}/pmc_{tag}_roofline_*/*.db")):
+    con = sqlite3.connect(f)
+    try:
+        for k, c, v in con.execute("select kernel_name, counter_name, avg(value) from counters_collection "
+                                   "where kernel_name like '%gemm_bf16_ring%' group by kernel_name, counter_name"):
+            vals[c] = v
+    except Exception:  # noqa: BLE001
+        pass
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    out = {"kernel": "gemm_bf16_ring_kernel<GELU> M=24576+384 N=12288 K=3072 (bench.py roofline launch)",
+           "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+           "traffic_bytes": 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024,
+           "note": "fabric-side bytes per launch = 2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE; "
+                   "Infinity-Cache hits are included, so this bounds HBM traffic from above",
+           "tcc_hit": vals.get("TCC_HIT_sum"), "tcc_miss": vals.get("TCC_MISS_sum")}
+    with open(f"profiles/{tag}_roofline_traffic_pmc.json", "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("wrote", f"profiles/{tag}_roofline_traffic_pmc.json", out["traffic_bytes"] / 1e6, "MB")
