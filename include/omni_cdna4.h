@@ -61,7 +61,11 @@ typedef enum {
   OMNI_EPI_BIAS = 0,          /* y = acc + bias                                              */
   OMNI_EPI_BIAS_GELU_TANH = 1,/* y = gelu_tanh(acc + bias)                                   */
   OMNI_EPI_BIAS_GATE_RES = 2, /* y = res + gate[item(row)] * (acc + bias)   (res may alias y) */
-  OMNI_EPI_BIAS_SPLIT3 = 3    /* y = acc + bias, column block n/split_n selects out/out1/out2 */
+  OMNI_EPI_BIAS_SPLIT3 = 3,   /* y = acc + bias, column block n/split_n selects out/out1/out2 */
+  OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE = 4 /* SPLIT3, and the out / out1 blocks (q, k) additionally get the per-head
+                               * RMSNorm(128) * w and the interleaved RoPE of omni_qk_norm_rope applied to the bf16-rounded
+                               * linear output before the store (bit-identical to SPLIT3 followed by omni_qk_norm_rope);
+                               * needs split_n % 128 == 0 and the qk_* fields of every group */
 } omni_epilogue;
 
 typedef struct {
@@ -82,6 +86,14 @@ typedef struct {
   int64_t gate_item_stride;
   const int32_t* row_item_map; /* nullable: item (batch element) of logical row r          */
   int32_t rows_per_item;    /* used when row_item_map == NULL: item = r / rows_per_item    */
+  /* SPLIT3_QKNORM_ROPE only: RMSNorm weights [128] of the q and k heads of this stream, RoPE tables [npos, 64] and the
+   * table row of every OUTPUT row (indexed by out_row_map[r], or r) */
+  const omni_bf16* qk_norm_q_w;
+  const omni_bf16* qk_norm_k_w;
+  const omni_bf16* qk_rope_cos;
+  const omni_bf16* qk_rope_sin;
+  const int32_t* qk_row_pos;
+  float qk_eps;
   int32_t a_k32_rows;       /* 0: A is row-major [*, lda].  R > 0: A is K32-blocked [K/32][R][32] (element (r,k) at
                              * ((k/32)*R + r)*32 + k%32; lda ignored; a_row_map still picks r).  Same idea as
                              * omni_gemm_params.w_k32_blocked, for activations produced by this library's own kernels */

@@ -184,6 +184,42 @@ def test_gemm_split3_scatter_to_joint():
         assert rel_l2(got, ref[:, j * D:(j + 1) * D]) <= 4e-3
 
 
+def test_gemm_split3_fused_qk_norm_rope_is_bit_identical_to_the_two_kernel_path():
+    """OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE == SPLIT3 followed by omni_qk_norm_rope on q and k (and v untouched)."""
+    from vllm_omni_amd import ops
+    from vllm_omni_amd.diffusion.models.qwen_image.rope import rope_table
+
+    H, D, K = 2, 256, 128
+    T, grid = 20, (1, 18, 16)                      # 20 text rows, 288 image rows -> two m-tiles for the image group
+    Mi, Mt = grid[1] * grid[2], T
+    rows = Mi + Mt
+    xi, xt = rnd((Mi, K), 1), rnd((Mt, K), 2)
+    wi, wt, bi, bt = rnd((3 * D, K), 3, 0.05), rnd((3 * D, K), 4, 0.05), rnd((3 * D,), 5), rnd((3 * D,), 6)
+    nw = [bf16_round(rnd((128,), 10 + i, 0.2) + 1) for i in range(4)]      # q_img, k_img, q_txt, k_txt
+    cos, sin = rope_table(grid, T)
+    cosb, sinb = g_(bf16_round(cos)), g_(bf16_round(sin))
+    joint_pos = torch.arange(rows, dtype=torch.int32)                        # joint order: text first, then image
+    mt, mi = joint_pos[:T].clone(), joint_pos[T:].clone()                     # out_row_map of each stream
+    outs = []
+    for fused in (False, True):
+        q = torch.zeros(rows, D, dtype=BF16, device=dev())
+        k, v = torch.zeros_like(q), torch.zeros_like(q)
+        kw_i = dict(qk_norm_q_w=g_(nw[0]), qk_norm_k_w=g_(nw[1]), qk_rope_cos=cosb, qk_rope_sin=sinb,
+                    qk_row_pos=joint_pos[mi.long()].to(dev())) if fused else {}
+        kw_t = dict(qk_norm_q_w=g_(nw[2]), qk_norm_k_w=g_(nw[3]), qk_rope_cos=cosb, qk_rope_sin=sinb,
+                    qk_row_pos=joint_pos[mt.long()].to(dev())) if fused else {}
+        ops.gemm([ops.GemmGroupArgs(g_(xi), g_(wi), g_(bi), q, out1=k, out2=v, out_row_map=mi.to(dev()), **kw_i),
+                  ops.GemmGroupArgs(g_(xt), g_(wt), g_(bt), q, out1=k, out2=v, out_row_map=mt.to(dev()), **kw_t)],
+                 ops.EPI_BIAS_SPLIT3_QKNORM_ROPE if fused else ops.EPI_BIAS_SPLIT3, split_n=D)
+        if not fused:
+            ops.qk_norm_rope_(q, H, g_(nw[0]), g_(nw[2]), cosb, sinb, joint_pos.to(dev()), T)
+            ops.qk_norm_rope_(k, H, g_(nw[1]), g_(nw[3]), cosb, sinb, joint_pos.to(dev()), T)
+        torch.cuda.synchronize()
+        outs.append((q, k, v))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_gemm_rejects_bad_k():
     from vllm_omni_amd import ops
     from vllm_omni_amd._native import OmniNativeError

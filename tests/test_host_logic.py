@@ -34,7 +34,7 @@ def test_ctypes_struct_layout_matches_c():
     # sizes the C compiler produces for the ABI structs (computed with the same alignment rules)
     from vllm_omni_amd import _native as N
 
-    assert ctypes.sizeof(N.GemmGroup) == 144 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 144
+    assert ctypes.sizeof(N.GemmGroup) == 192 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 192
     assert ctypes.sizeof(N.DitLayerWeights) == 24 * 8
     assert N.GemmParams.g.offset == 24 and N.DitWeights.t_lin1_w.offset == 32   # w_k32_blocked flags live in padding / ABI v2
 

@@ -32,6 +32,8 @@ class GemmGroup(C.Structure):
         ("res", c_bf16_p), ("ldres", C.c_int64),
         ("gate", c_bf16_p), ("gate_item_stride", C.c_int64),
         ("row_item_map", c_i32_p), ("rows_per_item", C.c_int32),
+        ("qk_norm_q_w", c_bf16_p), ("qk_norm_k_w", c_bf16_p), ("qk_rope_cos", c_bf16_p), ("qk_rope_sin", c_bf16_p),
+        ("qk_row_pos", c_i32_p), ("qk_eps", C.c_float),
         ("a_k32_rows", C.c_int32), ("out_k32_rows", C.c_int32),
     ]
 

@@ -371,8 +371,13 @@ OMNI_DEVINL float xhalf_sum(float x) {
 #endif
 // NW = waves per workgroup sharing one K/V tile stream: 4 (128 queries, 2 workgroups per CU) or 8 (256 queries, one
 // workgroup per CU: half the LDS-DMA write traffic per query; the LDS write port is shared with the fragment reads).
-template <int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pipe_kernel(
+// NQ = 32-query blocks per wave.  NQ = 2 (with NW = 4: 256 queries per workgroup, ONE wave per SIMD and its whole
+// 512-entry register file): every K / V^T fragment read from LDS feeds two MFMAs and the DMA per query halves — the two
+// resources the ablations show this loop to be limited by.  The accumulators then live in AGPRs (an inline
+// asm with an "a" constraint switches hipcc to the AGPR form of the MFMAs; without it the second half of the register file
+// is only used as spill space).
+template <int NW, int NQ = 1>
+__global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash_attn_fwd_pipe_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
     const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e, int out_k32_rows) {
@@ -387,21 +392,26 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
   const int b = hb / H, h = hb - b * H;
   const int seq_start = cu_seqlens[b];
   const int seq_len = cu_seqlens[b + 1] - seq_start;
-  constexpr int QBLK = 32 * NW;
+  constexpr int QBLK = 32 * NW * NQ;
   constexpr int NPIECE = 16 / NW;   // DMA pieces (1 KiB) per wave per operand per tile
   if (qb * QBLK >= seq_len) return;
 
   const char* kbase = reinterpret_cast<const char*>(k + (int64_t)seq_start * ldk + h * DH);
   const char* vbase = reinterpret_cast<const char*>(v + (int64_t)seq_start * ldv + h * DH);
 
-  bf16x8_t qf[8];
-  {
-    const int qrow = min(qb * QBLK + wave * 32 + l31, seq_len - 1);
+  if (NQ == 2) {
+    float agpr_form_ = 0.f;
+    asm volatile("" : "+a"(agpr_form_));   // see the note above the kernel
+  }
+  bf16x8_t qf[NQ][8];
+#pragma unroll
+  for (int bq = 0; bq < NQ; ++bq) {
+    const int qrow = min(qb * QBLK + (wave * NQ + bq) * 32 + l31, seq_len - 1);
     const uint16_t* qp = q + (int64_t)(seq_start + qrow) * ldq + h * DH + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+    for (int ks = 0; ks < 8; ++ks) qf[bq][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));   // see flash_attn_fwd_kernel: no rematerialisation
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[bq][ks]));   // see flash_attn_fwd_kernel: no rematerialisation
   }
 
   // ---- DMA sources.  One wave-instruction = 1 KiB of the LDS image, lane L -> byte 16*L of the piece.
@@ -454,12 +464,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
   for (int ks = 0; ks < 8; ++ks) k_addr[ks] = l31 * 256 + ((((uint32_t)(ks * 2 + hi)) ^ (l31 & 15)) << 4);
   const uint32_t v_lane_off = K_TILE_BYTES + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + hi * 256;
 
-  f32x16_t o[4];
+  f32x16_t o[NQ][4];
+  float m_run[NQ], l_run[NQ];
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int bq = 0; bq < NQ; ++bq) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[d][i] = 0.0f;
-  float m_run = -INFINITY, l_run = 0.0f;
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[bq][d][i] = 0.0f;
+    m_run[bq] = -INFINITY;
+    l_run[bq] = 0.0f;
+  }
 
   bf16x8_t kf[4];
 #define OMNI_KREAD(i, kst)                                                                                          \
@@ -474,7 +489,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
     else if ((i) == 14) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");                       \
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                           \
-    SN[(i) >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[(i) & 3], qf[(i) & 7], SN[(i) >> 3], 0, 0, 0); \
+    _Pragma("unroll") for (int bq_ = 0; bq_ < NQ; ++bq_)                                          \
+      SN[bq_][(i) >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[(i) & 3], qf[bq_][(i) & 7], SN[bq_][(i) >> 3], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     if ((i) + 4 < 16) OMNI_KREAD((i) + 4, kst);                                                  \
     CHUNK;                                                                                       \
@@ -492,20 +508,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
   } while (0)
 #define OMNI_NOCHUNK(i) (void)0
 
-  auto mask_tail = [&](f32x16_t (&S)[2], int kv0) {
+  auto mask_tail = [&](f32x16_t (&S)[NQ][2], int kv0) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (key >= seq_len) S[j][r] = -INFINITY;
+        if (key >= seq_len) {
+#pragma unroll
+          for (int bq = 0; bq < NQ; ++bq) S[bq][j][r] = -INFINITY;
+        }
       }
   };
-  auto zero_s = [&](f32x16_t (&S)[2]) {
+  auto zero_s = [&](f32x16_t (&S)[NQ][2]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int bq = 0; bq < NQ; ++bq)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) S[j][i] = 0.0f;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[bq][j][i] = 0.0f;
   };
 
   // ---- prologue: tiles 0 (K, V) and 1 (K) in flight, S(0) and its row max -------------------------------------
@@ -514,23 +535,26 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
   if (ntiles > 1) issue_K(1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  f32x16_t sA[2], sB[2];
-  float mxA, mxB = 0.0f;
+  f32x16_t sA[NQ][2], sB[NQ][2];
+  float mxA[NQ], mxB[NQ];
   zero_s(sA);
   OMNI_QK_ALL(sA, lds0, OMNI_NOCHUNK);
   if (KVBLK > seq_len) mask_tail(sA, 0);
-  {
-    float mx = sA[0][0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sA[0][r]);
+  for (int bq = 0; bq < NQ; ++bq) {
+    float mx = sA[bq][0][0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sA[1][r]);
-    mxA = xhalf_max(mx);
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sA[bq][0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sA[bq][1][r]);
+    mxA[bq] = xhalf_max(mx);
+    mxB[bq] = 0.0f;
   }
 
   // One iteration; SC = S(t) (complete, row max mxc known), SN receives S(t+1).
   // has_next is a compile-time constant: a run-time flag puts a branch between every two MFMAs of the P.V phase.
-  auto iteration = [&](auto has_next_c, int t, f32x16_t (&SC)[2], f32x16_t (&SN)[2], float mxc, float& mxn) {
+  auto iteration = [&](auto has_next_c, int t, f32x16_t (&SC)[NQ][2], f32x16_t (&SN)[NQ][2], float (&mxc)[NQ],
+                       float (&mxn)[NQ]) {
     constexpr bool has_next = decltype(has_next_c)::value;
     const bool dma_k = !(OMNI_ATTN_ABL & 4) && t + 2 < ntiles, dma_v = !(OMNI_ATTN_ABL & 4) && has_next;
     if (OMNI_ATTN_DMA_BURST) {
@@ -540,36 +564,43 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
 
     // defer-max decision (see flash_attn_fwd_kernel); the rescale is rare after the first tiles
     constexpr float DEFER = 6.0f;
-    if (!__all((mxc - m_run) * scale_log2e <= DEFER)) {
-      const float m_new = fmaxf(m_run, mxc);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
-    }
-    const float mneg = -m_run * scale_log2e;
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    const f32x2_t scale2 = {scale_log2e, scale_log2e}, mneg2 = {mneg, mneg};
-    f32x2_t psum2 = {0.0f, 0.0f};
-    uint32_t pfu[2][2][4];
+    const f32x2_t scale2 = {scale_log2e, scale_log2e};
+    f32x2_t mneg2[NQ], psum2[NQ];
+    uint32_t pfu[NQ][2][2][4];
+#pragma unroll
+    for (int bq = 0; bq < NQ; ++bq) {
+      if (!__all((mxc[bq] - m_run[bq]) * scale_log2e <= DEFER)) {
+        const float m_new = fmaxf(m_run[bq], mxc[bq]);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[bq] - m_new) * scale_log2e);
+        m_run[bq] = m_new;
+        l_run[bq] *= alpha;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[bq][d][i] *= alpha;
+      }
+      const float mneg = -m_run[bq] * scale_log2e;
+      mneg2[bq][0] = mneg; mneg2[bq][1] = mneg;
+      psum2[bq][0] = 0.0f; psum2[bq][1] = 0.0f;
+    }
     // exp chunk i: S elements (flat index over j, r) 2i and 2i+1 -> one packed bf16 pair of P
 #define OMNI_EXP_CHUNK(i)                                                                                        \
   do {                                                                                                           \
-    if (OMNI_ATTN_ABL & 8) { pfu[(i) >> 3][((i) >> 2) & 1][(i) & 3] = 0x3c003c00u; break; }                        \
-    /* packed fp32 (v_pk_fma_f32 / v_pk_add_f32): S elements 2i, 2i+1 are an aligned register pair */          \
-    const f32x2_t x_ = {SC[(i) >> 3][(2 * (i)) & 15], SC[(i) >> 3][((2 * (i)) & 15) + 1]};                         \
-    f32x2_t y_;                                                                                                  \
-    if (OMNI_ATTN_PKFMA) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y_) : "v"(x_), "v"(scale2), "v"(mneg2)); /* hipcc scalarises the builtin */ \
-    else y_ = __builtin_elementwise_fma(x_, scale2, mneg2);                                                      \
-    const float p0_ = __builtin_amdgcn_exp2f(y_[0]), p1_ = __builtin_amdgcn_exp2f(y_[1]);                         \
-    const f32x2_t pp_ = {p0_, p1_};                                                                              \
-    psum2 += pp_;                                                                                                \
-    uint32_t pk_ = pack_bf16x2(p0_, p1_);                                                                        \
-    asm volatile("" : "+v"(pk_), "+v"(psum2)); /* pin: pure arithmetic is otherwise sunk below the whole MFMA run */ \
-    pfu[(i) >> 3][((i) >> 2) & 1][(i) & 3] = pk_;                                                                \
+    _Pragma("unroll") for (int bq_ = 0; bq_ < NQ; ++bq_) {                                                        \
+      if (OMNI_ATTN_ABL & 8) { pfu[bq_][(i) >> 3][((i) >> 2) & 1][(i) & 3] = 0x3c003c00u; continue; }              \
+      /* packed fp32 (v_pk_add_f32): S elements 2i, 2i+1 are an aligned register pair */                         \
+      const f32x2_t x_ = {SC[bq_][(i) >> 3][(2 * (i)) & 15], SC[bq_][(i) >> 3][((2 * (i)) & 15) + 1]};             \
+      f32x2_t y_;                                                                                                \
+      if (OMNI_ATTN_PKFMA) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y_) : "v"(x_), "v"(scale2), "v"(mneg2[bq_])); \
+      else y_ = __builtin_elementwise_fma(x_, scale2, mneg2[bq_]);                                               \
+      const float p0_ = __builtin_amdgcn_exp2f(y_[0]), p1_ = __builtin_amdgcn_exp2f(y_[1]);                       \
+      const f32x2_t pp_ = {p0_, p1_};                                                                            \
+      psum2[bq_] += pp_;                                                                                         \
+      uint32_t pk_ = pack_bf16x2(p0_, p1_);                                                                      \
+      asm volatile("" : "+v"(pk_), "+v"(psum2[bq_])); /* pin: pure arithmetic is otherwise sunk below the MFMA run */ \
+      pfu[bq_][(i) >> 3][((i) >> 2) & 1][(i) & 3] = pk_;                                                         \
+    }                                                                                                            \
   } while (0)
     if (has_next) {
       const uint32_t kst = lds0 + ((t + 1) & 1) * STAGE_BYTES;
@@ -582,11 +613,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
       for (int i = 0; i < 16; ++i) OMNI_EXP_CHUNK(i);
     }
 #undef OMNI_EXP_CHUNK
-    l_run += psum2[0] + psum2[1];
+#pragma unroll
+    for (int bq = 0; bq < NQ; ++bq) l_run[bq] += psum2[bq][0] + psum2[bq][1];
     if (has_next && (t + 2) * KVBLK > seq_len) mask_tail(SN, (t + 1) * KVBLK);
 
     // ---- O^T += V^T P^T (tile t), with the row max of S(t+1) in the MFMA shadows
-    float mx = has_next ? SN[0][0] : 0.0f;
+    float mx[NQ];
+#pragma unroll
+    for (int bq = 0; bq < NQ; ++bq) mx[bq] = has_next ? SN[bq][0][0] : 0.0f;
     {
       const uint32_t vb = lds0 + (t & 1) * STAGE_BYTES + v_lane_off;
       u32x2_t vlo[4], vhi[4];
@@ -609,19 +643,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     {                                                                                                          \
       const u32x4_t w_ = {vlo[(i) & 3][0], vlo[(i) & 3][1], vhi[(i) & 3][0], vhi[(i) & 3][1]};                 \
-      const u32x4_t p_ = {pfu[(i) >> 3][((i) >> 2) & 1][0], pfu[(i) >> 3][((i) >> 2) & 1][1],                  \
-                          pfu[(i) >> 3][((i) >> 2) & 1][2], pfu[(i) >> 3][((i) >> 2) & 1][3]};                 \
-      o[(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w_),                   \
-                                                           __builtin_bit_cast(bf16x8_t, p_), o[(i) & 3], 0, 0, 0); \
+      _Pragma("unroll") for (int bq_ = 0; bq_ < NQ; ++bq_) {                                                    \
+        const u32x4_t p_ = {pfu[bq_][(i) >> 3][((i) >> 2) & 1][0], pfu[bq_][(i) >> 3][((i) >> 2) & 1][1],      \
+                            pfu[bq_][(i) >> 3][((i) >> 2) & 1][2], pfu[bq_][(i) >> 3][((i) >> 2) & 1][3]};     \
+        o[bq_][(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w_),            \
+                                                    __builtin_bit_cast(bf16x8_t, p_), o[bq_][(i) & 3], 0, 0, 0); \
+      }                                                                                                        \
     }                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
 #define OMNI_MAX_CHUNK(c)                                                                                       \
   do {                                                                                                          \
     if (has_next) {                                                                                             \
-      mx = fmaxf(fmaxf(mx, SN[(c) >> 2][((c) & 3) * 4 + 0]), SN[(c) >> 2][((c) & 3) * 4 + 1]);                   \
-      mx = fmaxf(fmaxf(mx, SN[(c) >> 2][((c) & 3) * 4 + 2]), SN[(c) >> 2][((c) & 3) * 4 + 3]);                   \
-      asm volatile("" : "+v"(mx));                                                                              \
+      _Pragma("unroll") for (int bq_ = 0; bq_ < NQ; ++bq_) {                                                     \
+        mx[bq_] = fmaxf(fmaxf(mx[bq_], SN[bq_][(c) >> 2][((c) & 3) * 4 + 0]), SN[bq_][(c) >> 2][((c) & 3) * 4 + 1]); \
+        mx[bq_] = fmaxf(fmaxf(mx[bq_], SN[bq_][(c) >> 2][((c) & 3) * 4 + 2]), SN[bq_][(c) >> 2][((c) & 3) * 4 + 3]); \
+        asm volatile("" : "+v"(mx[bq_]));                                                                       \
+      }                                                                                                         \
     }                                                                                                           \
   } while (0)
 // DMA slot j (0 .. 2*NPIECE-1): K(t+2) pieces first (needed one iteration from now), then V(t+1) pieces
@@ -650,7 +688,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
 #undef OMNI_VREAD
 #undef OMNI_VOFF
     }
-    if (has_next) mxn = xhalf_max(mx);
+    if (has_next) {
+#pragma unroll
+      for (int bq = 0; bq < NQ; ++bq) mxn[bq] = xhalf_max(mx[bq]);
+    }
     if (!(OMNI_ATTN_ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this iteration's DMA has landed
     if (!(OMNI_ATTN_ABL & 2)) __syncthreads();          // ... for every wave; and every wave is done with K(t+1), V(t)
   };
@@ -676,9 +717,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
 #undef OMNI_NOCHUNK
 
   // ---- epilogue -------------------------------------------------------------------------------------------------
-  {
-    const float inv = 1.0f / xhalf_sum(l_run);
-    const int qrow = qb * QBLK + wave * 32 + l31;
+#pragma unroll
+  for (int bq = 0; bq < NQ; ++bq) {
+    const float inv = 1.0f / xhalf_sum(l_run[bq]);
+    const int qrow = qb * QBLK + (wave * NQ + bq) * 32 + l31;
     if (qrow < seq_len) {
       // row-major: out[row][h*128 + d*32 + qd*8 + hi*4 ..];  K32-blocked: slab h*4 + d, [slab][row][qd*8 + hi*4 ..]
       uint16_t* op = out_k32_rows ? out + ((int64_t)(h * 4) * out_k32_rows + seq_start + qrow) * 32 + hi * 4
@@ -689,8 +731,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pip
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           u32x2_t w;
-          w[0] = pack_bf16x2(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv);
-          w[1] = pack_bf16x2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
+          w[0] = pack_bf16x2(o[bq][d][qd * 4 + 0] * inv, o[bq][d][qd * 4 + 1] * inv);
+          w[1] = pack_bf16x2(o[bq][d][qd * 4 + 2] * inv, o[bq][d][qd * 4 + 3] * inv);
           *reinterpret_cast<u32x2_t*>(op + d * dstep + qd * 8) = w;
         }
     }
@@ -734,20 +776,20 @@ int attn_pipe_waves(int n_heads_total, int max_seqlen) {
   const long wgs8 = (long)n_heads_total * ((max_seqlen + 255) / 256);
   return wgs8 >= 6 * 256 ? 8 : 4;
 }
-template <int NW>
+template <int NW, int NQ = 1>
 int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
                 int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
                 float softmax_scale, int out_k32_rows, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe_kernel<NW>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe_kernel<NW, NQ>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
     attr_set = true;
   }
-  const int qblocks = (max_seqlen + 32 * NW - 1) / (32 * NW);
+  const int qblocks = (max_seqlen + 32 * NW * NQ - 1) / (32 * NW * NQ);
   const int nh = B * H;
-  hipLaunchKernelGGL(flash_attn_fwd_pipe_kernel<NW>, dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
+  hipLaunchKernelGGL((flash_attn_fwd_pipe_kernel<NW, NQ>), dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
                      ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows);
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
@@ -785,6 +827,8 @@ extern "C" int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, co
     return OMNI_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (attn_pipelined()) {
+    if (attn_variant() == 2)   // OMNI_ATTN_NQ=2: 4 waves x 64 queries, one wave per SIMD
+      return launch_pipe<4, 2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s);
     if (attn_pipe_waves(B * H, max_seqlen) == 8)
       return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s);
     return launch_pipe<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s);

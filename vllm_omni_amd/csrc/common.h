@@ -54,3 +54,6 @@ OMNI_DEVINL float wave_max(float v) {
   } while (0)
 
 static inline bool omni_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// internal (not part of the C-ABI): dst[i] = src[idx[i]] for int32 maps; used by omni_dit_forward
+int omni_internal_gather_i32(int32_t* dst, const int32_t* src, const int32_t* idx, int32_t n, void* stream);

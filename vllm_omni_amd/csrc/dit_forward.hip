@@ -17,6 +17,7 @@ namespace {
 struct Workspace {
   omni_bf16 *tproj, *th, *temb, *mod_img, *mod_txt, *emb_out;
   omni_bf16 *hidden_img, *hidden_txt, *xn, *txt_normed, *q, *k, *v, *attn, *mlp_h;
+  int32_t *img_pos, *txt_pos;   // RoPE table row of every image / text stream row (joint_pos gathered through the joint-row maps)
   size_t total;
 };
 
@@ -48,6 +49,8 @@ Workspace carve(void* base, const omni_dit_weights* w, int64_t Ri, int64_t Rt, i
   ws.v = take(Rj * D);
   ws.attn = take(Rj * D);
   ws.mlp_h = take(Rj * 4 * D);
+  ws.img_pos = reinterpret_cast<int32_t*>(take(Ri * 2));
+  ws.txt_pos = reinterpret_cast<int32_t*>(take(Rt * 2));
   ws.total = off;
   return ws;
 }
@@ -125,6 +128,16 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     const char* e = getenv("OMNI_DIT_ACT_BLOCKED");
     return e ? atoi(e) != 0 : true;
   }();
+  // q/k RMSNorm + RoPE inside the QKV GEMM's coalesced epilogue (saves two passes over q and k per layer); dev knob
+  // OMNI_DIT_FUSE_QKROPE=0 restores the separate omni_qk_norm_rope launches (bit-identical results).
+  static const bool fuse_qkrope = [] {
+    const char* e = getenv("OMNI_DIT_FUSE_QKROPE");
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (fuse_qkrope) {
+    OMNI_TRY(omni_internal_gather_i32(ws.img_pos, b->joint_pos, b->img_joint_row, Ri, stream));
+    OMNI_TRY(omni_internal_gather_i32(ws.txt_pos, b->joint_pos, b->txt_joint_row, Rt, stream));
+  }
   const bool blk = act_blocked && (D % 32 == 0);
   const int32_t bRi = blk ? Ri : 0, bRt = blk ? Rt : 0, bRj = blk ? Ri + Rt : 0;
 
@@ -143,7 +156,15 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     // fused QKV projections of both streams, scattered into the joint q/k/v (reference :380-394, :414-416)
     {
       omni_gemm_params p = {};
-      p.ngroups = 2; p.N = 3 * D; p.K = D; p.epilogue = OMNI_EPI_BIAS_SPLIT3; p.split_n = D; p.w_k32_blocked = w->gemm_w_k32_blocked;
+      p.ngroups = 2; p.N = 3 * D; p.K = D; p.split_n = D; p.w_k32_blocked = w->gemm_w_k32_blocked;
+      p.epilogue = fuse_qkrope ? OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE : OMNI_EPI_BIAS_SPLIT3;
+      if (fuse_qkrope) {
+        p.g[0].qk_norm_q_w = L.norm_q_w; p.g[0].qk_norm_k_w = L.norm_k_w; p.g[0].qk_row_pos = ws.img_pos;
+        p.g[1].qk_norm_q_w = L.norm_added_q_w; p.g[1].qk_norm_k_w = L.norm_added_k_w; p.g[1].qk_row_pos = ws.txt_pos;
+        for (int g = 0; g < 2; ++g) {
+          p.g[g].qk_rope_cos = b->rope_cos; p.g[g].qk_rope_sin = b->rope_sin; p.g[g].qk_eps = eps;
+        }
+      }
       p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt;
       p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = L.to_qkv_w; p.g[0].bias = L.to_qkv_b;
       p.g[0].out = ws.q; p.g[0].out1 = ws.k; p.g[0].out2 = ws.v; p.g[0].ldo = D; p.g[0].out_row_map = b->img_joint_row;
@@ -152,10 +173,12 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
       OMNI_TRY(omni_gemm_bf16(&p, stream));
     }
     // per-head RMSNorm + RoPE on q and k (reference :397-410)
-    OMNI_TRY(omni_qk_norm_rope(ws.q, D, Ri + Rt, w->num_heads, L.norm_q_w, L.norm_added_q_w, b->rope_cos, b->rope_sin,
-                               b->joint_pos, b->txt_pos_end, eps, stream));
-    OMNI_TRY(omni_qk_norm_rope(ws.k, D, Ri + Rt, w->num_heads, L.norm_k_w, L.norm_added_k_w, b->rope_cos, b->rope_sin,
-                               b->joint_pos, b->txt_pos_end, eps, stream));
+    if (!fuse_qkrope) {
+      OMNI_TRY(omni_qk_norm_rope(ws.q, D, Ri + Rt, w->num_heads, L.norm_q_w, L.norm_added_q_w, b->rope_cos, b->rope_sin,
+                                 b->joint_pos, b->txt_pos_end, eps, stream));
+      OMNI_TRY(omni_qk_norm_rope(ws.k, D, Ri + Rt, w->num_heads, L.norm_k_w, L.norm_added_k_w, b->rope_cos, b->rope_sin,
+                                 b->joint_pos, b->txt_pos_end, eps, stream));
+    }
     // joint attention (reference :437-443 -> attention/backends/sdpa.py:46-66)
     OMNI_TRY(omni_flash_attn_fwd_ex(ws.q, ws.k, ws.v, ws.attn, D, D, D, D, b->cu_seqlens, b->n_items, w->num_heads,
                                     w->head_dim, b->max_seqlen, sm_scale, bRj, stream));

@@ -320,6 +320,22 @@ __global__ __launch_bounds__(256) void cfg_euler_kernel(const uint16_t* __restri
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void gather_i32_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src,
+                                                         const int32_t* __restrict__ idx, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+}  // namespace
+
+int omni_internal_gather_i32(int32_t* dst, const int32_t* src, const int32_t* idx, int32_t n, void* stream) {
+  if (!dst || !src || !idx || n <= 0) return OMNI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gather_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), dst, src,
+                     idx, n);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
 extern "C" int omni_adaln_modulate_ex(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows,
                                       int32_t D, const omni_bf16* scale, const omni_bf16* shift,
                                       int64_t mod_item_stride, const int32_t* row_item_map, int32_t rows_per_item,

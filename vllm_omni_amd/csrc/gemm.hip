@@ -133,6 +133,8 @@ OMNI_DEVINL omni_gemm_group pick_group(const omni_gemm_params& P, int gi) {
   OMNI_PICK(out1); OMNI_PICK(out2); OMNI_PICK(ldo); OMNI_PICK(out_row_map); OMNI_PICK(res); OMNI_PICK(ldres);
   OMNI_PICK(gate); OMNI_PICK(gate_item_stride); OMNI_PICK(row_item_map); OMNI_PICK(rows_per_item);
   OMNI_PICK(a_k32_rows); OMNI_PICK(out_k32_rows);
+  OMNI_PICK(qk_norm_q_w); OMNI_PICK(qk_norm_k_w); OMNI_PICK(qk_rope_cos); OMNI_PICK(qk_rope_sin); OMNI_PICK(qk_row_pos);
+  OMNI_PICK(qk_eps);
 #undef OMNI_PICK
   return G;
 }
@@ -163,7 +165,7 @@ OMNI_DEVINL void gemm_epilogue_t(const omni_gemm_params& P, const omni_gemm_grou
           v[0] += bf16_lo(b[0]); v[1] += bf16_hi(b[0]); v[2] += bf16_lo(b[1]); v[3] += bf16_hi(b[1]);
         }
         uint16_t* dst;
-        if (EPI == OMNI_EPI_BIAS_SPLIT3) {
+        if (EPI == OMNI_EPI_BIAS_SPLIT3 || EPI == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE) {
           const int which = n / P.split_n;
           uint16_t* base = which == 0 ? G.out : (which == 1 ? G.out1 : G.out2);
           dst = base + orow * G.ldo + (n - which * P.split_n);
@@ -219,8 +221,10 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
   // in a ROLLED loop: fully unrolled, hipcc hoists all 16 rows' 64-bit addresses and predicates above phase 1, where
   // they are live together with the 128 accumulator registers and spill.
   constexpr int BATCH = 4, NBATCH = BM / 16 / BATCH;
-  struct RowIdx { int ro[BATCH], im[BATCH]; };
-  struct RowData { u32x4_t c[BATCH], g[BATCH], r[BATCH]; int ro[BATCH]; };
+  constexpr bool SPLIT = EPI == OMNI_EPI_BIAS_SPLIT3 || EPI == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE;
+  constexpr bool QKROPE = EPI == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE;
+  struct RowIdx { int ro[BATCH], im[BATCH], ps[BATCH]; };
+  struct RowData { u32x4_t c[BATCH], g[BATCH], r[BATCH]; u32x2_t cw[BATCH], sw[BATCH]; int ro[BATCH]; };
   const int rsub = tid >> 5;
   const float inv_rpi = 1.0f / (float)max(G.rows_per_item, 1);
   auto load_maps = [&](int b, RowIdx& x) {
@@ -233,6 +237,10 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
     if (G.out_row_map) {                 // uniform branches around whole groups of loads, none between the loads
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) x.ro[j] = G.out_row_map[mc[j]];
+    }
+    if (QKROPE) {
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) x.ps[j] = G.qk_row_pos[mc[j]];     // RoPE table row of the LOGICAL row
     }
     if (EPI == OMNI_EPI_BIAS_GATE_RES) {
       if (G.row_item_map) {
@@ -295,8 +303,9 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
   if (n >= N) return;
   uint16_t* obase = G.out;
   int ncol_out = n;
-  if (EPI == OMNI_EPI_BIAS_SPLIT3) {
-    const int which = n / P.split_n;
+  int which = 0;
+  if (SPLIT) {
+    which = n / P.split_n;
     const uintptr_t o0 = (uintptr_t)G.out, o1 = (uintptr_t)G.out1, o2 = (uintptr_t)G.out2;   // integer selects: a
     uintptr_t ob = which == 1 ? o1 : o0;                    // pointer select chain is turned into an indexed
     ob = which == 2 ? o2 : ob;                              // load from a scratch copy of G
@@ -313,8 +322,19 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
         d.r[j] = *reinterpret_cast<const u32x4_t*>(G.res + (int64_t)x.ro[j] * G.ldres + n);
       }
       d.c[j] = *reinterpret_cast<const u32x4_t*>(lds_row + (b * BATCH + j) * 16 * EPI_LDS_STRIDE);
+      if (QKROPE) {       // cos / sin of the 4 rotation pairs this lane holds (sub = lane's 16-B chunk within its head)
+        d.cw[j] = *reinterpret_cast<const u32x2_t*>(G.qk_rope_cos + (int64_t)x.ps[j] * 64 + (chunk & 15) * 4);
+        d.sw[j] = *reinterpret_cast<const u32x2_t*>(G.qk_rope_sin + (int64_t)x.ps[j] * 64 + (chunk & 15) * 4);
+      }
     }
   };
+  // q / k heads: RMSNorm(128) weight of this lane's 8 columns (a head = 16 consecutive lanes; which is uniform per head)
+  float qkw[8];
+  if (QKROPE) {
+    const u32x4_t wv = *reinterpret_cast<const u32x4_t*>((which == 1 ? G.qk_norm_k_w : G.qk_norm_q_w) + (chunk & 15) * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { qkw[2 * e] = bf16_lo(wv[e]); qkw[2 * e + 1] = bf16_hi(wv[e]); }
+  }
   RowData d0, d1;
   load_data(0, x0, d0);
 #pragma unroll 1
@@ -324,6 +344,29 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
       u32x4_t o = d0.c[j];
+      if (QKROPE) {
+        // identical arithmetic (and order) to qk_norm_rope_kernel on the bf16-rounded linear output
+        float f[8], r8[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[2 * e] = bf16_lo(o[e]); f[2 * e + 1] = bf16_hi(o[e]); }
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+        ss = wave_sum<16>(ss);
+        const float rstd = rsqrtf(ss * (1.0f / 128.0f) + G.qk_eps);
+        const float cc[4] = {bf16_lo(d0.cw[j][0]), bf16_hi(d0.cw[j][0]), bf16_lo(d0.cw[j][1]), bf16_hi(d0.cw[j][1])};
+        const float sn[4] = {bf16_lo(d0.sw[j][0]), bf16_hi(d0.sw[j][0]), bf16_lo(d0.sw[j][1]), bf16_hi(d0.sw[j][1])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a_ = f[2 * e] * rstd * qkw[2 * e], b_ = f[2 * e + 1] * rstd * qkw[2 * e + 1];
+          r8[2 * e] = a_ * cc[e] - b_ * sn[e];
+          r8[2 * e + 1] = b_ * cc[e] + a_ * sn[e];
+        }
+        if (which < 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(r8[2 * e], r8[2 * e + 1]);
+        }
+      }
       if (EPI == OMNI_EPI_BIAS_GATE_RES) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -852,7 +895,9 @@ bool epilogue_rows_coalescable(const omni_gemm_params* p) {
     if (p->epilogue == OMNI_EPI_BIAS_GATE_RES &&
         (!omni_aligned16(G.res) || !omni_aligned16(G.gate) || (G.ldres % 8) != 0 || (G.gate_item_stride % 8) != 0))
       return false;
-    if (p->epilogue == OMNI_EPI_BIAS_SPLIT3 && (!omni_aligned16(G.out1) || !omni_aligned16(G.out2))) return false;
+    if ((p->epilogue == OMNI_EPI_BIAS_SPLIT3 || p->epilogue == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE) &&
+        (!omni_aligned16(G.out1) || !omni_aligned16(G.out2)))
+      return false;
   }
   return true;
 }
@@ -947,12 +992,22 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
       if (!G.res || !G.gate || (!G.row_item_map && G.rows_per_item <= 0)) return OMNI_ERR_BAD_ARG;
       if ((G.ldres % 4) != 0 || (G.gate_item_stride % 4) != 0) return OMNI_ERR_ALIGN;
     }
-    if (p->epilogue == OMNI_EPI_BIAS_SPLIT3) {
+    if (p->epilogue == OMNI_EPI_BIAS_SPLIT3 || p->epilogue == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE) {
       if (!G.out1 || !G.out2) return OMNI_ERR_BAD_ARG;
     }
+    if (p->epilogue == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE) {
+      if (!G.qk_norm_q_w || !G.qk_norm_k_w || !G.qk_rope_cos || !G.qk_rope_sin || !G.qk_row_pos) return OMNI_ERR_BAD_ARG;
+      if (!omni_aligned16(G.qk_norm_q_w) || !omni_aligned16(G.qk_norm_k_w) ||
+          (reinterpret_cast<uintptr_t>(G.qk_rope_cos) & 7) || (reinterpret_cast<uintptr_t>(G.qk_rope_sin) & 7))
+        return OMNI_ERR_ALIGN;
+    }
   }
-  if (p->epilogue == OMNI_EPI_BIAS_SPLIT3 && (p->split_n <= 0 || p->split_n % 32 != 0 || p->N != 3 * p->split_n))
-    return OMNI_ERR_UNSUPPORTED;
+  const bool split3 = p->epilogue == OMNI_EPI_BIAS_SPLIT3 || p->epilogue == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE;
+  if (split3 && (p->split_n <= 0 || p->split_n % 32 != 0 || p->N != 3 * p->split_n)) return OMNI_ERR_UNSUPPORTED;
+  if (p->epilogue == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE) {     // the fused norm+RoPE exists in the ring kernel's coalesced epilogue only
+    if (p->split_n % 128 != 0 || gemm_variant() != 1) return OMNI_ERR_UNSUPPORTED;
+    if (!epilogue_rows_coalescable(p)) return OMNI_ERR_ALIGN;
+  }
   for (int g = 0; g < p->ngroups; ++g) {
     const omni_gemm_group& G = p->g[g];
     if (G.a_k32_rows < 0 || G.out_k32_rows < 0) return OMNI_ERR_BAD_ARG;
@@ -972,6 +1027,7 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
     case OMNI_EPI_BIAS_GELU_TANH: return launch<OMNI_EPI_BIAS_GELU_TANH>(p, s);
     case OMNI_EPI_BIAS_GATE_RES: return launch<OMNI_EPI_BIAS_GATE_RES>(p, s);
     case OMNI_EPI_BIAS_SPLIT3: return launch<OMNI_EPI_BIAS_SPLIT3>(p, s);
+    case OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE: return launch<OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE>(p, s);
     default: return OMNI_ERR_BAD_ARG;
   }
 }

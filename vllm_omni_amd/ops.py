@@ -14,7 +14,7 @@ from . import _native as N
 
 BF16 = torch.bfloat16
 
-EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RES, EPI_BIAS_SPLIT3 = 0, 1, 2, 3
+EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RES, EPI_BIAS_SPLIT3, EPI_BIAS_SPLIT3_QKNORM_ROPE = 0, 1, 2, 3, 4
 
 
 def _stream() -> int:
@@ -45,8 +45,10 @@ class GemmGroupArgs:
 
     def __init__(self, a, w, bias=None, out=None, *, a_row_map=None, out_row_map=None, out1=None, out2=None,
                  res=None, gate=None, gate_item_stride=0, row_item_map=None, rows_per_item=0,
-                 a_k32_blocked=False, out_k32_blocked=False):
+                 a_k32_blocked=False, out_k32_blocked=False, qk_norm_q_w=None, qk_norm_k_w=None, qk_rope_cos=None,
+                 qk_rope_sin=None, qk_row_pos=None, qk_eps=1e-6):
         self.a_k32_blocked, self.out_k32_blocked = a_k32_blocked, out_k32_blocked
+        self.qk = (qk_norm_q_w, qk_norm_k_w, qk_rope_cos, qk_rope_sin, qk_row_pos, qk_eps)
         self.a, self.w, self.bias, self.out = a, w, bias, out
         self.a_row_map, self.out_row_map, self.out1, self.out2 = a_row_map, out_row_map, out1, out2
         self.res, self.gate, self.gate_item_stride = res, gate, gate_item_stride
@@ -91,6 +93,10 @@ def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0
         G.gate, G.gate_item_stride = _p(g.gate, name="gate"), g.gate_item_stride
         G.row_item_map = _p(g.row_item_map, torch.int32, "row_item_map")
         G.rows_per_item = g.rows_per_item
+        qw, kw, cos, sin, pos, eps = g.qk
+        G.qk_norm_q_w, G.qk_norm_k_w = _p(qw, name="qk_norm_q_w"), _p(kw, name="qk_norm_k_w")
+        G.qk_rope_cos, G.qk_rope_sin = _p(cos, name="qk_rope_cos"), _p(sin, name="qk_rope_sin")
+        G.qk_row_pos, G.qk_eps = _p(pos, torch.int32, "qk_row_pos"), eps
         G.a_k32_rows = g.a.shape[0] if g.a_k32_blocked else 0       # blocked tensors keep their [rows, K] shape
         G.out_k32_rows = g.out.shape[0] if g.out_k32_blocked else 0
     N.check(N.lib().omni_gemm_bf16(C.byref(p), _stream()), "omni_gemm_bf16")
