@@ -96,3 +96,66 @@ def test_cfg_euler_fullsize_scale_one_is_positive_branch():
     ops.cfg_euler_step_(a, pos, neg, 1.0, dt)
     ops.cfg_euler_step_(b, pos, None, 1.0, dt)
     assert ((a.float() - b.float()).abs().max()) <= 2 ** -7 * lat.float().abs().max()
+
+
+def test_attention_8wave_workgroups_equal_4wave_workgroups_bitwise():
+    """B*H*ceil(S/256) >= 1536 selects 256-query workgroups (8 waves), below that 128-query ones (4 waves): the per-wave
+    arithmetic is the same, so running the batch in one call or in two halves must give identical bits."""
+    from vllm_omni_amd import ops
+
+    B, H, S = 8, 24, 2048
+    q, k, v = rnd(B * S, H * 128, seed=11), rnd(B * S, H * 128, seed=12), rnd(B * S, H * 128, seed=13)
+    cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(DEV)
+    full = ops.flash_attn_varlen(q, k, v, cu, H, S, 1 / math.sqrt(128))
+    h = B // 2 * S
+    cu_h = (torch.arange(B // 2 + 1, dtype=torch.int32) * S).to(DEV)
+    lo = ops.flash_attn_varlen(q[:h], k[:h], v[:h], cu_h, H, S, 1 / math.sqrt(128))
+    hi = ops.flash_attn_varlen(q[h:], k[h:], v[h:], cu_h, H, S, 1 / math.sqrt(128))
+    assert torch.equal(full, torch.cat([lo, hi]))
+    ref = torch.nn.functional.scaled_dot_product_attention(
+        *(t[:S].view(1, S, H, 128).permute(0, 2, 1, 3).float() for t in (q, k, v))).permute(0, 2, 1, 3).reshape(S, H * 128)
+    assert ((full[:S].float() - ref).norm() / ref.norm()) < 4e-3
+
+
+def test_fullwidth_layer_gemms_blocked_layouts_and_fused_qk_epilogue_are_bit_identical():
+    """At D=3072, 24 heads, one CFG pair (8192 + 128 rows): K32-blocked A / W / out and the fused q/k norm+RoPE epilogue
+    against the row-major two-kernel path — identical bits (the layouts only move bytes; the fused math is the same)."""
+    from vllm_omni_amd import ops
+    from vllm_omni_amd.diffusion.batch import build_ragged_batch
+    from vllm_omni_amd.diffusion.models.qwen_image.rope import rope_table
+
+    D, H, T, grid = 3072, 24, 64, (1, 64, 64)
+    rb = build_ragged_batch([T, T], grid, [0, 1], T)
+    maps = rb.device_maps(torch.device(DEV))
+    Ri, Rt, Rj = rb.n_img_rows, rb.n_txt_rows, rb.n_joint_rows
+    cos, sin = rope_table(grid, T)
+    cosb, sinb = cos.to(DEV, BF16), sin.to(DEV, BF16)
+    xi, xt = rnd(Ri, D, seed=21), rnd(Rt, D, seed=22)
+    wi, wt = rnd(3 * D, D, seed=23, s=0.02), rnd(3 * D, D, seed=24, s=0.02)
+    bi, bt = rnd(3 * D, seed=25, s=0.1), rnd(3 * D, seed=26, s=0.1)
+    nw = [(1 + rnd(128, seed=30 + i, s=0.1).float()).to(BF16) for i in range(4)]
+    jp = maps["joint_pos"]
+    outs = []
+    for fancy in (False, True):
+        q = torch.zeros(Rj, D, dtype=BF16, device=DEV)
+        k, v = torch.zeros_like(q), torch.zeros_like(q)
+        a_i, a_t = (ops.w_to_k32_blocked(xi), ops.w_to_k32_blocked(xt)) if fancy else (xi, xt)
+        w_i, w_t = (ops.w_to_k32_blocked(wi), ops.w_to_k32_blocked(wt)) if fancy else (wi, wt)
+        kw_i = dict(qk_norm_q_w=nw[0], qk_norm_k_w=nw[1], qk_rope_cos=cosb, qk_rope_sin=sinb,
+                    qk_row_pos=jp[maps["img_joint_row"].long()].contiguous()) if fancy else {}
+        kw_t = dict(qk_norm_q_w=nw[2], qk_norm_k_w=nw[3], qk_rope_cos=cosb, qk_rope_sin=sinb,
+                    qk_row_pos=jp[maps["txt_joint_row"].long()].contiguous()) if fancy else {}
+        ops.gemm([ops.GemmGroupArgs(a_i, w_i, bi, q, out1=k, out2=v, out_row_map=maps["img_joint_row"],
+                                    a_k32_blocked=fancy, **kw_i),
+                  ops.GemmGroupArgs(a_t, w_t, bt, q, out1=k, out2=v, out_row_map=maps["txt_joint_row"],
+                                    a_k32_blocked=fancy, **kw_t)],
+                 ops.EPI_BIAS_SPLIT3_QKNORM_ROPE if fancy else ops.EPI_BIAS_SPLIT3, split_n=D, w_k32_blocked=fancy)
+        if not fancy:
+            ops.qk_norm_rope_(q, H, nw[0], nw[2], cosb, sinb, jp, rb.txt_pos_end)
+            ops.qk_norm_rope_(k, H, nw[1], nw[3], cosb, sinb, jp, rb.txt_pos_end)
+        outs.append((q, k, v))
+    torch.cuda.synchronize()
+    for name, a, b in zip("qkv", *outs):
+        ndiff = int((a != b).sum())
+        assert ndiff == 0, f"{name}: {ndiff} of {a.numel()} elements differ, max |d| {float((a.float() - b.float()).abs().max())}"
+    assert torch.isfinite(outs[1][0].float()).all() and outs[1][0].float().abs().mean() > 0.05

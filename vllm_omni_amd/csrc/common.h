@@ -48,6 +48,25 @@ OMNI_DEVINL float wave_max(float v) {
   return v;
 }
 
+// Per-head RMSNorm(128) + interleaved RoPE on the 8 consecutive columns one lane holds (16 lanes = one head).  ONE
+// definition with explicit fma / no implicit contraction, shared by qk_norm_rope_kernel and the fused QKV-GEMM epilogue, so
+// that the two paths produce identical bits (left to the compiler, `a*c - b*s` contracts differently in the two contexts).
+OMNI_DEVINL void qk_norm_rope_lane(const float (&f)[8], const float (&w)[8], const float (&c)[4], const float (&s)[4],
+                                   float eps, float (&o)[8]) {
+#pragma clang fp contract(off)
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ss = __builtin_fmaf(f[i], f[i], ss);
+  ss = wave_sum<16>(ss);
+  const float rstd = rsqrtf(__builtin_fmaf(ss, 1.0f / 128.0f, eps));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = (f[2 * i] * rstd) * w[2 * i], b = (f[2 * i + 1] * rstd) * w[2 * i + 1];
+    o[2 * i] = __builtin_fmaf(a, c[i], -(b * s[i]));
+    o[2 * i + 1] = __builtin_fmaf(b, c[i], a * s[i]);
+  }
+}
+
 #define OMNI_CHECK_LAUNCH()                                   \
   do {                                                        \
     if (hipGetLastError() != hipSuccess) return OMNI_ERR_LAUNCH; \

@@ -137,23 +137,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict_
   uint16_t* p = x + (int64_t)row * ldx + head * 128 + sub * 8;
   float f[8], w[8], o[8];
   unpack8(*reinterpret_cast<const u32x4_t*>(p), f);
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
-  ss = wave_sum<16>(ss);
-  const float rstd = rsqrtf(ss * (1.0f / 128.0f) + eps);
   const int pos = row_pos[row];
   unpack8(*reinterpret_cast<const u32x4_t*>((pos < txt_pos_end ? w_txt : w_img) + sub * 8), w);
   const u32x2_t cw = *reinterpret_cast<const u32x2_t*>(cos_tab + (int64_t)pos * 64 + sub * 4);
   const u32x2_t sw = *reinterpret_cast<const u32x2_t*>(sin_tab + (int64_t)pos * 64 + sub * 4);
   const float c[4] = {bf16_lo(cw[0]), bf16_hi(cw[0]), bf16_lo(cw[1]), bf16_hi(cw[1])};
   const float s[4] = {bf16_lo(sw[0]), bf16_hi(sw[0]), bf16_lo(sw[1]), bf16_hi(sw[1])};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = f[2 * i] * rstd * w[2 * i], b = f[2 * i + 1] * rstd * w[2 * i + 1];
-    o[2 * i] = a * c[i] - b * s[i];
-    o[2 * i + 1] = b * c[i] + a * s[i];
-  }
+  qk_norm_rope_lane(f, w, c, s, eps, o);
   *reinterpret_cast<u32x4_t*>(p) = pack8(o);
 }
 

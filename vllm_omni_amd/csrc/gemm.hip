@@ -349,19 +349,9 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
         float f[8], r8[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { f[2 * e] = bf16_lo(o[e]); f[2 * e + 1] = bf16_hi(o[e]); }
-        float ss = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
-        ss = wave_sum<16>(ss);
-        const float rstd = rsqrtf(ss * (1.0f / 128.0f) + G.qk_eps);
         const float cc[4] = {bf16_lo(d0.cw[j][0]), bf16_hi(d0.cw[j][0]), bf16_lo(d0.cw[j][1]), bf16_hi(d0.cw[j][1])};
         const float sn[4] = {bf16_lo(d0.sw[j][0]), bf16_hi(d0.sw[j][0]), bf16_lo(d0.sw[j][1]), bf16_hi(d0.sw[j][1])};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a_ = f[2 * e] * rstd * qkw[2 * e], b_ = f[2 * e + 1] * rstd * qkw[2 * e + 1];
-          r8[2 * e] = a_ * cc[e] - b_ * sn[e];
-          r8[2 * e + 1] = b_ * cc[e] + a_ * sn[e];
-        }
+        qk_norm_rope_lane(f, qkw, cc, sn, G.qk_eps, r8);
         if (which < 2) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(r8[2 * e], r8[2 * e + 1]);
