@@ -1,7 +1,11 @@
 // Flash attention forward for gfx950: non-causal, no mask, head_dim 128, bf16 in/out, fp32 softmax.
 //
-// One workgroup = 4 waves = 128 query rows of one (item, head); each wave owns 32 queries.  K/V tiles of
-// 64 keys are staged through LDS (2 stages x (16 KiB K + 16 KiB V) = 64 KiB -> 2 workgroups / CU).
+// Production kernel: flash_attn_fwd_pipe_kernel<NW, NQ> (second half of this file; software-pipelined, LDS-DMA staging).
+// flash_attn_fwd_kernel<NQ> (first half) is the unskewed, register-staged predecessor, kept for A/B runs
+// (OMNI_ATTN_PIPE=0).  Both share the scheme below.
+//
+// One workgroup = NW waves x 32 (x NQ) query rows of one (item, head).  K/V tiles of 64 keys are staged through LDS
+// (2 stages x (16 KiB K + 16 KiB V) = 64 KiB -> 2 workgroups / CU at 4 waves).
 //
 //   Sᵀ = K·Qᵀ  (SWAPPED operands): A-operand = K fragment from LDS, B-operand = Q fragment held in
 //        registers for the whole kernel.  The 32x32 accumulator then puts ONE query in each lane
@@ -13,7 +17,6 @@
 //        so the online-softmax rescale of O is a per-lane scalar multiply.
 //   LDS images: K row-major [64][128] with the 16-B chunk index XOR (key&15) (conflict-free ds_read_b128);
 //        V as [dblk 4][key/4 16][4 keys][32 d] (each 32-lane half of a tr-read covers one contiguous 256 B).
-//   Loads are register-staged and split (issue global loads before the MFMAs, ds_write after them).
 //
 // Layout contract: q/k/v/out are [total_rows, H*128] (the reference's [B,S,H,dh] flattened), item b owns rows
 // [cu_seqlens[b], cu_seqlens[b+1]).  Roofline: MFMA-bound, 4*S^2*128 flop per (item, head).

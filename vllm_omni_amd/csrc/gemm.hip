@@ -1,21 +1,22 @@
 // Grouped bf16 GEMM with fused epilogues for gfx950:  Y_g = epi(A_g · W_gᵀ + bias_g).
 //
-// Geometry (one workgroup = one 256x256 output tile, 8 waves = 2(M) x 4(N), 512 threads, 1 WG / CU):
-//   BK = 64;  LDS = 2 stages x (A tile 32 KiB + W tile 32 KiB) = 128 KiB of the CU's 160 KiB.
-//   Staging is direct-to-LDS (global_load_lds_dwordx4, 1 KiB per wave-instruction = 8 rows x 128 B,
-//   i.e. full 128-B lines of 8 consecutive rows).  The LDS image is row-major [256][64] bf16 whose
-//   16-byte chunk index is XOR-swizzled with (row>>1)&7; because the DMA destination is lane-linear
-//   the swizzle is applied to the per-lane SOURCE address and again on the ds_read_b128 address
-//   (cdna_hip_programming.md rule 21).  With it the four 16-lane groups of a ds_read_b128 hit 16
-//   distinct 16-byte slots (conflict-free).
-//   MFMA: v_mfma_f32_32x32x16_bf16 with SWAPPED operands (A-operand = W fragment, B-operand = A fragment),
-//   so a wave's accumulator holds Cᵀ blocks: lane (l&31) owns ONE output row and, per 4 registers,
-//   FOUR CONSECUTIVE output columns -> bias/gate/residual are 8-byte vector loads and the store is
-//   8 bytes per lane (hi/lo half-waves adjacent -> 16 B contiguous per row).
-//   One barrier per K tile: wait own DMA (vmcnt 0) -> barrier -> issue DMA for tile t+1 into the other
-//   stage -> 24 ds_read_b128 + 32 MFMA on tile t.
-//   blockIdx is remapped so that each XCD (block b runs on XCD b % 8) owns a contiguous band of tiles
-//   and walks it GROUP_M row-tiles at a time: neighbours share A/W panels in that XCD's private L2.
+// Three kernels share one tile geometry (one workgroup = one 256x256 output tile, 8 waves = 2(M) x 4(N), 512 threads,
+// 1 WG / CU) and one MFMA scheme; OMNI_GEMM_VARIANT picks between them (default 1):
+//   1  gemm_bf16_ring_kernel — the production kernel: BK = 32 stages in a 5-deep LDS ring (all 160 KiB), a continuous
+//      DMA / fragment-read / MFMA pipeline (see the comment above the kernel), K32-blocked operand layouts for full-line
+//      DMA requests, row-coalesced epilogue through LDS (gemm_epilogue_lds) incl. the fused q/k norm + RoPE.
+//   0  gemm_bf16_kernel — the first design, kept for A/B runs: BK = 64, 2 stages x (A 32 KiB + W 32 KiB) = 128 KiB,
+//      one barrier per K tile (wait own DMA -> barrier -> issue tile t+1 -> 24 ds_read_b128 + 32 MFMA on tile t).
+//   2  gemm_bf16_w4_kernel — 4 waves x (128 x 128), one wave per SIMD (slower: exposes the DMA issue cost).
+// Common to all:
+//   Staging is direct-to-LDS (global_load_lds_dwordx4, 1 KiB per wave-instruction).  The LDS image is row-major with the
+//   16-byte chunk index XOR-swizzled; because the DMA destination is lane-linear the swizzle is applied to the per-lane
+//   SOURCE address and again on the ds_read_b128 address (cdna_hip_programming.md rule 21): the four 16-lane groups of a
+//   ds_read_b128 hit 16 distinct 16-byte slots (0 conflicts measured).
+//   MFMA: v_mfma_f32_32x32x16_bf16 with SWAPPED operands (A-operand = W fragment, B-operand = A fragment), so a wave's
+//   accumulator holds Cᵀ blocks: lane (l&31) owns ONE output row and, per 4 registers, FOUR CONSECUTIVE output columns.
+//   blockIdx is remapped so that each XCD (block b runs on XCD b % 8) owns a contiguous band of tiles and walks it
+//   GROUP_M row-tiles at a time: neighbours share A/W panels in that XCD's private L2.
 //
 // Roofline: MFMA-bound.  Algorithmic work = 2*M*N*K flop per launch.
 #include <stdlib.h>
