@@ -210,6 +210,19 @@ OMNI_DEVINL void gemm_epilogue(const omni_gemm_params& P, const omni_gemm_group&
 // GATE_RES note: acc+bias is rounded to bf16 in LDS before res + gate*x — exactly the rounding point of the
 // reference's bf16 nn.Linear output (qwen_image_transformer.py: `hidden_states + gate * attn_output`).
 // ------------------------------------------------------------------------------------------------
+#ifndef OMNI_EPI_STORE_POLICY_ID
+#define OMNI_EPI_STORE_POLICY_ID 1   // cache-policy bits of the output stores: 0 none, 1 nt, 2 sc0 sc1, 3 sc1.  Same-box A/B
+                                     // at the bench QKV shape: 1176 / 1160 / 1180 / 1184 us; bench 0.3709 -> 0.3725 images/s with nt
+#endif
+#if OMNI_EPI_STORE_POLICY_ID == 1
+#define OMNI_EPI_STORE_POLICY " nt"
+#elif OMNI_EPI_STORE_POLICY_ID == 2
+#define OMNI_EPI_STORE_POLICY " sc0 sc1"
+#elif OMNI_EPI_STORE_POLICY_ID == 3
+#define OMNI_EPI_STORE_POLICY " sc1"
+#else
+#define OMNI_EPI_STORE_POLICY ""
+#endif
 constexpr int EPI_LDS_STRIDE = BN * 2 + 16;              // 528 B per C row in LDS
 constexpr int EPI_LDS_BYTES = BM * EPI_LDS_STRIDE;       // 132 KiB
 
@@ -369,7 +382,8 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
                           : obase + (int64_t)d0.ro[j] * G.ldo + ncol_out;
       // The store is issued from inline asm: `res` may alias `out` (in-place residual), and for a compiler-visible
       // store hipcc drains vmcnt(0) before the next loads although a thread never re-reads a row it has written.
-      if (m0 + (b * BATCH + j) * 16 + rsub < M) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(o));
+      if (m0 + (b * BATCH + j) * 16 + rsub < M)
+        asm volatile("global_store_dwordx4 %0, %1, off" OMNI_EPI_STORE_POLICY ::"v"(dst), "v"(o));
     }
     d0 = d1;
   }
