@@ -30,9 +30,14 @@ OMNI_DEVINL uint32_t pack_bf16x2(float lo, float hi) {
 
 OMNI_DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // GELU tanh approximation: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  == x * sigmoid(2u)
+// = x / (1 + exp(-2u)), u = sqrt(2/pi) (x + 0.044715 x^3), as 7 VALU operations: the exponent is formed directly in the
+// exp2 domain, x * (C1 + C2 x^2) with C1 = -2 sqrt(2/pi) log2(e), and the division is a v_rcp_f32 (1 ulp; the result is
+// rounded to bf16 anyway).  The IEEE division + expf form cost ~22 operations per element: 7 us of a 92-us MLP-up tile.
 OMNI_DEVINL float gelu_tanh_f(float x) {
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  constexpr float C1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+  constexpr float C2 = C1 * 0.044715f;
+  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, C2, C1));
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 template <int W>
