@@ -34,6 +34,10 @@ OMNI_DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exp2 domain, x * (C1 + C2 x^2) with C1 = -2 sqrt(2/pi) log2(e), and the division is a v_rcp_f32 (1 ulp; the result is
 // rounded to bf16 anyway).  The IEEE division + expf form cost ~22 operations per element: 7 us of a 92-us MLP-up tile.
 OMNI_DEVINL float gelu_tanh_f(float x) {
+#ifdef OMNI_GELU_LEGACY   // dev A/B: the first formulation (IEEE division, expf)
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+#endif
   constexpr float C1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
   constexpr float C2 = C1 * 0.044715f;
   const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, C2, C1));
