@@ -1,6 +1,8 @@
 // Shared device helpers for the gfx950 (CDNA4) kernels.  wave = 64 lanes everywhere.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/omni_cdna4.h"
@@ -57,6 +59,20 @@ OMNI_DEVINL float wave_max(float v) {
   return v;
 }
 
+// Sum over each aligned group of 16 lanes (one DPP row), every lane receiving the same symmetric tree: xor-1 and xor-2 by
+// quad_perm, then row_half_mirror and row_mirror (after the quad steps all four lanes of a quad hold the same value, so
+// the mirrors act like xor-4 / xor-8).  VALU only — __shfl_xor compiles to ds_bpermute here (an LDS round trip per step).
+OMNI_DEVINL float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  return v;
+}
+
 // Per-head RMSNorm(128) + interleaved RoPE on the 8 consecutive columns one lane holds (16 lanes = one head).  ONE
 // definition with explicit fma / no implicit contraction, shared by qk_norm_rope_kernel and the fused QKV-GEMM epilogue, so
 // that the two paths produce identical bits (left to the compiler, `a*c - b*s` contracts differently in the two contexts).
@@ -66,7 +82,7 @@ OMNI_DEVINL void qk_norm_rope_lane(const float (&f)[8], const float (&w)[8], con
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ss = __builtin_fmaf(f[i], f[i], ss);
-  ss = wave_sum<16>(ss);
+  ss = row16_sum(ss);
   const float rstd = rsqrtf(__builtin_fmaf(ss, 1.0f / 128.0f, eps));
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
