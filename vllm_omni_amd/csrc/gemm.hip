@@ -278,16 +278,7 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
   __builtin_amdgcn_s_barrier();          // every wave has finished reading the operand ring
   {
     const int ncol = wn * 64 + hi * 4;   // tile-local column of this lane's first value
-    u32x2_t bvp[2][4];                   // bias stays PACKED (8 VGPRs, not 32 floats) next to the 128 accumulators
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + ncol + nb * 32 + q * 8;
-        u32x2_t b = {0u, 0u};
-        if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
-        bvp[nb][q] = b;
-      }
+    // (the bias is already in the accumulators: see the ring kernel's accumulator initialisation)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       char* rowp = smem + (wm * 128 + mb * 32 + l31) * EPI_LDS_STRIDE + ncol * 2;
@@ -295,13 +286,10 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          u32x2_t b = bvp[nb][q];
-          asm volatile("" : "+v"(b));    // unpack here, every time: hoisted, the 32 floats would be live across mb
-          const float bf[4] = {bf16_lo(b[0]), bf16_hi(b[0]), bf16_lo(b[1]), bf16_hi(b[1])};
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            v[j] = acc[nb][mb][q * 4 + j] + bf[j];
+            v[j] = acc[nb][mb][q * 4 + j];
             if (EPI == OMNI_EPI_BIAS_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
           }
           u32x2_t o;
@@ -572,13 +560,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
     w_base[ks] = (wn * 64 + l31) * 64 + chunk;
   }
 
+  // The accumulators start at the BIAS (coalesced epilogue) instead of 0: same cost as the zero fill, and the epilogue's 128
+  // adds + 128 bf16 unpacks per lane (with all 8 waves in the epilogue at once) disappear.
   f32x16_t acc[2][4];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
+  for (int nb = 0; nb < 2; ++nb) {
+    float bini[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + wn * 64 + hi * 4 + nb * 32 + q * 8;
+      u32x2_t b = {0u, 0u};
+      if (COALESCED && G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
+      bini[q * 4 + 0] = bf16_lo(b[0]); bini[q * 4 + 1] = bf16_hi(b[0]);
+      bini[q * 4 + 2] = bf16_lo(b[1]); bini[q * 4 + 3] = bf16_hi(b[1]);
+    }
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.0f;
+      for (int i = 0; i < 16; ++i) acc[nb][mb][i] = bini[i];
+  }
 
   // ---- continuous pipeline ---------------------------------------------------------------------------------
   // global k-step g = 2*stage + ks.  Fragment reads run TWO k-steps ahead of the MFMAs and cross stage boundaries:
