@@ -984,7 +984,7 @@ extern "C" int omni_dev_gemm_ablate(const omni_gemm_params* p, int mode, omni_st
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define OMNI_ABL(A)                                                                                                \
   case A:                                                                                                          \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<OMNI_EPI_BIAS, A>),                         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<OMNI_EPI_BIAS, A>),                         \
                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                                    \
     hipLaunchKernelGGL((gemm_bf16_kernel<OMNI_EPI_BIAS, A>), dim3(tiles_m * tiles_n), dim3(NTHREADS), LDS_BYTES, s, \
                        *p, mt0, tiles_m, tiles_n, GROUP_M_DEFAULT);                                                                 \
@@ -1004,7 +1004,7 @@ extern "C" int omni_dev_gemm_ring_ablate(const omni_gemm_params* p, int mode, om
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define OMNI_ABL(A)                                                                                                  \
   case A:                                                                                                            \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<OMNI_EPI_BIAS, A>),                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<OMNI_EPI_BIAS, A>),                      \
                         hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES);                                     \
     hipLaunchKernelGGL((gemm_bf16_ring_kernel<OMNI_EPI_BIAS, A>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, \
                        s, *p, mt0, tiles_m, tiles_n, GROUP_M_DEFAULT);                                               \
