@@ -159,3 +159,25 @@ def test_fullwidth_layer_gemms_blocked_layouts_and_fused_qk_epilogue_are_bit_ide
         ndiff = int((a != b).sum())
         assert ndiff == 0, f"{name}: {ndiff} of {a.numel()} elements differ, max |d| {float((a.float() - b.float()).abs().max())}"
     assert torch.isfinite(outs[1][0].float()).all() and outs[1][0].float().abs().mean() > 0.05
+
+
+def test_forward_2048px_token_count_item_order_equivariance():
+    """BASELINE config 5 geometry (2048x2048 -> 16384 image tokens per item, joint 16448): one full-width layer, two items
+    of different text length in one ragged forward; swapping the items swaps the outputs.  Exercises the largest sequence
+    the path names: 258 key tiles per attention row block, 130 m-tiles per GEMM, RoPE table of 16384 + text rows."""
+    from vllm_omni_amd.diffusion.batch import build_ragged_batch
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+
+    m = QwenImageTransformer2DModel(num_layers=1, device=DEV).init_random_(seed=5)
+    grid, S = (1, 128, 128), 16384
+    lat = [rnd(S, 64, seed=30 + i) for i in range(2)]
+    txt = [rnd(t, 3584, seed=40 + i) for i, t in enumerate((64, 19))]
+    sig = torch.tensor([0.37, 0.37], dtype=torch.float32, device=DEV)
+    ab = m.forward_ragged(m.prepare_batch(build_ragged_batch([64, 19], grid)), torch.cat(lat), torch.cat(txt), sig).clone()
+    ba = m.forward_ragged(m.prepare_batch(build_ragged_batch([19, 64], grid)), torch.cat(lat[::-1]), torch.cat(txt[::-1]),
+                          sig).clone()
+    torch.cuda.synchronize()
+    assert ab.shape == (2 * S, 64) and torch.isfinite(ab.float()).all() and ab.float().abs().mean() > 1e-3
+    d0 = (ab[:S].float() - ba[S:].float()).norm() / ab[:S].float().norm()
+    d1 = (ab[S:].float() - ba[:S].float()).norm() / ab[S:].float().norm()
+    assert d0 < 5e-3 and d1 < 5e-3
