@@ -476,6 +476,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const omni_gemm_
 #ifndef OMNI_RING_SETPRIO
 #define OMNI_RING_SETPRIO 1
 #endif
+#ifndef OMNI_RING_STAGGER
+#define OMNI_RING_STAGGER 0   // 1: the two waves of a SIMD (wm = 0 / 1) issue their DMA pieces in DIFFERENT MFMA slots
+                              // (measured -1..2 %: 1167 -> 1155 TF/s MLP-up, 1220 -> 1197 QKV, same box)
+#endif
 #if OMNI_RING_STAGES == 5
 #define OMNI_RING_VMCNT "s_waitcnt vmcnt(8)"   // (LEAD - 2) stages x 4 DMA pieces per wave stay in flight across a barrier
 #elif OMNI_RING_STAGES == 4
@@ -620,14 +624,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     OMNI_RING_PAIR(buf, 0)                                                                                   \
     if (PREFETCH) af[buf][0] = lds_read16<0, ABL == 3>(aa_);                                                           \
-    DMA_A;                                                                                                   \
+    if (!OMNI_RING_STAGGER || !wm) { DMA_A; }                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     OMNI_RING_PAIR(buf, 1)                                                                                   \
     if (PREFETCH) af[buf][1] = lds_read16<32 * 64, ABL == 3>(aa_);                                                     \
+    if (OMNI_RING_STAGGER && wm) { DMA_A; }                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     OMNI_RING_PAIR(buf, 2)                                                                                   \
     if (PREFETCH) af[buf][2] = lds_read16<2 * 32 * 64, ABL == 3>(aa_);                                                 \
-    DMA_B;                                                                                                   \
+    if (!OMNI_RING_STAGGER || !wm) { DMA_B; }                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     OMNI_RING_PAIR(buf, 3)                                                                                   \
     if (PREFETCH) {                                                                                          \
@@ -635,6 +640,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
       wf[buf][0] = lds_read16<ROP_BYTES, ABL == 3>(wa_);                                                               \
       wf[buf][1] = lds_read16<ROP_BYTES + 32 * 64, ABL == 3>(wa_);                                                     \
     }                                                                                                        \
+    if (OMNI_RING_STAGGER && wm) { DMA_B; }                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     if (OMNI_RING_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
