@@ -38,6 +38,19 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 #ifndef OMNI_GLDS_AUX
 #define OMNI_GLDS_AUX 0   // cache-policy bits of the DMA loads: 1 = sc0, 2 = nt, 16 = sc1
 #endif
+// The ring kernel issues its LDS-DMA from inline asm (M0 = wave-uniform LDS byte address; the hardware adds lane*16), in
+// the SADDR form whenever the operand's byte offsets fit 32 bits: uniform 64-bit stage base in SGPRs + ONE 32-bit per-lane
+// offset instead of a 64-bit VGPR address pair per piece.  Same-box A/B at the bench shapes: MLP-up 1175 -> 1236 TF/s,
+// QKV 1235 -> 1294 (the per-piece issue cost of global_load_lds is what the k-loop is most sensitive to).  Both forms come
+// from asm so that M0 has a single writer in that kernel (the builtin's M0 tracking would not see the asm's writes).
+OMNI_DEVINL void glds16_saddr(const char* base, uint32_t lane_byte_off, uint32_t lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(lds_byte_addr), "v"(lane_byte_off), "s"(base) : "memory");
+}
+OMNI_DEVINL void glds16_vaddr(const void* gsrc, uint32_t lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(lds_byte_addr), "v"(gsrc) : "memory");
+}
 OMNI_DEVINL void glds16(const void* gsrc, uint32_t lds_byte_addr) {
   // wave-uniform LDS base (goes to M0); the hardware adds lane*16.
   __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)(uintptr_t)lds_byte_addr, 16, 0, OMNI_GLDS_AUX);
@@ -494,7 +507,7 @@ constexpr int RLDS_BYTES = RSTAGES * RSTAGE_BYTES;  // 160 KiB
 
 // ABL: dev-only ablation (1 no DMA in loop, 3 no fragment reads, 4 no vmcnt/barrier).  COALESCED selects the epilogue at
 // compile time: with both in one kernel their hoisted set-up code overlaps the live accumulators and spills.
-template <int EPI, int ABL = 0, bool COALESCED = false>
+template <int EPI, int ABL = 0, bool COALESCED = false, bool SADDR = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_gemm_params P, int mtiles0,
                                                                        int tiles_m, int tiles_n, int GROUP_M) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -533,6 +546,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
     const int wr = min(n0 + r, N - 1);
     w_src[j] = G.W + (P.w_k32_blocked ? (int64_t)wr * RBK : (int64_t)wr * K) + c * 8;
   }
+  // SADDR (template): the host has checked that every operand byte offset fits 32 bits (ring_saddr_ok)
+  uint32_t a_off[2], w_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    a_off[j] = (uint32_t)(reinterpret_cast<const char*>(a_src[j]) - reinterpret_cast<const char*>(G.A));
+    w_off[j] = (uint32_t)(reinterpret_cast<const char*>(w_src[j]) - reinterpret_cast<const char*>(G.W));
+  }
   // elements between two k-stages of one W row: 32 in row-major, a whole [N][32] slab in the K32-blocked layout (where
   // the 16 rows of a DMA piece are 1 KiB contiguous -> 8 full-line requests per piece instead of 16 half-line ones)
   const int64_t wstep = P.w_k32_blocked ? (int64_t)N * RBK : RBK;
@@ -541,8 +561,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
   auto issue_piece = [&](int slot, int st, int piece) {   // piece 0..3 = A0, W0, A1, W1 (1 KiB each)
     const uint32_t base = lds0 + slot * RSTAGE_BYTES + (wave * 2) * 1024;
     const int part = piece >> 1;
-    if (piece & 1) glds16(w_src[part] + st * wstep, base + ROP_BYTES + part * 1024);
-    else glds16(a_src[part] + st * astep, base + part * 1024);
+    if (piece & 1) {
+      if (SADDR) glds16_saddr(reinterpret_cast<const char*>(G.W) + st * wstep * 2, w_off[part], base + ROP_BYTES + part * 1024);
+      else glds16_vaddr(w_src[part] + st * wstep, base + ROP_BYTES + part * 1024);
+    } else {
+      if (SADDR) glds16_saddr(reinterpret_cast<const char*>(G.A) + st * astep * 2, a_off[part], base + part * 1024);
+      else glds16_vaddr(a_src[part] + st * astep, base + part * 1024);
+    }
   };
   auto issue_part = [&](int slot, int st, int part) {   // part 0..1
     issue_piece(slot, st, 2 * part);
@@ -931,6 +956,26 @@ int gemm_num_cus() {
   }
   return n;
 }
+// SADDR-form DMA needs every byte offset of both operands to fit 32 bits (dev knob OMNI_GEMM_SADDR=0 disables it)
+bool ring_saddr_ok(const omni_gemm_params* p) {
+  static int knob = -1;
+  if (knob < 0) {
+    const char* e = getenv("OMNI_GEMM_SADDR");
+    knob = e ? atoi(e) : 1;
+  }
+  if (!knob) return false;
+  const int64_t lim = 1ll << 32;
+  if (p->w_k32_blocked ? ((int64_t)p->N * RBK * 2 >= lim) : ((int64_t)p->N * p->K * 2 >= lim)) return false;
+  for (int g = 0; g < p->ngroups; ++g) {
+    const omni_gemm_group& G = p->g[g];
+    if (G.a_k32_rows) {
+      if ((int64_t)G.a_k32_rows * RBK * 2 >= lim) return false;
+    } else if (G.a_row_map || (int64_t)G.M * G.lda * 2 >= lim) {
+      return false;
+    }
+  }
+  return true;
+}
 bool gemm_persistent() {
   // dev knob: OMNI_GEMM_PERSISTENT=1 -> one workgroup per CU walking the tiles.  Measured neutral (0.3688 vs 0.3690 images/s,
   // same box): workgroup launch is not what the ~8 us per-tile overhead consists of, so the default stays one workgroup
@@ -956,6 +1001,8 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI, 0, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI, 0, true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_w4_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
@@ -970,8 +1017,12 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
   else if (epilogue_rows_coalescable(p)) {
     int grid = tiles_m * tiles_n;
     if (gemm_persistent() && grid > gemm_num_cus()) grid = gemm_num_cus() & ~7;
-    hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI, 0, true>), dim3(grid), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
-                       tiles_n, gemm_group_m());
+    if (ring_saddr_ok(p))
+      hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI, 0, true, true>), dim3(grid), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
+                         tiles_m, tiles_n, gemm_group_m());
+    else
+      hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI, 0, true>), dim3(grid), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
+                         tiles_m, tiles_n, gemm_group_m());
   }
   else
     hipLaunchKernelGGL(gemm_bf16_ring_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
