@@ -117,7 +117,7 @@ def measure_roofline(dev, R: int = 3) -> dict:
             traffic, traffic_src = json.load(fh)["traffic_bytes"], "profiles/r01_roofline_traffic_pmc.json (rocprofv3 --pmc)"
     except (OSError, KeyError, ValueError):
         pass
-    return {"bound": "mfma", "kernel": f"gemm_bf16_ring_kernel<OMNI_EPI_BIAS_GELU_TANH, 0, true> M={Mi}+{Mt} N=12288 K=3072"
+    return {"bound": "mfma", "kernel": f"gemm_bf16_ring_kernel<OMNI_EPI_BIAS_GELU_TANH, 0, true, true> M={Mi}+{Mt} N=12288 K=3072"
                                       + (" (W" + (", A, out" if ablk else "") + " K32-blocked)" if blocked else ""),
             "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
             "flop_per_launch": flops, "avg_launch_us": sec * 1e6, "traffic": traffic, "traffic_source": traffic_src,
