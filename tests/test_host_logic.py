@@ -183,3 +183,42 @@ def test_dp_worker_two_ranks_gloo():
         assert p.exitcode == 0
     assert res[0] == (None, [0.0, 1.0, 2.0, 3.0, 4.0])     # request order restored on the output rank
     assert res[1] == (None, None)
+
+
+def test_k32_blocked_layout_roundtrip_and_element_map():
+    """ops.w_to_k32_blocked / k32_blocked_to_rows are pure index permutations (documented map: element (r, k) lives at
+    ((k // 32) * R + r) * 32 + k % 32); the transformer's in-place layout switch is its own inverse."""
+    import torch
+
+    from vllm_omni_amd import ops
+
+    R, K = 12, 96
+    x = torch.arange(R * K, dtype=torch.float32).view(R, K)
+    b = ops.w_to_k32_blocked(x)
+    assert b.shape == x.shape and torch.equal(ops.k32_blocked_to_rows(b), x)
+    flat = b.reshape(-1)
+    for r, k in ((0, 0), (5, 31), (5, 32), (11, 95), (3, 70)):
+        assert flat[((k // 32) * R + r) * 32 + k % 32] == x[r, k]
+    with pytest.raises(ValueError):
+        ops.w_to_k32_blocked(torch.zeros(4, 40))
+
+
+def test_transformer_weight_layout_switch_is_lossless_on_cpu_tensors():
+    import torch
+
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+
+    m = QwenImageTransformer2DModel(num_layers=1, num_attention_heads=2, joint_attention_dim=64, device="cpu")
+    g = torch.Generator().manual_seed(0)
+    for p in m.parameters():
+        p.data.copy_(torch.randn(p.shape, generator=g).to(p.dtype))
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    m._set_weight_layout(True)
+    changed = [n for n, p in m.named_parameters() if not torch.equal(p, before[n])]
+    assert len(changed) == 8 and all(("attn" in n or "mlp" in n) and n.endswith("weight") for n in changed)
+    m._set_weight_layout(False)
+    assert all(torch.equal(p, before[n]) for n, p in m.named_parameters())
+    # load_weights always sees (and leaves) the reference layout, whatever the state before
+    m._set_weight_layout(True)
+    m.load_weights([(n, t) for n, t in before.items()])
+    assert not m._w_blocked and all(torch.equal(p, before[n]) for n, p in m.named_parameters())
