@@ -50,7 +50,10 @@ def main():
         xi, xt = rn(Mi, K), rn(Mt, K)
         wi, wt, b = rn(N, K, s=0.02), rn(N, K, s=0.02), rn(N)
         oi, ot = torch.empty(Mi, N, dtype=BF16, device=dev), torch.empty(Mt, N, dtype=BF16, device=dev)
-        fn = lambda: ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi), ops.GemmGroupArgs(xt, wt, b, ot)], epi)
+        # production layouts: K32-blocked A and W (row-major output), same values
+        xib, xtb, wib, wtb = (ops.w_to_k32_blocked(z) for z in (xi, xt, wi, wt))
+        fn = lambda: ops.gemm([ops.GemmGroupArgs(xib, wib, b, oi, a_k32_blocked=True),
+                               ops.GemmGroupArgs(xtb, wtb, b, ot, a_k32_blocked=True)], epi, w_k32_blocked=True)
         t = timeit(fn)
         fl = 2.0 * (Mi + Mt) * N * K
         t_ref = timeit(lambda: (torch.mm(xi, wi.t()), torch.mm(xt, wt.t())))
