@@ -187,6 +187,11 @@ class QwenImageTransformer2DModel(nn.Module):
         self._w_blocked = blocked
         self._native = None
 
+    def unblock_weights(self) -> None:
+        """Put every parameter back into the reference's row-major layout (e.g. before `state_dict()` / saving: after the
+        first forward the eight GEMM matrices per layer hold the K32-blocked re-layout of the same values)."""
+        self._set_weight_layout(False)
+
     def init_random_(self, seed: int = 1234, std: float = 0.02) -> "QwenImageTransformer2DModel":
         """Synthetic weights ON DEVICE (bench only): >=2-D ~ N(0, std^2), biases 0, norm weights 1."""
         self._set_weight_layout(False)
