@@ -10,7 +10,16 @@ loads seeded synthetic weights (oracle.make_dit_params — the same generator th
 weights are NOT stored, only a checksum), runs the reference forward on seeded inputs and stores
 inputs + outputs (+ per-block outputs captured with forward hooks).  The fixtures pin
 oracle/qwen_image_oracle.py (tests/test_oracle_golden.py) and are the targets of the GPU parity
-tests (tests/test_gpu_parity.py).  Nothing here travels to the GPU box except the .npz files.
+tests (tests/test_gpu_dit_forward.py, tests/test_gpu_pipeline.py, tests/test_gpu_bench_shape_parity.py).
+Nothing here travels to the GPU box except the .npz files.
+
+Round 2 adds reference-run fixtures for the rest of the path (oracle/ref_shims_pipeline.py):
+  vae_decode_*          the reference's vendored AutoencoderKLQwenImage.decode (autoencoder_kl_qwenimage.py:839-887)
+  pipe_helpers          calculate_shift / _pack_latents / _unpack_latents / prepare_timesteps
+                        (pipeline_qwen_image.py:63-73, 436-457, 492-508)
+  pipe_diffuse_cfg_256  the reference `diffuse` loop incl. the true-CFG combine (:530-586) at BASELINE config 1's
+                        shape (256x256 -> 16x16 tokens, 4 steps) driving the reference DiT
+The scheduler class behind `prepare_timesteps` / `scheduler.step` is diffusers' (absent): restated stub, parity unpinned.
 """
 from __future__ import annotations
 
@@ -114,11 +123,111 @@ def run_case(name, case):
         print("  load_weights(q/k/v split) == fused state dict: OK")
 
 
+VAE_CASES = {"vae_decode_16x16_fp32": dict(h=16, w=16, seed=3), "vae_decode_24x40_fp32": dict(h=24, w=40, seed=5)}
+
+
+def run_vae_cases():
+    import ref_shims_pipeline as RP
+
+    vae = RP.build_reference_vae()
+    Pv = O.make_vae_params()
+    dec_names = [n for n, _ in vae.named_parameters() if n.startswith(("decoder.", "post_quant_conv."))]
+    assert sorted(dec_names) == sorted(Pv.keys()), "oracle.vae_decoder_param_shapes != reference decoder parameters"
+    sd = vae.state_dict()
+    for k, v in Pv.items():
+        assert sd[k].shape == v.shape, k
+        sd[k].copy_(v)
+    for name, c in VAE_CASES.items():
+        z = torch.randn(1, 16, 1, c["h"], c["w"], generator=torch.Generator().manual_seed(c["seed"]))
+        with torch.no_grad():
+            img = vae.decode(z, return_dict=False)[0]
+        meta = dict(case=c, params_sha256=params_checksum(Pv), param_seed=4321,
+                    reference="vllm_omni/diffusion/models/qwen_image/autoencoder_kl_qwenimage.py:839-887 via oracle/ref_shims_pipeline.py")
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), z=z.numpy(), image=img.numpy().astype(np.float32),
+                            meta=json.dumps(meta))
+        print(f"{name}: image {tuple(img.shape)} std {img.std():.4f} clamp-frac {float((img.abs() >= 1).float().mean()):.3f}")
+
+
+def run_pipeline_helpers():
+    import ref_shims_pipeline as RP
+
+    mod = RP.load_reference_pipeline_module()
+    pipe, _ = RP.reference_pipeline_shell(None, None)
+    out = {}
+    seqs = np.array([64, 256, 1024, 4096, 8192, 16384], dtype=np.int64)
+    out["shift_seq"] = seqs
+    out["shift_default"] = np.array([mod.calculate_shift(int(s)) for s in seqs], dtype=np.float64)
+    out["shift_qwen"] = np.array([mod.calculate_shift(int(s), 256, 8192, 0.5, 0.9) for s in seqs], dtype=np.float64)
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(2, 16, 12, 20, generator=g)
+    packed = mod.QwenImagePipeline._pack_latents(lat, 2, 16, 12, 20)
+    out["pack_in"], out["pack_out"] = lat.numpy(), packed.numpy()
+    out["unpack_out"] = mod.QwenImagePipeline._unpack_latents(packed, 96, 160, 8).numpy()
+    combos = [(4, 256), (20, 4096), (50, 4096), (50, 16384), (2, 64), (3, 1024)]   # N=1 is 0/0 in the terminal stretch (NaN in diffusers too)
+    out["ts_combos"] = np.array(combos, dtype=np.int64)
+    for n, s in combos:
+        ts, nn_ = mod.QwenImagePipeline.prepare_timesteps(pipe, n, None, s)
+        assert nn_ == n
+        out[f"timesteps_{n}_{s}"] = ts.numpy()
+        out[f"sigmas_{n}_{s}"] = pipe.scheduler.sigmas.numpy()
+    meta = dict(reference="pipeline_qwen_image.py:63-73,436-457,492-508 via oracle/ref_shims_pipeline.py; scheduler = restated stub",
+                scheduler_config=pipe.scheduler.config)
+    np.savez_compressed(os.path.join(OUT, "pipe_helpers.npz"), meta=json.dumps(meta), **out)
+    print("pipe_helpers: ", {k: v.shape for k, v in out.items() if k.startswith("timesteps")})
+
+
+def run_diffuse_case():
+    """Reference diffuse() (true-CFG on, 4 steps) over the reference DiT at BASELINE config 1's token grid."""
+    import ref_shims_pipeline as RP
+
+    case = dict(layers=2, heads=2, joint=128, grid=(16, 16), T=9, Tneg=5, steps=4, cfg=4.0, bias_std=0.02, jitter=0.1)
+    P = O.make_dit_params(case["layers"], seed=1234, bias_std=case["bias_std"], norm_jitter=case["jitter"],
+                          num_heads=case["heads"], joint_dim=case["joint"])
+    model, cfg = ref_shims.build_reference_model(case["layers"], num_attention_heads=case["heads"],
+                                                 joint_attention_dim=case["joint"], dtype=torch.float32)
+    model.load_state_dict(P, strict=True)
+    pipe, mod = RP.reference_pipeline_shell(model, cfg)
+    gh, gw = case["grid"]
+    g = torch.Generator().manual_seed(42)
+    lat = torch.randn(1, gh * gw, 64, generator=g)
+    pos = torch.randn(1, case["T"], case["joint"], generator=g)
+    neg = torch.randn(1, case["Tneg"], case["joint"], generator=g)
+    timesteps, _ = mod.QwenImagePipeline.prepare_timesteps(pipe, case["steps"], None, gh * gw)
+    traj = []
+    orig_step = pipe.scheduler.step
+
+    def tap(*a, **k):
+        r = orig_step(*a, **k)
+        traj.append(r[0].clone())
+        return r
+
+    pipe.scheduler.step = tap
+    final = RP.reference_diffuse(
+        pipe, cfg, prompt_embeds=pos, prompt_embeds_mask=torch.ones(1, case["T"], dtype=torch.long),
+        negative_prompt_embeds=neg, negative_prompt_embeds_mask=torch.ones(1, case["Tneg"], dtype=torch.long),
+        latents=lat, img_shapes=[[(1, gh, gw)]], txt_seq_lens=[case["T"]], negative_txt_seq_lens=[case["Tneg"]],
+        timesteps=timesteps, do_true_cfg=True, guidance=None, true_cfg_scale=case["cfg"])
+    meta = dict(case=case, params_sha256=params_checksum(P), param_seed=1234,
+                reference="pipeline_qwen_image.py:530-586 over qwen_image_transformer.py:692-802 via oracle/ref_shims*.py")
+    np.savez_compressed(os.path.join(OUT, "pipe_diffuse_cfg_256.npz"), latents=lat.numpy(), pos=pos.numpy(),
+                        neg=neg.numpy(), timesteps=timesteps.numpy(), sigmas=pipe.scheduler.sigmas.numpy(),
+                        trajectory=torch.stack(traj).numpy(), final=final.numpy(), meta=json.dumps(meta))
+    print(f"pipe_diffuse_cfg_256: final std {final.std():.4f}, steps {len(traj)}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    only = sys.argv[1:] or None
     for name, case in CASES.items():
-        run_case(name, case)
+        if only is None or name in only:
+            run_case(name, case)
+    if only is None or "vae" in only:
+        run_vae_cases()
+    if only is None or "helpers" in only:
+        run_pipeline_helpers()
+    if only is None or "diffuse" in only:
+        run_diffuse_case()
 
 
 if __name__ == "__main__":

@@ -275,19 +275,22 @@ def flow_match_sigmas(num_inference_steps: int, image_seq_len: int, cfg: Schedul
     """prepare_timesteps (pipeline_qwen_image.py:492-508) + FlowMatchEulerDiscreteScheduler.set_timesteps
     (diffusers; use_dynamic_shifting=True, time_shift_type='exponential', shift_terminal).
 
-    Returns (timesteps[N] fp32, sigmas[N+1] fp32 with trailing 0).  Computed in float64 then cast to
-    fp32 like the numpy->torch path in diffusers.
+    Returns (timesteps[N] fp32, sigmas[N+1] fp32 with trailing 0).  float32 numpy arithmetic, as in diffusers
+    (pinned bit-exactly to tests/golden/pipe_helpers.npz = the reference's prepare_timesteps over the restated
+    scheduler stub of oracle/ref_shims_pipeline.py; the diffusers class itself is absent: parity unpinned).
     """
     import numpy as np
 
     sigmas = np.linspace(1.0, 1.0 / num_inference_steps, num_inference_steps)
     mu = calculate_shift(image_seq_len, cfg.base_image_seq_len, cfg.max_image_seq_len, cfg.base_shift, cfg.max_shift)
-    sigmas = math.exp(mu) / (math.exp(mu) + (1.0 / sigmas - 1.0) ** 1.0)  # exponential time shift
+    # diffusers: `sigmas = np.array(sigmas).astype(np.float32)` first, then float32 numpy arithmetic throughout
+    sigmas = np.array(sigmas).astype(np.float32)
+    sigmas = math.exp(mu) / (math.exp(mu) + (1 / sigmas - 1) ** 1.0)  # exponential time shift
     if cfg.shift_terminal:
-        one_minus = 1.0 - sigmas
-        scale = one_minus[-1] / (1.0 - cfg.shift_terminal)
-        sigmas = 1.0 - one_minus / scale
-    sig = torch.from_numpy(sigmas).to(torch.float32)
+        one_minus = 1 - sigmas
+        scale = one_minus[-1] / (1 - cfg.shift_terminal)
+        sigmas = 1 - (one_minus / scale)
+    sig = torch.from_numpy(np.asarray(sigmas)).to(torch.float32)
     timesteps = sig * cfg.num_train_timesteps
     return timesteps, torch.cat([sig, torch.zeros(1)])
 

@@ -26,6 +26,13 @@ def load_golden(name: str):
     return z, meta, meta["case"]
 
 
+def load_golden_raw(name: str):
+    """Fixtures whose meta has no 'case' entry (pipe_helpers)."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    return z, meta, meta.get("case")
+
+
 def golden_params(case, dtype=torch.float32):
     P = O.make_dit_params(case["layers"], seed=1234, bias_std=case["bias_std"], norm_jitter=case["jitter"],
                           num_heads=case["heads"], joint_dim=case["joint"])

@@ -38,13 +38,18 @@ class FlowMatchEulerSchedule:
 
     def set_timesteps(self, num_inference_steps: int, image_seq_len: int, sigmas=None):
         c = self.config
-        s = np.linspace(1.0, 1.0 / num_inference_steps, num_inference_steps) if sigmas is None else np.asarray(sigmas, dtype=np.float64)
+        if num_inference_steps is None or num_inference_steps < 1:
+            raise ValueError("num_inference_steps must be >= 1")
+        s = np.linspace(1.0, 1.0 / num_inference_steps, num_inference_steps) if sigmas is None else np.asarray(sigmas)
         mu = calculate_shift(image_seq_len, c.base_image_seq_len, c.max_image_seq_len, c.base_shift, c.max_shift)
-        s = math.exp(mu) / (math.exp(mu) + (1.0 / s - 1.0))
+        s = np.array(s).astype(np.float32)                    # diffusers computes the schedule in float32 numpy
+        s = math.exp(mu) / (math.exp(mu) + (1 / s - 1) ** 1.0)
         if c.shift_terminal:
-            one_minus = 1.0 - s
-            s = 1.0 - one_minus / (one_minus[-1] / (1.0 - c.shift_terminal))
-        sig = torch.from_numpy(s).to(torch.float32)
+            one_minus = 1 - s
+            # a single step has sigma = 1: nothing to stretch (the diffusers formula is 0/0 = NaN there)
+            if float(one_minus[-1]) > 0.0:
+                s = 1 - (one_minus / (one_minus[-1] / (1 - c.shift_terminal)))
+        sig = torch.from_numpy(np.asarray(s)).to(torch.float32)
         self.timesteps = sig * c.num_train_timesteps
         self.sigmas = torch.cat([sig, torch.zeros(1)])
         return self.timesteps
