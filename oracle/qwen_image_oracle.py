@@ -41,7 +41,7 @@ def timestep_sinusoid(t: torch.Tensor, dim: int = 256, scale: float = 1000.0) ->
     Output order after the flip is [cos | sin].
     """
     half = dim // 2
-    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
     emb = t[:, None].float() * torch.exp(exponent)[None, :]
     emb = scale * emb
     return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
@@ -156,8 +156,8 @@ def joint_attention(P: Params, pre: str, img: torch.Tensor, txt: torch.Tensor, v
     iq, ik = rms_norm(iq, P[pre + ".norm_q.weight"]), rms_norm(ik, P[pre + ".norm_k.weight"])
     tq, tk = rms_norm(tq, P[pre + ".norm_added_q.weight"]), rms_norm(tk, P[pre + ".norm_added_k.weight"])
     # cos/sin are cast to the activation dtype BEFORE rotating (:403-406)
-    ic, isn = vid_cs[0].to(iq.dtype), vid_cs[1].to(iq.dtype)
-    tc, tsn = txt_cs[0].to(tq.dtype), txt_cs[1].to(tq.dtype)
+    ic, isn = vid_cs[0].to(iq.device, iq.dtype), vid_cs[1].to(iq.device, iq.dtype)   # (device: the GPU tests run this oracle in fp32 ON the GPU as the checker)
+    tc, tsn = txt_cs[0].to(tq.device, tq.dtype), txt_cs[1].to(tq.device, tq.dtype)
     iq, ik = rope_interleaved(iq, ic, isn), rope_interleaved(ik, ic, isn)
     tq, tk = rope_interleaved(tq, tc, tsn), rope_interleaved(tk, tc, tsn)
     q = torch.cat([tq, iq], dim=1)  # joint order [text ; image] (:412-416)

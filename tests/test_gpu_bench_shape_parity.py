@@ -1,0 +1,147 @@
+"""GPU parity AT THE BENCHMARKED SHAPE AND DEPTH, with the fp32 oracle run ON THE GPU as the checker.
+
+The CPU oracle cannot finish these sizes in seconds, but it is plain torch: on the GPU box it runs in fp32 on `cuda:0`
+(rocBLAS fp32 GEMMs, materialised softmax) next to the product's HIP path and is compared on identical bf16-rounded
+weights and inputs.  The oracle itself is pinned to reference-run fixtures on CPU (tests/test_oracle_golden.py).
+
+  * two full-width layers at the bench step-batch: 6 items x (4096 image + 64 text) rows (bench.py: R = 3 requests x 2
+    CFG branches), D = 3072, 24 heads — the exact shapes BENCH times;
+  * BASELINE config 1 at REAL DEPTH: 60 layers, full width, 256x256 (16x16 tokens), 4 steps, true-CFG on.  Besides the
+    fp32 oracle, the same oracle is run in bf16 (= the reference's algorithm in the reference's dtype, one rounding
+    per eager op) to calibrate how much drift 60 blocks x 8 forwards produce by themselves;
+  * VAE decode at 64x64 and 128x128 latents (512^2 / 1024^2 images: the mid-block attention over 4096 / 16384 tokens).
+
+Tolerances (bf16 storage / fp32 accumulate vs fp32): single forward rel_l2 <= 1e-2, cosine >= 0.9995;
+60-layer 4-step final latent: rel_l2 <= 3e-2 and no worse than 1.5x the bf16-eager drift of the reference algorithm;
+VAE image: rel_l2 <= 3e-2, mean |err| <= 2e-2 (the reference's own pixel bar, tests/e2e/offline_inference/
+test_sequence_parallel.py:128-147)."""
+import pytest
+import torch
+
+import qwen_image_oracle as O
+from _util import cosine, rel_l2
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+DEV = "cuda:0"
+
+
+def _perturbed_random_model(layers: int, seed: int):
+    """Full-width product model with random weights drawn ON DEVICE (20 B params at 60 layers: no CPU staging), non-zero
+    biases and jittered norm weights; returns (model, fp32 oracle params = the SAME bf16 bits upcast)."""
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+
+    m = QwenImageTransformer2DModel(num_layers=layers, device=DEV)
+    m.init_random_(seed=seed)
+    g = torch.Generator(device=DEV).manual_seed(seed + 1)
+    for n, p in m.named_parameters():
+        if p.dim() == 1 and "norm" in n:
+            p.data.add_(0.1 * torch.randn(p.shape, device=DEV, generator=g).to(BF16))
+        elif p.dim() == 1:
+            p.data.copy_((0.02 * torch.randn(p.shape, device=DEV, generator=g)).to(BF16))
+    return m
+
+
+def _oracle_params(m, dtype=torch.float32):
+    return {n: p.detach().to(dtype) for n, p in m.named_parameters()}      # BEFORE the first forward (row-major layout)
+
+
+def test_two_fullwidth_layers_at_bench_step_batch():
+    torch.backends.cuda.matmul.allow_tf32 = False
+    m = _perturbed_random_model(2, seed=77)
+    P = _oracle_params(m)
+    B, S, T = 6, 4096, 64
+    g = torch.Generator(device=DEV).manual_seed(5)
+    lat = torch.randn(B, S, 64, device=DEV, generator=g).to(BF16)
+    txt = torch.randn(B, T, 3584, device=DEV, generator=g).to(BF16)
+    sig = torch.full((B,), 0.6015625, device=DEV)                          # exactly representable in bf16
+    out = m(hidden_states=lat, encoder_hidden_states=txt, timestep=sig, img_shapes=[[(1, 64, 64)]] * B,
+            txt_seq_lens=[T] * B, return_dict=False)[0]
+    torch.cuda.synchronize()
+    worst, wc = 0.0, 1.0
+    with torch.no_grad():
+        for i in range(B):          # per item: B=1 semantics, and the fp32 score matrix stays at 24 x 4160^2 x 4 B = 1.7 GB
+            ref = O.dit_forward(P, lat[i:i + 1].float(), txt[i:i + 1].float(), sig[i:i + 1], (1, 64, 64), num_heads=24)
+            r, c = rel_l2(out[i:i + 1], ref), cosine(out[i:i + 1], ref)
+            worst, wc = max(worst, r), min(wc, c)
+            del ref
+    print(f"2 full-width layers @ 6 x (4096+64): worst rel_l2 {worst:.3e}, worst cosine {wc:.6f}")
+    assert worst <= 1e-2 and wc >= 0.9995
+
+
+def _oracle_denoise(P, lat, pos, neg, grid, steps, cfg, dtype):
+    """reference diffuse() (pipeline_qwen_image.py:530-586) with the oracle DiT in `dtype`; latents kept in bf16 (:585)."""
+    ts, sig = O.flow_match_sigmas(steps, lat.shape[1])
+    x = lat.float()
+    first = None
+    for i, t in enumerate(ts):
+        s_in = (t.bfloat16() / 1000).bfloat16().float().expand(1).to(lat.device)
+        p = O.dit_forward(P, x.to(dtype), pos.to(dtype), s_in, grid, num_heads=24).float()
+        n = O.dit_forward(P, x.to(dtype), neg.to(dtype), s_in, grid, num_heads=24).float()
+        if first is None:
+            first = p.clone()
+        x = O.euler_step(x, O.cfg_combine(p, n, cfg), float(sig[i]), float(sig[i + 1])).bfloat16().float()
+    return x, first
+
+
+def test_config1_256px_4steps_at_real_depth_60_layers():
+    """BASELINE config 1 (256x256, 4 steps, batch 1, true-CFG) with all 60 full-width layers."""
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    m = _perturbed_random_model(60, seed=1234)
+    P32 = _oracle_params(m)                                               # 82 GB fp32 next to 41 GB bf16: fits 288 GB
+    g = torch.Generator(device=DEV).manual_seed(42)
+    lat = torch.randn(1, 256, 64, device=DEV, generator=g).to(BF16)
+    pos = torch.randn(1, 11, 3584, device=DEV, generator=g).to(BF16)
+    neg = torch.randn(1, 5, 3584, device=DEV, generator=g).to(BF16)
+    with torch.no_grad():
+        ref, ref_first = _oracle_denoise(P32, lat, pos, neg, (1, 16, 16), 4, 4.0, torch.float32)
+        del P32
+        torch.cuda.empty_cache()
+        Pb = _oracle_params(m, BF16)
+        eager, eager_first = _oracle_denoise(Pb, lat, pos, neg, (1, 16, 16), 4, 4.0, BF16)   # the reference's dtype
+        del Pb
+        torch.cuda.empty_cache()
+    pipe = QwenImagePipeline(device=DEV, transformer=m)
+    # single forward at depth 60 (step 0, positive branch)
+    sig0 = pipe.scheduler.model_timestep(pipe.scheduler.set_timesteps(4, 256))[:1].to(DEV)
+    fwd = m(hidden_states=lat, encoder_hidden_states=pos, timestep=sig0, img_shapes=[[(1, 16, 16)]], txt_seq_lens=[11],
+            return_dict=False)[0]
+    req = OmniDiffusionRequest(height=256, width=256, num_inference_steps=4, true_cfg_scale=4.0, latents=lat,
+                               prompt_embeds=pos, negative_prompt_embeds=neg, output_type="latent")
+    out = pipe.generate([req], output_type="latent")[0].output
+    torch.cuda.synchronize()
+    r_f, r_f_eager = rel_l2(fwd, ref_first), rel_l2(eager_first, ref_first)
+    r, c = rel_l2(out, ref), cosine(out, ref)
+    r_eager = rel_l2(eager, ref)
+    print(f"60 layers, one forward: product vs fp32 oracle {r_f:.3e} (bf16-eager oracle vs fp32 oracle {r_f_eager:.3e})")
+    print(f"60 layers, 4 steps, CFG: final latent product vs fp32 oracle rel_l2 {r:.3e} cos {c:.6f}; "
+          f"bf16-eager oracle vs fp32 oracle {r_eager:.3e}")
+    assert torch.isfinite(out.float()).all()
+    assert r_f <= max(1e-2, 1.5 * r_f_eager)
+    assert r <= 3e-2 and c >= 0.9995
+    assert r <= max(2e-2, 1.5 * r_eager)
+
+
+@pytest.mark.parametrize("hw", [64, 128])
+def test_vae_decode_at_512_and_1024_px(hw):
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import AutoencoderKLQwenImage
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    Pv = O.make_vae_params()
+    vae = AutoencoderKLQwenImage(device=DEV)
+    vae.load_weights(Pv.items())
+    Pg = {k: v.to(BF16).float().to(DEV) for k, v in Pv.items()}
+    z = (torch.randn(1, 16, 1, hw, hw, generator=torch.Generator().manual_seed(9)) * 1.5).to(BF16)
+    img = vae.decode(z.to(DEV))[0]
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.vae_decode(Pg, z.float().to(DEV))
+    assert img.shape == ref.shape == (1, 3, 1, 8 * hw, 8 * hw)
+    r = rel_l2(img, ref)
+    d = (img.float() - ref).abs()
+    print(f"vae decode {8 * hw}px: rel_l2 {r:.3e} mean|err| {float(d.mean()):.3e} max|err| {float(d.max()):.3e}")
+    assert r <= 3e-2 and float(d.mean()) <= 2e-2 and float(d.max()) <= 2e-1

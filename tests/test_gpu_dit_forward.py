@@ -47,7 +47,7 @@ def test_dit_forward_matches_reference_golden(name):
     r_or, r_ref = rel_l2(out, oracle), rel_l2(out, ref)
     print(f"{name}: rel_l2 vs oracle(bf16-rounded inputs) {r_or:.3e}  vs reference golden {r_ref:.3e}  cos {cosine(out, oracle):.6f}")
     assert r_or <= 1e-2 and cosine(out, oracle) >= 0.9995
-    assert r_ref <= 3e-2
+    assert r_ref <= 1.5e-2     # measured 3.4e-3 .. 1.0e-2 (round 1): includes rounding the fp32 inputs/weights to bf16
 
 
 def test_ragged_batch_equals_per_request():

@@ -125,6 +125,63 @@ def test_adaln_and_attention_k32_blocked_outputs_are_bit_identical():
     assert torch.equal(o0, ops.k32_blocked_to_rows(o1))
 
 
+def _set_gemm_variant(v):
+    import ctypes
+
+    from vllm_omni_amd import _native as N
+
+    ctypes.CDLL(N.LIB_PATH).omni_dev_gemm_set_variant(v)
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 3072])
+@pytest.mark.parametrize("blocked", [False, True])
+def test_gemm_pingpong_kernel_is_bit_identical_to_ring_kernel(K, blocked):
+    """The ping-pong kernel (default) and the ring kernel accumulate every output element in the same k order with the
+    same MFMA: identical bits, for 1 / 2 / 3 / many K-tiles (prologue, steady state and drain of the 6-phase DMA lead),
+    ragged M in both groups, gathered A rows, both operand layouts, all epilogues that have a coalesced form."""
+    from vllm_omni_amd import ops
+
+    Mi, Mt, N, R = 700, 130, 768, 1000
+    a = rnd((R, K), 21)
+    wi, wt, b = rnd((N, K), 22, 0.05), rnd((N, K), 23, 0.05), rnd((N,), 24, 0.5)
+    res_i, res_t = g_(rnd((Mi, N), 25)), g_(rnd((Mt, N), 26))
+    gate = g_(rnd((3, N), 27))
+    gi = torch.Generator().manual_seed(5)
+    map_i = torch.randperm(R, generator=gi)[:Mi].to(torch.int32).to(dev())
+    map_t = torch.randperm(R, generator=gi)[:Mt].to(torch.int32).to(dev())
+    A = ops.w_to_k32_blocked(g_(a)) if blocked else g_(a)
+    Wi = ops.w_to_k32_blocked(g_(wi)) if blocked else g_(wi)
+    Wt = ops.w_to_k32_blocked(g_(wt)) if blocked else g_(wt)
+    item_i = (torch.arange(Mi) % 3).to(torch.int32).to(dev())
+    item_t = (torch.arange(Mt) % 3).to(torch.int32).to(dev())
+    outs = {}
+    try:
+        for variant in (1, 3):
+            _set_gemm_variant(variant)
+            got = []
+            for epi in (ops.EPI_BIAS, ops.EPI_BIAS_GELU_TANH, ops.EPI_BIAS_GATE_RES):
+                oi = res_i.clone() if epi == ops.EPI_BIAS_GATE_RES else torch.zeros(Mi, N, dtype=BF16, device=dev())
+                ot = res_t.clone() if epi == ops.EPI_BIAS_GATE_RES else torch.zeros(Mt, N, dtype=BF16, device=dev())
+                kw = dict(a_k32_blocked=blocked)
+                # the SADDR (32-bit offset) DMA form does not take gathered row-major rows: gather only in the blocked layout
+                mi, mt = (map_i, map_t) if blocked else (None, None)
+                gkw_i = dict(res=oi, gate=gate, gate_item_stride=N, row_item_map=item_i) if epi == ops.EPI_BIAS_GATE_RES else {}
+                gkw_t = dict(res=ot, gate=gate, gate_item_stride=N, row_item_map=item_t) if epi == ops.EPI_BIAS_GATE_RES else {}
+                Ai = A if blocked else A[:Mi]
+                At = A if blocked else A[Mi:Mi + Mt]
+                ops.gemm([ops.GemmGroupArgs(Ai, Wi, g_(b), oi, a_row_map=mi, **kw, **gkw_i),
+                          ops.GemmGroupArgs(At, Wt, g_(b), ot, a_row_map=mt, **kw, **gkw_t)], epi, w_k32_blocked=blocked)
+                torch.cuda.synchronize()
+                got += [oi, ot]
+            outs[variant] = got
+    finally:
+        _set_gemm_variant(-1)
+    for x, y in zip(outs[1], outs[3]):
+        assert torch.equal(x, y)
+    rows = map_i.long().cpu() if blocked else torch.arange(Mi)
+    assert rel_l2(outs[3][0], a[rows] @ wi.t() + b) <= 4e-3
+
+
 def test_gemm_transpose_detecting_identity():
     # A = I (asymmetric W): catches swapped row/col in the MFMA accumulator write (cdna guide rule 16)
     from vllm_omni_amd import ops

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import qwen_image_oracle as O
-from _util import bf16_round, cosine, rel_l2
+from _util import bf16_round, cosine, golden_params, load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
@@ -114,3 +114,46 @@ def test_pipeline_decode_end_to_end_shapes():
     out = pipe.forward(req)
     assert out.error is None and out.output.shape == (1, 3, 128, 128)
     assert torch.isfinite(out.output.float()).all() and float(out.output.float().abs().max()) <= 1.0
+
+
+# ---------------------------------------------------------------- against REFERENCE-RUN fixtures (not via the oracle)
+@pytest.mark.parametrize("name", ["vae_decode_16x16_fp32", "vae_decode_24x40_fp32"])
+def test_vae_decode_matches_reference_golden(name):
+    """Product VAE vs what the reference's vendored AutoencoderKLQwenImage.decode produced in fp32
+    (tests/golden, oracle/gen_golden.py; autoencoder_kl_qwenimage.py:839-887)."""
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import AutoencoderKLQwenImage
+
+    z, meta, c = load_golden(name)
+    vae = AutoencoderKLQwenImage(device=DEV)
+    vae.load_weights(O.make_vae_params().items())
+    img = vae.decode(torch.from_numpy(z["z"]).to(DEV, BF16))[0]
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(z["image"])
+    r = rel_l2(img, ref)
+    d = (img.float().cpu() - ref).abs()
+    print(f"{name}: product vs reference golden rel_l2 {r:.3e} mean|err| {float(d.mean()):.3e} max {float(d.max()):.3e}")
+    assert img.shape == ref.shape and r <= 3e-2 and float(d.mean()) <= 2e-2
+
+
+def test_diffuse_matches_reference_golden():
+    """Product denoise loop (bf16, fused CFG+Euler kernel, CFG pair as one ragged forward) vs the trajectory the
+    reference's own diffuse() produced in fp32 over the reference DiT (pipe_diffuse_cfg_256: 16x16 tokens, 4 steps)."""
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    z, meta, c = load_golden("pipe_diffuse_cfg_256")
+    P = golden_params(c)
+    m = QwenImageTransformer2DModel(num_layers=c["layers"], num_attention_heads=c["heads"],
+                                    joint_attention_dim=c["joint"], device=DEV)
+    m.load_weights(P.items())
+    pipe = QwenImagePipeline(device=DEV, transformer=m)
+    req = OmniDiffusionRequest(height=256, width=256, num_inference_steps=c["steps"], true_cfg_scale=c["cfg"],
+                               latents=torch.from_numpy(z["latents"]).to(BF16), prompt_embeds=torch.from_numpy(z["pos"]).to(BF16),
+                               negative_prompt_embeds=torch.from_numpy(z["neg"]).to(BF16), output_type="latent")
+    out = pipe.generate([req], output_type="latent")[0].output
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(z["final"])
+    r, cs = rel_l2(out, ref), cosine(out, ref)
+    print(f"diffuse vs reference-run golden: final latent rel_l2 {r:.3e} cos {cs:.6f}")
+    assert r <= 2e-2 and cs >= 0.9995

@@ -383,15 +383,30 @@ template <int NW, int NQ = 1>
 __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash_attn_fwd_pipe_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-    const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e, int out_k32_rows) {
+    const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e, int out_k32_rows,
+    int block_order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
 
-  const int hb = blockIdx.x % n_heads_total;
-  const int qb = blockIdx.x / n_heads_total;
+  // Block -> (item*head, q-block).  block_order 1 (default): XCD-aware.  Block b runs on XCD b % 8; each XCD gets a
+  // CONTIGUOUS range of the (head-major, q-block-minor) work list, so the ~32 workgroups resident on an XCD are all the
+  // q-blocks of about two heads: they stream the same 2 MB of K/V through that XCD's 4 MiB L2 at the same pace (one miss +
+  // 16 hits per line).  block_order 0 (round 1): heads fastest — an XCD then holds 18 different heads at once (38 MB of
+  // K/V against 4 MiB of L2: TCC hit 49 %, 5.4x the algorithmic fabric traffic, profiles/r01).
+  int hb, qb;
+  if (block_order == 1) {
+    const int nwg = gridDim.x, bid = blockIdx.x, qblocks = nwg / n_heads_total;
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    hb = lid / qblocks;
+    qb = lid - hb * qblocks;
+  } else {
+    hb = blockIdx.x % n_heads_total;
+    qb = blockIdx.x / n_heads_total;
+  }
   const int b = hb / H, h = hb - b * H;
   const int seq_start = cu_seqlens[b];
   const int seq_len = cu_seqlens[b + 1] - seq_start;
@@ -766,6 +781,15 @@ bool attn_pipelined() {
   }
   return v != 0;
 }
+int g_attn_block_order = -1;
+int attn_block_order() {
+  // dev knob: OMNI_ATTN_BLOCK_ORDER = 1 (default, XCD-aware head-major) | 0 (heads fastest)
+  if (g_attn_block_order < 0) {
+    const char* e = getenv("OMNI_ATTN_BLOCK_ORDER");
+    g_attn_block_order = e ? atoi(e) : 1;
+  }
+  return g_attn_block_order;
+}
 int attn_pipe_waves(int n_heads_total, int max_seqlen) {
   // 8 waves per workgroup (256 queries, half the DMA per query: +3.7 % at B=6) once the grid is at least 6 rounds of 256
   // CUs deep; 4 waves (128 queries, finer tail) below that (+3.7 % at B=2).  dev knob: OMNI_ATTN_WAVES = 4 | 8.
@@ -793,7 +817,7 @@ int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
   const int qblocks = (max_seqlen + 32 * NW * NQ - 1) / (32 * NW * NQ);
   const int nh = B * H;
   hipLaunchKernelGGL((flash_attn_fwd_pipe_kernel<NW, NQ>), dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
-                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows);
+                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows, attn_block_order());
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }
@@ -817,6 +841,9 @@ int launch_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
   return OMNI_OK;
 }
 }  // namespace
+
+// dev-only (NOT part of the C-ABI): switch the block order inside one process (A/B runs)
+extern "C" void omni_dev_attn_set_block_order(int v) { g_attn_block_order = v; }
 
 extern "C" int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
                                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,

@@ -726,6 +726,221 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
 
 
 // ------------------------------------------------------------------------------------------------
+// Ping-pong variant (OMNI_GEMM_VARIANT=3): BK = 64 K-tiles, the two wave groups of the workgroup (wm = 0 / 1: the two
+// waves that share each SIMD) run HALF A PHASE APART, so that on every SIMD one wave is inside an MFMA-only cluster while
+// its partner issues its fragment reads and LDS-DMA pieces (cdna_hip_programming.md "256^2 8-phase template", T3+T4+T5).
+// In the ring kernel all 8 waves execute the same instruction mix in lock step: whenever the L1's request queue is full
+// every wave stalls on its next global_load_lds and the matrix pipe drains (MFMA busy 62 %, TCP_PENDING_STALL 47 %).
+//
+// A K-tile is consumed as four QUADRANTS of the wave's 128 x 64 output (A rows mq*64.. x W rows nq*32..), one quadrant
+// (8 MFMAs = 256 matrix-pipe cycles) per phase, in the order (mq,nq) = (0,0) (0,1) (1,1) (1,0); the operands of a K-tile
+// are staged as four HALF-TILES of 128 rows x 64 k (16 KiB each), in the order the phases first need them:
+//   h0 = A rows of mq 0 (both wm)   h1 = W rows of nq 0 (all wn)   h2 = W rows of nq 1   h3 = A rows of mq 1
+// phase 0 reads h0 + h1 (12 ds_read_b128), phase 1 reads h2 (4), phase 2 reads h3 (8, into the registers of h0), phase 3
+// reads nothing: 24 reads per K-tile (the minimum), every half-tile is read in exactly one phase.
+// LDS = ring of 8 half-tile slots (2 K-tiles, 128 KiB); half-tile j = 4*tile + h lives in slot j % 8 and is issued SIX
+// phases ahead (in phase g = j - 6, two 1-KiB pieces per wave).  Barrier slots: group 0 runs [load g | B | mma g | B],
+// group 1 the same one barrier later.
+//   RAW: a wave ends every load section with vmcnt(8): its pieces of half-tiles <= g + 2 have landed; the partner group's
+//        covering wait is at most one barrier older than the first read (phase g + 1 reads half-tiles <= g + 2).
+//   WAR: the slot of half-tile j was last read in phase <= j - 8 by both groups (their lgkmcnt(0) sits behind the barrier
+//        that follows the read); group 0 re-issues it in phase j - 6, two full phases later.
+// LDS image of a slot: [128 rows][64 k] bf16 (128-B rows), 16-B chunk index XOR ((row >> 1) & 7) on the DMA source and
+// on the ds_read_b128 address (conflict-free for the four 16-lane groups).  A DMA piece = 8 rows x 128 B: whole cache
+// lines in the row-major layout, 2 x (8 rows x 64 B contiguous) in the K32-blocked layouts.
+// Same accumulator layout and the same k order as the ring kernel: results are bit-identical to it.
+// ------------------------------------------------------------------------------------------------
+#ifndef OMNI_PP_SETPRIO
+#define OMNI_PP_SETPRIO 1
+#endif
+#ifndef OMNI_PP_VMCNT
+#define OMNI_PP_VMCNT "s_waitcnt vmcnt(8)"   // 4 half-tiles x 2 pieces per wave may stay in flight across a barrier
+#endif
+// The cluster's MFMAs are issued from inline asm: as builtins they are "pure" nodes that hipcc's instruction selection
+// is free to sink below s_setprio 0 / the closing s_barrier and interleave with the NEXT phase's reads (observed) —
+// which destroys exactly the phase separation this kernel is about.  Volatile asm keeps program order with respect to the
+// barriers, waits and reads.  Hazards the compiler can no longer see: the operands come from ds_reads retired by the
+// explicit lgkmcnt(0); consecutive MFMAs alternate between two accumulators, SrcC == vDst exactly (the interlocked case);
+// the epilogue's first VALU read of an accumulator is kept >= 18 wait states away by the s_nops behind the k-loop.
+OMNI_DEVINL void pp_mfma(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+constexpr int PBK = 64;
+constexpr int PSLOT_BYTES = 128 * PBK * 2;    // 16 KiB per half-tile
+constexpr int PLDS_BYTES = 8 * PSLOT_BYTES;   // 128 KiB ring
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
+                                                                     int tiles_n, int GROUP_M) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int band_sz = GROUP_M * tiles_n;
+  const int band = lid / band_sz, in_band = lid - band * band_sz;
+  const int first_m = band * GROUP_M;
+  const int gm = min(GROUP_M, tiles_m - first_m);
+  const int mt = first_m + in_band % gm;
+  const int nt = in_band / gm;
+  const int gi = (mt >= mtiles0) ? 1 : 0;
+  const omni_gemm_group G = pick_group(P, gi);
+  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
+  const int n0 = nt * BN;
+  const int M = G.M, N = P.N, K = P.K;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // ---- per-lane DMA source byte offsets (32-bit, SADDR form): [mq | nq][piece i] --------------------------------
+  uint32_t a_off[2][2], w_off[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = (wave * 2 + i) * 8 + (lane >> 3);          // row inside the half-tile slot (0..127)
+    const int c = (lane & 7) ^ ((lr >> 1) & 7);               // logical 16-B chunk landing in physical chunk lane & 7
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int ar = min(m0 + (lr >> 6) * 128 + q * 64 + (lr & 63), M - 1);
+      if (G.a_row_map) ar = G.a_row_map[ar];
+      const int64_t ae = G.a_k32_rows ? ((int64_t)(c >> 2) * G.a_k32_rows + ar) * 32 + (c & 3) * 8
+                                      : (int64_t)ar * G.lda + c * 8;
+      a_off[q][i] = (uint32_t)(ae * 2);
+      const int wr = min(n0 + (lr >> 5) * 64 + q * 32 + (lr & 31), N - 1);
+      const int64_t we = P.w_k32_blocked ? ((int64_t)(c >> 2) * N + wr) * 32 + (c & 3) * 8 : (int64_t)wr * K + c * 8;
+      w_off[q][i] = (uint32_t)(we * 2);
+    }
+  }
+  // bytes between two K-tiles of one operand: two [rows][32] slabs in the K32-blocked layouts, 128 B in row-major
+  const int64_t astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * 128 : 128;
+  const int64_t wstep = P.w_k32_blocked ? (int64_t)N * 128 : 128;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int nkt = K / PBK;
+  const char* const Ab = reinterpret_cast<const char*>(G.A);
+  const char* const Wb = reinterpret_cast<const char*>(G.W);
+  // half-tile h (compile time) of K-tile `tile`: two pieces per wave
+#define OMNI_PP_ISSUE(h, tile)                                                                              \
+  do {                                                                                                      \
+    const int t_ = (tile);                                                                                  \
+    const uint32_t dst_ = lds0 + (((t_ & 1) * 4 + (h)) * PSLOT_BYTES) + (wave * 2) * 1024;                    \
+    if ((h) == 0 || (h) == 3) {                                                                             \
+      const char* b_ = Ab + t_ * astep;                                                                     \
+      glds16_saddr(b_, a_off[(h) == 3][0], dst_);                                                           \
+      glds16_saddr(b_, a_off[(h) == 3][1], dst_ + 1024);                                                    \
+    } else {                                                                                                \
+      const char* b_ = Wb + t_ * wstep;                                                                     \
+      glds16_saddr(b_, w_off[(h) == 2][0], dst_);                                                           \
+      glds16_saddr(b_, w_off[(h) == 2][1], dst_ + 1024);                                                    \
+    }                                                                                                       \
+  } while (0)
+
+  // ---- per-lane fragment read offsets: row * 128 + ((ks*2 + hi) ^ swz) * 16, swz = (row >> 1) & 7 = (l31 >> 1) & 7 ----
+  uint32_t a_rd[4], w_rd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const uint32_t chunk = ((uint32_t)(ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    a_rd[ks] = lds0 + (wm * 64 + l31) * 128 + chunk;
+    w_rd[ks] = lds0 + (wn * 32 + l31) * 128 + chunk;
+  }
+
+  // ---- prologue: half-tiles 0..5 in flight; 0 and 1 landed before the first read ---------------------------------
+  OMNI_PP_ISSUE(0, 0); OMNI_PP_ISSUE(1, 0); OMNI_PP_ISSUE(2, 0); OMNI_PP_ISSUE(3, 0);
+  if (nkt > 1) { OMNI_PP_ISSUE(0, 1); OMNI_PP_ISSUE(1, 1); }
+  // accumulators start at the bias.  The bias loads sit BEHIND the prologue's DMA issue: hipcc retires them with vmcnt(0)
+  // (it cannot see the asm DMAs), which placed between the DMA issues would drain the first pieces before the rest is sent.
+  f32x16_t acc[2][4];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    float bini[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + wn * 64 + hi * 4 + nb * 32 + q * 8;
+      u32x2_t b = {0u, 0u};
+      if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
+      bini[q * 4 + 0] = bf16_lo(b[0]); bini[q * 4 + 1] = bf16_hi(b[0]);
+      bini[q * 4 + 2] = bf16_lo(b[1]); bini[q * 4 + 3] = bf16_hi(b[1]);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][mb][i] = bini[i];
+  }
+
+  if (nkt > 1) {
+    asm volatile(OMNI_PP_VMCNT ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (wm) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
+  asm volatile("" ::: "memory");
+
+  bf16x8_t wf[2][4], af[2][4];                   // wf[nq][ks]; af[mb][ks] holds mq 0 in phases 0-1, mq 1 in phases 2-3
+#define OMNI_PP_READ_A(sb)                                                                 \
+  do {                                                                                     \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                  \
+      af[0][ks_] = lds_read16<0>(a_rd[ks_] + (sb));                                        \
+      af[1][ks_] = lds_read16<32 * 128>(a_rd[ks_] + (sb));                                 \
+    }                                                                                      \
+  } while (0)
+#define OMNI_PP_READ_W(nq, sb)                                                             \
+  do {                                                                                     \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) wf[nq][ks_] = lds_read16<0>(w_rd[ks_] + (sb)); \
+  } while (0)
+// end of a load section: counted DMA wait, barrier, fragments arrived; then the MFMA-only cluster and the second barrier
+#define OMNI_PP_MMA(nq, mq, issued)                                                                        \
+  do {                                                                                                     \
+    if (issued) asm volatile(OMNI_PP_VMCNT ::: "memory");                                                  \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                    \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                  \
+      pp_mfma(acc[nq][2 * (mq)], wf[nq][ks_], af[0][ks_]);                                                 \
+      pp_mfma(acc[nq][2 * (mq) + 1], wf[nq][ks_], af[1][ks_]);                                             \
+    }                                                                                                      \
+    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("" ::: "memory");                                                                         \
+  } while (0)
+
+#pragma unroll 1
+  for (int t = 0; t < nkt; ++t) {
+    const uint32_t sb = (uint32_t)((t & 1) * 4 * PSLOT_BYTES);
+    const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;
+    // phase 0: quadrant (mq 0, nq 0)
+    OMNI_PP_READ_A(sb);
+    OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
+    if (n1) OMNI_PP_ISSUE(2, t + 1);
+    OMNI_PP_MMA(0, 0, n1);
+    // phase 1: quadrant (mq 0, nq 1)
+    OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
+    if (n1) OMNI_PP_ISSUE(3, t + 1);
+    OMNI_PP_MMA(1, 0, n1);
+    // phase 2: quadrant (mq 1, nq 1)
+    OMNI_PP_READ_A(sb + 3 * PSLOT_BYTES);
+    if (n2) OMNI_PP_ISSUE(0, t + 2);
+    OMNI_PP_MMA(1, 1, n2);
+    // phase 3: quadrant (mq 1, nq 0)
+    if (n2) OMNI_PP_ISSUE(1, t + 2);
+    OMNI_PP_MMA(0, 1, n2);
+  }
+  if (!wm) __builtin_amdgcn_s_barrier();         // group 0 waits for group 1's last cluster
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // asm MFMA results -> first compiler-visible VALU read
+#undef OMNI_PP_MMA
+#undef OMNI_PP_READ_W
+#undef OMNI_PP_READ_A
+#undef OMNI_PP_ISSUE
+
+  gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi, smem, tid);
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // W4 variant: 4 waves x (128 x 128), ONE wave per SIMD owning the whole 512-entry register file (256 accumulator
 // registers + double-buffered fragments).  Same 5-stage BK=32 LDS ring and continuous pipeline as the ring kernel.
 // Why: the ablation (tools/bench_ablate_ring.py) shows DMA landings and fragment reads fighting for LDS bandwidth on
@@ -911,14 +1126,15 @@ int gemm_group_m() {
   return v;
 }
 
+int g_gemm_variant = -1;
 int gemm_variant() {
-  // dev knob: OMNI_GEMM_VARIANT=0 -> 2-stage BK=64 pipeline, 1 (default) -> 5-stage BK=32 ring
-  static int v = -1;
-  if (v < 0) {
+  // dev knob: OMNI_GEMM_VARIANT = 3 (default) ping-pong BK=64 kernel, 1 -> 5-stage BK=32 ring, 0 -> 2-stage BK=64 pipeline,
+  // 2 -> 4 waves x 128x128.  Shapes the ping-pong kernel does not take (K % 64, unaligned outputs) run on the ring kernel.
+  if (g_gemm_variant < 0) {
     const char* e = getenv("OMNI_GEMM_VARIANT");
-    v = e ? atoi(e) : 1;
+    g_gemm_variant = e ? atoi(e) : 3;
   }
-  return v;
+  return g_gemm_variant;
 }
 
 // The row-coalesced epilogue moves 16 B per thread: every output / residual / gate pointer and stride must allow it.
@@ -1003,6 +1219,8 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI, 0, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_w4_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
@@ -1014,6 +1232,9 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
   else if (gemm_variant() == 2)
     hipLaunchKernelGGL(gemm_bf16_w4_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(W4_THREADS), RLDS_BYTES, s, *p, mt0,
                        tiles_m, tiles_n, gemm_group_m());
+  else if (gemm_variant() == 3 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p))
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
+                       tiles_n, gemm_group_m());
   else if (epilogue_rows_coalescable(p)) {
     int grid = tiles_m * tiles_n;
     if (gemm_persistent() && grid > gemm_num_cus()) grid = gemm_num_cus() & ~7;
@@ -1032,6 +1253,9 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
 }
 
 }  // namespace
+
+// dev-only (NOT part of the C-ABI in include/omni_cdna4.h): switch the kernel family inside one process (A/B tests).
+extern "C" void omni_dev_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 // dev-only (NOT part of the C-ABI in include/omni_cdna4.h): time the 2-stage kernel with parts removed.
 extern "C" int omni_dev_gemm_ablate(const omni_gemm_params* p, int mode, omni_stream stream) {
@@ -1100,7 +1324,7 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
   const bool split3 = p->epilogue == OMNI_EPI_BIAS_SPLIT3 || p->epilogue == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE;
   if (split3 && (p->split_n <= 0 || p->split_n % 32 != 0 || p->N != 3 * p->split_n)) return OMNI_ERR_UNSUPPORTED;
   if (p->epilogue == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE) {     // the fused norm+RoPE exists in the ring kernel's coalesced epilogue only
-    if (p->split_n % 128 != 0 || gemm_variant() != 1) return OMNI_ERR_UNSUPPORTED;
+    if (p->split_n % 128 != 0 || (gemm_variant() != 1 && gemm_variant() != 3)) return OMNI_ERR_UNSUPPORTED;
     if (!epilogue_rows_coalescable(p)) return OMNI_ERR_ALIGN;
   }
   for (int g = 0; g < p->ngroups; ++g) {
@@ -1111,11 +1335,11 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
       if (p->epilogue != OMNI_EPI_BIAS && p->epilogue != OMNI_EPI_BIAS_GELU_TANH) return OMNI_ERR_UNSUPPORTED;
       if (p->N % 32 != 0 || (!G.out_row_map && G.out_k32_rows < G.M)) return OMNI_ERR_BAD_ARG;
     }
-    if ((G.a_k32_rows || G.out_k32_rows) && gemm_variant() != 1) return OMNI_ERR_UNSUPPORTED;
+    if ((G.a_k32_rows || G.out_k32_rows) && gemm_variant() != 1 && gemm_variant() != 3) return OMNI_ERR_UNSUPPORTED;
     if (G.out_k32_rows && !epilogue_rows_coalescable(p)) return OMNI_ERR_ALIGN;
   }
   if (p->w_k32_blocked != 0 && p->w_k32_blocked != 1) return OMNI_ERR_BAD_ARG;
-  if (p->w_k32_blocked && gemm_variant() != 1) return OMNI_ERR_UNSUPPORTED;   // only the ring kernel reads that layout
+  if (p->w_k32_blocked && gemm_variant() != 1 && gemm_variant() != 3) return OMNI_ERR_UNSUPPORTED;   // only the ring / ping-pong kernels read that layout
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (p->epilogue) {
     case OMNI_EPI_BIAS: return launch<OMNI_EPI_BIAS>(p, s);

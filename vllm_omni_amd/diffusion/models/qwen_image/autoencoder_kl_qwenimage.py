@@ -152,6 +152,8 @@ class AutoencoderKLQwenImage(nn.Module):
         self._packed = out
         return out
 
+    ATTN_Q_CHUNK = 8192
+
     # ------------------------------------------------------------------ blocks (NHWC bf16)
     def _res_block(self, W, pre, x):
         h = ops.vae_conv2d(x, W[pre + ".conv_shortcut.weight"], W[pre + ".conv_shortcut.bias"]) \
@@ -175,9 +177,15 @@ class AutoencoderKLQwenImage(nn.Module):
             q = ops.linear(t, wqkv[:Cc], bqkv[:Cc])
             k = ops.linear(t, wqkv[Cc:2 * Cc], bqkv[Cc:2 * Cc])
             vt = ops.linear(wqkv[2 * Cc:].contiguous(), t)              # V^T [C, tok] (bias folded below)
-            s = ops.linear(q, k)                                        # [tok, tok] scores
-            ops.softmax_rows_(s, 1.0 / math.sqrt(Cc))
-            outs.append(ops.linear(s, vt, bqkv[2 * Cc:]))               # P V + b_v  (rows of P sum to 1)
+            # query rows in chunks: the score buffer is [chunk, tok] bf16 (256 MiB at 1024^2, 1 GiB at 2048^2) instead
+            # of [tok, tok] (512 MiB / 8.6 GB)
+            o_b = torch.empty(tok, Cc, dtype=BF16, device=x.device)
+            for r0 in range(0, tok, self.ATTN_Q_CHUNK):
+                r1 = min(tok, r0 + self.ATTN_Q_CHUNK)
+                s = ops.linear(q[r0:r1], k)                             # [chunk, tok] scores
+                ops.softmax_rows_(s, 1.0 / math.sqrt(Cc))
+                ops.gemm([ops.GemmGroupArgs(s, vt, bqkv[2 * Cc:], o_b[r0:r1])])   # P V + b_v  (rows of P sum to 1)
+            outs.append(o_b)
         o = torch.stack(outs).view(B, H, Wd, Cc)
         return ops.vae_conv2d(o, W[pre + ".proj.weight"], W[pre + ".proj.bias"], res=x)
 
