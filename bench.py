@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches itself: the parent spawns N ranks of this
+file (env:// rendezvous on 127.0.0.1, one rank per GPU, same model as the reference's engine spawning one WorkerProc per
+GPU, diffusion_engine.py:203-260) and relays rank 0's JSON line; under torch.distributed.run the ranks are used as given.
+
 One "step" = every rank serves one STEP-BATCH of R (default 3) independent 1024x1024 requests end to end on the
 hot path: 20 denoising steps with true-CFG (2 DiT forwards of the 60-layer Qwen-Image transformer per request per
 step; all 2R items of the step-batch share ONE ragged DiT forward, per-request B=1 semantics), fused CFG+Euler
@@ -19,8 +23,11 @@ Also printed in the same JSON line:
   roofline     — dominant kernel = gemm_bf16_ring_kernel<GELU> (MLP up-projection, 27 % of the DiT FLOPs, one shape
                  per launch so rocprofv3's per-kernel average is shape-pure): algorithmic 2*M*N*K flop per launch
                  / average launch duration measured here with HIP events on the launch stream.
-  cpu_baseline — the fp32 CPU oracle (kind "port") timed on this box's host cores on a bounded sample and
+  cpu_baseline — the fp32 CPU oracle (kind "port": /root/reference does not exist on the GPU box, so the shim-imported
+                 reference cannot be timed there) on this box's host cores on a bounded sample of 2 full-width blocks,
                  extrapolated linearly in layers/forwards (rank 0, N=1 only).
+  secondary    — (N=1 only) the no-CFG variant of the same workload (1 forward per step), BASELINE config 1
+                 (256x256, 4 steps, batch 1) eager vs hipGraph replay, and TeaCache rel_l1_thresh 0.2 when available.
 """
 from __future__ import annotations
 
@@ -44,7 +51,7 @@ PFLOP_PER_IMAGE = 2.777e15          # 40 x 69.310 TF (DiT) + 4.7
 PEAK_BF16 = 2.5e15                  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(layers_sample: int = 1) -> dict:
+def cpu_baseline(layers_sample: int = 2) -> dict:
     """Oracle DiT blocks at full width on the host cores; extrapolated to images/sec."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import qwen_image_oracle as O
@@ -112,16 +119,89 @@ def measure_roofline(dev, R: int = 3) -> dict:
     # HBM/fabric bytes per launch of this very kernel + shape: bench.py cannot run rocprofv3 on itself, so it reports the
     # committed PMC measurement (tools/profile_round.sh -> tools/summarize_prof.py; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)
     traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_roofline_traffic_pmc.json")) as fh:
-            traffic, traffic_src = json.load(fh)["traffic_bytes"], "profiles/r01_roofline_traffic_pmc.json (rocprofv3 --pmc)"
-    except (OSError, KeyError, ValueError):
-        pass
-    return {"bound": "mfma", "kernel": f"gemm_bf16_ring_kernel<OMNI_EPI_BIAS_GELU_TANH, 0, true, true> M={Mi}+{Mt} N=12288 K=3072"
+    variant = os.environ.get("OMNI_GEMM_VARIANT", "3")
+    kname = "gemm_bf16_pp_kernel<OMNI_EPI_BIAS_GELU_TANH>" if variant == "3" else "gemm_bf16_ring_kernel<OMNI_EPI_BIAS_GELU_TANH, 0, true, true>"
+    for tag in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_roofline_traffic_pmc.json")) as fh:
+                j = json.load(fh)
+            if kname.split("<")[0] in j.get("kernel", ""):
+                traffic, traffic_src = j["traffic_bytes"], f"profiles/{tag}_roofline_traffic_pmc.json (rocprofv3 --pmc, {j['kernel']})"
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    return {"bound": "mfma", "kernel": f"{kname} M={Mi}+{Mt} N=12288 K=3072"
                                       + (" (W" + (", A, out" if ablk else "") + " K32-blocked)" if blocked else ""),
             "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
             "flop_per_launch": flops, "avg_launch_us": sec * 1e6, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": 2.0 * ((Mi + Mt) * K + 2 * N * K + (Mi + Mt) * N)}
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without torchrun: spawn the N ranks ourselves (one process per GPU, env:// rendezvous on
+    127.0.0.1) and pass rank 0's stdout (the JSON line) through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
+    """SURVEY.md §8d secondary measurements on one GPU (rank 0, N = 1): no-CFG line and BASELINE config 1 eager vs graph."""
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    out = {}
+    g = torch.Generator().manual_seed(3)
+
+    def reqs(n, hw, steps, cfg, T=T_TXT):
+        S = (hw // 16) ** 2
+        rs = []
+        for _ in range(n):
+            kw = dict(negative_prompt_embeds=torch.randn(1, T, 3584, generator=g).to(dev, torch.bfloat16)) if cfg else {}
+            rs.append(OmniDiffusionRequest(height=hw, width=hw, num_inference_steps=steps, true_cfg_scale=TRUE_CFG,
+                                           latents=torch.randn(1, S, 64, generator=g).to(dev, torch.bfloat16),
+                                           prompt_embeds=torch.randn(1, T, 3584, generator=g).to(dev, torch.bfloat16),
+                                           output_type="latent", **kw))
+        return rs
+
+    def timed(fn, n=1):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    # no-CFG: 2R requests per step-batch keeps the same 2R items per forward as the headline line
+    nocfg = reqs(2 * R, HEIGHT, STEPS_DENOISE, cfg=False)
+    old_cap = pipe.od_config.max_step_batch
+    pipe.od_config.max_step_batch = 2 * R
+    t = timed(lambda: [pipe.decode_latents(o.output, HEIGHT, WIDTH) for o in pipe.generate(nocfg, output_type="latent")])
+    pipe.od_config.max_step_batch = old_cap
+    out["no_cfg_images_per_sec"] = 2 * R / t
+    out["no_cfg_note"] = f"1024^2, 20 steps, 1 forward/step, {2 * R} requests step-batched, incl. VAE decode"
+    # BASELINE config 1 at real depth: 256x256, 4 steps, batch 1, true-CFG; eager launches vs hipGraph replay
+    one = reqs(1, 256, 4, cfg=True)
+    for name, flag in (("eager", False), ("hipgraph", True)):
+        pipe.od_config.use_hip_graph = flag
+        t = timed(lambda: pipe.decode_latents(pipe.generate(one, output_type="latent")[0].output, 256, 256), n=5)
+        out[f"config1_256px_4step_{name}_ms_per_image"] = t * 1e3
+    pipe.od_config.use_hip_graph = None
+    out["config1_note"] = f"256x256, 4 steps, true-CFG (8 forwards of {layers} layers), batch 1, + VAE decode"
+    return out
 
 
 def main():
@@ -132,6 +212,7 @@ def main():
     ap.add_argument("--layers", type=int, default=LAYERS, help=argparse.SUPPRESS)      # dev only; default = real model
     ap.add_argument("--requests", type=int, default=3, help="requests step-batched per rank per step (R)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     from vllm_omni_amd.diffusion.data import OmniDiffusionConfig, TransformerConfig
@@ -139,9 +220,11 @@ def main():
     from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
     from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     rank, world, local = dp.init_distributed()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product kernels")
     torch.cuda.set_device(local)
@@ -204,6 +287,11 @@ def main():
             "dit_mfma_roofline_frac": (value / world) * PFLOP_PER_IMAGE * (args.layers / LAYERS) / PEAK_BF16,
             "roofline": measure_roofline(dev, R),
         }
+        if world == 1 and not args.no_secondary:
+            try:
+                line["secondary"] = secondary_lines(pipe, dev, R, args.layers)
+            except Exception as e:  # noqa: BLE001 - the headline line must survive a failing secondary measurement
+                line["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

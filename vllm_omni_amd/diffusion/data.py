@@ -50,26 +50,27 @@ class DiffusionParallelConfig:
         return cls(**data)
 
 
-@dataclass
-class TransformerConfig:
-    params: dict[str, Any] = field(default_factory=dict)
+class TransformerConfig(dict):
+    """`transformer/config.json` as a mapping with attribute access (role of vllm_omni/diffusion/data.py:94-117; the DiT
+    reads `num_layers` only, qwen_image_transformer.py:652-653).  A plain dict subclass: `TransformerConfig(num_layers=2)`,
+    `TransformerConfig.from_dict({...})`, `.get(k, default)`, `.num_layers`, `.to_dict()`, `.params`."""
 
     @classmethod
     def from_dict(cls, data: dict[str, Any]) -> "TransformerConfig":
         if not isinstance(data, dict):
             raise TypeError(f"Expected transformer config dict, got {type(data)!r}")
-        return cls(params=dict(data))
+        return cls(data)
 
     def to_dict(self) -> dict[str, Any]:
-        return dict(self.params)
+        return dict(self)
 
-    def get(self, key: str, default: Any | None = None) -> Any:
-        return self.params.get(key, default)
+    @property
+    def params(self) -> "TransformerConfig":
+        return self
 
     def __getattr__(self, item: str) -> Any:
-        params = object.__getattribute__(self, "params")
         try:
-            return params[item]
+            return self[item]
         except KeyError as exc:
             raise AttributeError(item) from exc
 
@@ -88,11 +89,12 @@ class OmniDiffusionConfig:
     output_type: str = "pil"
     max_step_batch: int = 4          # NEW (not in the reference): requests whose steps share one DiT forward
     dist_timeout: int | None = None
+    use_hip_graph: bool | None = None   # NEW: capture one denoise step as a hipGraph (None = automatic by size)
 
     def __post_init__(self):
         if isinstance(self.parallel_config, dict):
             self.parallel_config = DiffusionParallelConfig.from_dict(self.parallel_config)
-        if isinstance(self.tf_model_config, dict):
+        if not isinstance(self.tf_model_config, TransformerConfig):
             self.tf_model_config = TransformerConfig.from_dict(self.tf_model_config)
         if self.num_gpus is None:
             self.num_gpus = self.parallel_config.world_size

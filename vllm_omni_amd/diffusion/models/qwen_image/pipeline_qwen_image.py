@@ -58,6 +58,7 @@ class QwenImagePipeline(nn.Module):
         self._latents_mean = torch.tensor(self.vae.config.latents_mean).view(1, -1, 1, 1, 1)
         self._latents_std = torch.tensor(self.vae.config.latents_std).view(1, -1, 1, 1, 1)
         self.weights_sources: list = []
+        self._step_state: dict = {}     # hipGraph + static buffers per step-batch shape
 
     # ------------------------------------------------------------------ helpers with the reference's semantics
     @staticmethod
@@ -112,7 +113,12 @@ class QwenImagePipeline(nn.Module):
     def _denoise(self, latents: list[torch.Tensor], pos: list[torch.Tensor], neg: list[torch.Tensor] | None,
                  grid, timesteps: torch.Tensor, dts: torch.Tensor, cfg_scales: list[float]) -> list[torch.Tensor]:
         """Step-batched denoising of R requests sharing (grid, schedule).  latents[r] [S_img, 64];
-        pos[r]/neg[r] [T, joint_dim] (ragged T).  Item order: pos_0..pos_{R-1}, then neg_0..neg_{R-1}."""
+        pos[r]/neg[r] [T, joint_dim] (ragged T).  Item order: pos_0..pos_{R-1}, then neg_0..neg_{R-1}.
+
+        One step = copy latents into the forward's input rows -> ONE ragged DiT forward over all items -> fused
+        CFG-combine + norm-rescale + Euler update.  When `use_hip_graph` applies, that step (~670 launches at 60 layers) is
+        captured once per (batch shape, cfg) as a hipGraph and replayed: at 256^2 a forward is ~4 ms of GPU work against
+        ~2.5 ms of host launch time (SURVEY.md §7 'Hard parts')."""
         tr, dev = self.transformer, self.device
         R = len(latents)
         S = latents[0].shape[0]
@@ -124,20 +130,69 @@ class QwenImagePipeline(nn.Module):
         # all requests are at the same timestep: ONE temb row, shared by every item (both CFG branches included)
         rb = build_ragged_batch(lens, grid, temb_rows=[0] * len(lens))
         prepared = tr.prepare_batch(rb)
-        prompt_rows = torch.cat(txt).contiguous()
-        lat = torch.cat([x.to(dev, BF16) for x in latents]).contiguous()            # [R*S, 64]
-        lat_in = torch.empty((2 if do_cfg else 1) * R * S, lat.shape[1], dtype=BF16, device=dev)
-        pred = torch.empty_like(lat_in)
+        n_items = (2 if do_cfg else 1) * R
         sig_in = self.scheduler.model_timestep(timesteps).to(dev)                   # bf16-rounded t/1000, fp32 [N]
         dt_dev = dts.to(dev, torch.float32).contiguous()
-        for i in range(len(timesteps)):
+        graph_on = self._use_graph(n_items * S)
+        key = (tuple(lens), tuple(grid), do_cfg, float(cfg_scales[0]), R)
+        st = self._step_state.get(key) if graph_on else None
+        if st is None:
+            st = dict(lat=torch.empty(R * S, tr.in_channels, dtype=BF16, device=dev),
+                      lat_in=torch.empty(n_items * S, tr.in_channels, dtype=BF16, device=dev),
+                      pred=torch.empty(n_items * S, tr.in_channels, dtype=BF16, device=dev),
+                      prompt=torch.empty(sum(lens), tr.joint_attention_dim, dtype=BF16, device=dev),
+                      sig=torch.empty(1, dtype=torch.float32, device=dev), dt=torch.empty(1, dtype=torch.float32, device=dev),
+                      graph=None)
+            if graph_on:
+                if len(self._step_state) >= 8:
+                    self._step_state.clear()
+                self._step_state[key] = st
+        st["lat"].copy_(torch.cat([x.to(dev, BF16) for x in latents]))
+        st["prompt"].copy_(torch.cat(txt))
+        lat, lat_in, pred = st["lat"], st["lat_in"], st["pred"]
+        tr.do_true_cfg = do_cfg
+
+        def step(sig1, dt1):
             lat_in[: R * S].copy_(lat)
             if do_cfg:
                 lat_in[R * S:].copy_(lat)
-            tr.do_true_cfg = do_cfg
-            tr.forward_ragged(prepared, lat_in, prompt_rows, sig_in[i:i + 1], out=pred)
-            ops.cfg_euler_step_(lat, pred[: R * S], pred[R * S:] if do_cfg else None, cfg_scales[0], dt_dev[i:i + 1])
-        return list(lat.view(R, S, -1).unbind(0))
+            tr.forward_ragged(prepared, lat_in, st["prompt"], sig1, out=pred)
+            ops.cfg_euler_step_(lat, pred[: R * S], pred[R * S:] if do_cfg else None, cfg_scales[0], dt1)
+
+        if not graph_on:
+            for i in range(len(timesteps)):
+                step(sig_in[i:i + 1], dt_dev[i:i + 1])
+            return list(lat.clone().view(R, S, -1).unbind(0))
+        if st["graph"] is None or st.get("gen") != tr._native_gen:
+            # warm-up on a side stream (lazy initialisation inside the native library: function attributes, workspace),
+            # then capture; the warm-up step advances `lat`, so the real inputs are restored afterwards
+            saved = lat.clone()
+            st["sig"].copy_(sig_in[:1]); st["dt"].zero_()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                step(st["sig"], st["dt"])
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step(st["sig"], st["dt"])
+            st["graph"] = g
+            # everything whose device address is baked into the captured kernel arguments stays referenced by the entry
+            st["keepalive"], st["gen"] = (prepared, tr._workspace, tr._native), tr._native_gen
+            lat.copy_(saved)
+        for i in range(len(timesteps)):
+            st["sig"].copy_(sig_in[i:i + 1], non_blocking=True)
+            st["dt"].copy_(dt_dev[i:i + 1], non_blocking=True)
+            st["graph"].replay()
+        return list(lat.clone().view(R, S, -1).unbind(0))
+
+    def _use_graph(self, img_rows: int) -> bool:
+        """`od_config.use_hip_graph`: True / False, or None = automatic (on while a forward is short enough for the host's
+        launch rate to matter: <= 4096 image rows, i.e. up to 512^2 x 4 items or one 1024^2 item)."""
+        flag = getattr(self.od_config, "use_hip_graph", None)
+        if flag is None:
+            return img_rows <= 4096
+        return bool(flag)
 
     # ------------------------------------------------------------------ decode
     @torch.no_grad()

@@ -154,6 +154,7 @@ class QwenImageTransformer2DModel(nn.Module):
         self.norm_out = _NormOut(D, device, dtype)
         self.proj_out = _linear(D, patch_size * patch_size * self.out_channels, device, dtype)
         self._native = None        # (DitWeights struct, keep-alive list)
+        self._native_gen = 0       # bumped whenever the pointer table is rebuilt (captured hipGraphs must be re-captured)
         self._w_blocked = False    # the 8 big matrices per layer currently hold the K32-blocked re-layout
         self._workspace = None
         self._batch_cache: dict = {}
@@ -274,6 +275,7 @@ class QwenImageTransformer2DModel(nn.Module):
         w.proj_out_w, w.proj_out_b = self.proj_out.weight.data_ptr(), self.proj_out.bias.data_ptr()
         w.layers = C.cast(layers, C.POINTER(N.DitLayerWeights))
         self._native = (w, layers)
+        self._native_gen += 1
         return w
 
     # ------------------------------------------------------------------ batches
