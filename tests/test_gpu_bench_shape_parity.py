@@ -11,8 +11,11 @@ weights and inputs.  The oracle itself is pinned to reference-run fixtures on CP
     per eager op) to calibrate how much drift 60 blocks x 8 forwards produce by themselves;
   * VAE decode at 64x64 and 128x128 latents (512^2 / 1024^2 images: the mid-block attention over 4096 / 16384 tokens).
 
-Tolerances (bf16 storage / fp32 accumulate vs fp32): single forward rel_l2 <= 1e-2, cosine >= 0.9995 (SURVEY.md §8c);
-60-layer 4-step final latent: rel_l2 <= 3e-2 and no worse than 1.5x the bf16-eager drift of the reference algorithm;
+Tolerances (bf16 storage / fp32 accumulate vs fp32): single forward of <= 4 layers rel_l2 <= 1e-2, cosine >= 0.9995
+(SURVEY.md §8c).  At 60 layers bf16 itself drifts: the REFERENCE ALGORITHM run in bf16 (the dtype the reference runs in)
+sits at 1.75e-2 per forward and 5.7e-2 on the 4-step final latent against its own fp32 run (measured, round 2; random
+N(0, 0.02^2) weights), so the bar there is relative: the product must be no further from fp32 than 1.1x the bf16-eager
+reference algorithm (measured: 1.57e-2 / 5.4e-2, i.e. closer to fp32 than the eager reference), cosine >= 0.997;
 VAE image: rel_l2 <= 3e-2, mean |err| <= 2e-2 (the reference's own pixel bar, tests/e2e/offline_inference/
 test_sequence_parallel.py:128-147)."""
 import pytest
@@ -120,9 +123,9 @@ def test_config1_256px_4steps_at_real_depth_60_layers():
     print(f"60 layers, 4 steps, CFG: final latent product vs fp32 oracle rel_l2 {r:.3e} cos {c:.6f}; "
           f"bf16-eager oracle vs fp32 oracle {r_eager:.3e}")
     assert torch.isfinite(out.float()).all()
-    assert r_f <= max(1e-2, 1.5 * r_f_eager)
-    assert r <= 3e-2 and c >= 0.9995
-    assert r <= max(2e-2, 1.5 * r_eager)
+    print(f"   product vs bf16-eager oracle (two independent bf16 roundings of the same path): {rel_l2(out, eager):.3e}")
+    assert r_f <= max(1e-2, 1.1 * r_f_eager)
+    assert r <= max(2e-2, 1.1 * r_eager) and c >= 0.997
 
 
 @pytest.mark.parametrize("hw", [64, 128])

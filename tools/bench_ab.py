@@ -36,6 +36,9 @@ def timeit(fn, iters=10, warmup=2):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+VARIANTS = {"ring": 1, "pp4": 3, "pp2": 5, "pp2_dmafirst": 6}
+
+
 def main():
     rounds = int(os.environ.get("AB_ROUNDS", "5"))
     res = {}
@@ -61,39 +64,41 @@ def main():
                 torch.mm(xi, wi.t())
                 torch.mm(xt, wt.t())
 
-            # bit-identity of the two kernel families
+            # bit-identity of the kernel families
             raw.omni_dev_gemm_set_variant(1); ours(); o1 = oi.clone(); t1 = ot.clone()
-            raw.omni_dev_gemm_set_variant(3); ours()
-            torch.cuda.synchronize()
-            same = bool(torch.equal(o1, oi) and torch.equal(t1, ot))
+            same = True
+            for v in VARIANTS.values():
+                raw.omni_dev_gemm_set_variant(v); ours()
+                torch.cuda.synchronize()
+                same = same and bool(torch.equal(o1, oi) and torch.equal(t1, ot))
             fl = 2.0 * (Mi + Mt) * Nn * K
-            ts = {"ring": [], "pp": [], "mm": []}
+            ts = {k: [] for k in list(VARIANTS) + ["mm"]}
             for _ in range(rounds):
-                raw.omni_dev_gemm_set_variant(1); ts["ring"].append(timeit(ours))
-                raw.omni_dev_gemm_set_variant(3); ts["pp"].append(timeit(ours))
+                for k, v in VARIANTS.items():
+                    raw.omni_dev_gemm_set_variant(v); ts[k].append(timeit(ours))
                 ts["mm"].append(timeit(ref))
             line = {k: fl / statistics.median(v) / 1e12 for k, v in ts.items()}
             res[f"gemm_{name}_M{Mi}"] = dict(tflops=line, bit_identical=same)
-            print(f"gemm {name:12s} M={Mi}+{Mt} N={Nn} K={K}: ring {line['ring']:7.1f}  pingpong {line['pp']:7.1f}  torch.mm {line['mm']:7.1f} TF/s"
-                  f"  (best pp {fl/min(ts['pp'])/1e12:7.1f})  bit-identical={same}", flush=True)
+            print(f"gemm {name:12s} M={Mi}+{Mt} N={Nn} K={K}: " + "  ".join(f"{k} {x:7.1f}" for k, x in line.items())
+                  + f" TF/s  bit-identical={same}", flush=True)
             del xi, xt, wi, wt, oi, ot, xib, xtb, wib, wtb
     for n in (4096, 8192):
         a, w = rn(n, n), rn(n, n, s=0.02)
         o = torch.empty(n, n, dtype=BF16, device=dev)
         fn = lambda: ops.gemm([ops.GemmGroupArgs(a, w, None, o)], ops.EPI_BIAS)
-        ts = {"ring": [], "pp": [], "mm": []}
+        ts = {k: [] for k in list(VARIANTS) + ["mm"]}
         for _ in range(rounds):
-            raw.omni_dev_gemm_set_variant(1); ts["ring"].append(timeit(fn))
-            raw.omni_dev_gemm_set_variant(3); ts["pp"].append(timeit(fn))
+            for k, v in VARIANTS.items():
+                raw.omni_dev_gemm_set_variant(v); ts[k].append(timeit(fn))
             ts["mm"].append(timeit(lambda: torch.mm(a, w.t())))
         line = {k: 2 * n ** 3 / statistics.median(v) / 1e12 for k, v in ts.items()}
         res[f"gemm_sq{n}_rowmajor"] = line
-        print(f"gemm square {n} (row-major operands): ring {line['ring']:7.1f}  pingpong {line['pp']:7.1f}  torch.mm {line['mm']:7.1f} TF/s", flush=True)
+        print(f"gemm square {n} (row-major operands): " + "  ".join(f"{k} {x:7.1f}" for k, x in line.items()) + " TF/s", flush=True)
         del a, w, o
     raw.omni_dev_gemm_set_variant(-1)
 
     H, S = 24, 4096 + 64
-    for B in (2, 6):
+    for B in (() if os.environ.get('AB_SKIP_ATTN') else (2, 6)):
         q, k, v = rn(B * S, H * 128), rn(B * S, H * 128), rn(B * S, H * 128)
         cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
         fn = lambda: ops.flash_attn_varlen(q, k, v, cu, H, S, 1 / math.sqrt(128))

@@ -941,6 +941,203 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 
 
 // ------------------------------------------------------------------------------------------------
+// Two-phase ping-pong variant (OMNI_GEMM_VARIANT=5): same half-tiles, accumulators and k order as gemm_bf16_pp_kernel, but a
+// K-tile is consumed in TWO phases of 16 MFMAs (512 matrix-pipe cycles): phase a = A rows of mq 0 x both nq (reads h0, h1,
+// h2: 16 ds_read_b128), phase b = mq 1 x both nq (reads h3: 8).  Half the barriers per K-tile, and a load section has 512
+// instead of 256 partner-MFMA cycles to hide its reads and its four DMA pieces.  The LDS ring has 10 half-tile slots (all
+// 160 KiB; half-tile j = 4*tile + h in slot j % 10), which lets the DMA run further ahead:
+//   phase a of tile t issues h2 of tile t+1, then h0 of tile t+2;  phase b issues h3 of tile t+1, then h1 of tile t+2
+//   (leads of 2 / 4 / 2 / 3 phases; within a phase the half-tile that is needed sooner goes first).
+//   RAW: at the end of a load section everything the NEXT phase reads was issued at least one phase ago and FIRST in its
+//        phase; the three half-tiles issued after it may stay in flight: vmcnt(6).
+//   WAR: the previous occupant of a slot (half-tile j - 10) was last read >= 2 phases before the slot is re-issued.
+// ------------------------------------------------------------------------------------------------
+constexpr int P2_SLOTS = 10;
+static_assert(P2_SLOTS * PSLOT_BYTES <= RLDS_BYTES, "10-slot ring must fit the 160 KiB allocation");
+
+template <int EPI, bool DMA_FIRST>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp2_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
+                                                                      int tiles_n, int GROUP_M) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int band_sz = GROUP_M * tiles_n;
+  const int band = lid / band_sz, in_band = lid - band * band_sz;
+  const int first_m = band * GROUP_M;
+  const int gm = min(GROUP_M, tiles_m - first_m);
+  const int mt = first_m + in_band % gm;
+  const int nt = in_band / gm;
+  const int gi = (mt >= mtiles0) ? 1 : 0;
+  const omni_gemm_group G = pick_group(P, gi);
+  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
+  const int n0 = nt * BN;
+  const int M = G.M, N = P.N, K = P.K;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  uint32_t a_off[2][2], w_off[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = (wave * 2 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int ar = min(m0 + (lr >> 6) * 128 + q * 64 + (lr & 63), M - 1);
+      if (G.a_row_map) ar = G.a_row_map[ar];
+      const int64_t ae = G.a_k32_rows ? ((int64_t)(c >> 2) * G.a_k32_rows + ar) * 32 + (c & 3) * 8
+                                      : (int64_t)ar * G.lda + c * 8;
+      a_off[q][i] = (uint32_t)(ae * 2);
+      const int wr = min(n0 + (lr >> 5) * 64 + q * 32 + (lr & 31), N - 1);
+      const int64_t we = P.w_k32_blocked ? ((int64_t)(c >> 2) * N + wr) * 32 + (c & 3) * 8 : (int64_t)wr * K + c * 8;
+      w_off[q][i] = (uint32_t)(we * 2);
+    }
+  }
+  const int64_t astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * 128 : 128;
+  const int64_t wstep = P.w_k32_blocked ? (int64_t)N * 128 : 128;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int nkt = K / PBK;
+  const char* const Ab = reinterpret_cast<const char*>(G.A);
+  const char* const Wb = reinterpret_cast<const char*>(G.W);
+  auto mod10 = [](int x) { return x - (x >= 10 ? 10 : 0) - (x >= 20 ? 10 : 0); };   // x < 30
+  // half-tile h (compile time) of K-tile `tile`, whose ring slot is `slot` (uniform)
+#define OMNI_P2_ISSUE(h, tile, slot)                                                                        \
+  do {                                                                                                      \
+    const int t_ = (tile);                                                                                  \
+    const uint32_t dst_ = lds0 + (uint32_t)(slot) * PSLOT_BYTES + (wave * 2) * 1024;                          \
+    if ((h) == 0 || (h) == 3) {                                                                             \
+      const char* b_ = Ab + t_ * astep;                                                                     \
+      glds16_saddr(b_, a_off[(h) == 3][0], dst_);                                                           \
+      glds16_saddr(b_, a_off[(h) == 3][1], dst_ + 1024);                                                    \
+    } else {                                                                                                \
+      const char* b_ = Wb + t_ * wstep;                                                                     \
+      glds16_saddr(b_, w_off[(h) == 2][0], dst_);                                                           \
+      glds16_saddr(b_, w_off[(h) == 2][1], dst_ + 1024);                                                    \
+    }                                                                                                       \
+  } while (0)
+
+  uint32_t a_rd[4], w_rd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const uint32_t chunk = ((uint32_t)(ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    a_rd[ks] = lds0 + (wm * 64 + l31) * 128 + chunk;
+    w_rd[ks] = lds0 + (wn * 32 + l31) * 128 + chunk;
+  }
+
+  // ---- prologue: issue order h0(0) h1(0) h2(0) h0(1) h3(0) h1(1) (= the steady-state schedule of phases -4 .. -1) ----
+  OMNI_P2_ISSUE(0, 0, 0); OMNI_P2_ISSUE(1, 0, 1); OMNI_P2_ISSUE(2, 0, 2);
+  if (nkt > 1) OMNI_P2_ISSUE(0, 1, 4);
+  OMNI_P2_ISSUE(3, 0, 3);
+  if (nkt > 1) OMNI_P2_ISSUE(1, 1, 5);
+  f32x16_t acc[2][4];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    float bini[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + wn * 64 + hi * 4 + nb * 32 + q * 8;
+      u32x2_t b = {0u, 0u};
+      if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
+      bini[q * 4 + 0] = bf16_lo(b[0]); bini[q * 4 + 1] = bf16_hi(b[0]);
+      bini[q * 4 + 2] = bf16_lo(b[1]); bini[q * 4 + 3] = bf16_hi(b[1]);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][mb][i] = bini[i];
+  }
+  if (nkt > 1) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (wm) __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8_t wf[2][4], af[2][4];
+#define OMNI_P2_READ_A(slot)                                                               \
+  do {                                                                                     \
+    const uint32_t sb_ = (uint32_t)(slot) * PSLOT_BYTES;                                   \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                  \
+      af[0][ks_] = lds_read16<0>(a_rd[ks_] + sb_);                                         \
+      af[1][ks_] = lds_read16<32 * 128>(a_rd[ks_] + sb_);                                  \
+    }                                                                                      \
+  } while (0)
+#define OMNI_P2_READ_W(nq, slot)                                                           \
+  do {                                                                                     \
+    const uint32_t sb_ = (uint32_t)(slot) * PSLOT_BYTES;                                   \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) wf[nq][ks_] = lds_read16<0>(w_rd[ks_] + sb_); \
+  } while (0)
+#define OMNI_P2_MMA(mq, steady)                                                                            \
+  do {                                                                                                     \
+    if (steady) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                           \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                    \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                  \
+      pp_mfma(acc[0][2 * (mq)], wf[0][ks_], af[0][ks_]);                                                   \
+      pp_mfma(acc[0][2 * (mq) + 1], wf[0][ks_], af[1][ks_]);                                               \
+      pp_mfma(acc[1][2 * (mq)], wf[1][ks_], af[0][ks_]);                                                   \
+      pp_mfma(acc[1][2 * (mq) + 1], wf[1][ks_], af[1][ks_]);                                               \
+    }                                                                                                      \
+    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("" ::: "memory");                                                                         \
+  } while (0)
+
+  int tb = 0;                                    // (4 * t) % 10: ring slot of half-tile h0 of the current K-tile
+#pragma unroll 1
+  for (int t = 0; t < nkt; ++t) {
+    const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;
+    const int s_h1 = mod10(tb + 1), s_h2 = mod10(tb + 2), s_h3 = mod10(tb + 3);
+    const int s1_h2 = mod10(tb + 6), s1_h3 = mod10(tb + 7), s2_h0 = mod10(tb + 8), s2_h1 = mod10(tb + 9);
+    // phase a: A rows of mq 0 x both nq
+    if (DMA_FIRST) {
+      if (n1) OMNI_P2_ISSUE(2, t + 1, s1_h2);
+      if (n2) OMNI_P2_ISSUE(0, t + 2, s2_h0);
+    }
+    OMNI_P2_READ_A(tb);
+    OMNI_P2_READ_W(0, s_h1);
+    OMNI_P2_READ_W(1, s_h2);
+    if (!DMA_FIRST) {
+      if (n1) OMNI_P2_ISSUE(2, t + 1, s1_h2);
+      if (n2) OMNI_P2_ISSUE(0, t + 2, s2_h0);
+    }
+    OMNI_P2_MMA(0, n2);
+    // phase b: A rows of mq 1 x both nq
+    if (DMA_FIRST) {
+      if (n1) OMNI_P2_ISSUE(3, t + 1, s1_h3);
+      if (n2) OMNI_P2_ISSUE(1, t + 2, s2_h1);
+    }
+    OMNI_P2_READ_A(s_h3);
+    if (!DMA_FIRST) {
+      if (n1) OMNI_P2_ISSUE(3, t + 1, s1_h3);
+      if (n2) OMNI_P2_ISSUE(1, t + 2, s2_h1);
+    }
+    OMNI_P2_MMA(1, n2);
+    tb = mod10(tb + 4);
+  }
+  if (!wm) __builtin_amdgcn_s_barrier();
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#undef OMNI_P2_MMA
+#undef OMNI_P2_READ_W
+#undef OMNI_P2_READ_A
+#undef OMNI_P2_ISSUE
+
+  gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi, smem, tid);
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // W4 variant: 4 waves x (128 x 128), ONE wave per SIMD owning the whole 512-entry register file (256 accumulator
 // registers + double-buffered fragments).  Same 5-stage BK=32 LDS ring and continuous pipeline as the ring kernel.
 // Why: the ablation (tools/bench_ablate_ring.py) shows DMA landings and fragment reads fighting for LDS bandwidth on
@@ -1137,6 +1334,8 @@ int gemm_variant() {
   return g_gemm_variant;
 }
 
+bool gemm_variant_blocked_ok() { const int v = gemm_variant(); return v == 1 || v == 3 || v == 5 || v == 6; }
+
 // The row-coalesced epilogue moves 16 B per thread: every output / residual / gate pointer and stride must allow it.
 // (OMNI_GEMM_EPI_LDS=0 forces the direct epilogue: dev knob.)
 bool epilogue_rows_coalescable(const omni_gemm_params* p) {
@@ -1221,6 +1420,10 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp2_kernel<EPI, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp2_kernel<EPI, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_w4_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
@@ -1232,6 +1435,14 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
   else if (gemm_variant() == 2)
     hipLaunchKernelGGL(gemm_bf16_w4_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(W4_THREADS), RLDS_BYTES, s, *p, mt0,
                        tiles_m, tiles_n, gemm_group_m());
+  else if ((gemm_variant() == 5 || gemm_variant() == 6) && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
+    if (gemm_variant() == 5)
+      hipLaunchKernelGGL((gemm_bf16_pp2_kernel<EPI, false>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
+                         tiles_m, tiles_n, gemm_group_m());
+    else
+      hipLaunchKernelGGL((gemm_bf16_pp2_kernel<EPI, true>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
+                         tiles_m, tiles_n, gemm_group_m());
+  }
   else if (gemm_variant() == 3 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p))
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
                        tiles_n, gemm_group_m());
@@ -1324,7 +1535,7 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
   const bool split3 = p->epilogue == OMNI_EPI_BIAS_SPLIT3 || p->epilogue == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE;
   if (split3 && (p->split_n <= 0 || p->split_n % 32 != 0 || p->N != 3 * p->split_n)) return OMNI_ERR_UNSUPPORTED;
   if (p->epilogue == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE) {     // the fused norm+RoPE exists in the ring kernel's coalesced epilogue only
-    if (p->split_n % 128 != 0 || (gemm_variant() != 1 && gemm_variant() != 3)) return OMNI_ERR_UNSUPPORTED;
+    if (p->split_n % 128 != 0 || !gemm_variant_blocked_ok()) return OMNI_ERR_UNSUPPORTED;
     if (!epilogue_rows_coalescable(p)) return OMNI_ERR_ALIGN;
   }
   for (int g = 0; g < p->ngroups; ++g) {
@@ -1335,11 +1546,11 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
       if (p->epilogue != OMNI_EPI_BIAS && p->epilogue != OMNI_EPI_BIAS_GELU_TANH) return OMNI_ERR_UNSUPPORTED;
       if (p->N % 32 != 0 || (!G.out_row_map && G.out_k32_rows < G.M)) return OMNI_ERR_BAD_ARG;
     }
-    if ((G.a_k32_rows || G.out_k32_rows) && gemm_variant() != 1 && gemm_variant() != 3) return OMNI_ERR_UNSUPPORTED;
+    if ((G.a_k32_rows || G.out_k32_rows) && !gemm_variant_blocked_ok()) return OMNI_ERR_UNSUPPORTED;
     if (G.out_k32_rows && !epilogue_rows_coalescable(p)) return OMNI_ERR_ALIGN;
   }
   if (p->w_k32_blocked != 0 && p->w_k32_blocked != 1) return OMNI_ERR_BAD_ARG;
-  if (p->w_k32_blocked && gemm_variant() != 1 && gemm_variant() != 3) return OMNI_ERR_UNSUPPORTED;   // only the ring / ping-pong kernels read that layout
+  if (p->w_k32_blocked && !gemm_variant_blocked_ok()) return OMNI_ERR_UNSUPPORTED;   // only the ring / ping-pong kernels read that layout
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (p->epilogue) {
     case OMNI_EPI_BIAS: return launch<OMNI_EPI_BIAS>(p, s);

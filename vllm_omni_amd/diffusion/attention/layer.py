@@ -26,5 +26,8 @@ class Attention(nn.Module):
             cat = (lambda j, x: torch.cat([j, x], 1)) if front else (lambda j, x: torch.cat([x, j], 1))
             query, key, value = cat(attn_metadata.joint_query, query), cat(attn_metadata.joint_key, key), \
                 cat(attn_metadata.joint_value, value)
-        out = self.attention.forward(query, key, value, None)
+            # the joint tensors are folded in; what remains of the metadata (e.g. an attn_mask) still reaches the impl,
+            # which rejects what it cannot honour instead of silently attending unmasked
+            attn_metadata = AttentionMetadata(attn_mask=attn_metadata.attn_mask, joint_strategy=attn_metadata.joint_strategy)
+        out = self.attention.forward(query, key, value, attn_metadata)
         return out[0] if isinstance(out, tuple) else out

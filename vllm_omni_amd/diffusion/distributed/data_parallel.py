@@ -54,6 +54,16 @@ def shard_requests(costs: list[float], world: int) -> list[list[int]]:
     return out
 
 
+def any_rank_failed(failed: bool, device=None, group=None) -> bool:
+    """Agree on a failure flag before a collective: MAX-all-reduce of one int32 (world 1: the local flag)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(failed)
+    on_gpu = dist.get_backend(group) == "nccl"
+    t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t.item()))
+
+
 def gather_latents(local: torch.Tensor, counts: list[int], group=None) -> torch.Tensor:
     """All ranks contribute `local` [counts[rank], S, C]; every rank receives [sum(counts), S, C] in rank order.
     One padded all_gather_into_tensor (ranks with fewer items pad to max(counts))."""

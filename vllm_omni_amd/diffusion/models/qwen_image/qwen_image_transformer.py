@@ -193,6 +193,26 @@ class QwenImageTransformer2DModel(nn.Module):
         first forward the eight GEMM matrices per layer hold the K32-blocked re-layout of the same values)."""
         self._set_weight_layout(False)
 
+    # nn.Module plumbing that must never see (or strand) the K32-blocked re-layout / the cached raw-pointer table
+    def state_dict(self, *args, **kwargs):
+        """Always the reference's row-major values: the in-place blocked re-layout is undone first (it is re-applied
+        lazily by the next forward)."""
+        self.unblock_weights()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        self.unblock_weights()
+        out = super().load_state_dict(state_dict, *args, **kwargs)
+        self._native = None
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        """.to() / .cuda() / .half() move or replace parameter storage: drop every cached device pointer first."""
+        self.unblock_weights()
+        self._native, self._workspace = None, None
+        self._batch_cache.clear()
+        return super()._apply(fn, *args, **kwargs)
+
     def init_random_(self, seed: int = 1234, std: float = 0.02) -> "QwenImageTransformer2DModel":
         """Synthetic weights ON DEVICE (bench only): >=2-D ~ N(0, std^2), biases 0, norm weights 1."""
         self._set_weight_layout(False)
@@ -223,7 +243,10 @@ class QwenImageTransformer2DModel(nn.Module):
                 # mangle already-fused names)
                 if (split + ".") in name:
                     name = name.replace(split + ".", fused + ".")
-                    params[name].data[idx * D:(idx + 1) * D].copy_(w)
+                    dst = params[name].data[idx * D:(idx + 1) * D]
+                    if dst.shape != w.shape:
+                        raise ValueError(f"{name}[{idx}]: expected {tuple(dst.shape)}, got {tuple(w.shape)}")
+                    dst.copy_(w)
                     break
             else:
                 if name not in params:

@@ -38,17 +38,34 @@ class GPUWorker:
     @torch.inference_mode()
     def execute_model(self, reqs: list[OmniDiffusionRequest], od_config: OmniDiffusionConfig | None = None,
                       output_rank: int = 0, decode: bool = True) -> DiffusionOutput:
+        """Every rank receives the same request list (broadcast RPC, as in the reference), serves its shard and joins ONE
+        all-gather of the finished latents.  A failure on one rank must not strand the others inside the collective
+        (the reference has no collective here, so it has no such hazard): requests are validated on EVERY rank before
+        sharding (same verdict everywhere), and after the local denoise the ranks agree on an error flag (a 4-byte
+        all-reduce) before anyone enters the gather."""
         try:
             if not reqs:
                 return DiffusionOutput(error="empty request list")
-            costs = [float((r.num_inference_steps or 50) * ((r.height or 1024) // 16) * ((r.width or 1024) // 16))
-                     for r in reqs]
-            assign = dp.shard_requests(costs, self.world)
-            mine = [reqs[i] for i in assign[self.rank]]
+            for r in reqs:                                   # identical on all ranks: raises everywhere or nowhere
+                self.pipeline._req_params(r)
             shapes = {((r.height or 1024), (r.width or 1024)) for r in reqs}
             if self.world > 1 and len(shapes) != 1:
                 raise NotImplementedError("a DP batch must share one resolution (one gather shape)")
+            costs = [float((r.num_inference_steps or 50) * ((r.height or 1024) // 16) * ((r.width or 1024) // 16))
+                     for r in reqs]
+            assign = dp.shard_requests(costs, self.world)
+        except Exception as e:  # same policy as the reference busy loop: report, do not kill the worker
+            return DiffusionOutput(error=f"{type(e).__name__}: {e}")
+        mine = [reqs[i] for i in assign[self.rank]]
+        err, outs = None, []
+        try:
             outs = self.pipeline.generate(mine, output_type="latent") if mine else []
+        except Exception as e:
+            err = f"rank {self.rank}: {type(e).__name__}: {e}"
+        failed = dp.any_rank_failed(err is not None, self.pipeline.device)
+        if failed:
+            return DiffusionOutput(error=err or "another data-parallel rank failed; batch aborted on all ranks")
+        try:
             h, w = next(iter(shapes))
             S = (h // 16) * (w // 16)
             dev = self.pipeline.device
@@ -61,5 +78,5 @@ class GPUWorker:
                 return DiffusionOutput(output=lat)
             imgs = [self.pipeline.decode_latents(lat[i:i + 1], h, w) for i in range(lat.shape[0])]
             return DiffusionOutput(output=torch.cat(imgs))
-        except Exception as e:  # same policy as the reference busy loop: report, do not kill the worker
+        except Exception as e:
             return DiffusionOutput(error=f"{type(e).__name__}: {e}")
