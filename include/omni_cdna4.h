@@ -99,6 +99,9 @@ typedef struct {
                              * omni_gemm_params.w_k32_blocked, for activations produced by this library's own kernels */
   int32_t out_k32_rows;     /* 0: out is row-major [*, ldo].  R > 0: out is written K32-blocked [N/32][R][32] (ldo
                              * ignored; BIAS / BIAS_GELU_TANH epilogues only) so that the next GEMM can read it blocked */
+  const int32_t* tile_skip; /* nullable DEVICE array, one int32 per 256-row tile of this group: non-zero = the workgroups of
+                             * that row tile return at once (its rows belong to items whose block stack is skipped this
+                             * forward, omni_teacache).  A device-side predicate: no host round trip.  ABI v3. */
 } omni_gemm_group;
 
 typedef struct {
@@ -262,6 +265,33 @@ typedef struct {
   const omni_dit_layer_weights* layers; /* HOST array [num_layers] of device pointers */
 } omni_dit_weights;
 
+/* ------------------------------------------------------------------------------------------------
+ * TeaCache state of one step-batch (vllm_omni/diffusion/cache/teacache/hook.py:82-217, state.py, config.py), kept ON THE
+ * DEVICE and evaluated by kernels inside omni_dit_forward, PER ITEM (request x CFG branch — the reference keeps one state
+ * per CFG branch of its single request, hook.py:113-121):
+ *   rel = mean|mod - prev_mod| / (mean|prev_mod| + 1e-8)   over the item's first-block modulated input (:195-206)
+ *   acc += |poly(rel)|;  cnt == 0 -> compute (acc = 0);  acc < thresh -> SKIP the 60 blocks, else compute and acc = 0
+ *   skip   : hidden_img += prev_res                       (:127-134; the encoder residual is dead code there: only
+ *   compute: prev_res = hidden_img_after - hidden_img_before   (:135-157)   hidden_states reaches norm_out / proj_out)
+ * The reference reads the decision back with .cpu().item() (a host sync per forward); here the decision stays on the
+ * device: skipped items' GEMM row tiles and attention blocks return immediately (omni_gemm_group.tile_skip), so the launch
+ * sequence is fixed, sync-free and hipGraph-capturable, and step-batched items keep their own B=1 decisions.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  float rel_l1_thresh;
+  float coeff[5];        /* polynomial, highest power first (numpy.poly1d order, config.py:9-31) */
+  omni_bf16* prev_mod;   /* [n_img_rows * D] previous modulated input (layout = whatever the first AdaLN writes) */
+  omni_bf16* prev_res;   /* [n_img_rows, D] cached residual of the image stream */
+  float* acc_dist;       /* [n_items] accumulated rescaled distance */
+  int32_t* cnt;          /* [n_items] forwards seen since reset (0 -> always compute) */
+  int32_t* skip;         /* [n_items] out: this forward's decision (1 = blocks skipped) */
+  int32_t* skip_total;   /* [n_items] out: running count of skipped forwards (statistics) */
+  float* scratch;        /* [2 * n_items] zero-initialised partial sums (left zeroed by every forward) */
+  int32_t* tile_skip_img;/* [ceil(n_img_rows / 256)] scratch */
+  int32_t* tile_skip_txt;/* [ceil(n_txt_rows / 256)] scratch */
+  const int32_t* txt_cu; /* [n_items + 1] prefix sums of the text rows */
+} omni_teacache;
+
 typedef struct {
   /* ragged batch of n_items sequences; item i: T_i text rows then S_img image rows in the joint order */
   int32_t n_items, n_img_rows, n_txt_rows, n_joint_rows, n_temb, max_seqlen;
@@ -280,10 +310,19 @@ typedef struct {
   /* workspace (caller-allocated, sizes from omni_dit_workspace_bytes) */
   void* workspace;
   size_t workspace_bytes;
+  const omni_teacache* teacache;  /* nullable: TeaCache off.  All items must have the same number of image rows.  ABI v3 */
 } omni_dit_batch;
 
 size_t omni_dit_workspace_bytes(const omni_dit_weights* w, int32_t n_img_rows, int32_t n_txt_rows, int32_t n_temb);
 int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch* b, omni_stream stream);
+
+/* One dual-stream block (QwenImageTransformerBlock.forward, qwen_image_transformer.py:541-605) on caller-owned residual
+ * streams: hidden_img [n_img_rows, D], hidden_txt [n_txt_rows, D] (updated in place), temb [n_temb, D].  Same kernels and
+ * the same batch descriptor as omni_dit_forward (latents / prompt_embeds / timestep / noise_pred of `b` are not read).
+ * This is the entry point behind the module-level plug-in surface that cache hooks walk
+ * (cache/teacache/extractors.py:216-233 calls `block(hidden_states=..., encoder_hidden_states=..., temb=...)`). */
+int omni_dit_block(const omni_dit_weights* w, int32_t layer, const omni_dit_batch* b, omni_bf16* hidden_img,
+                   omni_bf16* hidden_txt, const omni_bf16* temb, omni_stream stream);
 
 #ifdef __cplusplus
 }

@@ -34,9 +34,41 @@ def test_ctypes_struct_layout_matches_c():
     # sizes the C compiler produces for the ABI structs (computed with the same alignment rules)
     from vllm_omni_amd import _native as N
 
-    assert ctypes.sizeof(N.GemmGroup) == 192 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 192
+    assert ctypes.sizeof(N.GemmGroup) == 200 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 200     # ABI v3: + tile_skip
+    assert ctypes.sizeof(N.TeaCache) == 24 + 10 * 8 and N.DitBatch.teacache.offset == ctypes.sizeof(N.DitBatch) - 8
     assert ctypes.sizeof(N.DitLayerWeights) == 24 * 8
     assert N.GemmParams.g.offset == 24 and N.DitWeights.t_lin1_w.offset == 32   # w_k32_blocked flags live in padding / ABI v2
+
+
+def test_ctypes_structs_match_what_a_c_compiler_sees(tmp_path):
+    """Compile include/omni_cdna4.h with gcc (plain C: the header is the ABI) and compare sizeof / offsetof of every ABI
+    struct with the ctypes mirrors in vllm_omni_amd/_native.py."""
+    import subprocess
+
+    from vllm_omni_amd import _native as N
+
+    src = tmp_path / "abi.c"
+    src.write_text('''
+#include <stdio.h>
+#include <stddef.h>
+#include "omni_cdna4.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(omni_gemm_group), sizeof(omni_gemm_params), sizeof(omni_conv_params),
+         sizeof(omni_dit_layer_weights), sizeof(omni_dit_weights), sizeof(omni_dit_batch), sizeof(omni_teacache));
+  printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(omni_gemm_group, tile_skip), offsetof(omni_gemm_params, g),
+         offsetof(omni_dit_weights, layers), offsetof(omni_dit_batch, teacache), offsetof(omni_teacache, prev_mod),
+         offsetof(omni_dit_batch, rope_cos));
+  return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    sizes = [ctypes.sizeof(c) for c in (N.GemmGroup, N.GemmParams, N.ConvParams, N.DitLayerWeights, N.DitWeights,
+                                        N.DitBatch, N.TeaCache)]
+    offs = [N.GemmGroup.tile_skip.offset, N.GemmParams.g.offset, N.DitWeights.layers.offset, N.DitBatch.teacache.offset,
+            N.TeaCache.prev_mod.offset, N.DitBatch.rope_cos.offset]
+    assert [int(x) for x in out] == sizes + offs
 
 
 def test_product_path_fails_loudly_without_gpu():

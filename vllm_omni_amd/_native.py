@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OMNI_CDNA4_LIB", os.path.join(_HERE, "libomni_cdna4.so"))   # env override: dev sweeps
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_bf16_p = C.c_void_p  # device pointer to uint16_t bf16 bits
 c_i32_p = C.c_void_p
@@ -35,6 +35,7 @@ class GemmGroup(C.Structure):
         ("qk_norm_q_w", c_bf16_p), ("qk_norm_k_w", c_bf16_p), ("qk_rope_cos", c_bf16_p), ("qk_rope_sin", c_bf16_p),
         ("qk_row_pos", c_i32_p), ("qk_eps", C.c_float),
         ("a_k32_rows", C.c_int32), ("out_k32_rows", C.c_int32),
+        ("tile_skip", c_i32_p),
     ]
 
 
@@ -80,6 +81,16 @@ class DitWeights(C.Structure):
     ]
 
 
+class TeaCache(C.Structure):
+    """omni_teacache: device-side TeaCache state of one step-batch (include/omni_cdna4.h)."""
+    _fields_ = [
+        ("rel_l1_thresh", C.c_float), ("coeff", C.c_float * 5),
+        ("prev_mod", c_bf16_p), ("prev_res", c_bf16_p), ("acc_dist", c_f32_p), ("cnt", c_i32_p), ("skip", c_i32_p),
+        ("skip_total", c_i32_p), ("scratch", c_f32_p), ("tile_skip_img", c_i32_p), ("tile_skip_txt", c_i32_p),
+        ("txt_cu", c_i32_p),
+    ]
+
+
 class DitBatch(C.Structure):
     _fields_ = [
         ("n_items", C.c_int32), ("n_img_rows", C.c_int32), ("n_txt_rows", C.c_int32), ("n_joint_rows", C.c_int32),
@@ -91,6 +102,7 @@ class DitBatch(C.Structure):
         ("rope_cos", c_bf16_p), ("rope_sin", c_bf16_p),
         ("noise_pred", c_bf16_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("teacache", C.POINTER(TeaCache)),
     ]
 
 
@@ -126,6 +138,8 @@ PROTOTYPES = {
     "omni_softmax_rows": (C.c_int, [c_bf16_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "omni_dit_workspace_bytes": (C.c_size_t, [C.POINTER(DitWeights), C.c_int32, C.c_int32, C.c_int32]),
     "omni_dit_forward": (C.c_int, [C.POINTER(DitWeights), C.POINTER(DitBatch), C.c_void_p]),
+    "omni_dit_block": (C.c_int, [C.POINTER(DitWeights), C.c_int32, C.POINTER(DitBatch), c_bf16_p, c_bf16_p, c_bf16_p,
+                                 C.c_void_p]),
 }
 
 _lib = None

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
     const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e, int out_k32_rows,
-    int block_order) {
+    int block_order, const int32_t* __restrict__ item_skip) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -408,6 +408,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     qb = blockIdx.x / n_heads_total;
   }
   const int b = hb / H, h = hb - b * H;
+  if (item_skip && item_skip[b]) return;          // device-side predicate: this item's block stack is skipped (omni_teacache)
   const int seq_start = cu_seqlens[b];
   const int seq_len = cu_seqlens[b + 1] - seq_start;
   constexpr int QBLK = 32 * NW * NQ;
@@ -806,7 +807,7 @@ int attn_pipe_waves(int n_heads_total, int max_seqlen) {
 template <int NW, int NQ = 1>
 int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
                 int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
-                float softmax_scale, int out_k32_rows, hipStream_t s) {
+                float softmax_scale, int out_k32_rows, hipStream_t s, const int32_t* item_skip = nullptr) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe_kernel<NW, NQ>),
@@ -817,7 +818,7 @@ int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
   const int qblocks = (max_seqlen + 32 * NW * NQ - 1) / (32 * NW * NQ);
   const int nh = B * H;
   hipLaunchKernelGGL((flash_attn_fwd_pipe_kernel<NW, NQ>), dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
-                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows, attn_block_order());
+                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows, attn_block_order(), item_skip);
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }
@@ -845,10 +846,10 @@ int launch_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
 // dev-only (NOT part of the C-ABI): switch the block order inside one process (A/B runs)
 extern "C" void omni_dev_attn_set_block_order(int v) { g_attn_block_order = v; }
 
-extern "C" int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
-                                      int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,
-                                      int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
-                                      int32_t out_k32_rows, omni_stream stream) {
+int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq,
+                             int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H,
+                             int32_t head_dim, int32_t max_seqlen, float softmax_scale, int32_t out_k32_rows,
+                             const int32_t* item_skip, void* stream) {
   if (!q || !k || !v || !out || !cu_seqlens || B <= 0 || H <= 0 || max_seqlen <= 0 || out_k32_rows < 0)
     return OMNI_ERR_BAD_ARG;
   if (head_dim != DH) return OMNI_ERR_UNSUPPORTED;
@@ -858,15 +859,23 @@ extern "C" int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, co
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (attn_pipelined()) {
     if (attn_variant() == 2)   // OMNI_ATTN_NQ=2: 4 waves x 64 queries, one wave per SIMD
-      return launch_pipe<4, 2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s);
+      return launch_pipe<4, 2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
     if (attn_pipe_waves(B * H, max_seqlen) == 8)
-      return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s);
-    return launch_pipe<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s);
+      return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
+    return launch_pipe<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
   }
   if (out_k32_rows) return OMNI_ERR_UNSUPPORTED;   // only the pipelined kernel writes the blocked layout
   if (attn_variant() == 1)
     return launch_attn<1>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
   return launch_attn<2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
+}
+
+extern "C" int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
+                                      int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,
+                                      int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
+                                      int32_t out_k32_rows, omni_stream stream) {
+  return omni_internal_flash_attn(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, head_dim, max_seqlen, softmax_scale,
+                                  out_k32_rows, nullptr, stream);
 }
 
 extern "C" int omni_flash_attn_fwd(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,

@@ -16,7 +16,7 @@ namespace {
 
 struct Workspace {
   omni_bf16 *tproj, *th, *temb, *mod_img, *mod_txt, *emb_out;
-  omni_bf16 *hidden_img, *hidden_txt, *xn, *txt_normed, *q, *k, *v, *attn, *mlp_h;
+  omni_bf16 *hidden_img, *hidden_txt, *xn, *txt_normed, *q, *k, *v, *attn, *mlp_h, *h_in;
   int32_t *img_pos, *txt_pos;   // RoPE table row of every image / text stream row (joint_pos gathered through the joint-row maps)
   size_t total;
 };
@@ -49,6 +49,7 @@ Workspace carve(void* base, const omni_dit_weights* w, int64_t Ri, int64_t Rt, i
   ws.v = take(Rj * D);
   ws.attn = take(Rj * D);
   ws.mlp_h = take(Rj * 4 * D);
+  ws.h_in = take(Ri * D);           // image stream at block-stack entry (TeaCache residual / skip path)
   ws.img_pos = reinterpret_cast<int32_t*>(take(Ri * 2));
   ws.txt_pos = reinterpret_cast<int32_t*>(take(Rt * 2));
   ws.total = off;
@@ -61,9 +62,151 @@ Workspace carve(void* base, const omni_dit_weights* w, int64_t Ri, int64_t Rt, i
     if (_st != OMNI_OK) return _st; \
   } while (0)
 
+
+// Activations that only travel from one of this library's kernels into a GEMM A operand (AdaLN output, attention output,
+// GELU output) are kept K32-blocked ([K/32][rows][32], same bytes) so that the GEMM's LDS-DMA pieces fetch whole cache
+// lines (include/omni_cdna4.h: omni_gemm_group.a_k32_rows).  The residual stream, q/k/v and everything the caller sees stay
+// row-major.  dev knob: OMNI_DIT_ACT_BLOCKED=0.
+bool dit_act_blocked() {
+  static const bool v = [] {
+    const char* e = getenv("OMNI_DIT_ACT_BLOCKED");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
+// q/k RMSNorm + RoPE inside the QKV GEMM's coalesced epilogue (saves two passes over q and k per layer); dev knob
+// OMNI_DIT_FUSE_QKROPE=0 restores the separate omni_qk_norm_rope launches (bit-identical results).
+bool dit_fuse_qkrope() {
+  static const bool v = [] {
+    const char* e = getenv("OMNI_DIT_FUSE_QKROPE");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
+
+struct BlockPred { const int32_t *tile_img, *tile_txt, *item; };
+
+// One dual-stream block (reference QwenImageTransformerBlock.forward, qwen_image_transformer.py:541-605) on the residual
+// streams hidden_img / hidden_txt (in place).  `after_img_norm1` (nullable) runs right after the image stream's first AdaLN:
+// omni_dit_forward hooks the TeaCache decision there (the "modulated input" of extractors.py:189-194).
+template <typename Hook>
+int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const Workspace& ws, omni_bf16* hidden_img,
+              omni_bf16* hidden_txt, const omni_bf16* temb, const BlockPred& pr, Hook&& after_img_norm1, omni_stream stream) {
+  const omni_dit_layer_weights& L = w->layers[l];
+  const int32_t Ri = b->n_img_rows, Rt = b->n_txt_rows, nT = b->n_temb;
+  const int32_t D = w->num_heads * w->head_dim;
+  const float eps = 1e-6f;
+  omni_bf16* xn_img = ws.xn;
+  omni_bf16* xn_txt = ws.xn + (int64_t)Ri * D;
+  omni_bf16* h_img = ws.mlp_h;
+  omni_bf16* h_txt = ws.mlp_h + (int64_t)Ri * 4 * D;
+  const float sm_scale = 1.0f / sqrtf((float)w->head_dim);
+  const bool fuse_qkrope = dit_fuse_qkrope();
+  const bool blk = dit_act_blocked() && (D % 32 == 0);
+  const int32_t bRi = blk ? Ri : 0, bRt = blk ? Rt : 0, bRj = blk ? Ri + Rt : 0;
+  // modulation vectors [shift1|scale1|gate1|shift2|scale2|gate2]  (reference :552-561)
+  OMNI_TRY(omni_linear_smallbatch(temb, D, nT, L.img_mod_w, L.img_mod_b, 6 * (int64_t)D, D, ws.mod_img, 6 * D, 1,
+                                  0, stream));
+  OMNI_TRY(omni_linear_smallbatch(temb, D, nT, L.txt_mod_w, L.txt_mod_b, 6 * (int64_t)D, D, ws.mod_txt, 6 * D, 1,
+                                  0, stream));
+  // norm1 + modulate (reference :564-567)
+  OMNI_TRY(omni_adaln_modulate_ex(hidden_img, D, xn_img, D, Ri, D, ws.mod_img + D, ws.mod_img, 6 * D, b->img_item,
+                                  0, eps, bRi, stream));
+  OMNI_TRY(after_img_norm1(xn_img));
+  OMNI_TRY(omni_adaln_modulate_ex(hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + D, ws.mod_txt, 6 * D, b->txt_item,
+                                  0, eps, bRt, stream));
+  // fused QKV projections of both streams, scattered into the joint q/k/v (reference :380-394, :414-416)
+  {
+    omni_gemm_params p = {};
+    p.ngroups = 2; p.N = 3 * D; p.K = D; p.split_n = D; p.w_k32_blocked = w->gemm_w_k32_blocked;
+    p.epilogue = fuse_qkrope ? OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE : OMNI_EPI_BIAS_SPLIT3;
+    if (fuse_qkrope) {
+      p.g[0].qk_norm_q_w = L.norm_q_w; p.g[0].qk_norm_k_w = L.norm_k_w; p.g[0].qk_row_pos = ws.img_pos;
+      p.g[1].qk_norm_q_w = L.norm_added_q_w; p.g[1].qk_norm_k_w = L.norm_added_k_w; p.g[1].qk_row_pos = ws.txt_pos;
+      for (int g = 0; g < 2; ++g) {
+        p.g[g].qk_rope_cos = b->rope_cos; p.g[g].qk_rope_sin = b->rope_sin; p.g[g].qk_eps = eps;
+      }
+    }
+    p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt;
+    p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = L.to_qkv_w; p.g[0].bias = L.to_qkv_b;
+    p.g[0].out = ws.q; p.g[0].out1 = ws.k; p.g[0].out2 = ws.v; p.g[0].ldo = D; p.g[0].out_row_map = b->img_joint_row;
+    p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.add_qkv_w; p.g[1].bias = L.add_qkv_b;
+    p.g[1].out = ws.q; p.g[1].out1 = ws.k; p.g[1].out2 = ws.v; p.g[1].ldo = D; p.g[1].out_row_map = b->txt_joint_row;
+    p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
+    OMNI_TRY(omni_gemm_bf16(&p, stream));
+  }
+  // per-head RMSNorm + RoPE on q and k (reference :397-410)
+  if (!fuse_qkrope) {
+    OMNI_TRY(omni_qk_norm_rope(ws.q, D, Ri + Rt, w->num_heads, L.norm_q_w, L.norm_added_q_w, b->rope_cos, b->rope_sin,
+                               b->joint_pos, b->txt_pos_end, eps, stream));
+    OMNI_TRY(omni_qk_norm_rope(ws.k, D, Ri + Rt, w->num_heads, L.norm_k_w, L.norm_added_k_w, b->rope_cos, b->rope_sin,
+                               b->joint_pos, b->txt_pos_end, eps, stream));
+  }
+  // joint attention (reference :437-443 -> attention/backends/sdpa.py:46-66)
+  OMNI_TRY(omni_internal_flash_attn(ws.q, ws.k, ws.v, ws.attn, D, D, D, D, b->cu_seqlens, b->n_items, w->num_heads,
+                                    w->head_dim, b->max_seqlen, sm_scale, bRj, pr.item, stream));
+  // output projections + gated residual (reference :448-456, :586-587)
+  {
+    omni_gemm_params p = {};
+    p.ngroups = 2; p.N = D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GATE_RES; p.w_k32_blocked = w->gemm_w_k32_blocked;
+    p.g[0].a_k32_rows = bRj; p.g[1].a_k32_rows = bRj;
+    p.g[0].A = ws.attn; p.g[0].lda = D; p.g[0].a_row_map = b->img_joint_row; p.g[0].M = Ri;
+    p.g[0].W = L.to_out_w; p.g[0].bias = L.to_out_b; p.g[0].out = hidden_img; p.g[0].ldo = D;
+    p.g[0].res = hidden_img; p.g[0].ldres = D; p.g[0].gate = ws.mod_img + 2 * D; p.g[0].gate_item_stride = 6 * D;
+    p.g[0].row_item_map = b->img_item;
+    p.g[1].A = ws.attn; p.g[1].lda = D; p.g[1].a_row_map = b->txt_joint_row; p.g[1].M = Rt;
+    p.g[1].W = L.to_add_out_w; p.g[1].bias = L.to_add_out_b; p.g[1].out = hidden_txt; p.g[1].ldo = D;
+    p.g[1].res = hidden_txt; p.g[1].ldres = D; p.g[1].gate = ws.mod_txt + 2 * D; p.g[1].gate_item_stride = 6 * D;
+    p.g[1].row_item_map = b->txt_item;
+    p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
+    OMNI_TRY(omni_gemm_bf16(&p, stream));
+  }
+  // norm2 + modulate (reference :590, :595)
+  OMNI_TRY(omni_adaln_modulate_ex(hidden_img, D, xn_img, D, Ri, D, ws.mod_img + 4 * D, ws.mod_img + 3 * D, 6 * D,
+                                  b->img_item, 0, eps, bRi, stream));
+  OMNI_TRY(omni_adaln_modulate_ex(hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + 4 * D, ws.mod_txt + 3 * D, 6 * D,
+                                  b->txt_item, 0, eps, bRt, stream));
+  // MLP up + GELU-tanh (reference :591, :596 -> diffusers FeedForward)
+  {
+    omni_gemm_params p = {};
+    p.ngroups = 2; p.N = 4 * D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GELU_TANH; p.w_k32_blocked = w->gemm_w_k32_blocked;
+    p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt; p.g[0].out_k32_rows = bRi; p.g[1].out_k32_rows = bRt;
+    p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = L.img_mlp_w1; p.g[0].bias = L.img_mlp_b1;
+    p.g[0].out = h_img; p.g[0].ldo = 4 * D;
+    p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w1; p.g[1].bias = L.txt_mlp_b1;
+    p.g[1].out = h_txt; p.g[1].ldo = 4 * D;
+    p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
+    OMNI_TRY(omni_gemm_bf16(&p, stream));
+  }
+  // MLP down + gated residual (reference :592, :597)
+  {
+    omni_gemm_params p = {};
+    p.ngroups = 2; p.N = D; p.K = 4 * D; p.epilogue = OMNI_EPI_BIAS_GATE_RES; p.w_k32_blocked = w->gemm_w_k32_blocked;
+    p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt;
+    p.g[0].A = h_img; p.g[0].lda = 4 * D; p.g[0].M = Ri; p.g[0].W = L.img_mlp_w2; p.g[0].bias = L.img_mlp_b2;
+    p.g[0].out = hidden_img; p.g[0].ldo = D; p.g[0].res = hidden_img; p.g[0].ldres = D;
+    p.g[0].gate = ws.mod_img + 5 * D; p.g[0].gate_item_stride = 6 * D; p.g[0].row_item_map = b->img_item;
+    p.g[1].A = h_txt; p.g[1].lda = 4 * D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w2; p.g[1].bias = L.txt_mlp_b2;
+    p.g[1].out = hidden_txt; p.g[1].ldo = D; p.g[1].res = hidden_txt; p.g[1].ldres = D;
+    p.g[1].gate = ws.mod_txt + 5 * D; p.g[1].gate_item_stride = 6 * D; p.g[1].row_item_map = b->txt_item;
+    p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
+    OMNI_TRY(omni_gemm_bf16(&p, stream));
+  }
+  return OMNI_OK;
+}
+struct NoHook { int operator()(omni_bf16*) const { return OMNI_OK; } };
+
+// RoPE table row of every image / text stream row (joint_pos gathered through the joint-row maps): input of the fused
+// q/k norm + RoPE epilogue
+int prepare_positions(const omni_dit_batch* b, const Workspace& ws, omni_stream stream) {
+  if (!dit_fuse_qkrope()) return OMNI_OK;
+  OMNI_TRY(omni_internal_gather_i32(ws.img_pos, b->joint_pos, b->img_joint_row, b->n_img_rows, stream));
+  OMNI_TRY(omni_internal_gather_i32(ws.txt_pos, b->joint_pos, b->txt_joint_row, b->n_txt_rows, stream));
+  return OMNI_OK;
+}
 }  // namespace
 
-extern "C" int omni_abi_version(void) { return 2; }
+extern "C" int omni_abi_version(void) { return 3; }
 extern "C" const char* omni_build_arch(void) { return "gfx950"; }
 extern "C" const char* omni_status_string(int status) {
   switch (status) {
@@ -115,119 +258,33 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
 
-  omni_bf16* xn_img = ws.xn;
-  omni_bf16* xn_txt = ws.xn + (int64_t)Ri * D;
-  omni_bf16* h_img = ws.mlp_h;
-  omni_bf16* h_txt = ws.mlp_h + (int64_t)Ri * 4 * D;
-  const float sm_scale = 1.0f / sqrtf((float)w->head_dim);
-  // Activations that only travel from one of this library's kernels into a GEMM A operand (AdaLN output, attention
-  // output, GELU output) are kept K32-blocked ([K/32][rows][32], same bytes) so that the GEMM's LDS-DMA pieces fetch
-  // whole cache lines (include/omni_cdna4.h: omni_gemm_group.a_k32_rows).  The residual stream, q/k/v and everything
-  // the caller sees stay row-major.  dev knob: OMNI_DIT_ACT_BLOCKED=0.
-  static const bool act_blocked = [] {
-    const char* e = getenv("OMNI_DIT_ACT_BLOCKED");
-    return e ? atoi(e) != 0 : true;
-  }();
-  // q/k RMSNorm + RoPE inside the QKV GEMM's coalesced epilogue (saves two passes over q and k per layer); dev knob
-  // OMNI_DIT_FUSE_QKROPE=0 restores the separate omni_qk_norm_rope launches (bit-identical results).
-  static const bool fuse_qkrope = [] {
-    const char* e = getenv("OMNI_DIT_FUSE_QKROPE");
-    return e ? atoi(e) != 0 : true;
-  }();
-  if (fuse_qkrope) {
-    OMNI_TRY(omni_internal_gather_i32(ws.img_pos, b->joint_pos, b->img_joint_row, Ri, stream));
-    OMNI_TRY(omni_internal_gather_i32(ws.txt_pos, b->joint_pos, b->txt_joint_row, Rt, stream));
+  OMNI_TRY(prepare_positions(b, ws, stream));
+  const omni_teacache* tc = b->teacache;
+  const int32_t rows_per_item = b->n_items > 0 ? Ri / b->n_items : 0;
+  if (tc) {
+    if (rows_per_item * b->n_items != Ri || b->n_items > 64) return OMNI_ERR_UNSUPPORTED;
+    // the image stream as it enters the block stack: residual = out - this; skipped items leave as this + cached residual
+    if (hipMemcpyAsync(ws.h_in, ws.hidden_img, (size_t)Ri * D * sizeof(omni_bf16), hipMemcpyDeviceToDevice,
+                       static_cast<hipStream_t>(stream)) != hipSuccess)
+      return OMNI_ERR_LAUNCH;
   }
-  const bool blk = act_blocked && (D % 32 == 0);
-  const int32_t bRi = blk ? Ri : 0, bRt = blk ? Rt : 0, bRj = blk ? Ri + Rt : 0;
-
+  const BlockPred pred = tc ? BlockPred{tc->tile_skip_img, tc->tile_skip_txt, tc->skip} : BlockPred{nullptr, nullptr, nullptr};
+  const int32_t blocked = (dit_act_blocked() && (D % 32 == 0)) ? 1 : 0;
   for (int l = 0; l < w->num_layers; ++l) {
-    const omni_dit_layer_weights& L = w->layers[l];
-    // modulation vectors [shift1|scale1|gate1|shift2|scale2|gate2]  (reference :552-561)
-    OMNI_TRY(omni_linear_smallbatch(ws.temb, D, nT, L.img_mod_w, L.img_mod_b, 6 * (int64_t)D, D, ws.mod_img, 6 * D, 1,
-                                    0, stream));
-    OMNI_TRY(omni_linear_smallbatch(ws.temb, D, nT, L.txt_mod_w, L.txt_mod_b, 6 * (int64_t)D, D, ws.mod_txt, 6 * D, 1,
-                                    0, stream));
-    // norm1 + modulate (reference :564-567)
-    OMNI_TRY(omni_adaln_modulate_ex(ws.hidden_img, D, xn_img, D, Ri, D, ws.mod_img + D, ws.mod_img, 6 * D, b->img_item,
-                                    0, eps, bRi, stream));
-    OMNI_TRY(omni_adaln_modulate_ex(ws.hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + D, ws.mod_txt, 6 * D, b->txt_item,
-                                    0, eps, bRt, stream));
-    // fused QKV projections of both streams, scattered into the joint q/k/v (reference :380-394, :414-416)
-    {
-      omni_gemm_params p = {};
-      p.ngroups = 2; p.N = 3 * D; p.K = D; p.split_n = D; p.w_k32_blocked = w->gemm_w_k32_blocked;
-      p.epilogue = fuse_qkrope ? OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE : OMNI_EPI_BIAS_SPLIT3;
-      if (fuse_qkrope) {
-        p.g[0].qk_norm_q_w = L.norm_q_w; p.g[0].qk_norm_k_w = L.norm_k_w; p.g[0].qk_row_pos = ws.img_pos;
-        p.g[1].qk_norm_q_w = L.norm_added_q_w; p.g[1].qk_norm_k_w = L.norm_added_k_w; p.g[1].qk_row_pos = ws.txt_pos;
-        for (int g = 0; g < 2; ++g) {
-          p.g[g].qk_rope_cos = b->rope_cos; p.g[g].qk_rope_sin = b->rope_sin; p.g[g].qk_eps = eps;
-        }
-      }
-      p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt;
-      p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = L.to_qkv_w; p.g[0].bias = L.to_qkv_b;
-      p.g[0].out = ws.q; p.g[0].out1 = ws.k; p.g[0].out2 = ws.v; p.g[0].ldo = D; p.g[0].out_row_map = b->img_joint_row;
-      p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.add_qkv_w; p.g[1].bias = L.add_qkv_b;
-      p.g[1].out = ws.q; p.g[1].out1 = ws.k; p.g[1].out2 = ws.v; p.g[1].ldo = D; p.g[1].out_row_map = b->txt_joint_row;
-      OMNI_TRY(omni_gemm_bf16(&p, stream));
-    }
-    // per-head RMSNorm + RoPE on q and k (reference :397-410)
-    if (!fuse_qkrope) {
-      OMNI_TRY(omni_qk_norm_rope(ws.q, D, Ri + Rt, w->num_heads, L.norm_q_w, L.norm_added_q_w, b->rope_cos, b->rope_sin,
-                                 b->joint_pos, b->txt_pos_end, eps, stream));
-      OMNI_TRY(omni_qk_norm_rope(ws.k, D, Ri + Rt, w->num_heads, L.norm_k_w, L.norm_added_k_w, b->rope_cos, b->rope_sin,
-                                 b->joint_pos, b->txt_pos_end, eps, stream));
-    }
-    // joint attention (reference :437-443 -> attention/backends/sdpa.py:46-66)
-    OMNI_TRY(omni_flash_attn_fwd_ex(ws.q, ws.k, ws.v, ws.attn, D, D, D, D, b->cu_seqlens, b->n_items, w->num_heads,
-                                    w->head_dim, b->max_seqlen, sm_scale, bRj, stream));
-    // output projections + gated residual (reference :448-456, :586-587)
-    {
-      omni_gemm_params p = {};
-      p.ngroups = 2; p.N = D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GATE_RES; p.w_k32_blocked = w->gemm_w_k32_blocked;
-      p.g[0].a_k32_rows = bRj; p.g[1].a_k32_rows = bRj;
-      p.g[0].A = ws.attn; p.g[0].lda = D; p.g[0].a_row_map = b->img_joint_row; p.g[0].M = Ri;
-      p.g[0].W = L.to_out_w; p.g[0].bias = L.to_out_b; p.g[0].out = ws.hidden_img; p.g[0].ldo = D;
-      p.g[0].res = ws.hidden_img; p.g[0].ldres = D; p.g[0].gate = ws.mod_img + 2 * D; p.g[0].gate_item_stride = 6 * D;
-      p.g[0].row_item_map = b->img_item;
-      p.g[1].A = ws.attn; p.g[1].lda = D; p.g[1].a_row_map = b->txt_joint_row; p.g[1].M = Rt;
-      p.g[1].W = L.to_add_out_w; p.g[1].bias = L.to_add_out_b; p.g[1].out = ws.hidden_txt; p.g[1].ldo = D;
-      p.g[1].res = ws.hidden_txt; p.g[1].ldres = D; p.g[1].gate = ws.mod_txt + 2 * D; p.g[1].gate_item_stride = 6 * D;
-      p.g[1].row_item_map = b->txt_item;
-      OMNI_TRY(omni_gemm_bf16(&p, stream));
-    }
-    // norm2 + modulate (reference :590, :595)
-    OMNI_TRY(omni_adaln_modulate_ex(ws.hidden_img, D, xn_img, D, Ri, D, ws.mod_img + 4 * D, ws.mod_img + 3 * D, 6 * D,
-                                    b->img_item, 0, eps, bRi, stream));
-    OMNI_TRY(omni_adaln_modulate_ex(ws.hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + 4 * D, ws.mod_txt + 3 * D, 6 * D,
-                                    b->txt_item, 0, eps, bRt, stream));
-    // MLP up + GELU-tanh (reference :591, :596 -> diffusers FeedForward)
-    {
-      omni_gemm_params p = {};
-      p.ngroups = 2; p.N = 4 * D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GELU_TANH; p.w_k32_blocked = w->gemm_w_k32_blocked;
-      p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt; p.g[0].out_k32_rows = bRi; p.g[1].out_k32_rows = bRt;
-      p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = L.img_mlp_w1; p.g[0].bias = L.img_mlp_b1;
-      p.g[0].out = h_img; p.g[0].ldo = 4 * D;
-      p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w1; p.g[1].bias = L.txt_mlp_b1;
-      p.g[1].out = h_txt; p.g[1].ldo = 4 * D;
-      OMNI_TRY(omni_gemm_bf16(&p, stream));
-    }
-    // MLP down + gated residual (reference :592, :597)
-    {
-      omni_gemm_params p = {};
-      p.ngroups = 2; p.N = D; p.K = 4 * D; p.epilogue = OMNI_EPI_BIAS_GATE_RES; p.w_k32_blocked = w->gemm_w_k32_blocked;
-      p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt;
-      p.g[0].A = h_img; p.g[0].lda = 4 * D; p.g[0].M = Ri; p.g[0].W = L.img_mlp_w2; p.g[0].bias = L.img_mlp_b2;
-      p.g[0].out = ws.hidden_img; p.g[0].ldo = D; p.g[0].res = ws.hidden_img; p.g[0].ldres = D;
-      p.g[0].gate = ws.mod_img + 5 * D; p.g[0].gate_item_stride = 6 * D; p.g[0].row_item_map = b->img_item;
-      p.g[1].A = h_txt; p.g[1].lda = 4 * D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w2; p.g[1].bias = L.txt_mlp_b2;
-      p.g[1].out = ws.hidden_txt; p.g[1].ldo = D; p.g[1].res = ws.hidden_txt; p.g[1].ldres = D;
-      p.g[1].gate = ws.mod_txt + 5 * D; p.g[1].gate_item_stride = 6 * D; p.g[1].row_item_map = b->txt_item;
-      OMNI_TRY(omni_gemm_bf16(&p, stream));
+    if (l == 0 && tc) {
+      // decision on the first block's modulated input, BEFORE anything of the block stack that could be skipped; the
+      // predicates it writes gate every GEMM row tile / attention block of skipped items from here on
+      auto hook = [&](omni_bf16* xn_img) {
+        return omni_internal_teacache_decide(tc, xn_img, b->n_items, rows_per_item, Ri, Rt, D, blocked, stream);
+      };
+      OMNI_TRY(run_block(w, l, b, ws, ws.hidden_img, ws.hidden_txt, ws.temb, pred, hook, stream));
+    } else {
+      OMNI_TRY(run_block(w, l, b, ws, ws.hidden_img, ws.hidden_txt, ws.temb, pred, NoHook{}, stream));
     }
   }
+  if (tc) OMNI_TRY(omni_internal_teacache_post(tc, ws.hidden_img, ws.h_in, Ri, rows_per_item, D, stream));
 
+  omni_bf16* xn_img = ws.xn;
   // --- output head: AdaLayerNormContinuous (scale first, then shift) + proj_out (reference :797-798) -------
   OMNI_TRY(omni_linear_smallbatch(ws.temb, D, nT, w->norm_out_w, w->norm_out_b, 2 * (int64_t)D, D, ws.emb_out, 2 * D, 1,
                                   0, stream));
@@ -241,4 +298,17 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
   return OMNI_OK;
+}
+
+extern "C" int omni_dit_block(const omni_dit_weights* w, int32_t layer, const omni_dit_batch* b, omni_bf16* hidden_img,
+                              omni_bf16* hidden_txt, const omni_bf16* temb, omni_stream stream) {
+  if (!w || !b || !w->layers || !b->workspace || !hidden_img || !hidden_txt || !temb) return OMNI_ERR_BAD_ARG;
+  if (layer < 0 || layer >= w->num_layers) return OMNI_ERR_BAD_ARG;
+  if (w->head_dim != 128) return OMNI_ERR_UNSUPPORTED;
+  const int32_t Ri = b->n_img_rows, Rt = b->n_txt_rows, nT = b->n_temb;
+  if (Ri <= 0 || Rt <= 0 || nT <= 0 || b->n_joint_rows != Ri + Rt) return OMNI_ERR_BAD_ARG;
+  const Workspace ws = carve(b->workspace, w, Ri, Rt, nT);
+  if (ws.total > b->workspace_bytes) return OMNI_ERR_BAD_ARG;
+  OMNI_TRY(prepare_positions(b, ws, stream));
+  return run_block(w, layer, b, ws, hidden_img, hidden_txt, temb, BlockPred{nullptr, nullptr, nullptr}, NoHook{}, stream);
 }

@@ -326,6 +326,145 @@ int omni_internal_gather_i32(int32_t* dst, const int32_t* src, const int32_t* id
   return OMNI_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// TeaCache on the device (reference vllm_omni/diffusion/cache/teacache/hook.py:170-217; see omni_teacache in the header).
+// ------------------------------------------------------------------------------------------------
+namespace {
+// Partial sums of |mod - prev| and |prev| per item, and prev <- mod, in one pass.  The buffer is NSEG x n_items segments of
+// `seg_elems` contiguous elements: (NSEG, W) = (D/32, 32) for the K32-blocked layout [D/32][rows][32], (1, D) for row-major.
+// grid = (blocks per segment, n_items, NSEG)
+__global__ __launch_bounds__(256) void teacache_reduce_kernel(const uint16_t* __restrict__ mod, uint16_t* __restrict__ prev,
+                                                              float* __restrict__ scratch, int64_t seg_stride_item,
+                                                              int64_t seg_stride_slab, int64_t seg_elems) {
+  const int item = blockIdx.y;
+  const int64_t base = (int64_t)blockIdx.z * seg_stride_slab + (int64_t)item * seg_stride_item;
+  const int64_t nchunk = seg_elems / 8;
+  float sd = 0.f, sp = 0.f;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
+    const u32x4_t m = *reinterpret_cast<const u32x4_t*>(mod + base + c * 8);
+    const u32x4_t p = *reinterpret_cast<const u32x4_t*>(prev + base + c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float m0 = bf16_lo(m[e]), m1 = bf16_hi(m[e]), p0 = bf16_lo(p[e]), p1 = bf16_hi(p[e]);
+      // the reference subtracts two bf16 tensors (result rounded to bf16) before abs().mean()
+      sd += fabsf(bf16_bits_to_f32(f32_to_bf16_bits(m0 - p0))) + fabsf(bf16_bits_to_f32(f32_to_bf16_bits(m1 - p1)));
+      sp += fabsf(p0) + fabsf(p1);
+    }
+    *reinterpret_cast<u32x4_t*>(prev + base + c * 8) = m;
+  }
+  sd = wave_sum<64>(sd);
+  sp = wave_sum<64>(sp);
+  __shared__ float red[2][4];
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = sd; red[1][wv] = sp; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(scratch + 2 * item, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(scratch + 2 * item + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// one workgroup: per-item decision, statistics, and the per-row-tile predicates of both streams
+__global__ __launch_bounds__(256) void teacache_decide_kernel(omni_teacache tc, int n_items, int rows_per_item,
+                                                              int n_img_rows, int n_txt_rows, float inv_count) {
+  __shared__ int s_skip[64];
+  const int i = threadIdx.x;
+  if (i < n_items) {
+    int skip = 0;
+    const int cnt = tc.cnt[i];
+    float acc = tc.acc_dist[i];
+    if (cnt == 0) {
+      acc = 0.f;                                           // first forward of a generation: always compute (:185-188)
+    } else {
+      // the reference forms this ratio from bf16 tensors: .abs().mean() -> bf16, (+ 1e-8) -> bf16, division -> bf16
+      auto rb = [](float x) { return bf16_bits_to_f32(f32_to_bf16_bits(x)); };
+      const float rel = rb(rb(tc.scratch[2 * i] * inv_count) / rb(rb(tc.scratch[2 * i + 1] * inv_count) + 1e-8f));
+      float r = tc.coeff[0];
+#pragma unroll
+      for (int c = 1; c < 5; ++c) r = r * rel + tc.coeff[c];   // numpy.poly1d, highest power first
+      acc += fabsf(r);
+      if (acc < tc.rel_l1_thresh) skip = 1;
+      else acc = 0.f;
+    }
+    tc.acc_dist[i] = acc;
+    tc.cnt[i] = cnt + 1;
+    tc.skip[i] = skip;
+    tc.skip_total[i] += skip;
+    tc.scratch[2 * i] = 0.f;
+    tc.scratch[2 * i + 1] = 0.f;
+    s_skip[i] = skip;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < (n_img_rows + 255) / 256; t += blockDim.x) {
+    const int first = (t * 256) / rows_per_item, last = min(t * 256 + 255, n_img_rows - 1) / rows_per_item;
+    int all = 1;
+    for (int it = first; it <= last; ++it) all &= s_skip[it];
+    tc.tile_skip_img[t] = all;
+  }
+  for (int t = threadIdx.x; t < (n_txt_rows + 255) / 256; t += blockDim.x) {
+    const int r0 = t * 256, r1 = min(t * 256 + 255, n_txt_rows - 1);
+    int all = 1;
+    for (int it = 0; it < n_items; ++it)
+      if (tc.txt_cu[it] <= r1 && tc.txt_cu[it + 1] > r0) all &= s_skip[it];
+    tc.tile_skip_txt[t] = all;
+  }
+}
+
+// after the block stack: skipped items take hidden_in + cached residual; computed items refresh the residual
+__global__ __launch_bounds__(256) void teacache_post_kernel(uint16_t* __restrict__ hidden, const uint16_t* __restrict__ hin,
+                                                            uint16_t* __restrict__ res, const int32_t* __restrict__ skip,
+                                                            int64_t nchunk, int chunks_per_item) {
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
+    const int item = (int)(c / chunks_per_item);
+    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(hin + c * 8);
+    u32x4_t o;
+    if (skip[item]) {
+      const u32x4_t r = *reinterpret_cast<const u32x4_t*>(res + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(bf16_lo(a[e]) + bf16_lo(r[e]), bf16_hi(a[e]) + bf16_hi(r[e]));
+      *reinterpret_cast<u32x4_t*>(hidden + c * 8) = o;
+    } else {
+      const u32x4_t h = *reinterpret_cast<const u32x4_t*>(hidden + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(bf16_lo(h[e]) - bf16_lo(a[e]), bf16_hi(h[e]) - bf16_hi(a[e]));
+      *reinterpret_cast<u32x4_t*>(res + c * 8) = o;
+    }
+  }
+}
+}  // namespace
+
+int omni_internal_teacache_decide(const omni_teacache* tc, const omni_bf16* mod, int32_t n_items, int32_t rows_per_item,
+                                  int32_t n_img_rows, int32_t n_txt_rows, int32_t D, int32_t blocked, void* stream) {
+  if (!tc || !mod || !tc->prev_mod || !tc->prev_res || !tc->acc_dist || !tc->cnt || !tc->skip || !tc->skip_total ||
+      !tc->scratch || !tc->tile_skip_img || !tc->tile_skip_txt || !tc->txt_cu)
+    return OMNI_ERR_BAD_ARG;
+  if (n_items <= 0 || n_items > 64 || rows_per_item <= 0 || n_items * rows_per_item != n_img_rows || D % 32)
+    return OMNI_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nseg = blocked ? D / 32 : 1, W = blocked ? 32 : D;
+  const int64_t seg_elems = (int64_t)rows_per_item * W;
+  int bx = (int)((seg_elems / 8 + 255) / 256);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(teacache_reduce_kernel, dim3(bx, n_items, nseg), dim3(256), 0, s, mod, tc->prev_mod, tc->scratch,
+                     seg_elems, (int64_t)n_img_rows * W, seg_elems);
+  OMNI_CHECK_LAUNCH();
+  hipLaunchKernelGGL(teacache_decide_kernel, dim3(1), dim3(256), 0, s, *tc, n_items, rows_per_item, n_img_rows, n_txt_rows,
+                     1.0f / ((float)rows_per_item * (float)D));
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+int omni_internal_teacache_post(const omni_teacache* tc, omni_bf16* hidden, const omni_bf16* hidden_in, int32_t n_img_rows,
+                                int32_t rows_per_item, int32_t D, void* stream) {
+  if (!tc || !hidden || !hidden_in) return OMNI_ERR_BAD_ARG;
+  const int64_t nchunk = (int64_t)n_img_rows * D / 8;
+  hipLaunchKernelGGL(teacache_post_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, hidden_in,
+                     tc->prev_res, tc->skip, nchunk, rows_per_item * (D / 8));
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
 extern "C" int omni_adaln_modulate_ex(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows,
                                       int32_t D, const omni_bf16* scale, const omni_bf16* shift,
                                       int64_t mod_item_stride, const int32_t* row_item_map, int32_t rows_per_item,

@@ -148,7 +148,7 @@ OMNI_DEVINL omni_gemm_group pick_group(const omni_gemm_params& P, int gi) {
   OMNI_PICK(gate); OMNI_PICK(gate_item_stride); OMNI_PICK(row_item_map); OMNI_PICK(rows_per_item);
   OMNI_PICK(a_k32_rows); OMNI_PICK(out_k32_rows);
   OMNI_PICK(qk_norm_q_w); OMNI_PICK(qk_norm_k_w); OMNI_PICK(qk_rope_cos); OMNI_PICK(qk_rope_sin); OMNI_PICK(qk_row_pos);
-  OMNI_PICK(qk_eps);
+  OMNI_PICK(qk_eps); OMNI_PICK(tile_skip);
 #undef OMNI_PICK
   return G;
 }
@@ -533,6 +533,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
   const int m0 = (gi ? mt - mtiles0 : mt) * BM;
   const int n0 = nt * BN;
   const int M = G.M, N = P.N, K = P.K;
+  if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) continue;   // device-side predicate (omni_teacache)
 
   const uint16_t* a_src[2];
   const uint16_t* w_src[2];
@@ -791,6 +792,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   const int m0 = (gi ? mt - mtiles0 : mt) * BM;
   const int n0 = nt * BN;
   const int M = G.M, N = P.N, K = P.K;
+  if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;   // device-side predicate (omni_teacache)
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, hi = lane >> 5;
 
@@ -977,6 +979,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp2_kernel(const omni_g
   const int m0 = (gi ? mt - mtiles0 : mt) * BM;
   const int n0 = nt * BN;
   const int M = G.M, N = P.N, K = P.K;
+  if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;   // device-side predicate (omni_teacache)
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, hi = lane >> 5;
 

@@ -98,8 +98,11 @@ class OmniDiffusionConfig:
             self.tf_model_config = TransformerConfig.from_dict(self.tf_model_config)
         if self.num_gpus is None:
             self.num_gpus = self.parallel_config.world_size
-        if self.cache_backend not in ("none", None):
-            raise NotImplementedError("cache backends (TeaCache / cache-dit) are SURVEY.md §8f row N3")
+        if self.cache_backend is None:
+            self.cache_backend = "none"
+        if self.cache_backend not in ("none", "tea_cache", "teacache"):
+            raise NotImplementedError(f"cache backend {self.cache_backend!r}: only 'none' and 'tea_cache' are built "
+                                      "(cache-dit is a third-party library)")
 
 
 _current: OmniDiffusionConfig | None = None

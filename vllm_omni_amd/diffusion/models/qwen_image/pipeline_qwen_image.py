@@ -59,6 +59,14 @@ class QwenImagePipeline(nn.Module):
         self._latents_std = torch.tensor(self.vae.config.latents_std).view(1, -1, 1, 1, 1)
         self.weights_sources: list = []
         self._step_state: dict = {}     # hipGraph + static buffers per step-batch shape
+        self.last_teacache_state = None
+        self.cache_backend = None
+        name = getattr(self.od_config, "cache_backend", "none")
+        if name not in (None, "", "none"):
+            from ...cache import get_cache_backend
+
+            self.cache_backend = get_cache_backend(name, getattr(self.od_config, "cache_config", {}) or {})
+            self.cache_backend.enable(self)
 
     # ------------------------------------------------------------------ helpers with the reference's semantics
     @staticmethod
@@ -134,7 +142,9 @@ class QwenImagePipeline(nn.Module):
         sig_in = self.scheduler.model_timestep(timesteps).to(dev)                   # bf16-rounded t/1000, fp32 [N]
         dt_dev = dts.to(dev, torch.float32).contiguous()
         graph_on = self._use_graph(n_items * S)
-        key = (tuple(lens), tuple(grid), do_cfg, float(cfg_scales[0]), R)
+        tcfg = getattr(tr, "teacache", None)
+        key = (tuple(lens), tuple(grid), do_cfg, float(cfg_scales[0]), R,
+               None if tcfg is None else (tcfg.rel_l1_thresh, tuple(tcfg.coefficients)))
         st = self._step_state.get(key) if graph_on else None
         if st is None:
             st = dict(lat=torch.empty(R * S, tr.in_channels, dtype=BF16, device=dev),
@@ -142,7 +152,11 @@ class QwenImagePipeline(nn.Module):
                       pred=torch.empty(n_items * S, tr.in_channels, dtype=BF16, device=dev),
                       prompt=torch.empty(sum(lens), tr.joint_attention_dim, dtype=BF16, device=dev),
                       sig=torch.empty(1, dtype=torch.float32, device=dev), dt=torch.empty(1, dtype=torch.float32, device=dev),
-                      graph=None)
+                      graph=None, tc=None)
+            if tcfg is not None:
+                from ...cache.teacache.native import TeaCacheDeviceState
+
+                st["tc"] = TeaCacheDeviceState(tcfg, rb, tr.inner_dim, dev)
             if graph_on:
                 if len(self._step_state) >= 8:
                     self._step_state.clear()
@@ -151,14 +165,18 @@ class QwenImagePipeline(nn.Module):
         st["prompt"].copy_(torch.cat(txt))
         lat, lat_in, pred = st["lat"], st["lat_in"], st["pred"]
         tr.do_true_cfg = do_cfg
+        tc = st["tc"]
+        if tc is not None:
+            tc.reset()                                       # a new generation: first forward always computes
 
         def step(sig1, dt1):
             lat_in[: R * S].copy_(lat)
             if do_cfg:
                 lat_in[R * S:].copy_(lat)
-            tr.forward_ragged(prepared, lat_in, st["prompt"], sig1, out=pred)
+            tr.forward_ragged(prepared, lat_in, st["prompt"], sig1, out=pred, teacache=tc)
             ops.cfg_euler_step_(lat, pred[: R * S], pred[R * S:] if do_cfg else None, cfg_scales[0], dt1)
 
+        self.last_teacache_state = tc                         # statistics: tc.skipped_forwards() per item after the loop
         if not graph_on:
             for i in range(len(timesteps)):
                 step(sig_in[i:i + 1], dt_dev[i:i + 1])
@@ -177,6 +195,8 @@ class QwenImagePipeline(nn.Module):
             with torch.cuda.graph(g):
                 step(st["sig"], st["dt"])
             st["graph"] = g
+            if tc is not None:
+                tc.reset()                                   # the warm-up / capture forwards advanced the counters
             # everything whose device address is baked into the captured kernel arguments stays referenced by the entry
             st["keepalive"], st["gen"] = (prepared, tr._workspace, tr._native), tr._native_gen
             lat.copy_(saved)

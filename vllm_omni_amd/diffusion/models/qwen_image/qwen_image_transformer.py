@@ -21,7 +21,10 @@ from collections.abc import Iterable
 import torch
 import torch.nn as nn
 
+import weakref
+
 from ...batch import RaggedBatch, build_ragged_batch
+from ...layers.adalayernorm import AdaLayerNorm
 from .... import _native as N
 from .... import ops
 from .rope import rope_table
@@ -30,21 +33,53 @@ BF16 = torch.bfloat16
 
 
 class _Param(nn.Module):
-    """weight (+bias) holder; parameters are allocated uninitialised on `device` (no CPU staging of 20 B params)."""
+    """weight (+bias) holder; parameters are allocated uninitialised on `device` (no CPU staging of 20 B params).
 
-    def __init__(self, out_features: int, in_features: int | None, bias: bool, device, dtype):
+    `forward(x)` = x @ W^T + b on the C-ABI kernels, so the modules the cache hooks call directly (`img_in`, `txt_in`,
+    `proj_out`, the timestep-embedder linears: cache/teacache/extractors.py:189-245) behave like the reference's
+    nn.Linear / ReplicatedLinear.  The eight big matrices of a block are `blockable`: the native runner may hold them in
+    the K32-blocked layout, so they are only reachable through the block's own forward."""
+
+    def __init__(self, out_features: int, in_features: int | None, bias: bool, device, dtype, blockable: bool = False):
         super().__init__()
         shape = (out_features,) if in_features is None else (out_features, in_features)
         self.weight = nn.Parameter(torch.empty(shape, device=device, dtype=dtype), requires_grad=False)
         self.bias = nn.Parameter(torch.empty(out_features, device=device, dtype=dtype), requires_grad=False) if bias else None
+        self.blockable = blockable
+
+    def forward(self, x: torch.Tensor, act_in: int = 0, act_out: int = 0) -> torch.Tensor:
+        if self.weight.dim() != 2:
+            raise TypeError("norm weight holder: not callable")
+        if self.blockable:
+            raise NotImplementedError("this projection lives inside the fused block kernels: call the block's forward")
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        if x2.shape[0] <= 8 and x2.shape[1] <= 4096:            # conditioning vectors: weight-streaming GEMV
+            y = ops.linear_smallbatch(x2, self.weight, self.bias, act_in=act_in, act_out=act_out)
+        else:
+            if act_in or act_out:
+                raise NotImplementedError("activations are fused only on the small-batch path")
+            y = ops.linear(x2, self.weight, self.bias)
+        return y.view(*x.shape[:-1], self.weight.shape[0])
 
 
-def _linear(i, o, device, dtype):
-    return _Param(o, i, True, device, dtype)
+class _RMSNormW(_Param):
+    """vllm RMSNorm(hidden, eps) look-alike: y = x * rsqrt(mean(x^2) + eps) * weight."""
+
+    def __init__(self, n, device, dtype, eps: float = 1e-6):
+        super().__init__(n, None, False, device, dtype)
+        self.variance_epsilon = eps
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        return ops.rmsnorm(x2, self.weight, self.variance_epsilon).view(x.shape)
+
+
+def _linear(i, o, device, dtype, blockable: bool = False):
+    return _Param(o, i, True, device, dtype, blockable)
 
 
 def _norm_w(n, device, dtype):
-    return _Param(n, None, False, device, dtype)
+    return _RMSNormW(n, device, dtype)
 
 
 class _TimestepEmbedder(nn.Module):
@@ -52,6 +87,14 @@ class _TimestepEmbedder(nn.Module):
         super().__init__()
         self.linear_1 = _linear(256, D, device, dtype)
         self.linear_2 = _linear(D, D, device, dtype)
+
+    def forward(self, sample: torch.Tensor) -> torch.Tensor:
+        """diffusers TimestepEmbedding: linear_1 -> SiLU -> linear_2."""
+        out = []
+        for i in range(0, sample.shape[0], 8):                  # the GEMV kernel takes <= 8 rows
+            h = self.linear_1(sample[i:i + 8], act_out=1)
+            out.append(self.linear_2(h))
+        return torch.cat(out) if len(out) > 1 else out[0]
 
 
 class QwenTimestepProjEmbeddings(nn.Module):
@@ -61,11 +104,17 @@ class QwenTimestepProjEmbeddings(nn.Module):
         super().__init__()
         self.timestep_embedder = _TimestepEmbedder(embedding_dim, device, dtype)
 
+    def forward(self, timestep: torch.Tensor, hidden_states: torch.Tensor, additional_t_cond=None) -> torch.Tensor:
+        if additional_t_cond is not None:
+            raise NotImplementedError("additional_t_cond belongs to the Layered variant (SURVEY.md §8f N4)")
+        proj = ops.timestep_sinusoid(timestep.to(torch.float32).contiguous(), 256, 1000.0)     # Timesteps(256, scale=1000)
+        return self.timestep_embedder(proj)
+
 
 class _GeluProj(nn.Module):
     def __init__(self, D, device, dtype):
         super().__init__()
-        self.proj = _linear(D, 4 * D, device, dtype)
+        self.proj = _linear(D, 4 * D, device, dtype, blockable=True)
 
 
 class _FeedForward(nn.Module):
@@ -73,40 +122,105 @@ class _FeedForward(nn.Module):
 
     def __init__(self, D, device, dtype):
         super().__init__()
-        self.net = nn.ModuleList([_GeluProj(D, device, dtype), nn.Identity(), _linear(4 * D, D, device, dtype)])
+        self.net = nn.ModuleList([_GeluProj(D, device, dtype), nn.Identity(), _linear(4 * D, D, device, dtype, blockable=True)])
 
 
 class QwenImageCrossAttention(nn.Module):
-    """Parameter holder for the joint attention of one block (reference :288-368)."""
+    """Parameter holder for the joint attention of one block (reference :288-368); it runs inside the block kernels."""
 
     def __init__(self, D, head_dim, device, dtype):
         super().__init__()
-        self.to_qkv = _linear(D, 3 * D, device, dtype)
+        self.to_qkv = _linear(D, 3 * D, device, dtype, blockable=True)
         self.norm_q = _norm_w(head_dim, device, dtype)
         self.norm_k = _norm_w(head_dim, device, dtype)
-        self.add_kv_proj = _linear(D, 3 * D, device, dtype)
-        self.to_add_out = _linear(D, D, device, dtype)
-        self.to_out = nn.ModuleList([_linear(D, D, device, dtype)])
+        self.add_kv_proj = _linear(D, 3 * D, device, dtype, blockable=True)
+        self.to_add_out = _linear(D, D, device, dtype, blockable=True)
+        self.to_out = nn.ModuleList([_linear(D, D, device, dtype, blockable=True)])
         self.norm_added_q = _norm_w(head_dim, device, dtype)
         self.norm_added_k = _norm_w(head_dim, device, dtype)
 
 
+class _Modulation(nn.Sequential):
+    """`nn.Sequential(nn.SiLU(), Linear(D, 6D))` (reference :478-481) as ONE weight-streaming GEMV with the SiLU applied
+    while the conditioning vector is staged (parameter names stay `img_mod.1.weight` / `.bias`)."""
+
+    def __init__(self, D, device, dtype):
+        super().__init__(nn.SiLU(), _linear(D, 6 * D, device, dtype))
+
+    def forward(self, temb: torch.Tensor) -> torch.Tensor:
+        out = [self[1](temb[i:i + 8], act_in=1) for i in range(0, temb.shape[0], 8)]
+        return torch.cat(out) if len(out) > 1 else out[0]
+
+
+class RotaryTables(tuple):
+    """What `pos_embed(...)` returns: `(vid_freqs, txt_freqs)` complex64 like the reference (:222-285), plus the grid /
+    text length they were built for so that a block called through the module surface can address the kernels' tables."""
+
+    def __new__(cls, vid, txt, grid, txt_len):
+        self = super().__new__(cls, (vid, txt))
+        self.grid, self.txt_len = grid, txt_len
+        return self
+
+
+class QwenEmbedRope(nn.Module):
+    """`pos_embed` (reference :179-285): no parameters; tables are cached per (grid, text length)."""
+
+    def forward(self, video_fhw, txt_seq_lens, device=None) -> RotaryTables:
+        shp = video_fhw[0] if isinstance(video_fhw, (list, tuple)) and isinstance(video_fhw[0], (list, tuple)) else video_fhw
+        if isinstance(shp[0], (list, tuple)):
+            shp = shp[0]                                   # the reference reads img_shapes[0] only (:231-232)
+        grid = tuple(int(v) for v in shp)
+        T = int(max(txt_seq_lens)) if not isinstance(txt_seq_lens, int) else int(txt_seq_lens)
+        cos, sin = rope_table(grid, T)
+        cplx = torch.complex(cos, sin).to(device) if device is not None else torch.complex(cos, sin)
+        return RotaryTables(cplx[T:], cplx[:T], grid, T)
+
+
 class QwenImageTransformerBlock(nn.Module):
-    """Parameter holder for one dual-stream MMDiT block (reference :461-503)."""
+    """One dual-stream MMDiT block (reference :461-605).  Inside `QwenImageTransformer2DModel.forward` the 60 blocks run in
+    ONE native call; this module's own `forward` runs a single block through `omni_dit_block` with the reference's
+    signature and `(encoder_hidden_states, hidden_states)` return, which is what cache hooks that re-walk the model need
+    (cache/teacache/extractors.py:216-233), together with `img_mod`, `img_norm1` (:189-194)."""
 
     def __init__(self, D, head_dim, device, dtype):
         super().__init__()
-        self.img_mod = nn.Sequential(nn.SiLU(), _linear(D, 6 * D, device, dtype))
+        self.img_mod = _Modulation(D, device, dtype)
+        self.img_norm1 = AdaLayerNorm(D, elementwise_affine=False, eps=1e-6)
         self.attn = QwenImageCrossAttention(D, head_dim, device, dtype)
+        self.img_norm2 = AdaLayerNorm(D, elementwise_affine=False, eps=1e-6)
         self.img_mlp = _FeedForward(D, device, dtype)
-        self.txt_mod = nn.Sequential(nn.SiLU(), _linear(D, 6 * D, device, dtype))
+        self.txt_mod = _Modulation(D, device, dtype)
+        self.txt_norm1 = AdaLayerNorm(D, elementwise_affine=False, eps=1e-6)
+        self.txt_norm2 = AdaLayerNorm(D, elementwise_affine=False, eps=1e-6)
         self.txt_mlp = _FeedForward(D, device, dtype)
+        self.layer_idx = -1
+        self._model_ref = None
+
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                encoder_hidden_states_mask: torch.Tensor = None, temb: torch.Tensor = None,
+                image_rotary_emb=None, joint_attention_kwargs=None, modulate_index=None):
+        if modulate_index is not None:
+            raise NotImplementedError("modulate_index belongs to the Layered variant (SURVEY.md §8f N4)")
+        model = self._model_ref() if self._model_ref is not None else None
+        if model is None:
+            raise RuntimeError("block is not attached to a QwenImageTransformer2DModel")
+        return model._run_block(self.layer_idx, hidden_states, encoder_hidden_states, temb, image_rotary_emb)
 
 
 class _NormOut(nn.Module):
+    """diffusers AdaLayerNormContinuous(D, D, elementwise_affine=False, eps=1e-6): emb = linear(silu(c));
+    scale, shift = emb.chunk(2); LN(x) * (1 + scale) + shift  (reference :686, :797)."""
+
     def __init__(self, D, device, dtype):
         super().__init__()
         self.linear = _linear(D, 2 * D, device, dtype)
+
+    def forward(self, x: torch.Tensor, conditioning_embedding: torch.Tensor) -> torch.Tensor:
+        B, S, D = x.shape
+        emb = torch.cat([self.linear(conditioning_embedding[i:i + 8], act_in=1) for i in range(0, B, 8)]).contiguous()
+        y = ops.adaln_modulate(x.reshape(B * S, D).contiguous(), emb, emb[:, D:], mod_item_stride=2 * D, rows_per_item=S)
+        return y.view(B, S, D)
 
 
 class Transformer2DModelOutput(tuple):
@@ -153,6 +267,10 @@ class QwenImageTransformer2DModel(nn.Module):
             [QwenImageTransformerBlock(D, attention_head_dim, device, dtype) for _ in range(num_layers)])
         self.norm_out = _NormOut(D, device, dtype)
         self.proj_out = _linear(D, patch_size * patch_size * self.out_channels, device, dtype)
+        self.pos_embed = QwenEmbedRope()
+        for i, blk in enumerate(self.transformer_blocks):
+            blk.layer_idx, blk._model_ref = i, weakref.ref(self)
+        self.teacache = None         # TeaCacheConfig when the native TeaCache path is enabled (cache/teacache/backend.py)
         self._native = None        # (DitWeights struct, keep-alive list)
         self._native_gen = 0       # bumped whenever the pointer table is rebuilt (captured hipGraphs must be re-captured)
         self._w_blocked = False    # the 8 big matrices per layer currently hold the K32-blocked re-layout
@@ -317,38 +435,68 @@ class QwenImageTransformer2DModel(nn.Module):
         self._batch_cache[key] = ent
         return ent
 
-    def forward_ragged(self, prepared: dict, latents: torch.Tensor, prompt_embeds: torch.Tensor,
-                       timestep: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        """latents [n_img_rows, 64] bf16, prompt_embeds [n_txt_rows, joint_dim] bf16, timestep [n_temb] fp32
-        (sigma = t/1000 exactly as the pipeline passes it) -> noise_pred [n_img_rows, 64] bf16."""
+    def _descriptor(self, prepared: dict, rows_img: int, rows_txt: int) -> tuple:
+        """DitBatch with the batch maps, RoPE tables and workspace filled in (the caller adds its tensors)."""
         rb: RaggedBatch = prepared["batch"]
         lib = N.lib()
         w = self._native_weights()
-        if latents.shape != (rb.n_img_rows, self.in_channels) or prompt_embeds.shape != (rb.n_txt_rows, self.joint_attention_dim):
+        if rows_img != rb.n_img_rows or rows_txt != rb.n_txt_rows:
+            raise ValueError(f"row counts do not match the batch descriptor: {rows_img} image / {rows_txt} text rows")
+        need = lib.omni_dit_workspace_bytes(C.byref(w), rb.n_img_rows, rb.n_txt_rows, rb.n_temb)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        m = prepared["maps"]
+        b = N.DitBatch()
+        b.n_items, b.n_img_rows, b.n_txt_rows = rb.n_items, rb.n_img_rows, rb.n_txt_rows
+        b.n_joint_rows, b.n_temb, b.max_seqlen = rb.n_joint_rows, rb.n_temb, rb.max_seqlen
+        b.cu_seqlens, b.img_item, b.txt_item = m["cu_seqlens"].data_ptr(), m["img_item"].data_ptr(), m["txt_item"].data_ptr()
+        b.img_joint_row, b.txt_joint_row = m["img_joint_row"].data_ptr(), m["txt_joint_row"].data_ptr()
+        b.joint_pos, b.txt_pos_end = m["joint_pos"].data_ptr(), rb.txt_pos_end
+        b.rope_cos, b.rope_sin = prepared["cos"].data_ptr(), prepared["sin"].data_ptr()
+        b.workspace, b.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
+        return lib, w, b
+
+    def forward_ragged(self, prepared: dict, latents: torch.Tensor, prompt_embeds: torch.Tensor,
+                       timestep: torch.Tensor, out: torch.Tensor | None = None, teacache=None) -> torch.Tensor:
+        """latents [n_img_rows, 64] bf16, prompt_embeds [n_txt_rows, joint_dim] bf16, timestep [n_temb] fp32
+        (sigma = t/1000 exactly as the pipeline passes it) -> noise_pred [n_img_rows, 64] bf16.
+        `teacache`: a cache.teacache.native.TeaCacheDeviceState for this batch (device-side decisions, no host sync)."""
+        rb: RaggedBatch = prepared["batch"]
+        if latents.dim() != 2 or prompt_embeds.dim() != 2 or latents.shape[1] != self.in_channels \
+                or prompt_embeds.shape[1] != self.joint_attention_dim:
             raise ValueError(f"row counts do not match the batch descriptor: {tuple(latents.shape)}, {tuple(prompt_embeds.shape)}")
+        lib, w, b = self._descriptor(prepared, latents.shape[0], prompt_embeds.shape[0])
         for t, dt, nm in ((latents, BF16, "latents"), (prompt_embeds, BF16, "prompt_embeds"), (timestep, torch.float32, "timestep")):
             if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
                 raise N.OmniNativeError(f"{nm} must be a contiguous {dt} GPU tensor")
         if timestep.numel() != rb.n_temb:
             raise ValueError("timestep must have one entry per temb row")
-        need = lib.omni_dit_workspace_bytes(C.byref(w), rb.n_img_rows, rb.n_txt_rows, rb.n_temb)
-        if self._workspace is None or self._workspace.numel() < need:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         if out is None:
             out = torch.empty(rb.n_img_rows, w.out_channels_packed, dtype=BF16, device=self.device)
-        m = prepared["maps"]
-        b = N.DitBatch()
-        b.n_items, b.n_img_rows, b.n_txt_rows = rb.n_items, rb.n_img_rows, rb.n_txt_rows
-        b.n_joint_rows, b.n_temb, b.max_seqlen = rb.n_joint_rows, rb.n_temb, rb.max_seqlen
         b.latents, b.prompt_embeds, b.timestep = latents.data_ptr(), prompt_embeds.data_ptr(), timestep.data_ptr()
-        b.cu_seqlens, b.img_item, b.txt_item = m["cu_seqlens"].data_ptr(), m["img_item"].data_ptr(), m["txt_item"].data_ptr()
-        b.img_joint_row, b.txt_joint_row = m["img_joint_row"].data_ptr(), m["txt_joint_row"].data_ptr()
-        b.joint_pos, b.txt_pos_end = m["joint_pos"].data_ptr(), rb.txt_pos_end
-        b.rope_cos, b.rope_sin = prepared["cos"].data_ptr(), prepared["sin"].data_ptr()
         b.noise_pred = out.data_ptr()
-        b.workspace, b.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
+        if teacache is not None:
+            b.teacache = C.pointer(teacache.struct_for(rb))
         N.check(lib.omni_dit_forward(C.byref(w), C.byref(b), torch.cuda.current_stream().cuda_stream), "omni_dit_forward")
         return out
+
+    def _run_block(self, layer: int, hidden_states, encoder_hidden_states, temb, image_rotary_emb):
+        """Module-surface entry of ONE block (QwenImageTransformerBlock.forward): [B,S,D], [B,T,D], temb [B,D] -> (enc, hid)."""
+        B, S, D = hidden_states.shape
+        T = encoder_hidden_states.shape[1]
+        grid = getattr(image_rotary_emb, "grid", None)
+        if grid is None or grid[0] * grid[1] * grid[2] != S:
+            raise ValueError("image_rotary_emb must come from this model's pos_embed(img_shapes, txt_seq_lens)")
+        prepared = self.prepare_batch(build_ragged_batch([T] * B, grid, txt_pos_end=max(T, getattr(image_rotary_emb, "txt_len", T))))
+        hid = hidden_states.reshape(B * S, D).to(BF16).clone()
+        enc = encoder_hidden_states.reshape(B * T, D).to(BF16).clone()
+        tb = temb.to(BF16).contiguous()
+        if tb.shape != (B, D):
+            raise ValueError(f"temb must be [B, D], got {tuple(tb.shape)}")
+        lib, w, b = self._descriptor(prepared, B * S, B * T)
+        N.check(lib.omni_dit_block(C.byref(w), layer, C.byref(b), hid.data_ptr(), enc.data_ptr(), tb.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream), "omni_dit_block")
+        return enc.view(B, T, D), hid.view(B, S, D)
 
     # ------------------------------------------------------------------ reference-shaped forward
     @torch.no_grad()
