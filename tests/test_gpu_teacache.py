@@ -123,22 +123,10 @@ def test_device_teacache_matches_host_hook(graph):
         # (c) an intermediate threshold placed between the observed rescaled distances: same skip counts per branch
         hook.config.rel_l1_thresh = 1e-12
         _host_hook_loop(m, hook, lat, pos, neg, steps)                     # all-compute run to observe the distances
+        observed = sorted(hook.rescaled_history)
     finally:
         HookRegistry.get_or_create(m).remove_hook("teacache")
-    # distances of the all-compute trajectory, measured with the reference formula on the module surface
-    from vllm_omni_amd.diffusion.cache.teacache.extractors import extract_qwen_context
-    from vllm_omni_amd.diffusion.models.qwen_image.scheduling_flow_match import FlowMatchEulerSchedule
-
-    poly = np.poly1d(TeaCacheConfig().coefficients)
-    sch = FlowMatchEulerSchedule()
-    sig_in = sch.model_timestep(sch.set_timesteps(steps, 256)).to(DEV)
-    ctx0 = extract_qwen_context(m, hidden_states=lat.to(DEV, BF16), encoder_hidden_states=pos.to(DEV, BF16),
-                                timestep=sig_in[0:1], img_shapes=[[(1, 16, 16)]], txt_seq_lens=[11])
-    ctx1 = extract_qwen_context(m, hidden_states=lat.to(DEV, BF16), encoder_hidden_states=pos.to(DEV, BF16),
-                                timestep=sig_in[1:2], img_shapes=[[(1, 16, 16)]], txt_seq_lens=[11])
-    a, b = ctx1.modulated_input, ctx0.modulated_input
-    d = abs(float(poly(((a - b).abs().mean() / (b.abs().mean() + 1e-8)).item())))
-    thresh = 2.5 * d                                                     # ~every third forward recomputes
+    thresh = 1.6 * observed[len(observed) // 2]                           # ~every other forward stays under it
     hook = apply_teacache_hook(m, TeaCacheConfig(rel_l1_thresh=thresh))
     try:
         host_mid, dec = _host_hook_loop(m, hook, lat, pos, neg, steps)

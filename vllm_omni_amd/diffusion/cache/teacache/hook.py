@@ -39,6 +39,7 @@ class TeaCacheHook(ModelHook):
         self.extractor_fn = None
         self._forward_cnt = 0
         self.decisions: list[bool] = []          # True = computed (kept for tests / statistics)
+        self.rescaled_history: list[float] = []  # |poly(rel)| of every decided forward
 
     def initialize_hook(self, module):
         self.extractor_fn = get_extractor(self.config.transformer_type)
@@ -75,7 +76,8 @@ class TeaCacheHook(ModelHook):
             return True
         prev = state.previous_modulated_input
         rel = ((modulated_inp - prev).abs().mean() / (prev.abs().mean() + 1e-8)).cpu().item()
-        state.accumulated_rel_l1_distance += abs(float(self.rescale_func(rel)))
+        self.rescaled_history.append(abs(float(self.rescale_func(rel))))
+        state.accumulated_rel_l1_distance += self.rescaled_history[-1]
         if state.accumulated_rel_l1_distance < self.config.rel_l1_thresh:
             return False
         state.accumulated_rel_l1_distance = 0.0
@@ -84,7 +86,7 @@ class TeaCacheHook(ModelHook):
     def reset_state(self, module):
         self.state_manager.reset()
         self._forward_cnt = 0
-        self.decisions = []
+        self.decisions, self.rescaled_history = [], []
         return module
 
 

@@ -11,7 +11,8 @@ What is new relative to the reference (SURVEY.md F6/F7 — neither exists there)
     forward over all their items, with per-request B=1 semantics (no padding, no cross-request attention);
   * CFG combine + norm rescale + Euler update (:580-585) are one fused kernel.
 
-The text encoder (Qwen2.5-VL, :357-433) is SURVEY.md §8f row N1: requests must carry `prompt_embeds`.
+Prompt encoding (Qwen2.5-VL through HF transformers, :357-433; text_encoder.py) is the request-side boundary (SURVEY.md
+§8f N1): a request carries either `prompt` strings (needs `text_encoder`) or pre-computed `prompt_embeds`.
 """
 from __future__ import annotations
 
@@ -32,11 +33,17 @@ BF16 = torch.bfloat16
 
 
 def get_qwen_image_post_process_func(od_config: OmniDiffusionConfig):
-    """VaeImageProcessor.postprocess equivalent: [-1,1] float image -> uint8 HWC (reference :41-60)."""
+    """VaeImageProcessor.postprocess(output_type="pil") equivalent (reference :41-60): [-1, 1] float images [B, 3, H, W]
+    -> list of PIL images (uint8 HWC arrays with od_config.output_type == "np")."""
 
     def post_process_func(images: torch.Tensor):
         x = (images.float() / 2 + 0.5).clamp(0, 1)
-        return (x.permute(0, 2, 3, 1) * 255).round().to(torch.uint8).cpu().numpy()
+        arr = (x.permute(0, 2, 3, 1) * 255).round().to(torch.uint8).cpu().numpy()
+        if getattr(od_config, "output_type", "pil") != "pil":
+            return arr
+        from PIL import Image
+
+        return [Image.fromarray(a) for a in arr]
 
     return post_process_func
 
@@ -44,7 +51,7 @@ def get_qwen_image_post_process_func(od_config: OmniDiffusionConfig):
 class QwenImagePipeline(nn.Module):
     def __init__(self, *, od_config: OmniDiffusionConfig | None = None, prefix: str = "", device=None,
                  transformer: QwenImageTransformer2DModel | None = None, vae: AutoencoderKLQwenImage | None = None,
-                 transformer_kwargs: dict | None = None):
+                 transformer_kwargs: dict | None = None, text_encoder=None):
         super().__init__()
         self.od_config = od_config or OmniDiffusionConfig()
         dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
@@ -53,6 +60,7 @@ class QwenImagePipeline(nn.Module):
             od_config=self.od_config, device=dev, **(transformer_kwargs or {}))
         self.vae = vae if vae is not None else AutoencoderKLQwenImage(device=dev)
         self.scheduler = FlowMatchEulerSchedule()
+        self.text_encoder = text_encoder      # QwenPromptEncoder (text_encoder.py) or None: requests then carry prompt_embeds
         self.vae_scale_factor = 8
         self.default_sample_size = 128
         self._latents_mean = torch.tensor(self.vae.config.latents_mean).view(1, -1, 1, 1, 1)
@@ -226,54 +234,174 @@ class QwenImagePipeline(nn.Module):
 
     # ------------------------------------------------------------------ request level
     def _req_params(self, req: OmniDiffusionRequest):
+        """(height, width, steps, cfg scale, true-CFG on?) with the reference's defaults (:614-624, :655-659): the negative
+        prompt defaults to "" — NOT None — so true-CFG is ON for a plain text request.  Raises the reference's
+        check_inputs errors (:288-349) for inconsistent requests."""
         height = req.height or self.default_sample_size * self.vae_scale_factor
         width = req.width or self.default_sample_size * self.vae_scale_factor
         steps = req.num_inference_steps or 50
         cfg = req.true_cfg_scale or 4.0
-        if req.prompt_embeds is None:
-            raise NotImplementedError("text encoding is not built (SURVEY.md §8f N1): pass prompt_embeds")
-        has_neg = req.negative_prompt_embeds is not None
+        if req.prompt is not None and req.prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one of the two.")
+        if req.prompt is None and req.prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        if req.prompt is not None and not isinstance(req.prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(req.prompt)}")
+        if req.negative_prompt is not None and req.negative_prompt_embeds is not None:
+            raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`.")
+        if req.prompt is not None and self.text_encoder is None:
+            raise NotImplementedError("this pipeline was built without a text encoder: pass prompt_embeds, or construct it "
+                                      "with text_encoder= / load one with load_text_encoder()")
+        if (req.num_outputs_per_prompt or 1) < 1:
+            raise ValueError("num_outputs_per_prompt must be >= 1")
+        if req.prompt is not None:
+            has_neg = True                       # negative_prompt defaults to "" in the reference's forward (:591-592)
+        else:
+            has_neg = req.negative_prompt_embeds is not None or req.negative_prompt is not None
         return height, width, steps, cfg, (cfg > 1 and has_neg)
+
+    def encode_prompt(self, prompt, num_images_per_prompt: int = 1, prompt_embeds=None, prompt_embeds_mask=None,
+                      max_sequence_length: int = 1024):
+        """Reference signature (:394-433): -> (prompt_embeds [B*n, T, 3584] zero-padded, mask [B*n, T])."""
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        if prompt_embeds is None:
+            prompt_embeds, prompt_embeds_mask = self.text_encoder.get_qwen_prompt_embeds(prompt, device=self.device)
+        B = prompt_embeds.shape[0]
+        prompt_embeds, prompt_embeds_mask = prompt_embeds[:, :max_sequence_length], prompt_embeds_mask[:, :max_sequence_length]
+        T = prompt_embeds.shape[1]
+        prompt_embeds = prompt_embeds.repeat(1, num_images_per_prompt, 1).view(B * num_images_per_prompt, T, -1)
+        prompt_embeds_mask = prompt_embeds_mask.repeat(1, num_images_per_prompt, 1).view(B * num_images_per_prompt, T)
+        return prompt_embeds, prompt_embeds_mask
+
+    def _rows_of(self, embeds, mask, prompts, n_per_prompt: int) -> list[torch.Tensor]:
+        """Per-sample [T_i, joint] rows (padding removed) from either pre-computed embeddings (+ mask) or prompt strings."""
+        if embeds is None:
+            embeds, mask = self.text_encoder.get_qwen_prompt_embeds([prompts] if isinstance(prompts, str) else list(prompts),
+                                                                    device=self.device)
+        if embeds.dim() == 2:
+            embeds = embeds.unsqueeze(0)
+        rows = []
+        for b in range(embeds.shape[0]):
+            t = int(mask[b].sum()) if mask is not None else embeds.shape[1]
+            rows += [embeds[b, :t]] * n_per_prompt
+        return rows
+
+    def resolve_request(self, req: OmniDiffusionRequest, index: int = 0) -> list[dict]:
+        """Expand one request into its SAMPLES (prompts x num_outputs_per_prompt, the reference's
+        `batch_size * num_images_per_prompt`, :663-683): each sample is an independent denoising problem with B=1 semantics."""
+        height, width, steps, cfg, do_cfg = self._req_params(req)
+        n = int(req.num_outputs_per_prompt or 1)
+        pos = self._rows_of(req.prompt_embeds, req.prompt_embeds_mask, req.prompt, n)
+        neg = None
+        if do_cfg:
+            neg_prompt = req.negative_prompt if req.negative_prompt is not None else ""
+            if isinstance(neg_prompt, str) and req.negative_prompt_embeds is None:
+                neg_prompt = [neg_prompt] * (len(pos) // n)
+            neg = self._rows_of(req.negative_prompt_embeds, req.negative_prompt_embeds_mask, neg_prompt, n)
+            if len(neg) != len(pos):
+                raise ValueError(f"{len(pos) // n} prompts but {len(neg) // n} negative prompts")
+        gh, gw = height // self.vae_scale_factor // 2, width // self.vae_scale_factor // 2
+        S = gh * gw
+        lat_all = None
+        if req.latents is not None:
+            lat_all = req.latents.reshape(-1, S, req.latents.shape[-1])
+            if lat_all.shape[0] not in (1, len(pos)):
+                raise ValueError(f"latents carry {lat_all.shape[0]} samples, the request expands to {len(pos)}")
+        gen = req.generator
+        if gen is None and req.seed is not None:
+            gen = torch.Generator(device="cpu").manual_seed(req.seed)
+        samples = []
+        for k in range(len(pos)):
+            if lat_all is not None:
+                lat = lat_all[k if lat_all.shape[0] > 1 else 0].to(self.device, BF16)
+            else:
+                g = gen[k] if isinstance(gen, (list, tuple)) else gen
+                lat = self.prepare_latents(1, self.transformer.in_channels // 4, height, width, BF16, self.device, g)[0]
+            samples.append(dict(req=index, k=k, height=height, width=width, steps=steps, cfg=float(cfg), do_cfg=do_cfg,
+                                grid=(1, gh, gw), lat=lat, pos=pos[k], neg=neg[k] if do_cfg else None))
+        return samples
 
     @torch.no_grad()
     def generate(self, requests: list[OmniDiffusionRequest], output_type: str = "pt") -> list[DiffusionOutput]:
-        """Run requests, step-batching those that share (height, width, steps, cfg on/off, cfg scale)."""
+        """Run requests; samples that share (height, width, steps, cfg on/off, cfg scale) are step-batched, up to
+        `od_config.max_step_batch` per DiT forward.  A request with several prompts / num_outputs_per_prompt > 1 returns
+        its samples stacked along dim 0."""
+        samples = [s for i, r in enumerate(requests) for s in self.resolve_request(r, i)]
         groups: dict[tuple, list[int]] = {}
-        for i, r in enumerate(requests):
-            groups.setdefault(self._req_params(r), []).append(i)
-        outs: list[DiffusionOutput | None] = [None] * len(requests)
+        for j, sm in enumerate(samples):
+            groups.setdefault((sm["height"], sm["width"], sm["steps"], sm["cfg"], sm["do_cfg"]), []).append(j)
         cap = max(1, int(getattr(self.od_config, "max_step_batch", 4)))
+        final: list[torch.Tensor | None] = [None] * len(samples)
         for (height, width, steps, cfg, do_cfg), idxs in groups.items():
-            gh, gw = height // self.vae_scale_factor // 2, width // self.vae_scale_factor // 2
             for s0 in range(0, len(idxs), cap):
-                chunk = idxs[s0:s0 + cap]
-                lats, pos, neg = [], [], []
-                for i in chunk:
-                    r = requests[i]
-                    gen = r.generator
-                    if gen is None and r.seed is not None:
-                        gen = torch.Generator(device="cpu").manual_seed(r.seed)
-                    lat = self.prepare_latents(1, self.transformer.in_channels // 4, height, width, BF16, self.device,
-                                               gen, r.latents)
-                    lats.append(lat.reshape(-1, lat.shape[-1]))
-                    pe = r.prompt_embeds.reshape(-1, r.prompt_embeds.shape[-1])
-                    if r.prompt_embeds_mask is not None:
-                        pe = pe[: int(r.prompt_embeds_mask.sum())]
-                    pos.append(pe)
-                    if do_cfg:
-                        ne = r.negative_prompt_embeds.reshape(-1, r.negative_prompt_embeds.shape[-1])
-                        if r.negative_prompt_embeds_mask is not None:
-                            ne = ne[: int(r.negative_prompt_embeds_mask.sum())]
-                        neg.append(ne)
-                timesteps, _ = self.prepare_timesteps(steps, None, lats[0].shape[0])
-                final = self._denoise(lats, pos, neg if do_cfg else None, (1, gh, gw), timesteps, self.scheduler.dt(),
-                                      [cfg] * len(chunk))
-                for i, lat in zip(chunk, final):
-                    if output_type == "latent" or requests[i].output_type == "latent":
-                        outs[i] = DiffusionOutput(output=lat.unsqueeze(0))
-                    else:
-                        outs[i] = DiffusionOutput(output=self.decode_latents(lat.unsqueeze(0), height, width))
-        return outs  # type: ignore[return-value]
+                chunk = [samples[j] for j in idxs[s0:s0 + cap]]
+                timesteps, _ = self.prepare_timesteps(steps, None, chunk[0]["lat"].shape[0])
+                outs = self._denoise([c["lat"] for c in chunk], [c["pos"] for c in chunk],
+                                     [c["neg"] for c in chunk] if do_cfg else None, chunk[0]["grid"], timesteps,
+                                     self.scheduler.dt(), [cfg] * len(chunk))
+                for j, o in zip(idxs[s0:s0 + cap], outs):
+                    final[j] = o
+        results = []
+        for i, r in enumerate(requests):
+            mine = [j for j, sm in enumerate(samples) if sm["req"] == i]
+            lat = torch.stack([final[j] for j in mine])                           # [n_samples, S, 64]
+            if output_type == "latent" or r.output_type == "latent":
+                results.append(DiffusionOutput(output=lat))
+            else:
+                sm = samples[mine[0]]
+                results.append(DiffusionOutput(output=torch.cat([self.decode_latents(lat[k:k + 1], sm["height"], sm["width"])
+                                                                 for k in range(lat.shape[0])])))
+        return results
+
+    # ------------------------------------------------------------------ continuous step batching (step_batcher.py)
+    def begin_sample(self, a) -> None:
+        """Schedule tensors of one sample: per-step model timestep (bf16-rounded t/1000) and dt, on the device."""
+        sm = a.sample
+        sch = FlowMatchEulerSchedule(self.scheduler.config)
+        ts = sch.set_timesteps(sm["steps"], sm["lat"].shape[0])
+        a.n_steps = len(ts)
+        a.state = dict(sig=sch.model_timestep(ts).to(self.device), dt=sch.dt().to(self.device, torch.float32),
+                       lat=sm["lat"].to(self.device, BF16).clone(), pos=sm["pos"].to(self.device, BF16),
+                       neg=None if sm["neg"] is None else sm["neg"].to(self.device, BF16))
+
+    @staticmethod
+    def batch_key(a):
+        sm = a.sample
+        return (sm["grid"], sm["do_cfg"], sm["cfg"])
+
+    @torch.no_grad()
+    def denoise_one_step(self, group: list) -> None:
+        """ONE ragged DiT forward for samples that may sit at different step indices: sample r owns temb row r (its CFG
+        pair shares it); the fused CFG + Euler kernel reads a per-sample dt."""
+        tr, dev = self.transformer, self.device
+        if getattr(tr, "teacache", None) is not None:
+            raise NotImplementedError("TeaCache state is kept per static step-batch; use generate() with it")
+        R = len(group)
+        sm0 = group[0].sample
+        S, do_cfg = group[0].state["lat"].shape[0], sm0["do_cfg"]
+        txt = [a.state["pos"] for a in group] + ([a.state["neg"] for a in group] if do_cfg else [])
+        lens = [int(t.shape[0]) for t in txt]
+        rb = build_ragged_batch(lens, sm0["grid"], temb_rows=list(range(R)) * (2 if do_cfg else 1))
+        prepared = tr.prepare_batch(rb)
+        lat = torch.cat([a.state["lat"] for a in group])
+        lat_in = torch.cat([lat, lat]) if do_cfg else lat
+        sig = torch.stack([a.state["sig"][a.step] for a in group]).contiguous()
+        dt = torch.stack([a.state["dt"][a.step] for a in group]).contiguous()
+        tr.do_true_cfg = do_cfg
+        pred = tr.forward_ragged(prepared, lat_in.contiguous(), torch.cat(txt).contiguous(), sig)
+        ops.cfg_euler_step_(lat, pred[: R * S], pred[R * S:] if do_cfg else None, sm0["cfg"], dt, dt_rows_per_item=S)
+        for r, a in enumerate(group):
+            a.state["lat"] = lat[r * S:(r + 1) * S]
+
+    def sample_result(self, a) -> torch.Tensor:
+        return a.state["lat"].clone()
+
+    def finish_request(self, req: OmniDiffusionRequest, latents: list[torch.Tensor], sample: dict) -> DiffusionOutput:
+        lat = torch.stack(latents)
+        if req.output_type == "latent":
+            return DiffusionOutput(output=lat)
+        return DiffusionOutput(output=torch.cat([self.decode_latents(lat[k:k + 1], sample["height"], sample["width"])
+                                                 for k in range(lat.shape[0])]))
 
     def forward(self, req: OmniDiffusionRequest, **_kw) -> DiffusionOutput:
         """Reference entry point (:588-750): one request in, DiffusionOutput out."""

@@ -10,6 +10,10 @@ finished latents are all-gathered over RCCL, and rank `output_rank` VAE-decodes 
 """
 from __future__ import annotations
 
+import os
+import queue
+import traceback
+
 import torch
 
 from ..data import DiffusionOutput, OmniDiffusionConfig
@@ -34,6 +38,9 @@ class GPUWorker:
                 pipeline_factory = lambda: QwenImagePipeline(od_config=self.od_config,  # noqa: E731
                                                              device=torch.device("cuda", self.local_rank))
             self.pipeline = pipeline_factory()
+
+    def is_ready(self) -> bool:
+        return self.pipeline is not None
 
     @torch.inference_mode()
     def execute_model(self, reqs: list[OmniDiffusionRequest], od_config: OmniDiffusionConfig | None = None,
@@ -80,3 +87,95 @@ class GPUWorker:
             return DiffusionOutput(output=torch.cat(imgs))
         except Exception as e:
             return DiffusionOutput(error=f"{type(e).__name__}: {e}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Worker process: one per GPU (reference WorkerProc, vllm_omni/diffusion/worker/gpu_worker.py:143-314).  The reference's
+# busy loop dequeues ONE broadcast RPC at a time from vLLM's shm MessageQueue and runs it to completion; here the loop is
+# the scheduling quantum of the continuous step batcher: between two denoising steps it drains its inbox, so newly arrived
+# requests join the running batch and finished ones are returned at once.  Queues are torch.multiprocessing queues
+# (CPU tensors only cross the process boundary); vLLM's MessageQueue / zmq are not part of this build.
+# ---------------------------------------------------------------------------------------------------------------------
+SHUTDOWN = {"type": "shutdown"}
+
+
+def _to_cpu(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().to("cpu")
+    if isinstance(x, DiffusionOutput):
+        return DiffusionOutput(output=_to_cpu(x.output), error=x.error, trajectory_timesteps=x.trajectory_timesteps,
+                               trajectory_latents=_to_cpu(x.trajectory_latents))
+    return x
+
+
+class WorkerProc:
+    def __init__(self, rank: int, od_config: OmniDiffusionConfig, inbox, outbox, pipeline=None, pipeline_factory=None):
+        from ..step_batcher import ContinuousStepBatcher
+
+        self.rank, self.inbox, self.outbox = rank, inbox, outbox
+        self.worker = GPUWorker(local_rank=rank, rank=rank, od_config=od_config, pipeline=pipeline)
+        self.worker.init_device_and_model(pipeline_factory)
+        self.batcher = ContinuousStepBatcher(self.worker.pipeline, max_items=od_config.max_step_batch)
+
+    # -- message handling -------------------------------------------------------------------------------------------
+    def _handle(self, msg) -> bool:
+        """Returns False on shutdown."""
+        kind = msg.get("type")
+        if kind == "shutdown":
+            return False
+        if kind == "add":
+            try:
+                self.batcher.add(msg["request"], tag=msg["id"])
+            except Exception as e:  # admission errors are per request: report, keep serving (reference :266-274)
+                self.outbox.put({"type": "done", "id": msg["id"], "rank": self.rank,
+                                 "output": DiffusionOutput(error=f"{type(e).__name__}: {e}")})
+        elif kind == "rpc":
+            try:
+                fn = getattr(self.worker, msg["method"], None) or getattr(self.worker.pipeline, msg["method"])
+                res = fn(*msg.get("args", ()), **msg.get("kwargs", {}))
+                if msg.get("output_rank") is None or msg["output_rank"] == self.rank:
+                    self.outbox.put({"type": "rpc_result", "id": msg["id"], "rank": self.rank, "result": _to_cpu(res)})
+            except Exception as e:
+                self.outbox.put({"type": "rpc_result", "id": msg["id"], "rank": self.rank,
+                                 "result": DiffusionOutput(error=f"{type(e).__name__}: {e}\n{traceback.format_exc()}")})
+        else:
+            self.outbox.put({"type": "error", "rank": self.rank, "error": f"unknown message type {kind!r}"})
+        return True
+
+    def worker_busy_loop(self) -> None:
+        while True:
+            try:
+                # idle: block for work; busy: only look (requests that arrive now join the batch at the next step)
+                msg = self.inbox.get(timeout=None) if not self.batcher.has_work() else self.inbox.get_nowait()
+                if not self._handle(msg):
+                    return
+                continue                                        # keep draining before the next step
+            except queue.Empty:
+                pass
+            try:
+                finished = self.batcher.step()
+            except Exception as e:  # a failing step aborts the samples that were in it, not the worker
+                finished = [(a.tag, DiffusionOutput(error=f"{type(e).__name__}: {e}")) for a in list(self.batcher.active)]
+                self.batcher.active.clear()
+                self.batcher._pending.clear()
+            for tag, out in finished:
+                self.outbox.put({"type": "done", "id": tag, "rank": self.rank, "output": _to_cpu(out),
+                                 "outstanding_steps": self.batcher.outstanding_steps()})
+
+    @staticmethod
+    def worker_main(rank: int, world: int, od_config: OmniDiffusionConfig, inbox, outbox, ready, pipeline_factory=None,
+                    master_port: int = 29533) -> None:
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(master_port))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        try:
+            proc = WorkerProc(rank, od_config, inbox, outbox, pipeline_factory=pipeline_factory)
+        except Exception as e:
+            ready.put({"rank": rank, "status": "failed", "error": f"{type(e).__name__}: {e}\n{traceback.format_exc()}"})
+            return
+        ready.put({"rank": rank, "status": "ready"})
+        try:
+            proc.worker_busy_loop()
+        finally:
+            if torch.distributed.is_initialized():
+                torch.distributed.destroy_process_group()
