@@ -27,11 +27,11 @@ def test_text_to_pil_end_to_end_through_engine():
         assert len(out.images) == 1 and out.images[0].size == (128, 128) and out.images[0].mode == "RGB"
         # same seed + prompt -> same pixels; another prompt -> different pixels; two outputs per prompt -> two images
         again = omni.generate("a red cube on a table", height=128, width=128, num_inference_steps=3, seed=7)
-        assert list(again.images[0].getdata()) == list(out.images[0].getdata())
+        assert again.images[0].tobytes() == out.images[0].tobytes()
         outs = omni.generate(["a red cube on a table", "a blue sphere"], height=128, width=128, num_inference_steps=3, seed=7,
                              num_outputs_per_prompt=2)
         assert isinstance(outs, list) and [len(o.images) for o in outs] == [2, 2]
-        assert list(outs[1].images[0].getdata()) != list(outs[0].images[0].getdata())
+        assert outs[1].images[0].tobytes() != outs[0].images[0].tobytes()
         assert omni.engine.collective_rpc("is_ready") == [True]
     finally:
         omni.close()

@@ -36,10 +36,10 @@ def _request_to_cpu(req: OmniDiffusionRequest) -> OmniDiffusionRequest:
 
 class DiffusionEngine:
     def __init__(self, od_config: OmniDiffusionConfig, pipeline_factory: Callable[[], Any] | None = None,
-                 post_process_func: Callable | None = None, pre_process_func: Callable | None = None,
+                 post_process_func: Callable | None | str = "default", pre_process_func: Callable | None = None,
                  start_timeout_s: float = 600.0):
         self.od_config = od_config
-        if post_process_func is None and pipeline_factory is None:
+        if post_process_func == "default":              # registry role of get_diffusion_post_process_func (registry.py:135-146)
             from .models.qwen_image.pipeline_qwen_image import get_qwen_image_post_process_func
 
             post_process_func = get_qwen_image_post_process_func(od_config)
