@@ -136,7 +136,7 @@ def _set_gemm_variant(v):
 @pytest.mark.parametrize("K", [64, 128, 192, 3072])
 @pytest.mark.parametrize("blocked", [False, True])
 def test_gemm_pingpong_kernel_is_bit_identical_to_ring_kernel(K, blocked):
-    """The ping-pong kernels (3 = four phases per K-tile, 5 / 6 = two phases) and the ring kernel (1) accumulate every output element in the same k order with the
+    """The ping-pong kernel (3, default) and the ring kernel (1, its fallback) accumulate every output element in the same k order with the
     same MFMA: identical bits, for 1 / 2 / 3 / many K-tiles (prologue, steady state and drain of the 6-phase DMA lead),
     ragged M in both groups, gathered A rows, both operand layouts, all epilogues that have a coalesced form."""
     from vllm_omni_amd import ops
@@ -156,7 +156,7 @@ def test_gemm_pingpong_kernel_is_bit_identical_to_ring_kernel(K, blocked):
     item_t = (torch.arange(Mt) % 3).to(torch.int32).to(dev())
     outs = {}
     try:
-        for variant in (1, 3, 5, 6):
+        for variant in (1, 3):
             _set_gemm_variant(variant)
             got = []
             for epi in (ops.EPI_BIAS, ops.EPI_BIAS_GELU_TANH, ops.EPI_BIAS_GATE_RES):
@@ -176,9 +176,8 @@ def test_gemm_pingpong_kernel_is_bit_identical_to_ring_kernel(K, blocked):
             outs[variant] = got
     finally:
         _set_gemm_variant(-1)
-    for v in (3, 5, 6):
-        for x, y in zip(outs[1], outs[v]):
-            assert torch.equal(x, y), f"variant {v} differs from the ring kernel"
+    for x, y in zip(outs[1], outs[3]):
+        assert torch.equal(x, y), "the ping-pong kernel differs from the ring kernel"
     rows = map_i.long().cpu() if blocked else torch.arange(Mi)
     assert rel_l2(outs[3][0], a[rows] @ wi.t() + b) <= 4e-3
 

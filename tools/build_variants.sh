@@ -10,7 +10,7 @@ tu=$1; shift
 mkdir -p $B/abl
 while [ $# -ge 2 ]; do
   n=$1; f=$2; shift 2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Iinclude -Ivllm_omni_amd/csrc $f \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DOMNI_DEV -Iinclude -Ivllm_omni_amd/csrc $f \
       -c vllm_omni_amd/csrc/$tu.hip -o $B/abl/${tu}_$n.o 2>/dev/null
   objs=""
   for t in gemm attention elementwise vae dit_forward; do

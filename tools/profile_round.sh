@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out
 mkdir -p $OUT
 cd $PWD
 # 1) per-kernel time of the SAME command as the judged bench
-timeout 900 rocprofv3 --kernel-trace --stats -T -d $OUT/prof_${TAG}_bench -o bench -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/prof_${TAG}_bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -T -d $OUT/prof_${TAG}_bench -o bench -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/prof_${TAG}_bench.log 2>&1
 # 2) counters: separate passes, --kernel-trace only
 rocprofv3 -L > $OUT/counters_avail.txt 2>&1
 for K in roofline attention6; do

@@ -48,12 +48,12 @@ for f in sorted(glob.glob(f"{root}/pmc_{tag}_roofline_*/*.db")):
     con = sqlite3.connect(f)
     try:
         for k, c, v in con.execute("select kernel_name, counter_name, avg(value) from counters_collection "
-                                   "where kernel_name like '%gemm_bf16_ring%' group by kernel_name, counter_name"):
+                                   "where kernel_name like '%gemm_bf16_pp%' or kernel_name like '%gemm_bf16_ring%' group by kernel_name, counter_name"):
             vals[c] = v
     except Exception:  # noqa: BLE001
         pass
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-    out = {"kernel": "gemm_bf16_ring_kernel<GELU> M=24576+384 N=12288 K=3072 (bench.py roofline launch)",
+    out = {"kernel": "gemm_bf16_pp_kernel<GELU> M=24576+384 N=12288 K=3072 (bench.py roofline launch)",
            "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
            "traffic_bytes": 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024,
            "note": "fabric-side bytes per launch = 2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE; "

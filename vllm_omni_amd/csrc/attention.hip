@@ -61,6 +61,7 @@ OMNI_DEVINL bf16x8_t tr_read_pair(uint32_t lds_addr_a, uint32_t lds_addr_b) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+#ifdef OMNI_DEV   // round-1 register-staged kernels (OMNI_ATTN_PIPE=0): dev builds only
 // NQ = 32-query blocks per wave.  NQ = 1: 4 waves x 32 queries, 2 workgroups / CU (two waves per SIMD overlap each other).
 // NQ = 2: 4 waves x 64 queries, ONE wave per SIMD with ~400 registers: every K / V^T fragment read from LDS feeds TWO
 // MFMAs, and staging traffic + barriers per query halve (the NQ = 1 loop is LDS-traffic-bound: each wave re-reads all
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NQ == 1 ? 2 : 1)) void flash_attn_fwd
   }
 }
 
+#endif  // OMNI_DEV
 
 // ------------------------------------------------------------------------------------------------
 // Software-pipelined variant (default).  Same tiling and LDS images as flash_attn_fwd_kernel<1>, but
@@ -822,6 +824,7 @@ int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }
+#ifdef OMNI_DEV
 template <int NQ>
 int launch_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
                 int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
@@ -841,6 +844,7 @@ int launch_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }
+#endif  // OMNI_DEV
 }  // namespace
 
 // dev-only (NOT part of the C-ABI): switch the block order inside one process (A/B runs)
@@ -857,17 +861,19 @@ int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_
       (ldq % 8) || (ldk % 8) || (ldv % 8) || (!out_k32_rows && (ldo % 4)))
     return OMNI_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (attn_pipelined()) {
-    if (attn_variant() == 2)   // OMNI_ATTN_NQ=2: 4 waves x 64 queries, one wave per SIMD
-      return launch_pipe<4, 2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
-    if (attn_pipe_waves(B * H, max_seqlen) == 8)
-      return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
-    return launch_pipe<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
+#ifdef OMNI_DEV
+  if (!attn_pipelined()) {
+    if (out_k32_rows) return OMNI_ERR_UNSUPPORTED;   // only the pipelined kernel writes the blocked layout
+    if (attn_variant() == 1)
+      return launch_attn<1>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
+    return launch_attn<2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
   }
-  if (out_k32_rows) return OMNI_ERR_UNSUPPORTED;   // only the pipelined kernel writes the blocked layout
-  if (attn_variant() == 1)
-    return launch_attn<1>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
-  return launch_attn<2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
+  if (attn_variant() == 2)   // OMNI_ATTN_NQ=2: 4 waves x 64 queries, one wave per SIMD (spills as compiled by hipcc)
+    return launch_pipe<4, 2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
+#endif
+  if (attn_pipe_waves(B * H, max_seqlen) == 8)
+    return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
+  return launch_pipe<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
 }
 
 extern "C" int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,

@@ -1,7 +1,13 @@
 // Grouped bf16 GEMM with fused epilogues for gfx950:  Y_g = epi(A_g · W_gᵀ + bias_g).
 //
-// Three kernels share one tile geometry (one workgroup = one 256x256 output tile, 8 waves = 2(M) x 4(N), 512 threads,
-// 1 WG / CU) and one MFMA scheme; OMNI_GEMM_VARIANT picks between them (default 1):
+// The kernels share one tile geometry (one workgroup = one 256x256 output tile, 8 waves = 2(M) x 4(N), 512 threads,
+// 1 WG / CU) and one MFMA scheme.  The product library holds TWO of them:
+//   3  gemm_bf16_pp_kernel   — the production kernel (default): BK = 64 K-tiles, the two wave groups of the workgroup run
+//      half a phase apart (one in an MFMA-only cluster while its SIMD partner issues reads and LDS-DMA), see its comment;
+//   1  gemm_bf16_ring_kernel — round 1's kernel, now the fallback for what the ping-pong kernel does not take (K % 64 != 0,
+//      operand offsets beyond 32 bits, outputs that cannot use the row-coalesced epilogue); bit-identical results.
+// The first design (0), the 4-wave kernel (2), the two-phase ping-pong variants (5, 6) and the ablation entry points are
+// compiled only with -DOMNI_DEV (tools/build_variants.sh).  OMNI_GEMM_VARIANT / omni_dev_gemm_set_variant pick a family:
 //   1  gemm_bf16_ring_kernel — the production kernel: BK = 32 stages in a 5-deep LDS ring (all 160 KiB), a continuous
 //      DMA / fragment-read / MFMA pipeline (see the comment above the kernel), K32-blocked operand layouts for full-line
 //      DMA requests, row-coalesced epilogue through LDS (gemm_epilogue_lds) incl. the fused q/k norm + RoPE.
@@ -390,6 +396,7 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
   }
 }
 
+#ifdef OMNI_DEV   // dev-only kernel family (OMNI_GEMM_VARIANT=0): built with -DOMNI_DEV, not part of the product library
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
                                                                   int tiles_n, int GROUP_M) {
@@ -474,6 +481,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const omni_gemm_
   gemm_epilogue<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi);
 }
 
+#endif  // OMNI_DEV
 // ------------------------------------------------------------------------------------------------
 // Ring variant: BK = 32 per stage, 5-deep LDS ring (5 x 32 KiB = the CU's whole 160 KiB), DMA issued FOUR
 // stages (= 2 BK64 tiles, ~2 us) ahead and retired with a COUNTED vmcnt(12); raw s_barrier (a __syncthreads()
@@ -942,6 +950,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 }
 
 
+#ifdef OMNI_DEV   // dev-only kernel families: two-phase ping-pong (variants 5 / 6: measured <= the four-phase kernel) and
+                  // 4 waves x 128x128 (variant 2)
 // ------------------------------------------------------------------------------------------------
 // Two-phase ping-pong variant (OMNI_GEMM_VARIANT=5): same half-tiles, accumulators and k order as gemm_bf16_pp_kernel, but a
 // K-tile is consumed in TWO phases of 16 MFMAs (512 matrix-pipe cycles): phase a = A rows of mq 0 x both nq (reads h0, h1,
@@ -1315,6 +1325,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_bf16_w4_kernel(const omni_
 }
 
 
+#endif  // OMNI_DEV
+
 int gemm_group_m() {
   // dev knob: OMNI_GEMM_GROUP_M = row-tiles per L2 band
   static int v = -1;
@@ -1413,16 +1425,9 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
   const int tiles_m = mt0 + mt1, tiles_n = (p->N + BN - 1) / BN;
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
+#ifdef OMNI_DEV
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI, 0, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI, 0, true, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp2_kernel<EPI, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp2_kernel<EPI, true>),
@@ -1430,21 +1435,43 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_w4_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
+#endif
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI, 0, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI, 0, true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
+      return OMNI_ERR_LAUNCH;
     attr_set = true;
   }
-  if (gemm_variant() == 0 && p->K % BK == 0)
+#ifdef OMNI_DEV
+  if (gemm_variant() == 0 && p->K % BK == 0) {
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(NTHREADS), LDS_BYTES, s, *p, mt0, tiles_m,
                        tiles_n, gemm_group_m());
-  else if (gemm_variant() == 2)
+    OMNI_CHECK_LAUNCH();
+    return OMNI_OK;
+  }
+  if (gemm_variant() == 2) {
     hipLaunchKernelGGL(gemm_bf16_w4_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(W4_THREADS), RLDS_BYTES, s, *p, mt0,
                        tiles_m, tiles_n, gemm_group_m());
-  else if ((gemm_variant() == 5 || gemm_variant() == 6) && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
+    OMNI_CHECK_LAUNCH();
+    return OMNI_OK;
+  }
+  if ((gemm_variant() == 5 || gemm_variant() == 6) && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
     if (gemm_variant() == 5)
       hipLaunchKernelGGL((gemm_bf16_pp2_kernel<EPI, false>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
                          tiles_m, tiles_n, gemm_group_m());
     else
       hipLaunchKernelGGL((gemm_bf16_pp2_kernel<EPI, true>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
                          tiles_m, tiles_n, gemm_group_m());
+    OMNI_CHECK_LAUNCH();
+    return OMNI_OK;
+  }
+#endif
+  if (false) {
   }
   else if (gemm_variant() == 3 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p))
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
@@ -1471,6 +1498,7 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
 // dev-only (NOT part of the C-ABI in include/omni_cdna4.h): switch the kernel family inside one process (A/B tests).
 extern "C" void omni_dev_gemm_set_variant(int v) { g_gemm_variant = v; }
 
+#ifdef OMNI_DEV
 // dev-only (NOT part of the C-ABI in include/omni_cdna4.h): time the 2-stage kernel with parts removed.
 extern "C" int omni_dev_gemm_ablate(const omni_gemm_params* p, int mode, omni_stream stream) {
   const int mt0 = (p->g[0].M + BM - 1) / BM;
@@ -1512,6 +1540,8 @@ extern "C" int omni_dev_gemm_ring_ablate(const omni_gemm_params* p, int mode, om
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }
+
+#endif  // OMNI_DEV
 
 extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
   if (!p || p->ngroups < 1 || p->ngroups > 2 || p->N <= 0 || p->K <= 0) return OMNI_ERR_BAD_ARG;
