@@ -515,6 +515,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     __builtin_amdgcn_sched_barrier(0);                                                           \
     if ((i) + 4 < 16) OMNI_KREAD((i) + 4, kst);                                                  \
     CHUNK;                                                                                       \
+    OMNI_QK_DMA(i);                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                           \
   } while (0)
 #define OMNI_QK_ALL(SN, kst, CH)                                                                                     \
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     OMNI_QK_STEP(15, SN, kst, CH(15));                                                                               \
   } while (0)
 #define OMNI_NOCHUNK(i) (void)0
+#define OMNI_QK_DMA(i) (void)0
 
   auto mask_tail = [&](f32x16_t (&S)[NQ][2], int kv0) {
 #pragma unroll
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
                        float (&mxn)[NQ]) {
     constexpr bool has_next = decltype(has_next_c)::value;
     const bool dma_k = !(OMNI_ATTN_ABL & 4) && t + 2 < ntiles, dma_v = !(OMNI_ATTN_ABL & 4) && has_next;
-    if (OMNI_ATTN_DMA_BURST) {
+    if (OMNI_ATTN_DMA_BURST == 1 || (OMNI_ATTN_DMA_BURST == 2 && (NW != 8 || !has_next))) {
       if (dma_k) issue_K(t + 2, t & 1);
       if (dma_v) issue_V(t + 1, (t + 1) & 1);
     }
@@ -622,6 +624,14 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
       asm volatile("" : "+v"(pk_), "+v"(psum2[bq_])); /* pin: pure arithmetic is otherwise sunk below the MFMA run */ \
       pfu[bq_][(i) >> 3][((i) >> 2) & 1][(i) & 3] = pk_;                                                         \
     }                                                                                                            \
+  } while (0)
+#undef OMNI_QK_DMA
+// OMNI_ATTN_DMA_BURST == 2: ONE piece per wave per slot, waves staggered over the slots (wave w: K pieces at QK steps w and
+// w + 8): at most one global_load_lds per CU is being issued at a time instead of a burst of 32 into a queue that holds ~8
+#define OMNI_QK_DMA(i)                                                                              \
+  do {                                                                                              \
+    if (OMNI_ATTN_DMA_BURST == 2 && NW == 8 && has_next && dma_k && ((i) & 7) == wave)               \
+      issue_K_piece(t + 2, t & 1, (i) >> 3);                                                         \
   } while (0)
     if (has_next) {
       const uint32_t kst = lds0 + ((t + 1) & 1) * STAGE_BYTES;
@@ -686,6 +696,11 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
 // DMA slot j (0 .. 2*NPIECE-1): K(t+2) pieces first (needed one iteration from now), then V(t+1) pieces
 #define OMNI_DMA_SLOT(j)                                                                  \
   do {                                                                                    \
+    if (OMNI_ATTN_DMA_BURST == 2 && NW == 8 && has_next) {                                 \
+      /* staggered: slots 0..3 = P.V steps 0..3 (piece 0), slots 4..7 are not used; waves 2s, 2s+1 issue in slot s */ \
+      if ((j) < 4 && dma_v && (wave >> 1) == (j)) { issue_V_piece(t + 1, (t + 1) & 1, 0); issue_V_piece(t + 1, (t + 1) & 1, 1); } \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+    } else                                                                                \
     if (!OMNI_ATTN_DMA_BURST && (j) < 2 * NPIECE) {                                       \
       if ((j) < NPIECE) { if (dma_k) issue_K_piece(t + 2, t & 1, (j) % NPIECE); }         \
       else { if (dma_v) issue_V_piece(t + 1, (t + 1) & 1, (j) % NPIECE); }                \

@@ -765,14 +765,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
 #ifndef OMNI_PP_VMCNT
 #define OMNI_PP_VMCNT "s_waitcnt vmcnt(8)"   // 4 half-tiles x 2 pieces per wave may stay in flight across a barrier
 #endif
+#ifndef OMNI_PP_DMA_IN_MMA
+#define OMNI_PP_DMA_IN_MMA 0   // 1: a phase's two DMA pieces are issued inside its MFMA cluster instead of its load section
+#endif
+#ifndef OMNI_PP_BALANCED
+#define OMNI_PP_BALANCED 0     // 1: second A-fragment register set; fragment reads per phase 4 / 4 / 8 / 8 instead of 12 / 4 / 8 / 0
+#endif
+// counted wait at the end of a load section inside the k-loop: with the DMA issued from the load sections the youngest FOUR
+// half-tiles may be in flight (vmcnt 8); with the DMA inside the clusters this phase's pieces are not issued yet: THREE (6)
+#if OMNI_PP_DMA_IN_MMA
+#define OMNI_PP_VMCNT_LOOP "s_waitcnt vmcnt(6)"
+#else
+#define OMNI_PP_VMCNT_LOOP OMNI_PP_VMCNT
+#endif
 // The cluster's MFMAs are issued from inline asm: as builtins they are "pure" nodes that hipcc's instruction selection
 // is free to sink below s_setprio 0 / the closing s_barrier and interleave with the NEXT phase's reads (observed) —
 // which destroys exactly the phase separation this kernel is about.  Volatile asm keeps program order with respect to the
 // barriers, waits and reads.  Hazards the compiler can no longer see: the operands come from ds_reads retired by the
 // explicit lgkmcnt(0); consecutive MFMAs alternate between two accumulators, SrcC == vDst exactly (the interlocked case);
 // the epilogue's first VALU read of an accumulator is kept >= 18 wait states away by the s_nops behind the k-loop.
+#ifndef OMNI_PP_ABL
+#define OMNI_PP_ABL 0   // dev-only timing ablations (results wrong by construction): 1 no MFMA, 2 no DMA inside the k-loop,
+                        // 3 no vmcnt waits, 4 no barriers, 6 = 2 + 4, 7 = 2 + no fragment reads
+#endif
 OMNI_DEVINL void pp_mfma(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
+#if OMNI_PP_ABL == 1
+  asm volatile("" : "+v"(acc) : "v"(a), "v"(b));
+#else
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#endif
 }
 constexpr int PBK = 64;
 constexpr int PSLOT_BYTES = 128 * PBK * 2;    // 16 KiB per half-tile
@@ -829,20 +850,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   const int nkt = K / PBK;
   const char* const Ab = reinterpret_cast<const char*>(G.A);
   const char* const Wb = reinterpret_cast<const char*>(G.W);
-  // half-tile h (compile time) of K-tile `tile`: two pieces per wave
-#define OMNI_PP_ISSUE(h, tile)                                                                              \
+  // piece i (0 / 1) of half-tile h (compile time) of K-tile `tile`
+#define OMNI_PP_ISSUE_PIECE(h, tile, i)                                                                     \
   do {                                                                                                      \
     const int t_ = (tile);                                                                                  \
-    const uint32_t dst_ = lds0 + (((t_ & 1) * 4 + (h)) * PSLOT_BYTES) + (wave * 2) * 1024;                    \
-    if ((h) == 0 || (h) == 3) {                                                                             \
-      const char* b_ = Ab + t_ * astep;                                                                     \
-      glds16_saddr(b_, a_off[(h) == 3][0], dst_);                                                           \
-      glds16_saddr(b_, a_off[(h) == 3][1], dst_ + 1024);                                                    \
-    } else {                                                                                                \
-      const char* b_ = Wb + t_ * wstep;                                                                     \
-      glds16_saddr(b_, w_off[(h) == 2][0], dst_);                                                           \
-      glds16_saddr(b_, w_off[(h) == 2][1], dst_ + 1024);                                                    \
-    }                                                                                                       \
+    const uint32_t dst_ = lds0 + (((t_ & 1) * 4 + (h)) * PSLOT_BYTES) + (wave * 2 + (i)) * 1024;              \
+    if ((h) == 0 || (h) == 3) glds16_saddr(Ab + t_ * astep, a_off[(h) == 3][i], dst_);                      \
+    else glds16_saddr(Wb + t_ * wstep, w_off[(h) == 2][i], dst_);                                           \
+  } while (0)
+#define OMNI_PP_ISSUE(h, tile)                                                                              \
+  do {                                                                                                      \
+    OMNI_PP_ISSUE_PIECE(h, tile, 0);                                                                        \
+    OMNI_PP_ISSUE_PIECE(h, tile, 1);                                                                        \
   } while (0)
 
   // ---- per-lane fragment read offsets: row * 128 + ((ks*2 + hi) ^ swz) * 16, swz = (row >> 1) & 7 = (l31 >> 1) & 7 ----
@@ -876,7 +895,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][mb][i] = bini[i];
   }
-
   if (nkt > 1) {
     asm volatile(OMNI_PP_VMCNT ::: "memory");
   } else {
@@ -887,64 +905,97 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   if (wm) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
   asm volatile("" ::: "memory");
 
-  bf16x8_t wf[2][4], af[2][4];                   // wf[nq][ks]; af[mb][ks] holds mq 0 in phases 0-1, mq 1 in phases 2-3
-#define OMNI_PP_READ_A(sb)                                                                 \
+  // wf[nq][ks]; afx[mb][ks] holds the A rows of mq 0, afy[mb][ks] those of mq 1 (OMNI_PP_BALANCED: two register sets, so
+  // that the 8 reads of the NEXT K-tile's mq-0 rows move from phase 0 into phase 3, which reads nothing otherwise: the
+  // phases then read 4 / 4 / 8 / 8 fragments instead of 12 / 4 / 8 / 0; without it afy aliases afx)
+  bf16x8_t wf[2][4], afx[2][4];
+#if OMNI_PP_BALANCED
+  bf16x8_t afy[2][4];
+#else
+  bf16x8_t (&afy)[2][4] = afx;
+#endif
+#define OMNI_PP_READ_A(AF, sb)                                                             \
   do {                                                                                     \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                  \
-      af[0][ks_] = lds_read16<0>(a_rd[ks_] + (sb));                                        \
-      af[1][ks_] = lds_read16<32 * 128>(a_rd[ks_] + (sb));                                 \
+      AF[0][ks_] = lds_read16<0, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));                      \
+      AF[1][ks_] = lds_read16<32 * 128, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));               \
     }                                                                                      \
   } while (0)
 #define OMNI_PP_READ_W(nq, sb)                                                             \
   do {                                                                                     \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) wf[nq][ks_] = lds_read16<0>(w_rd[ks_] + (sb)); \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) wf[nq][ks_] = lds_read16<0, OMNI_PP_ABL == 7>(w_rd[ks_] + (sb)); \
   } while (0)
-// end of a load section: counted DMA wait, barrier, fragments arrived; then the MFMA-only cluster and the second barrier
-#define OMNI_PP_MMA(nq, mq, issued)                                                                        \
+// end of a load section: counted DMA wait, barrier, fragments arrived; then the MFMA cluster and the second barrier.
+// `landed_ok`: the counted wait is valid (enough younger pieces were issued behind the ones that must have landed).
+// DMA0 / DMA1: with OMNI_PP_DMA_IN_MMA the phase's two DMA pieces are issued INSIDE the cluster (behind MFMA 2 and 6): a
+// global_load_lds costs its wave ~60 issue cycles among bare MFMAs but 100-185 next to a burst of ds_reads (MI355X_MICROARCH
+// "LDS-DMA piece issue cost"), and the load section is what the partner group's cluster has to cover.
+#define OMNI_PP_MMA(nq, mq, AF, landed_ok, DMA0, DMA1)                                                     \
   do {                                                                                                     \
-    if (issued) asm volatile(OMNI_PP_VMCNT ::: "memory");                                                  \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
-    __builtin_amdgcn_s_barrier();                                                                          \
+    if (OMNI_PP_ABL != 3) {                                                                                \
+      if (landed_ok) asm volatile(OMNI_PP_VMCNT_LOOP ::: "memory");                                        \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+    }                                                                                                      \
+    if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                                \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                    \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                  \
-      pp_mfma(acc[nq][2 * (mq)], wf[nq][ks_], af[0][ks_]);                                                 \
-      pp_mfma(acc[nq][2 * (mq) + 1], wf[nq][ks_], af[1][ks_]);                                             \
+      pp_mfma(acc[nq][2 * (mq)], wf[nq][ks_], AF[0][ks_]);                                                 \
+      pp_mfma(acc[nq][2 * (mq) + 1], wf[nq][ks_], AF[1][ks_]);                                             \
+      if (OMNI_PP_DMA_IN_MMA && ks_ == 0) { DMA0; }                                                        \
+      if (OMNI_PP_DMA_IN_MMA && ks_ == 2) { DMA1; }                                                        \
     }                                                                                                      \
     if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
-    __builtin_amdgcn_s_barrier();                                                                          \
+    if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                                \
     asm volatile("" ::: "memory");                                                                         \
   } while (0)
+// one phase: DMA of half-tile (h, tile) either in the load section (both pieces) or inside the cluster
+#define OMNI_PP_PHASE(nq, mq, AF, do_issue, prev_issued, h, tile)                                          \
+  do {                                                                                                     \
+    if (!OMNI_PP_DMA_IN_MMA) {                                                                             \
+      if (do_issue) OMNI_PP_ISSUE(h, tile);                                                                \
+      OMNI_PP_MMA(nq, mq, AF, do_issue, (void)0, (void)0);                                                 \
+    } else {                                                                                               \
+      OMNI_PP_MMA(nq, mq, AF, prev_issued, if (do_issue) OMNI_PP_ISSUE_PIECE(h, tile, 0),                  \
+                  if (do_issue) OMNI_PP_ISSUE_PIECE(h, tile, 1));                                          \
+    }                                                                                                      \
+  } while (0)
 
+#if OMNI_PP_BALANCED
+  OMNI_PP_READ_A(afx, 0u);                      // mq-0 rows of K-tile 0 (half-tile 0 has landed)
+#endif
 #pragma unroll 1
   for (int t = 0; t < nkt; ++t) {
     const uint32_t sb = (uint32_t)((t & 1) * 4 * PSLOT_BYTES);
-    const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;
+    const uint32_t sbn = (uint32_t)(((t + 1) & 1) * 4 * PSLOT_BYTES);
+    const bool n1 = OMNI_PP_ABL != 2 && OMNI_PP_ABL != 6 && OMNI_PP_ABL != 7 && t + 1 < nkt,
+               n2 = OMNI_PP_ABL != 2 && OMNI_PP_ABL != 6 && OMNI_PP_ABL != 7 && t + 2 < nkt;
+    // with the DMA inside the clusters, the pieces a load section's wait must leave in flight were issued by the
+    // PREVIOUS phase's cluster: phase 0 looks back at phase 3 of tile t-1 (issued iff t + 1 < nkt), etc.
     // phase 0: quadrant (mq 0, nq 0)
-    OMNI_PP_READ_A(sb);
+    if (!OMNI_PP_BALANCED) OMNI_PP_READ_A(afx, sb);
     OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
-    if (n1) OMNI_PP_ISSUE(2, t + 1);
-    OMNI_PP_MMA(0, 0, n1);
+    OMNI_PP_PHASE(0, 0, afx, n1, n1, 2, t + 1);
     // phase 1: quadrant (mq 0, nq 1)
     OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
-    if (n1) OMNI_PP_ISSUE(3, t + 1);
-    OMNI_PP_MMA(1, 0, n1);
+    OMNI_PP_PHASE(1, 0, afx, n1, n1, 3, t + 1);
     // phase 2: quadrant (mq 1, nq 1)
-    OMNI_PP_READ_A(sb + 3 * PSLOT_BYTES);
-    if (n2) OMNI_PP_ISSUE(0, t + 2);
-    OMNI_PP_MMA(1, 1, n2);
+    OMNI_PP_READ_A(afy, sb + 3 * PSLOT_BYTES);
+    OMNI_PP_PHASE(1, 1, afy, n2, n1, 0, t + 2);
     // phase 3: quadrant (mq 1, nq 0)
-    if (n2) OMNI_PP_ISSUE(1, t + 2);
-    OMNI_PP_MMA(0, 1, n2);
+    if (OMNI_PP_BALANCED && t + 1 < nkt) OMNI_PP_READ_A(afx, sbn);
+    OMNI_PP_PHASE(0, 1, afy, n2, n2, 1, t + 2);
   }
   if (!wm) __builtin_amdgcn_s_barrier();         // group 0 waits for group 1's last cluster
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // asm MFMA results -> first compiler-visible VALU read
+#undef OMNI_PP_PHASE
 #undef OMNI_PP_MMA
 #undef OMNI_PP_READ_W
 #undef OMNI_PP_READ_A
 #undef OMNI_PP_ISSUE
+#undef OMNI_PP_ISSUE_PIECE
 
   gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi, smem, tid);
 }
