@@ -324,6 +324,19 @@ int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch* b, omni_st
 int omni_dit_block(const omni_dit_weights* w, int32_t layer, const omni_dit_batch* b, omni_bf16* hidden_img,
                    omni_bf16* hidden_txt, const omni_bf16* temb, omni_stream stream);
 
+/* The two halves of a block around the attention, for SEQUENCE-PARALLEL callers (Ulysses: all-to-all of q/k/v before the
+ * attention and of its output after it — reference vllm_omni/diffusion/attention/parallel/ulysses.py:59-135,
+ * qwen_image_transformer.py:735-742,776-781,800-801).  `b` describes THIS RANK's rows (its chunk of the image tokens + the
+ * replicated text tokens).  omni_dit_block_qkv runs modulation + norm1 + the fused QKV projection (+ q/k norm + RoPE) and
+ * returns pointers to the joint-order [n_joint_rows, D] q/k/v inside the workspace; the caller exchanges them, runs
+ * omni_flash_attn_fwd on the head slice it owns, exchanges back, and hands the row-major [n_joint_rows, D] attention output of
+ * its own rows to omni_dit_block_post, which finishes the block (output projections, gated residuals, norm2, MLP). */
+int omni_dit_block_qkv(const omni_dit_weights* w, int32_t layer, const omni_dit_batch* b, omni_bf16* hidden_img,
+                       omni_bf16* hidden_txt, const omni_bf16* temb, omni_bf16** q, omni_bf16** k, omni_bf16** v,
+                       omni_stream stream);
+int omni_dit_block_post(const omni_dit_weights* w, int32_t layer, const omni_dit_batch* b, omni_bf16* hidden_img,
+                        omni_bf16* hidden_txt, const omni_bf16* temb, const omni_bf16* attn, omni_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

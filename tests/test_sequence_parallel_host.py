@@ -1,0 +1,94 @@
+"""CPU (gloo, 2 and 4 ranks): the Ulysses resharding collectives and the parallel-attention strategy.
+
+Mirrors the reference's own multi-GPU unit tests on CPU: tests/diffusion/distributed/test_comm.py (all-to-all twice ==
+identity) and tests/diffusion/attention/test_ulysses_sequence_parallel.py (sequence-parallel attention == single-rank
+attention, with a replicated joint text prefix, including a text length that is not divisible by the group size)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q_out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), DIFFUSION_ATTENTION_BACKEND="TORCH_SDPA")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from vllm_omni_amd.diffusion.attention.backends.abstract import AttentionMetadata
+    from vllm_omni_amd.diffusion.attention.layer import Attention
+    from vllm_omni_amd.diffusion.data import DiffusionParallelConfig, OmniDiffusionConfig, set_current_omni_diffusion_config
+    from vllm_omni_amd.diffusion.distributed.comm import SeqAllToAll4D, SeqAllToAll5D, all_to_all_4D
+
+    dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+    try:
+        bs, s_loc, H, d = 2, 8, 8, 32                    # the reference test's shape: bs 2, seq/rank 8, 8 heads x 32
+        g = torch.Generator().manual_seed(100 + rank)
+        x = torch.randn(bs, s_loc, H, d, generator=g)
+        y = SeqAllToAll4D.apply(None, x, 2, 1)
+        assert y.shape == (bs, s_loc * world, H // world, d)
+        # every rank's shard r of the gathered sequence is rank r's tensor restricted to my heads
+        ref = [torch.randn(bs, s_loc, H, d, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+        hp = H // world
+        assert torch.equal(y, torch.cat([t[:, :, rank * hp:(rank + 1) * hp] for t in ref], dim=1))
+        assert torch.equal(SeqAllToAll4D.apply(None, y, 1, 2), x)                      # twice == identity
+        x5 = torch.randn(bs, s_loc, 3, H, d, generator=g)
+        y5 = SeqAllToAll5D.apply(None, x5, 3, 1)
+        assert y5.shape == (bs, s_loc * world, 3, H // world, d)
+        for i in range(3):                                                              # fused == three separate exchanges
+            assert torch.equal(y5[:, :, i], all_to_all_4D(x5[:, :, i].contiguous(), 2, 1))
+        assert torch.equal(SeqAllToAll5D.apply(None, y5, 1, 3), x5)
+
+        # ---- Ulysses attention == single-rank attention (joint text prefix replicated on all ranks; T = 13 not divisible)
+        cfg = OmniDiffusionConfig(parallel_config=DiffusionParallelConfig(ulysses_degree=world))
+        with set_current_omni_diffusion_config(cfg):
+            sp_attn = Attention(num_heads=H, head_size=d, causal=False, softmax_scale=d ** -0.5)
+        assert sp_attn.parallel_strategy.name == "ulysses"
+        gg = torch.Generator().manual_seed(7)                                           # same on every rank
+        S, T = s_loc * world, 13
+        q, k, v = (torch.randn(bs, S, H, d, generator=gg) for _ in range(3))
+        tq, tk, tv = (torch.randn(bs, T, H, d, generator=gg) for _ in range(3))
+        sl = slice(rank * s_loc, (rank + 1) * s_loc)
+        for strategy in ("front", "rear"):
+            md = AttentionMetadata(joint_query=tq, joint_key=tk, joint_value=tv, joint_strategy=strategy)
+            out = sp_attn(q[:, sl].contiguous(), k[:, sl].contiguous(), v[:, sl].contiguous(), md)
+            cat = (lambda j, x_: torch.cat([j, x_], 1)) if strategy == "front" else (lambda j, x_: torch.cat([x_, j], 1))
+            full = torch.nn.functional.scaled_dot_product_attention(
+                cat(tq, q).permute(0, 2, 1, 3), cat(tk, k).permute(0, 2, 1, 3), cat(tv, v).permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+            # what a rank gets back: its joint rows = [text ; its image shard] ("front") or [its shard ; text] ("rear")
+            mine = torch.cat([full[:, :T], full[:, T:][:, sl]], 1) if strategy == "front" else \
+                torch.cat([full[:, :S][:, sl], full[:, S:]], 1)
+            assert out.shape == mine.shape, (out.shape, mine.shape)
+            assert torch.allclose(out, mine, atol=1e-5, rtol=1e-5), float((out - mine).abs().max())
+        q_out.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q_out.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ulysses_collectives_and_strategy_on_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(v == "ok" for v in res.values()), res

@@ -140,6 +140,10 @@ PROTOTYPES = {
     "omni_dit_forward": (C.c_int, [C.POINTER(DitWeights), C.POINTER(DitBatch), C.c_void_p]),
     "omni_dit_block": (C.c_int, [C.POINTER(DitWeights), C.c_int32, C.POINTER(DitBatch), c_bf16_p, c_bf16_p, c_bf16_p,
                                  C.c_void_p]),
+    "omni_dit_block_qkv": (C.c_int, [C.POINTER(DitWeights), C.c_int32, C.POINTER(DitBatch), c_bf16_p, c_bf16_p, c_bf16_p,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
+    "omni_dit_block_post": (C.c_int, [C.POINTER(DitWeights), C.c_int32, C.POINTER(DitBatch), c_bf16_p, c_bf16_p, c_bf16_p,
+                                      c_bf16_p, C.c_void_p]),
 }
 
 _lib = None

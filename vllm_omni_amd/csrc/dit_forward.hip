@@ -89,9 +89,16 @@ struct BlockPred { const int32_t *tile_img, *tile_txt, *item; };
 // One dual-stream block (reference QwenImageTransformerBlock.forward, qwen_image_transformer.py:541-605) on the residual
 // streams hidden_img / hidden_txt (in place).  `after_img_norm1` (nullable) runs right after the image stream's first AdaLN:
 // omni_dit_forward hooks the TeaCache decision there (the "modulated input" of extractors.py:189-194).
+enum BlockPhase { BLOCK_ALL = 0, BLOCK_QKV = 1, BLOCK_POST = 2 };
+
+// phase: BLOCK_ALL = the whole block; BLOCK_QKV = modulation, norm1, fused QKV projection (+ q/k norm + RoPE) into the joint
+// q/k/v buffers of the workspace, then stop; BLOCK_POST = from the output projections on, reading the attention output from
+// `attn_in` (ROW-MAJOR [n_joint_rows, D]) — the two halves a sequence-parallel caller runs around its all-to-alls
+// (reference attention/parallel/ulysses.py:59-135).  BLOCK_POST recomputes the block's modulation vectors (two GEMVs).
 template <typename Hook>
 int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const Workspace& ws, omni_bf16* hidden_img,
-              omni_bf16* hidden_txt, const omni_bf16* temb, const BlockPred& pr, Hook&& after_img_norm1, omni_stream stream) {
+              omni_bf16* hidden_txt, const omni_bf16* temb, const BlockPred& pr, Hook&& after_img_norm1, omni_stream stream,
+              BlockPhase phase = BLOCK_ALL, const omni_bf16* attn_in = nullptr) {
   const omni_dit_layer_weights& L = w->layers[l];
   const int32_t Ri = b->n_img_rows, Rt = b->n_txt_rows, nT = b->n_temb;
   const int32_t D = w->num_heads * w->head_dim;
@@ -109,6 +116,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
                                   0, stream));
   OMNI_TRY(omni_linear_smallbatch(temb, D, nT, L.txt_mod_w, L.txt_mod_b, 6 * (int64_t)D, D, ws.mod_txt, 6 * D, 1,
                                   0, stream));
+  if (phase != BLOCK_POST) {
   // norm1 + modulate (reference :564-567)
   OMNI_TRY(omni_adaln_modulate_ex(hidden_img, D, xn_img, D, Ri, D, ws.mod_img + D, ws.mod_img, 6 * D, b->img_item,
                                   0, eps, bRi, stream));
@@ -142,19 +150,23 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     OMNI_TRY(omni_qk_norm_rope(ws.k, D, Ri + Rt, w->num_heads, L.norm_k_w, L.norm_added_k_w, b->rope_cos, b->rope_sin,
                                b->joint_pos, b->txt_pos_end, eps, stream));
   }
+  if (phase == BLOCK_QKV) return OMNI_OK;
   // joint attention (reference :437-443 -> attention/backends/sdpa.py:46-66)
   OMNI_TRY(omni_internal_flash_attn(ws.q, ws.k, ws.v, ws.attn, D, D, D, D, b->cu_seqlens, b->n_items, w->num_heads,
                                     w->head_dim, b->max_seqlen, sm_scale, bRj, pr.item, stream));
+  }  // phase != BLOCK_POST
+  const omni_bf16* attn_src = phase == BLOCK_POST ? attn_in : ws.attn;
+  const int32_t attn_k32 = phase == BLOCK_POST ? 0 : bRj;       // a caller-provided attention output is row-major
   // output projections + gated residual (reference :448-456, :586-587)
   {
     omni_gemm_params p = {};
     p.ngroups = 2; p.N = D; p.K = D; p.epilogue = OMNI_EPI_BIAS_GATE_RES; p.w_k32_blocked = w->gemm_w_k32_blocked;
-    p.g[0].a_k32_rows = bRj; p.g[1].a_k32_rows = bRj;
-    p.g[0].A = ws.attn; p.g[0].lda = D; p.g[0].a_row_map = b->img_joint_row; p.g[0].M = Ri;
+    p.g[0].a_k32_rows = attn_k32; p.g[1].a_k32_rows = attn_k32;
+    p.g[0].A = attn_src; p.g[0].lda = D; p.g[0].a_row_map = b->img_joint_row; p.g[0].M = Ri;
     p.g[0].W = L.to_out_w; p.g[0].bias = L.to_out_b; p.g[0].out = hidden_img; p.g[0].ldo = D;
     p.g[0].res = hidden_img; p.g[0].ldres = D; p.g[0].gate = ws.mod_img + 2 * D; p.g[0].gate_item_stride = 6 * D;
     p.g[0].row_item_map = b->img_item;
-    p.g[1].A = ws.attn; p.g[1].lda = D; p.g[1].a_row_map = b->txt_joint_row; p.g[1].M = Rt;
+    p.g[1].A = attn_src; p.g[1].lda = D; p.g[1].a_row_map = b->txt_joint_row; p.g[1].M = Rt;
     p.g[1].W = L.to_add_out_w; p.g[1].bias = L.to_add_out_b; p.g[1].out = hidden_txt; p.g[1].ldo = D;
     p.g[1].res = hidden_txt; p.g[1].ldres = D; p.g[1].gate = ws.mod_txt + 2 * D; p.g[1].gate_item_stride = 6 * D;
     p.g[1].row_item_map = b->txt_item;
@@ -311,4 +323,33 @@ extern "C" int omni_dit_block(const omni_dit_weights* w, int32_t layer, const om
   if (ws.total > b->workspace_bytes) return OMNI_ERR_BAD_ARG;
   OMNI_TRY(prepare_positions(b, ws, stream));
   return run_block(w, layer, b, ws, hidden_img, hidden_txt, temb, BlockPred{nullptr, nullptr, nullptr}, NoHook{}, stream);
+}
+
+extern "C" int omni_dit_block_qkv(const omni_dit_weights* w, int32_t layer, const omni_dit_batch* b, omni_bf16* hidden_img,
+                                  omni_bf16* hidden_txt, const omni_bf16* temb, omni_bf16** q, omni_bf16** k, omni_bf16** v,
+                                  omni_stream stream) {
+  if (!w || !b || !w->layers || !b->workspace || !hidden_img || !hidden_txt || !temb || !q || !k || !v) return OMNI_ERR_BAD_ARG;
+  if (layer < 0 || layer >= w->num_layers) return OMNI_ERR_BAD_ARG;
+  if (w->head_dim != 128) return OMNI_ERR_UNSUPPORTED;
+  const int32_t Ri = b->n_img_rows, Rt = b->n_txt_rows, nT = b->n_temb;
+  if (Ri <= 0 || Rt <= 0 || nT <= 0 || b->n_joint_rows != Ri + Rt) return OMNI_ERR_BAD_ARG;
+  const Workspace ws = carve(b->workspace, w, Ri, Rt, nT);
+  if (ws.total > b->workspace_bytes) return OMNI_ERR_BAD_ARG;
+  OMNI_TRY(prepare_positions(b, ws, stream));
+  *q = ws.q; *k = ws.k; *v = ws.v;
+  return run_block(w, layer, b, ws, hidden_img, hidden_txt, temb, BlockPred{nullptr, nullptr, nullptr}, NoHook{}, stream,
+                   BLOCK_QKV);
+}
+
+extern "C" int omni_dit_block_post(const omni_dit_weights* w, int32_t layer, const omni_dit_batch* b, omni_bf16* hidden_img,
+                                   omni_bf16* hidden_txt, const omni_bf16* temb, const omni_bf16* attn, omni_stream stream) {
+  if (!w || !b || !w->layers || !b->workspace || !hidden_img || !hidden_txt || !temb || !attn) return OMNI_ERR_BAD_ARG;
+  if (layer < 0 || layer >= w->num_layers) return OMNI_ERR_BAD_ARG;
+  if (!omni_aligned16(attn)) return OMNI_ERR_ALIGN;
+  const int32_t Ri = b->n_img_rows, Rt = b->n_txt_rows, nT = b->n_temb;
+  if (Ri <= 0 || Rt <= 0 || nT <= 0 || b->n_joint_rows != Ri + Rt) return OMNI_ERR_BAD_ARG;
+  const Workspace ws = carve(b->workspace, w, Ri, Rt, nT);
+  if (ws.total > b->workspace_bytes) return OMNI_ERR_BAD_ARG;
+  return run_block(w, layer, b, ws, hidden_img, hidden_txt, temb, BlockPred{nullptr, nullptr, nullptr}, NoHook{}, stream,
+                   BLOCK_POST, attn);
 }

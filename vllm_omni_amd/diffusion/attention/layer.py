@@ -1,10 +1,11 @@
 """Attention layer — mirror of vllm_omni/diffusion/attention/layer.py:17-70 (backend impl between the
-parallel strategy's pre/post hooks).  Data-parallel serving needs no resharding, so the strategy is the
-identity (`NoParallelAttention` in the reference); Ulysses is SURVEY.md §8f row N2."""
+parallel strategy's pre/post hooks).  Data-parallel serving needs no resharding (identity strategy,
+`NoParallelAttention`); with `ulysses_degree > 1` the Ulysses strategy (parallel/ulysses.py) wraps the kernel in all-to-alls."""
 import torch
 import torch.nn as nn
 
 from .backends.abstract import AttentionMetadata
+from .parallel import build_parallel_attention_strategy
 from .selector import get_attn_backend
 
 
@@ -18,8 +19,16 @@ class Attention(nn.Module):
                                                           softmax_scale=softmax_scale, causal=causal,
                                                           num_kv_heads=num_kv_heads)
         self.softmax_scale = softmax_scale
+        # sharding / communication around the kernel is a separate, pluggable strategy (reference layer.py:41-52)
+        self.parallel_strategy = build_parallel_attention_strategy(scatter_idx=scatter_idx, gather_idx=gather_idx,
+                                                                   use_sync=use_sync)
 
     def forward(self, query, key, value, attn_metadata: AttentionMetadata = None) -> torch.Tensor:
+        if self.parallel_strategy.enabled:
+            query, key, value, attn_metadata, ctx = self.parallel_strategy.pre_attention(query, key, value, attn_metadata)
+            out = self.attention.forward(query, key, value, attn_metadata)
+            out = out[0] if isinstance(out, tuple) else out
+            return self.parallel_strategy.post_attention(out, ctx)
         if attn_metadata is not None and attn_metadata.joint_query is not None:
             # SP-style call: the replicated text q/k/v ride in the metadata (reference ulysses.py:83-121)
             front = attn_metadata.joint_strategy == "front"

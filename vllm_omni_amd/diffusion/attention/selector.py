@@ -1,7 +1,7 @@
 """Backend selection — mirror of vllm_omni/diffusion/attention/selector.py:18-77.
 
-Same env var (DIFFUSION_ATTENTION_BACKEND) and the same `{name: {module, class}}` registry shape; the only
-registered (and default) backend here is CDNA4_FLASH.  Unknown names raise ValueError like the reference.
+Same env var (DIFFUSION_ATTENTION_BACKEND) and the same `{name: {module, class}}` registry shape; CDNA4_FLASH is the default
+wherever a GPU is visible; TORCH_SDPA (the reference's default) serves CPU-only hosts and explicit requests.  Unknown names raise ValueError like the reference.
 """
 import importlib
 import os
@@ -11,6 +11,7 @@ from .backends.abstract import AttentionBackend
 
 _BACKEND_CONFIG = {
     "CDNA4_FLASH": {"module": "vllm_omni_amd.diffusion.attention.backends.cdna4_flash", "class": "CDNA4FlashBackend"},
+    "TORCH_SDPA": {"module": "vllm_omni_amd.diffusion.attention.backends.sdpa", "class": "SDPABackend"},
 }
 
 
@@ -28,4 +29,7 @@ def get_attn_backend(head_size: int) -> type[AttentionBackend]:
             raise ValueError(f"Invalid attention backend for diffusion: '{name}'. Valid backends are: "
                              f"{list(_BACKEND_CONFIG)}")
         return load_backend(up)
-    return load_backend("CDNA4_FLASH")
+    import torch
+
+    # default: the HIP kernel wherever a GPU is visible; a CPU-only host (host-logic tests) gets the reference's SDPA default
+    return load_backend("CDNA4_FLASH" if torch.cuda.is_available() else "TORCH_SDPA")

@@ -28,6 +28,7 @@ class RaggedBatch:
     n_temb: int
     grid: tuple[int, int, int]    # (frames, h/16, w/16) latent token grid, identical for all items
     txt_pos_end: int              # rope table rows [0, txt_pos_end) are text positions
+    img_start: int = 0            # first image token of the grid held by this batch (sequence-parallel chunk)
     cu_seqlens: np.ndarray = field(repr=False, default=None)
     img_item: np.ndarray = field(repr=False, default=None)
     txt_item: np.ndarray = field(repr=False, default=None)
@@ -61,12 +62,16 @@ class RaggedBatch:
 
 
 def build_ragged_batch(txt_lens: list[int], grid: tuple[int, int, int], temb_rows: list[int] | None = None,
-                       txt_pos_end: int | None = None) -> RaggedBatch:
-    """Build the int32 row maps for items with text lengths `txt_lens` on a common latent grid."""
+                       txt_pos_end: int | None = None, img_rows: tuple[int, int] | None = None) -> RaggedBatch:
+    """Build the int32 row maps for items with text lengths `txt_lens` on a common latent grid.
+    `img_rows = (start, count)`: every item holds only that slice of the grid's image tokens (a sequence-parallel rank's
+    chunk, reference qwen_image_transformer.py:735-738,772-781); RoPE positions stay those of the full grid."""
     if not txt_lens or any(t <= 0 for t in txt_lens):
         raise ValueError("every item needs at least one text token")
     f, h, w = grid
-    s_img = f * h * w
+    img_start, s_img = (0, f * h * w) if img_rows is None else (int(img_rows[0]), int(img_rows[1]))
+    if img_start < 0 or s_img <= 0 or img_start + s_img > f * h * w:
+        raise ValueError("img_rows outside the token grid")
     n = len(txt_lens)
     temb_rows = list(range(n)) if temb_rows is None else list(temb_rows)
     if len(temb_rows) != n:
@@ -85,9 +90,9 @@ def build_ragged_batch(txt_lens: list[int], grid: tuple[int, int, int], temb_row
     joint_pos = np.empty(int(cu[-1]), dtype=np.int32)
     for i in range(n):
         joint_pos[cu[i]: cu[i] + txt_lens[i]] = np.arange(txt_lens[i], dtype=np.int32)
-        joint_pos[cu[i] + txt_lens[i]: cu[i + 1]] = txt_pos_end + np.arange(s_img, dtype=np.int32)
+        joint_pos[cu[i] + txt_lens[i]: cu[i + 1]] = txt_pos_end + img_start + np.arange(s_img, dtype=np.int32)
     return RaggedBatch(txt_lens=list(txt_lens), s_img=s_img, temb_rows=temb_rows, n_temb=max(temb_rows) + 1,
-                       grid=tuple(grid), txt_pos_end=txt_pos_end, cu_seqlens=cu,
+                       grid=tuple(grid), txt_pos_end=txt_pos_end, img_start=img_start, cu_seqlens=cu,
                        img_item=img_item.astype(np.int32), txt_item=txt_item.astype(np.int32),
                        img_joint_row=img_joint.astype(np.int32), txt_joint_row=txt_joint.astype(np.int32),
                        joint_pos=joint_pos)

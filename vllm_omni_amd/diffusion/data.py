@@ -18,8 +18,8 @@ _PARALLEL_AXES = ("pipeline_parallel_size", "data_parallel_size", "tensor_parall
 @dataclass
 class DiffusionParallelConfig:
     """Degrees of every parallel axis the reference's config knows (same field names as
-    vllm_omni/diffusion/data.py:26-91).  This build shards by REQUEST only: `data_parallel_size` is
-    the world size and every other axis must stay 1."""
+    vllm_omni/diffusion/data.py:26-91).  This build shards by REQUEST (`data_parallel_size`) and,
+    for single-image latency, by SEQUENCE with Ulysses (`ulysses_degree`, §8f N2); every other axis must stay 1."""
     pipeline_parallel_size: int = 1
     data_parallel_size: int = 1
     tensor_parallel_size: int = 1
@@ -38,10 +38,11 @@ class DiffusionParallelConfig:
         if self.sequence_parallel_size != sp:
             raise AssertionError(f"sequence_parallel_size {self.sequence_parallel_size} != ulysses {self.ulysses_degree}"
                                  f" * ring {self.ring_degree}")
-        unsupported = [ax for ax in _PARALLEL_AXES if ax != "data_parallel_size" and getattr(self, ax) != 1]
+        unsupported = [ax for ax in _PARALLEL_AXES if ax not in ("data_parallel_size", "ulysses_degree") and getattr(self, ax) != 1]
         if unsupported:
-            raise NotImplementedError(f"{unsupported} > 1 is not built; the MI355X path is data-parallel over requests")
-        self.world_size = self.data_parallel_size
+            raise NotImplementedError(f"{unsupported} > 1 is not built; the MI355X path is data-parallel over requests, "
+                                      "optionally Ulysses sequence-parallel inside a request")
+        self.world_size = self.data_parallel_size * self.ulysses_degree
 
     @classmethod
     def from_dict(cls, data: dict[str, Any]) -> "DiffusionParallelConfig":

@@ -422,7 +422,7 @@ class QwenImageTransformer2DModel(nn.Module):
     # ------------------------------------------------------------------ batches
     def prepare_batch(self, batch: RaggedBatch) -> dict:
         """Upload the int32 maps and the bf16 RoPE table of a RaggedBatch (cache by content)."""
-        key = (tuple(batch.txt_lens), tuple(batch.temb_rows), batch.grid, batch.txt_pos_end)
+        key = (tuple(batch.txt_lens), tuple(batch.temb_rows), batch.grid, batch.txt_pos_end, batch.img_start, batch.s_img)
         hit = self._batch_cache.get(key)
         if hit is not None:
             return hit
@@ -497,6 +497,93 @@ class QwenImageTransformer2DModel(nn.Module):
         N.check(lib.omni_dit_block(C.byref(w), layer, C.byref(b), hid.data_ptr(), enc.data_ptr(), tb.data_ptr(),
                                    torch.cuda.current_stream().cuda_stream), "omni_dit_block")
         return enc.view(B, T, D), hid.view(B, S, D)
+
+    # ------------------------------------------------------------------ Ulysses sequence parallelism
+    def _sp_forward_gen(self, rank: int, P: int, latents: torch.Tensor, prompt_embeds: torch.Tensor, sigma: torch.Tensor,
+                        grid: tuple[int, int, int]):
+        """One DiT forward of ONE item with its image tokens split over P ranks (reference qwen_image_transformer.py:
+        735-742,776-781,800-801 + attention/parallel/ulysses.py:59-135), written as a generator that YIELDS its collectives
+        (`("all_to_all", send[P, ...])` -> recv, `("all_gather", x)` -> [P, ...]) so that the same code is driven by
+        torch.distributed (forward_sp) or, in tests, by an in-process exchange between P generators on one GPU.
+
+        latents [S_img, 64] (full; this rank takes rows [rank*S_img/P, ...)), prompt_embeds [T, joint] (replicated),
+        sigma fp32 [1].  Per block: omni_dit_block_qkv on the local rows -> ONE fused all-to-all of the image q/k/v
+        (sequence <-> heads; the replicated text q/k/v are only head-sliced, no communication — unlike the reference, which
+        sends P copies of the text queries through the all-to-all) -> flash attention over the whole sequence for H/P heads
+        -> ONE all-to-all back (image rows to their owners + the text rows' head slice to everyone) -> omni_dit_block_post."""
+        H, d, D = self.num_heads, self.head_dim, self.inner_dim
+        S = grid[0] * grid[1] * grid[2]
+        if S % P or H % P:
+            raise ValueError(f"Ulysses needs S_img ({S}) and heads ({H}) divisible by the degree ({P})")
+        S_loc, Hh, T = S // P, H // P, prompt_embeds.shape[0]
+        dev = self.device
+        rb = build_ragged_batch([T], grid, img_rows=(rank * S_loc, S_loc))
+        prepared = self.prepare_batch(rb)
+        lib = N.lib()
+        stream = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+        hid = self.img_in(latents[rank * S_loc:(rank + 1) * S_loc].to(dev, BF16)).contiguous()          # [S_loc, D]
+        enc = self.txt_in(self.txt_norm(prompt_embeds.to(dev, BF16))).contiguous()                      # [T, D]
+        temb = self.time_text_embed(sigma.to(dev), hid).contiguous()                                    # [1, D]
+        cu = torch.tensor([0, T + S], dtype=torch.int32, device=dev)
+        scale = 1.0 / (d ** 0.5)
+        for l in range(len(self.transformer_blocks)):
+            _, w, b = self._descriptor(prepared, S_loc, T)
+            ws_base, ws_t = self._workspace.data_ptr(), self._workspace
+            qp, kp, vp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            N.check(lib.omni_dit_block_qkv(C.byref(w), l, C.byref(b), hid.data_ptr(), enc.data_ptr(), temb.data_ptr(),
+                                           C.byref(qp), C.byref(kp), C.byref(vp), stream()), "omni_dit_block_qkv")
+            view = lambda p: ws_t[p.value - ws_base: p.value - ws_base + (T + S_loc) * D * 2].view(BF16).view(T + S_loc, H, d)  # noqa: E731
+            q, k, v = view(qp), view(kp), view(vp)                       # joint order: [text ; image chunk]
+            # my head slice of the replicated text rows (copied: the workspace is reused by the next native call)
+            hs = slice(rank * Hh, (rank + 1) * Hh)
+            txt_qkv = torch.stack([q[:T, hs], k[:T, hs], v[:T, hs]]).reshape(3, T, Hh * d).clone()
+            send = torch.stack([q[T:], k[T:], v[T:]]).view(3, S_loc, P, Hh * d).permute(2, 0, 1, 3).contiguous()
+            recv = yield ("all_to_all", send)                            # [P(source = sequence chunk), 3, S_loc, Hh*d]
+            img_qkv = recv.permute(1, 0, 2, 3).reshape(3, S, Hh * d)
+            full = torch.cat([txt_qkv, img_qkv], dim=1).contiguous()     # [3, T + S, Hh*d]
+            o = ops.flash_attn_varlen(full[0], full[1], full[2], cu, Hh, T + S, scale)           # [T + S, Hh*d]
+            send2 = torch.cat([o[T:].view(P, S_loc, Hh * d), o[:T].unsqueeze(0).expand(P, T, Hh * d)], dim=1).contiguous()
+            recv2 = yield ("all_to_all", send2)                          # [P(source = head slice), S_loc + T, Hh*d]
+            loc = recv2.permute(1, 0, 2).reshape(S_loc + T, D)           # heads in source-rank order = original order
+            attn = torch.cat([loc[S_loc:], loc[:S_loc]]).contiguous()    # back to the joint order [text ; image chunk]
+            _, w, b = self._descriptor(prepared, S_loc, T)
+            N.check(lib.omni_dit_block_post(C.byref(w), l, C.byref(b), hid.data_ptr(), enc.data_ptr(), temb.data_ptr(),
+                                            attn.data_ptr(), stream()), "omni_dit_block_post")
+        out_loc = self.proj_out(self.norm_out(hid.view(1, S_loc, D), temb)).view(S_loc, -1)
+        gathered = yield ("all_gather", out_loc.contiguous())            # [P, S_loc, 64]
+        return gathered.reshape(S, -1)
+
+    @torch.no_grad()
+    def forward_sp(self, latents: torch.Tensor, prompt_embeds: torch.Tensor, sigma: torch.Tensor,
+                   grid: tuple[int, int, int], group=None) -> torch.Tensor:
+        """Ulysses sequence-parallel forward over `group` (RCCL): every rank passes the same full `latents` / prompt and
+        receives the full noise prediction [S_img, 64].  240 all-to-alls + 1 all-gather per 60-layer forward."""
+        import torch.distributed as dist
+
+        P = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        gen = self._sp_forward_gen(rank, P, latents, prompt_embeds, sigma, grid)
+        msg = next(gen)
+        while True:
+            kind, t = msg
+            if kind == "all_to_all":
+                out = torch.empty_like(t)
+                if P > 1:
+                    dist.all_to_all_single(out, t, group=group)
+                else:
+                    out = t
+            elif kind == "all_gather":
+                out = torch.empty((P,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+                if P > 1:
+                    dist.all_gather_into_tensor(out, t, group=group)
+                else:
+                    out[0] = t
+            else:
+                raise RuntimeError(f"unknown collective {kind}")
+            try:
+                msg = gen.send(out)
+            except StopIteration as e:
+                return e.value
 
     # ------------------------------------------------------------------ reference-shaped forward
     @torch.no_grad()
