@@ -201,6 +201,26 @@ def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
         out[f"config1_256px_4step_{name}_ms_per_image"] = t * 1e3
     pipe.od_config.use_hip_graph = None
     out["config1_note"] = f"256x256, 4 steps, true-CFG (8 forwards of {layers} layers), batch 1, + VAE decode"
+    # the same small requests step-batched: one weight stream (41 GB per forward) serves 16 requests
+    many = reqs(16, 256, 4, cfg=True)
+    pipe.od_config.max_step_batch = 16
+    t = timed(lambda: [pipe.decode_latents(o.output, 256, 256) for o in pipe.generate(many, output_type="latent")], n=2)
+    pipe.od_config.max_step_batch = old_cap
+    out["config1_256px_4step_stepbatched16_images_per_sec"] = 16 / t
+    # TeaCache (device-side decisions, no host sync) on the headline workload
+    try:
+        from vllm_omni_amd.diffusion.cache.teacache.config import TeaCacheConfig
+
+        pipe.transformer.teacache = TeaCacheConfig(rel_l1_thresh=0.2)
+        head = reqs(R, HEIGHT, STEPS_DENOISE, cfg=True)
+        t = timed(lambda: [pipe.decode_latents(o.output, HEIGHT, WIDTH) for o in pipe.generate(head, output_type="latent")])
+        skipped = pipe.last_teacache_state.skipped_forwards()
+        out["teacache_thresh0.2_images_per_sec"] = R / t
+        out["teacache_skipped_forwards_per_item"] = skipped
+        out["teacache_note"] = (f"1024^2, 20 steps, true-CFG, {R} requests step-batched, rel_l1_thresh 0.2, Qwen-Image "
+                                "coefficients; random-init weights, so the skip pattern is NOT that of a trained model")
+    finally:
+        pipe.transformer.teacache = None
     return out
 
 

@@ -89,4 +89,6 @@ def test_worker_execute_model_single_rank_uses_all_requests():
     out = w.execute_model(reqs)
     assert out.error is None and out.output.shape == (3, 3, 128, 128)     # the reference would return 1 image (reqs[0])
     bad = w.execute_model([OmniDiffusionRequest(height=128, width=128, num_inference_steps=2)])   # no prompt_embeds
-    assert bad.output is None and "NotImplementedError" in bad.error      # errors are reported, not raised (gpu_worker.py:266-274)
+    assert bad.output is None and "Provide either `prompt` or `prompt_embeds`" in bad.error   # check_inputs' message (:304-308), reported not raised (gpu_worker.py:266-274)
+    txt = w.execute_model([OmniDiffusionRequest(prompt="a cat", height=128, width=128, num_inference_steps=2)])
+    assert txt.output is None and "text encoder" in txt.error                 # prompt strings need the pipeline's text encoder

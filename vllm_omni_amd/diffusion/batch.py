@@ -26,7 +26,8 @@ class RaggedBatch:
     s_img: int
     temb_rows: list[int]          # item -> row of the timestep-embedding table (items may share one)
     n_temb: int
-    grid: tuple[int, int, int]    # (frames, h/16, w/16) latent token grid, identical for all items
+    grid: tuple                   # (frames, h/16, w/16) latent token grid, or a tuple of such triples (target + condition
+                                  # images on one sequence axis), identical for all items
     txt_pos_end: int              # rope table rows [0, txt_pos_end) are text positions
     img_start: int = 0            # first image token of the grid held by this batch (sequence-parallel chunk)
     cu_seqlens: np.ndarray = field(repr=False, default=None)
@@ -68,9 +69,13 @@ def build_ragged_batch(txt_lens: list[int], grid: tuple[int, int, int], temb_row
     chunk, reference qwen_image_transformer.py:735-738,772-781); RoPE positions stay those of the full grid."""
     if not txt_lens or any(t <= 0 for t in txt_lens):
         raise ValueError("every item needs at least one text token")
-    f, h, w = grid
-    img_start, s_img = (0, f * h * w) if img_rows is None else (int(img_rows[0]), int(img_rows[1]))
-    if img_start < 0 or s_img <= 0 or img_start + s_img > f * h * w:
+    from .models.qwen_image.rope import grid_tokens, normalize_grids
+
+    grid = normalize_grids(grid)
+    grid = grid[0] if len(grid) == 1 else grid          # one image: the plain (f, h, w) triple; several: a tuple of triples
+    total = grid_tokens(grid)
+    img_start, s_img = (0, total) if img_rows is None else (int(img_rows[0]), int(img_rows[1]))
+    if img_start < 0 or s_img <= 0 or img_start + s_img > total:
         raise ValueError("img_rows outside the token grid")
     n = len(txt_lens)
     temb_rows = list(range(n)) if temb_rows is None else list(temb_rows)

@@ -27,7 +27,7 @@ from ...batch import RaggedBatch, build_ragged_batch
 from ...layers.adalayernorm import AdaLayerNorm
 from .... import _native as N
 from .... import ops
-from .rope import rope_table
+from .rope import grid_tokens, normalize_grids, rope_table
 
 BF16 = torch.bfloat16
 
@@ -162,14 +162,22 @@ class RotaryTables(tuple):
         return self
 
 
+def _grid_of(img_shapes):
+    """img_shapes as the pipelines pass it — [[(f, h, w)]] * B, or [[(f, h, w), (f2, h2, w2), ...]] * B for the Edit variants
+    — to this build's grid: the reference reads img_shapes[0] only (:231-232), i.e. all items share item 0's shapes."""
+    shp = img_shapes
+    if isinstance(shp, (list, tuple)) and shp and isinstance(shp[0], (list, tuple)) and shp[0] and \
+            isinstance(shp[0][0], (list, tuple)):
+        shp = shp[0]                                       # [[entries...]] * B -> entries of item 0
+    g = normalize_grids(tuple(tuple(int(v) for v in e) for e in shp) if isinstance(shp[0], (list, tuple)) else tuple(int(v) for v in shp))
+    return g[0] if len(g) == 1 else g
+
+
 class QwenEmbedRope(nn.Module):
     """`pos_embed` (reference :179-285): no parameters; tables are cached per (grid, text length)."""
 
     def forward(self, video_fhw, txt_seq_lens, device=None) -> RotaryTables:
-        shp = video_fhw[0] if isinstance(video_fhw, (list, tuple)) and isinstance(video_fhw[0], (list, tuple)) else video_fhw
-        if isinstance(shp[0], (list, tuple)):
-            shp = shp[0]                                   # the reference reads img_shapes[0] only (:231-232)
-        grid = tuple(int(v) for v in shp)
+        grid = _grid_of(video_fhw)
         T = int(max(txt_seq_lens)) if not isinstance(txt_seq_lens, int) else int(txt_seq_lens)
         cos, sin = rope_table(grid, T)
         cplx = torch.complex(cos, sin).to(device) if device is not None else torch.complex(cos, sin)
@@ -485,7 +493,7 @@ class QwenImageTransformer2DModel(nn.Module):
         B, S, D = hidden_states.shape
         T = encoder_hidden_states.shape[1]
         grid = getattr(image_rotary_emb, "grid", None)
-        if grid is None or grid[0] * grid[1] * grid[2] != S:
+        if grid is None or grid_tokens(grid) != S:
             raise ValueError("image_rotary_emb must come from this model's pos_embed(img_shapes, txt_seq_lens)")
         prepared = self.prepare_batch(build_ragged_batch([T] * B, grid, txt_pos_end=max(T, getattr(image_rotary_emb, "txt_len", T))))
         hid = hidden_states.reshape(B * S, D).to(BF16).clone()
@@ -512,7 +520,7 @@ class QwenImageTransformer2DModel(nn.Module):
         sends P copies of the text queries through the all-to-all) -> flash attention over the whole sequence for H/P heads
         -> ONE all-to-all back (image rows to their owners + the text rows' head slice to everyone) -> omni_dit_block_post."""
         H, d, D = self.num_heads, self.head_dim, self.inner_dim
-        S = grid[0] * grid[1] * grid[2]
+        S = grid_tokens(grid)
         if S % P or H % P:
             raise ValueError(f"Ulysses needs S_img ({S}) and heads ({H}) divisible by the degree ({P})")
         S_loc, Hh, T = S // P, H // P, prompt_embeds.shape[0]
@@ -596,11 +604,8 @@ class QwenImageTransformer2DModel(nn.Module):
             raise NotImplementedError("guidance / additional_t_cond variants are outside the Qwen-Image T2I path")
         B, S_img, _ = hidden_states.shape
         T = encoder_hidden_states.shape[1]
-        shp = img_shapes[0]
-        if isinstance(shp, (list, tuple)) and isinstance(shp[0], (list, tuple)):
-            shp = shp[0]  # reference reads img_shapes[0] only (:231-232)
-        grid = tuple(int(v) for v in shp)
-        if grid[0] * grid[1] * grid[2] != S_img:
+        grid = _grid_of(img_shapes)
+        if grid_tokens(grid) != S_img:
             raise ValueError(f"img_shapes {grid} does not match {S_img} image tokens")
         prepared = self.prepare_batch(build_ragged_batch([T] * B, grid))
         # the reference casts timestep to the activation dtype before the sinusoid (:746)

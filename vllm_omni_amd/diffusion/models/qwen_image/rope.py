@@ -24,20 +24,40 @@ def _axis_angles(index: torch.Tensor, dim: int) -> torch.Tensor:
     return index.to(torch.float32)[:, None] * inv_freq[None, :]
 
 
+def normalize_grids(grid) -> tuple[tuple[int, int, int], ...]:
+    """A token grid is one (frames, h, w) triple or a SEQUENCE of them: the Edit pipelines put the target latents and the
+    condition images on one sequence axis, each entry with its own frame index (reference :231-250, idx -> frame offset)."""
+    if len(grid) == 3 and all(isinstance(v, int) for v in grid):
+        return (tuple(grid),)
+    out = tuple(tuple(int(v) for v in g) for g in grid)
+    if not out or any(len(g) != 3 for g in out):
+        raise ValueError(f"bad token grid {grid!r}")
+    return out
+
+
+def grid_tokens(grid) -> int:
+    return sum(f * h * w for f, h, w in normalize_grids(grid))
+
+
 @functools.lru_cache(maxsize=64)
-def rope_table(grid: tuple[int, int, int], n_txt_pos: int) -> tuple[torch.Tensor, torch.Tensor]:
-    """(cos, sin) fp32 CPU tensors of shape [n_txt_pos + f*h*w, 64]; rows [0, n_txt_pos) are text positions."""
-    f, h, w = grid
-    fi = torch.arange(f)
-    hi = torch.arange(h) - (h - h // 2)
-    wi = torch.arange(w) - (w - w // 2)
-    af, ah, aw = (_axis_angles(i, d) for i, d in zip((fi, hi, wi), AXES_DIM))
-    ang_img = torch.cat([
-        af[:, None, None, :].expand(f, h, w, -1),
-        ah[None, :, None, :].expand(f, h, w, -1),
-        aw[None, None, :, :].expand(f, h, w, -1)], dim=-1).reshape(f * h * w, -1)
-    start = max(h // 2, w // 2)
+def _rope_table(grids: tuple[tuple[int, int, int], ...], n_txt_pos: int) -> tuple[torch.Tensor, torch.Tensor]:
+    parts, start = [], 0
+    for idx, (f, h, w) in enumerate(grids):
+        fi = torch.arange(idx, idx + f)                       # entry idx starts at frame position idx (:268)
+        hi = torch.arange(h) - (h - h // 2)
+        wi = torch.arange(w) - (w - w // 2)
+        af, ah, aw = (_axis_angles(i, d) for i, d in zip((fi, hi, wi), AXES_DIM))
+        parts.append(torch.cat([
+            af[:, None, None, :].expand(f, h, w, -1),
+            ah[None, :, None, :].expand(f, h, w, -1),
+            aw[None, None, :, :].expand(f, h, w, -1)], dim=-1).reshape(f * h * w, -1))
+        start = max(start, h // 2, w // 2)                    # text positions start behind the largest half-extent (:251-257)
     ti = torch.arange(start, start + n_txt_pos)
     ang_txt = torch.cat([_axis_angles(ti, d) for d in AXES_DIM], dim=-1)
-    ang = torch.cat([ang_txt, ang_img], dim=0)
+    ang = torch.cat([ang_txt] + parts, dim=0)
     return torch.cos(ang), torch.sin(ang)
+
+
+def rope_table(grid, n_txt_pos: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """(cos, sin) fp32 CPU tensors of shape [n_txt_pos + n_image_tokens, 64]; rows [0, n_txt_pos) are text positions."""
+    return _rope_table(normalize_grids(grid), int(n_txt_pos))
