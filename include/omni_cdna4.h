@@ -208,7 +208,7 @@ int omni_cfg_euler_step(const omni_bf16* pos, const omni_bf16* neg, omni_bf16* l
                         float true_cfg_scale, const float* dt, int32_t dt_rows_per_item, omni_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
- * VAE decode kernels (AutoencoderKLQwenImage.decode for one frame,
+ * VAE kernels (AutoencoderKLQwenImage.decode — and .encode for the Edit pipelines — for one frame,
  * vllm_omni/diffusion/models/qwen_image/autoencoder_kl_qwenimage.py:839-863 / diffusers twin).
  * Activations are NHWC bf16 ([B, H, W, C]); conv weights are pre-packed [Cout, 3, 3, Cin] bf16 from temporal
  * slice [-1] of the causal Conv3d weights (:69-84: the two zero front frames make the other slices dead).
@@ -228,6 +228,8 @@ typedef struct {
   int32_t upsample2x;     /* 1: Hout = 2*Hin (input index = out/2), else Hout = Hin */
   int32_t silu;           /* with gamma: apply SiLU after the norm */
   float clamp_lo, clamp_hi; /* applied if clamp_lo < clamp_hi */
+  int32_t downsample2x;   /* 1 (3x3 only): ZeroPad2d((0,1,0,1)) + stride-2 conv of the VAE ENCODER's downsample2d/3d
+                           * (autoencoder_kl_qwenimage.py:162-166): Hout = Hin / 2, source = 2*dst + tap.  ABI v3 */
 } omni_conv_params;
 int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream);
 

@@ -148,6 +148,54 @@ def run_vae_cases():
         print(f"{name}: image {tuple(img.shape)} std {img.std():.4f} clamp-frac {float((img.abs() >= 1).float().mean()):.3f}")
 
 
+def run_vae_encode_case():
+    """The reference's vendored AutoencoderKLQwenImage.encode(...).mode() (autoencoder_kl_qwenimage.py:788-835)."""
+    import ref_shims_pipeline as RP
+
+    vae = RP.build_reference_vae()
+    Pe = O.make_vae_encoder_params()
+    ref_names = {n for n, _ in vae.named_parameters() if n.startswith(("encoder.", "quant_conv.")) and "time_conv" not in n}
+    assert ref_names == set(Pe), "oracle.vae_encoder_param_shapes != reference encoder parameters (minus time_conv)"
+    sd = vae.state_dict()
+    for k, v in Pe.items():
+        assert sd[k].shape == v.shape, k
+        sd[k].copy_(v)
+    img = torch.rand(1, 3, 1, 64, 96, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    with torch.no_grad():
+        mean = vae.encode(img, return_dict=False)[0].mode()
+    meta = dict(case=dict(h=64, w=96, seed=2), params_sha256=params_checksum(Pe), param_seed=8765,
+                reference="autoencoder_kl_qwenimage.py:788-835 (+ DiagonalGaussianDistribution.mode) via oracle/ref_shims_pipeline.py")
+    np.savez_compressed(os.path.join(OUT, "vae_encode_64x96_fp32.npz"), image=img.numpy(), mean=mean.numpy(), meta=json.dumps(meta))
+    print(f"vae_encode_64x96_fp32: mean {tuple(mean.shape)} std {mean.std():.4f}")
+
+
+def run_edit_case():
+    """Reference DiT forward over a TWO-image sequence (target latents + one condition image of another size), the way the
+    Edit pipelines call it: img_shapes = [[(1, h, w), (1, h2, w2)]] -> per-image RoPE frame index
+    (qwen_image_transformer.py:231-250; pipeline_qwen_image_edit.py:600-632,770)."""
+    case = dict(layers=2, heads=2, joint=128, grids=[(1, 8, 8), (1, 6, 10)], T=9, B=1, bias_std=0.02, jitter=0.1,
+                dtype="float32", sigma=[0.62])
+    P = O.make_dit_params(case["layers"], seed=1234, bias_std=case["bias_std"], norm_jitter=case["jitter"],
+                          num_heads=case["heads"], joint_dim=case["joint"])
+    model, cfg = ref_shims.build_reference_model(case["layers"], num_attention_heads=case["heads"],
+                                                 joint_attention_dim=case["joint"], dtype=torch.float32)
+    model.load_state_dict(P, strict=True)
+    S = sum(f * h * w for f, h, w in case["grids"])
+    g = torch.Generator().manual_seed(42)
+    lat = torch.randn(1, S, 64, generator=g)
+    txt = torch.randn(1, case["T"], case["joint"], generator=g)
+    sig = torch.tensor(case["sigma"])
+    out = ref_shims.reference_forward(
+        model, cfg, hidden_states=lat, encoder_hidden_states=txt,
+        encoder_hidden_states_mask=torch.ones(1, case["T"], dtype=torch.long), timestep=sig,
+        img_shapes=[[tuple(gr) for gr in case["grids"]]], txt_seq_lens=[case["T"]])
+    meta = dict(case=case, params_sha256=params_checksum(P), param_seed=1234,
+                reference="qwen_image_transformer.py:692-802 with a two-entry img_shapes via oracle/ref_shims.py")
+    np.savez_compressed(os.path.join(OUT, "dit_edit_two_images_fp32.npz"), latents=lat.numpy(), prompt_embeds=txt.numpy(),
+                        sigma=sig.numpy(), noise_pred=out.float().numpy(), meta=json.dumps(meta))
+    print(f"dit_edit_two_images_fp32: out {tuple(out.shape)} std {out.std():.4f}")
+
+
 def run_pipeline_helpers():
     import ref_shims_pipeline as RP
 
@@ -228,6 +276,10 @@ def main():
         run_pipeline_helpers()
     if only is None or "diffuse" in only:
         run_diffuse_case()
+    if only is None or "encode" in only:
+        run_vae_encode_case()
+    if only is None or "edit" in only:
+        run_edit_case()
 
 
 if __name__ == "__main__":

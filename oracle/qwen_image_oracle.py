@@ -111,7 +111,24 @@ def rope_axis_freqs(index: torch.Tensor, dim: int, theta: float = 10000.0):
     return torch.cos(ang), torch.sin(ang)
 
 
-def rope_tables(frame: int, height: int, width: int, txt_len: int, axes_dim=(16, 56, 56), theta: float = 10000.0):
+def rope_tables_multi(grids, txt_len: int, axes_dim=(16, 56, 56), theta: float = 10000.0):
+    """QwenEmbedRope.forward for a LIST of (frame, height, width) entries (the Edit pipelines: target + condition images on
+    one sequence axis) — qwen_image_transformer.py:236-262: entry idx starts at frame position idx; the text positions start
+    behind the largest half-extent of any entry."""
+    cos, sin, start = [], [], 0
+    for idx, (f, h, w) in enumerate(grids):
+        (vc, vs), _ = rope_tables(f, h, w, 1, axes_dim, theta, frame_offset=idx)
+        cos.append(vc)
+        sin.append(vs)
+        start = max(start, h // 2, w // 2)
+    t_idx = torch.arange(start, start + txt_len)
+    tc = torch.cat([rope_axis_freqs(t_idx, d, theta)[0] for d in axes_dim], dim=1)
+    ts = torch.cat([rope_axis_freqs(t_idx, d, theta)[1] for d in axes_dim], dim=1)
+    return (torch.cat(cos), torch.cat(sin)), (tc, ts)
+
+
+def rope_tables(frame: int, height: int, width: int, txt_len: int, axes_dim=(16, 56, 56), theta: float = 10000.0,
+                frame_offset: int = 0):
     """QwenEmbedRope.forward + _compute_video_freqs, scale_rope=True — qwen_image_transformer.py:222-285.
 
     Returns (vid_cos, vid_sin) [f*h*w, 64] and (txt_cos, txt_sin) [txt_len, 64] in fp32.
@@ -121,7 +138,7 @@ def rope_tables(frame: int, height: int, width: int, txt_len: int, axes_dim=(16,
     def axis(idx, d):
         return rope_axis_freqs(idx, d, theta)
 
-    f_idx = torch.arange(frame)
+    f_idx = torch.arange(frame_offset, frame_offset + frame)
     h_idx = torch.cat([torch.arange(-(height - height // 2), 0), torch.arange(0, height // 2)])
     w_idx = torch.cat([torch.arange(-(width - width // 2), 0), torch.arange(0, width // 2)])
     fc, fs = axis(f_idx, axes_dim[0])
@@ -219,7 +236,10 @@ def dit_forward(P: Params, hidden_states: torch.Tensor, encoder_hidden_states: t
     enc = rms_norm(encoder_hidden_states, P["txt_norm.weight"])
     enc = F.linear(enc, P["txt_in.weight"], P["txt_in.bias"])
     temb = timestep_embedding(P, timestep, hidden.dtype)
-    vid_cs, txt_cs = rope_tables(*img_shape, T)
+    if isinstance(img_shape[0], (tuple, list)):          # several images on the sequence axis (Edit pipelines)
+        vid_cs, txt_cs = rope_tables_multi([tuple(g) for g in img_shape], T)
+    else:
+        vid_cs, txt_cs = rope_tables(*img_shape, T)
     if taps is not None:
         taps.update(temb=temb, hidden_in=hidden, enc_in=enc)
     for i in range(num_layers_of(P)):
@@ -419,6 +439,105 @@ def vae_decode(P: Params, z: torch.Tensor, cfg: VaeConfig = VaeConfig()) -> torc
     x = F.silu(vae_rms_norm(x, P["decoder.norm_out.gamma"]))
     x = _conv3d_as_2d(P, "decoder.conv_out", x)
     return torch.clamp(x, -1.0, 1.0).unsqueeze(2)
+
+
+def vae_downsample(P: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """QwenImageResample(downsample2d/3d) for a first chunk of T=1 — :162-166 (ZeroPad2d((0,1,0,1)) + Conv2d(3, stride 2));
+    the 3-D variant's time_conv only touches LATER chunks (:201-211: the first chunk just fills the cache)."""
+    return F.conv2d(F.pad(x, (0, 1, 0, 1)), P[pre + ".resample.1.weight"], P[pre + ".resample.1.bias"], stride=2)
+
+
+def vae_encode(P: Params, image: torch.Tensor, cfg: VaeConfig = VaeConfig()) -> torch.Tensor:
+    """AutoencoderKLQwenImage._encode for one frame + DiagonalGaussianDistribution.mode() — :788-835,
+    QwenImageEncoder3d.forward :430-477.  image [B, 3, 1, H, W] in [-1, 1] -> posterior mean [B, z_dim, 1, H/8, W/8]
+    (what the Edit pipelines take with sample_mode="argmax", pipeline_qwen_image_edit.py:459-467)."""
+    x = _conv3d_as_2d(P, "encoder.conv_in", image[:, :, 0])
+    dims = [cfg.base_dim * u for u in [1] + list(cfg.dim_mult)]
+    k = 0
+    for i, (i_dim, o_dim) in enumerate(zip(dims[:-1], dims[1:])):
+        for _ in range(cfg.num_res_blocks):
+            x = vae_res_block(P, f"encoder.down_blocks.{k}", x)
+            k += 1
+        if i != len(cfg.dim_mult) - 1:
+            x = vae_downsample(P, f"encoder.down_blocks.{k}", x)
+            k += 1
+    x = vae_res_block(P, "encoder.mid_block.resnets.0", x)
+    x = vae_attn_block(P, "encoder.mid_block.attentions.0", x)
+    x = vae_res_block(P, "encoder.mid_block.resnets.1", x)
+    x = F.silu(vae_rms_norm(x, P["encoder.norm_out.gamma"]))
+    x = _conv3d_as_2d(P, "encoder.conv_out", x)
+    x = _conv3d_as_2d(P, "quant_conv", x)
+    return x[:, : cfg.z_dim].unsqueeze(2)
+
+
+def image_to_latents(P: Params, image: torch.Tensor, cfg: VaeConfig = VaeConfig()) -> torch.Tensor:
+    """_encode_vae_image (pipeline_qwen_image_edit.py:459-480): (mean - latents_mean) / latents_std, then packed."""
+    z = vae_encode(P, image, cfg)
+    mean = torch.tensor(cfg.latents_mean).view(1, cfg.z_dim, 1, 1, 1).to(z)
+    std = torch.tensor(cfg.latents_std).view(1, cfg.z_dim, 1, 1, 1).to(z)
+    return pack_latents(((z - mean) / std)[:, :, 0])
+
+
+def vae_encoder_param_shapes(cfg: VaeConfig = VaeConfig()) -> dict:
+    """Encoder-side parameter names/shapes (time_conv weights of the 3-D downsamplers exist in checkpoints, unused for T=1)."""
+    s: dict[str, tuple] = {}
+    dims = [cfg.base_dim * u for u in [1] + list(cfg.dim_mult)]
+
+    def conv(name, i, o, k):
+        s[name + ".weight"] = (o, i, k, k, k)
+        s[name + ".bias"] = (o,)
+
+    def res(name, i, o):
+        s[name + ".norm1.gamma"] = (i, 1, 1, 1)
+        conv(name + ".conv1", i, o, 3)
+        s[name + ".norm2.gamma"] = (o, 1, 1, 1)
+        conv(name + ".conv2", o, o, 3)
+        if i != o:
+            conv(name + ".conv_shortcut", i, o, 1)
+
+    conv("encoder.conv_in", 3, dims[0], 3)
+    k = 0
+    for i, (i_dim, o_dim) in enumerate(zip(dims[:-1], dims[1:])):
+        cur = i_dim
+        for _ in range(cfg.num_res_blocks):
+            res(f"encoder.down_blocks.{k}", cur, o_dim)
+            cur = o_dim
+            k += 1
+        if i != len(cfg.dim_mult) - 1:
+            s[f"encoder.down_blocks.{k}.resample.1.weight"] = (o_dim, o_dim, 3, 3)
+            s[f"encoder.down_blocks.{k}.resample.1.bias"] = (o_dim,)
+            k += 1
+    top = dims[-1]
+    res("encoder.mid_block.resnets.0", top, top)
+    s["encoder.mid_block.attentions.0.norm.gamma"] = (top, 1, 1)
+    s["encoder.mid_block.attentions.0.to_qkv.weight"] = (top * 3, top, 1, 1)
+    s["encoder.mid_block.attentions.0.to_qkv.bias"] = (top * 3,)
+    s["encoder.mid_block.attentions.0.proj.weight"] = (top, top, 1, 1)
+    s["encoder.mid_block.attentions.0.proj.bias"] = (top,)
+    res("encoder.mid_block.resnets.1", top, top)
+    s["encoder.norm_out.gamma"] = (top, 1, 1, 1)
+    conv("encoder.conv_out", top, cfg.z_dim * 2, 3)
+    conv("quant_conv", cfg.z_dim * 2, cfg.z_dim * 2, 1)
+    return s
+
+
+def make_vae_encoder_params(seed: int = 8765, cfg: VaeConfig = VaeConfig(), dtype=torch.float32) -> Params:
+    g = torch.Generator().manual_seed(seed)
+    P: Params = {}
+    for name, shape in vae_encoder_param_shapes(cfg).items():
+        if name.endswith(".weight"):
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            if len(shape) == 5:
+                fan_in = fan_in // shape[2]
+            t = torch.randn(shape, generator=g, dtype=torch.float32) / math.sqrt(fan_in)
+        elif name.endswith(".gamma"):
+            t = torch.ones(shape)
+        else:
+            t = torch.zeros(shape)
+        P[name] = t.to(dtype)
+    return P
 
 
 def latents_to_vae_input(latents: torch.Tensor, height: int, width: int, cfg: VaeConfig = VaeConfig()) -> torch.Tensor:

@@ -1,0 +1,88 @@
+"""GPU: the image-editing variant — VAE encode, two-image token sequences, the Edit denoise loop."""
+import pytest
+import torch
+
+import qwen_image_oracle as O
+from _util import bf16_round, cosine, golden_params, load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+DEV = "cuda:0"
+
+
+def test_vae_encode_matches_reference_golden():
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import AutoencoderKLQwenImage
+
+    z, meta, c = load_golden("vae_encode_64x96_fp32")
+    vae = AutoencoderKLQwenImage(device=DEV, with_encoder=True)
+    Pe, Pd = O.make_vae_encoder_params(), O.make_vae_params()
+    assert vae.load_weights(list(Pe.items()) + list(Pd.items())) >= set(Pe)
+    mean = vae.encode(torch.from_numpy(z["image"]).to(DEV, BF16))
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(z["mean"])
+    r = rel_l2(mean, ref)
+    print(f"vae encode vs reference golden: rel_l2 {r:.3e} max|err| {float((mean.float().cpu() - ref).abs().max()):.3e}")
+    assert mean.shape == ref.shape and r <= 3e-2
+
+
+def test_two_image_sequence_forward_matches_reference_golden():
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+
+    z, meta, c = load_golden("dit_edit_two_images_fp32")
+    P = golden_params(c)
+    m = QwenImageTransformer2DModel(num_layers=c["layers"], num_attention_heads=c["heads"], joint_attention_dim=c["joint"],
+                                    device=DEV)
+    m.load_weights(P.items())
+    out = m(hidden_states=torch.from_numpy(z["latents"]).to(DEV, BF16), encoder_hidden_states=torch.from_numpy(z["prompt_embeds"]).to(DEV, BF16),
+            timestep=torch.from_numpy(z["sigma"]).to(DEV), img_shapes=[[tuple(g) for g in c["grids"]]], txt_seq_lens=[c["T"]],
+            return_dict=False)[0]
+    torch.cuda.synchronize()
+    r = rel_l2(out, torch.from_numpy(z["noise_pred"]))
+    print(f"two-image sequence forward vs reference golden: {r:.3e}")
+    assert r <= 1.5e-2 and cosine(out, torch.from_numpy(z["noise_pred"])) >= 0.9995
+
+
+def test_edit_pipeline_matches_oracle_loop():
+    """Edit denoise loop (condition-image latents appended on the sequence axis, prediction sliced back) vs the oracle."""
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import AutoencoderKLQwenImage
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image_edit import QwenImageEditPipeline, calculate_dimensions
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    assert calculate_dimensions(1024 * 1024, 16 / 9)[:2] == (1376, 768)
+    heads, joint, layers = 2, 128, 2
+    P = O.make_dit_params(layers, seed=1234, bias_std=0.02, norm_jitter=0.1, num_heads=heads, joint_dim=joint)
+    m = QwenImageTransformer2DModel(num_layers=layers, num_attention_heads=heads, joint_attention_dim=joint, device=DEV)
+    m.load_weights(P.items())
+    vae = AutoencoderKLQwenImage(device=DEV, with_encoder=True)
+    Pe, Pd = O.make_vae_encoder_params(), O.make_vae_params()
+    vae.load_weights(list(Pe.items()) + list(Pd.items()))
+    pipe = QwenImageEditPipeline(device=DEV, transformer=m, vae=vae)
+    g = torch.Generator().manual_seed(4)
+    image = bf16_round(torch.rand(1, 3, 64, 96, generator=g) * 2 - 1)            # condition image -> 4 x 6 tokens
+    lat = bf16_round(torch.randn(1, 64, 64, generator=g))                         # target 128 x 128 -> 8 x 8 tokens
+    pos, neg = bf16_round(torch.randn(1, 9, joint, generator=g)), bf16_round(torch.randn(1, 5, joint, generator=g))
+    req = OmniDiffusionRequest(height=128, width=128, num_inference_steps=3, true_cfg_scale=4.0, latents=lat.to(BF16),
+                               prompt_embeds=pos.to(BF16), negative_prompt_embeds=neg.to(BF16), output_type="latent",
+                               extra={"image": image})
+    out = pipe.generate([req], output_type="latent")[0].output[0]
+    torch.cuda.synchronize()
+    # oracle: same loop in fp32 on bf16-rounded weights
+    Pb = {k: bf16_round(v) for k, v in P.items()}
+    cond = bf16_round(O.image_to_latents({k: bf16_round(v) for k, v in Pe.items()}, image.unsqueeze(2)))      # [1, 24, 64]
+    grids = [(1, 8, 8), (1, 4, 6)]
+    ts, sig = O.flow_match_sigmas(3, 64)
+    x = lat.float()
+    for i, t in enumerate(ts):
+        s_in = (t.bfloat16() / 1000).bfloat16().float().expand(1)
+        inp = torch.cat([x, cond], dim=1)
+        p = O.dit_forward(Pb, inp, pos.float(), s_in, grids, num_heads=heads)[:, :64]
+        n = O.dit_forward(Pb, inp, neg.float(), s_in, grids, num_heads=heads)[:, :64]
+        x = bf16_round(O.euler_step(x, O.cfg_combine(p, n, 4.0), float(sig[i]), float(sig[i + 1])))
+    r = rel_l2(out, x[0])
+    print(f"edit loop final latent vs oracle: rel_l2 {r:.3e}; cond latents product-vs-oracle "
+          f"{rel_l2(pipe.resolve_request(req)[0]['cond'], cond[0]):.3e}")
+    assert r <= 2e-2
+    img = pipe.generate([OmniDiffusionRequest(height=128, width=128, num_inference_steps=2, seed=3, prompt_embeds=pos.to(BF16),
+                                              extra={"image": image})])[0].output
+    assert img.shape == (1, 3, 128, 128) and torch.isfinite(img.float()).all()

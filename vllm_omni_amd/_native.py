@@ -51,7 +51,7 @@ class ConvParams(C.Structure):
         ("x", c_bf16_p), ("w", c_bf16_p), ("bias", c_bf16_p), ("gamma", c_bf16_p), ("res", c_bf16_p), ("y", c_bf16_p),
         ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
         ("ksize", C.c_int32), ("upsample2x", C.c_int32), ("silu", C.c_int32),
-        ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
+        ("clamp_lo", C.c_float), ("clamp_hi", C.c_float), ("downsample2x", C.c_int32),
     ]
 
 

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const omni_conv_params P) {
   char* sW = smem + CBM * CBK * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int Hout = P.upsample2x ? 2 * P.Hin : P.Hin, Wout = P.upsample2x ? 2 * P.Win : P.Win;
+  const int Hout = P.upsample2x ? 2 * P.Hin : (P.downsample2x ? P.Hin / 2 : P.Hin);
+  const int Wout = P.upsample2x ? 2 * P.Win : (P.downsample2x ? P.Win / 2 : P.Win);
   const int64_t Mtot = (int64_t)P.B * Hout * Wout;
   const int Ktot = P.ksize * P.ksize * P.Cin;
   const int pad = P.ksize / 2;
@@ -60,10 +61,18 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const omni_conv_params P) {
       if (a_ok[i] && k < Ktot) {
         const int tap = k / P.Cin, ci = k - tap * P.Cin;
         const int ky = tap / P.ksize, kx = tap - ky * P.ksize;
+        if (P.downsample2x) {
+          // QwenImageResample('downsample2d/3d'): ZeroPad2d((0, 1, 0, 1)) then Conv2d(3, stride 2): source = 2*dst + tap,
+          // zero beyond the right / bottom edge (autoencoder_kl_qwenimage.py:162-166)
+          const int iy = 2 * a_oy[i] + ky, ix = 2 * a_ox[i] + kx;
+          if (iy < P.Hin && ix < P.Win)
+            v = *reinterpret_cast<const u32x4_t*>(x + (((int64_t)a_b[i] * P.Hin + iy) * P.Win + ix) * P.Cin + ci);
+        } else {
         const int uy = a_oy[i] + ky - pad, ux = a_ox[i] + kx - pad;
         if (uy >= 0 && uy < Hout && ux >= 0 && ux < Wout) {
           const int iy = P.upsample2x ? (uy >> 1) : uy, ix = P.upsample2x ? (ux >> 1) : ux;
           v = *reinterpret_cast<const u32x4_t*>(x + (((int64_t)a_b[i] * P.Hin + iy) * P.Win + ix) * P.Cin + ci);
+        }
         }
       }
       areg[i] = v;
@@ -239,8 +248,10 @@ extern "C" int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream) {
     return OMNI_ERR_BAD_ARG;
   if ((p->ksize != 1 && p->ksize != 3) || p->Cin % 8) return OMNI_ERR_UNSUPPORTED;
   if (p->gamma) return OMNI_ERR_UNSUPPORTED;  // fused norm prologue: not built yet (use omni_vae_rmsnorm_silu)
+  if (p->downsample2x && (p->upsample2x || p->ksize != 3 || (p->Hin & 1) || (p->Win & 1))) return OMNI_ERR_UNSUPPORTED;
   if (!omni_aligned16(p->x) || !omni_aligned16(p->w)) return OMNI_ERR_ALIGN;
-  const int Hout = p->upsample2x ? 2 * p->Hin : p->Hin, Wout = p->upsample2x ? 2 * p->Win : p->Win;
+  const int Hout = p->upsample2x ? 2 * p->Hin : (p->downsample2x ? p->Hin / 2 : p->Hin);
+  const int Wout = p->upsample2x ? 2 * p->Win : (p->downsample2x ? p->Win / 2 : p->Win);
   const int64_t M = (int64_t)p->B * Hout * Wout;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (p->Cout % 96 == 0) {

@@ -81,15 +81,59 @@ def decoder_param_shapes(cfg: _VaeConfig) -> dict[str, tuple]:
     return s
 
 
-class AutoencoderKLQwenImage(nn.Module):
-    """Decoder-only VAE.  `decode(z)` takes de-normalised latents [B, 16, 1, h, w] -> image [B, 3, 1, 8h, 8w]."""
+def encoder_param_shapes(cfg: _VaeConfig) -> dict[str, tuple]:
+    """Encoder-side checkpoint names -> shapes (QwenImageEncoder3d :372-477 + quant_conv; the time_conv weights of the 3-D
+    downsamplers exist in checkpoints but only act on later video chunks, :201-211)."""
+    s: dict[str, tuple] = {}
+    dims = [cfg.base_dim * u for u in [1] + list(cfg.dim_mult)]
 
-    def __init__(self, device=None, dtype=BF16, **cfg_kw):
+    def conv(n, i, o, k):
+        s[n + ".weight"], s[n + ".bias"] = (o, i, k, k, k), (o,)
+
+    def res(n, i, o):
+        s[n + ".norm1.gamma"] = (i, 1, 1, 1)
+        conv(n + ".conv1", i, o, 3)
+        s[n + ".norm2.gamma"] = (o, 1, 1, 1)
+        conv(n + ".conv2", o, o, 3)
+        if i != o:
+            conv(n + ".conv_shortcut", i, o, 1)
+
+    conv("encoder.conv_in", 3, dims[0], 3)
+    k = 0
+    for i, (i_dim, o_dim) in enumerate(zip(dims[:-1], dims[1:])):
+        cur = i_dim
+        for _ in range(cfg.num_res_blocks):
+            res(f"encoder.down_blocks.{k}", cur, o_dim)
+            cur, k = o_dim, k + 1
+        if i != len(cfg.dim_mult) - 1:
+            s[f"encoder.down_blocks.{k}.resample.1.weight"], s[f"encoder.down_blocks.{k}.resample.1.bias"] = (o_dim, o_dim, 3, 3), (o_dim,)
+            k += 1
+    top = dims[-1]
+    res("encoder.mid_block.resnets.0", top, top)
+    a = "encoder.mid_block.attentions.0"
+    s[a + ".norm.gamma"] = (top, 1, 1)
+    s[a + ".to_qkv.weight"], s[a + ".to_qkv.bias"] = (top * 3, top, 1, 1), (top * 3,)
+    s[a + ".proj.weight"], s[a + ".proj.bias"] = (top, top, 1, 1), (top,)
+    res("encoder.mid_block.resnets.1", top, top)
+    s["encoder.norm_out.gamma"] = (top, 1, 1, 1)
+    conv("encoder.conv_out", top, cfg.z_dim * 2, 3)
+    conv("quant_conv", cfg.z_dim * 2, cfg.z_dim * 2, 1)
+    return s
+
+
+class AutoencoderKLQwenImage(nn.Module):
+    """`decode(z)`: de-normalised latents [B, 16, 1, h, w] -> image [B, 3, 1, 8h, 8w].  With `with_encoder=True` also
+    `encode(image)` [B, 3, 1, H, W] -> posterior mean [B, 16, 1, H/8, W/8] (what the Edit pipelines feed the DiT)."""
+
+    def __init__(self, device=None, dtype=BF16, with_encoder: bool = False, **cfg_kw):
         super().__init__()
         self.config = _VaeConfig(**cfg_kw)
         self.dtype_ = dtype
         dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
         self._shapes = decoder_param_shapes(self.config)
+        self.with_encoder = with_encoder
+        if with_encoder:
+            self._shapes.update(encoder_param_shapes(self.config))
         self.params = nn.ParameterDict()
         self._names = {}
         for name, shape in self._shapes.items():
@@ -113,7 +157,7 @@ class AutoencoderKLQwenImage(nn.Module):
         loaded = set()
         for name, w in weights:
             if name not in self._names:
-                continue  # encoder / quant_conv / time_conv: not on the decode path
+                continue  # time_conv (and, without with_encoder, encoder / quant_conv): not on this build's path
             p = self.params[self._names[name]]
             if p.shape != w.shape:
                 raise ValueError(f"{name}: expected {tuple(p.shape)}, got {tuple(w.shape)}")
@@ -146,7 +190,10 @@ class AutoencoderKLQwenImage(nn.Module):
             if name.endswith(".weight"):
                 if p.dim() == 5:
                     p = p[:, :, -1]                       # only the last temporal slice sees the single frame
-                out[name] = p.permute(0, 2, 3, 1).contiguous()   # [O, kh, kw, I]
+                p = p.permute(0, 2, 3, 1)                         # [O, kh, kw, I]
+                if p.shape[-1] % 8:                                 # encoder.conv_in: 3 input channels -> zero-padded to 8
+                    p = torch.nn.functional.pad(p, (0, 8 - p.shape[-1] % 8))
+                out[name] = p.contiguous()
             else:
                 out[name] = p.reshape(-1).contiguous()
         self._packed = out
@@ -166,8 +213,8 @@ class AutoencoderKLQwenImage(nn.Module):
     def _attn_block(self, W, pre, x):
         B, H, Wd, Cc = x.shape
         tok = H * Wd
-        if tok % 64 or Cc % 64:
-            raise NotImplementedError("mid-block attention needs h*w and channels to be multiples of 64")
+        if tok % 32 or Cc % 64:
+            raise NotImplementedError("mid-block attention needs h*w to be a multiple of 32 and channels of 64")
         xn = ops.vae_rmsnorm_silu(x, W[pre + ".norm.gamma"], silu=False)
         wqkv = W[pre + ".to_qkv.weight"].reshape(3 * Cc, Cc)
         bqkv = W[pre + ".to_qkv.bias"]
@@ -188,6 +235,39 @@ class AutoencoderKLQwenImage(nn.Module):
             outs.append(o_b)
         o = torch.stack(outs).view(B, H, Wd, Cc)
         return ops.vae_conv2d(o, W[pre + ".proj.weight"], W[pre + ".proj.bias"], res=x)
+
+    @torch.no_grad()
+    def encode(self, image: torch.Tensor) -> torch.Tensor:
+        """image [B, 3, 1, H, W] in [-1, 1] -> posterior MEAN [B, z_dim, 1, H/8, W/8] (reference _encode :788-810 for one
+        frame + DiagonalGaussianDistribution.mode(); the Edit pipelines use sample_mode="argmax",
+        pipeline_qwen_image_edit.py:459-467)."""
+        if not self.with_encoder:
+            raise RuntimeError("this VAE was built without its encoder (with_encoder=True)")
+        if image.dim() != 5 or image.shape[2] != 1 or image.shape[1] != 3:
+            raise NotImplementedError("single-frame RGB images only")
+        if image.shape[3] % 8 or image.shape[4] % 8:
+            raise ValueError("image height and width must be multiples of 8")
+        W = self._pack()
+        c = self.config
+        x = image[:, :, 0].permute(0, 2, 3, 1).to(BF16)                      # NHWC
+        x = torch.nn.functional.pad(x, (0, 5)).contiguous()                   # 3 -> 8 channels (zeros), matches the packed weight
+        x = ops.vae_conv2d(x, W["encoder.conv_in.weight"], W["encoder.conv_in.bias"])
+        k = 0
+        for i in range(len(c.dim_mult)):
+            for _ in range(c.num_res_blocks):
+                x = self._res_block(W, f"encoder.down_blocks.{k}", x)
+                k += 1
+            if i != len(c.dim_mult) - 1:
+                d = f"encoder.down_blocks.{k}.resample.1"
+                x = ops.vae_conv2d(x, W[d + ".weight"], W[d + ".bias"], downsample2x=True)
+                k += 1
+        x = self._res_block(W, "encoder.mid_block.resnets.0", x)
+        x = self._attn_block(W, "encoder.mid_block.attentions.0", x)
+        x = self._res_block(W, "encoder.mid_block.resnets.1", x)
+        x = ops.vae_rmsnorm_silu(x, W["encoder.norm_out.gamma"])
+        x = ops.vae_conv2d(x, W["encoder.conv_out.weight"], W["encoder.conv_out.bias"])
+        x = ops.vae_conv2d(x, W["quant_conv.weight"], W["quant_conv.bias"])
+        return x[..., : c.z_dim].permute(0, 3, 1, 2).unsqueeze(2).contiguous()   # mean half, [B, 16, 1, h, w]
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = False):

@@ -127,17 +127,24 @@ class QwenImagePipeline(nn.Module):
 
     @torch.no_grad()
     def _denoise(self, latents: list[torch.Tensor], pos: list[torch.Tensor], neg: list[torch.Tensor] | None,
-                 grid, timesteps: torch.Tensor, dts: torch.Tensor, cfg_scales: list[float]) -> list[torch.Tensor]:
+                 grid, timesteps: torch.Tensor, dts: torch.Tensor, cfg_scales: list[float],
+                 cond: list[torch.Tensor] | None = None) -> list[torch.Tensor]:
         """Step-batched denoising of R requests sharing (grid, schedule).  latents[r] [S_img, 64];
         pos[r]/neg[r] [T, joint_dim] (ragged T).  Item order: pos_0..pos_{R-1}, then neg_0..neg_{R-1}.
 
         One step = copy latents into the forward's input rows -> ONE ragged DiT forward over all items -> fused
         CFG-combine + norm-rescale + Euler update.  When `use_hip_graph` applies, that step (~670 launches at 60 layers) is
         captured once per (batch shape, cfg) as a hipGraph and replayed: at 256^2 a forward is ~4 ms of GPU work against
-        ~2.5 ms of host launch time (SURVEY.md §7 'Hard parts')."""
+        ~2.5 ms of host launch time (SURVEY.md §7 'Hard parts').
+
+        `cond[r]` [S_c, 64] (Edit pipelines): packed condition-image latents appended to request r's rows on the sequence
+        axis in every forward and sliced off the prediction (pipeline_qwen_image_edit.py:600-632); `grid` is then the
+        sequence of token grids ((1, h, w), (1, h_c, w_c), ...)."""
         tr, dev = self.transformer, self.device
         R = len(latents)
         S = latents[0].shape[0]
+        S_c = 0 if cond is None else int(cond[0].shape[0])
+        S_tot = S + S_c
         do_cfg = neg is not None
         if do_cfg and len(set(cfg_scales)) != 1:
             raise NotImplementedError("step-batched requests must share true_cfg_scale")
@@ -156,8 +163,9 @@ class QwenImagePipeline(nn.Module):
         st = self._step_state.get(key) if graph_on else None
         if st is None:
             st = dict(lat=torch.empty(R * S, tr.in_channels, dtype=BF16, device=dev),
-                      lat_in=torch.empty(n_items * S, tr.in_channels, dtype=BF16, device=dev),
-                      pred=torch.empty(n_items * S, tr.in_channels, dtype=BF16, device=dev),
+                      lat_in=torch.empty(n_items * S_tot, tr.in_channels, dtype=BF16, device=dev),
+                      pred=torch.empty(n_items * S_tot, tr.in_channels, dtype=BF16, device=dev),
+                      pred_c=torch.empty(n_items * S, tr.in_channels, dtype=BF16, device=dev) if S_c else None,
                       prompt=torch.empty(sum(lens), tr.joint_attention_dim, dtype=BF16, device=dev),
                       sig=torch.empty(1, dtype=torch.float32, device=dev), dt=torch.empty(1, dtype=torch.float32, device=dev),
                       graph=None, tc=None)
@@ -172,17 +180,34 @@ class QwenImagePipeline(nn.Module):
         st["lat"].copy_(torch.cat([x.to(dev, BF16) for x in latents]))
         st["prompt"].copy_(torch.cat(txt))
         lat, lat_in, pred = st["lat"], st["lat_in"], st["pred"]
+        Cl = tr.in_channels
+        if S_c:                                              # the condition rows never change: written once per loop
+            cv = torch.stack([c.to(dev, BF16) for c in cond])                       # [R, S_c, 64]
+            li = lat_in.view(n_items, S_tot, Cl)
+            li[:R, S:].copy_(cv)
+            if do_cfg:
+                li[R:, S:].copy_(cv)
         tr.do_true_cfg = do_cfg
         tc = st["tc"]
         if tc is not None:
             tc.reset()                                       # a new generation: first forward always computes
 
         def step(sig1, dt1):
-            lat_in[: R * S].copy_(lat)
-            if do_cfg:
-                lat_in[R * S:].copy_(lat)
+            if S_c:
+                li = lat_in.view(n_items, S_tot, Cl)
+                li[:R, :S].copy_(lat.view(R, S, Cl))
+                if do_cfg:
+                    li[R:, :S].copy_(lat.view(R, S, Cl))
+            else:
+                lat_in[: R * S].copy_(lat)
+                if do_cfg:
+                    lat_in[R * S:].copy_(lat)
             tr.forward_ragged(prepared, lat_in, st["prompt"], sig1, out=pred, teacache=tc)
-            ops.cfg_euler_step_(lat, pred[: R * S], pred[R * S:] if do_cfg else None, cfg_scales[0], dt1)
+            pr = pred
+            if S_c:                                          # noise_pred[:, :latents.size(1)] (edit pipeline :632)
+                st["pred_c"].view(n_items, S, Cl).copy_(pred.view(n_items, S_tot, Cl)[:, :S])
+                pr = st["pred_c"]
+            ops.cfg_euler_step_(lat, pr[: R * S], pr[R * S:] if do_cfg else None, cfg_scales[0], dt1)
 
         self.last_teacache_state = tc                         # statistics: tc.skipped_forwards() per item after the loop
         if not graph_on:
@@ -329,16 +354,17 @@ class QwenImagePipeline(nn.Module):
         samples = [s for i, r in enumerate(requests) for s in self.resolve_request(r, i)]
         groups: dict[tuple, list[int]] = {}
         for j, sm in enumerate(samples):
-            groups.setdefault((sm["height"], sm["width"], sm["steps"], sm["cfg"], sm["do_cfg"]), []).append(j)
+            groups.setdefault((sm["height"], sm["width"], sm["steps"], sm["cfg"], sm["do_cfg"], sm["grid"]), []).append(j)
         cap = max(1, int(getattr(self.od_config, "max_step_batch", 4)))
         final: list[torch.Tensor | None] = [None] * len(samples)
-        for (height, width, steps, cfg, do_cfg), idxs in groups.items():
+        for (height, width, steps, cfg, do_cfg, _grid), idxs in groups.items():
             for s0 in range(0, len(idxs), cap):
                 chunk = [samples[j] for j in idxs[s0:s0 + cap]]
                 timesteps, _ = self.prepare_timesteps(steps, None, chunk[0]["lat"].shape[0])
                 outs = self._denoise([c["lat"] for c in chunk], [c["pos"] for c in chunk],
                                      [c["neg"] for c in chunk] if do_cfg else None, chunk[0]["grid"], timesteps,
-                                     self.scheduler.dt(), [cfg] * len(chunk))
+                                     self.scheduler.dt(), [cfg] * len(chunk),
+                                     cond=[c["cond"] for c in chunk] if chunk[0].get("cond") is not None else None)
                 for j, o in zip(idxs[s0:s0 + cap], outs):
                     final[j] = o
         results = []
@@ -362,7 +388,8 @@ class QwenImagePipeline(nn.Module):
         a.n_steps = len(ts)
         a.state = dict(sig=sch.model_timestep(ts).to(self.device), dt=sch.dt().to(self.device, torch.float32),
                        lat=sm["lat"].to(self.device, BF16).clone(), pos=sm["pos"].to(self.device, BF16),
-                       neg=None if sm["neg"] is None else sm["neg"].to(self.device, BF16))
+                       neg=None if sm["neg"] is None else sm["neg"].to(self.device, BF16),
+                       cond=None if sm.get("cond") is None else sm["cond"].to(self.device, BF16))
 
     @staticmethod
     def batch_key(a):
@@ -384,11 +411,18 @@ class QwenImagePipeline(nn.Module):
         rb = build_ragged_batch(lens, sm0["grid"], temb_rows=list(range(R)) * (2 if do_cfg else 1))
         prepared = tr.prepare_batch(rb)
         lat = torch.cat([a.state["lat"] for a in group])
-        lat_in = torch.cat([lat, lat]) if do_cfg else lat
+        if group[0].state.get("cond") is not None:           # Edit: [latents ; condition-image latents] per item
+            per = torch.cat([torch.cat([a.state["lat"], a.state["cond"]]) for a in group])
+            lat_in = torch.cat([per, per]) if do_cfg else per
+        else:
+            lat_in = torch.cat([lat, lat]) if do_cfg else lat
         sig = torch.stack([a.state["sig"][a.step] for a in group]).contiguous()
         dt = torch.stack([a.state["dt"][a.step] for a in group]).contiguous()
         tr.do_true_cfg = do_cfg
         pred = tr.forward_ragged(prepared, lat_in.contiguous(), torch.cat(txt).contiguous(), sig)
+        if group[0].state.get("cond") is not None:
+            n_it = (2 if do_cfg else 1) * R
+            pred = pred.view(n_it, -1, pred.shape[-1])[:, :S].reshape(n_it * S, -1).contiguous()
         ops.cfg_euler_step_(lat, pred[: R * S], pred[R * S:] if do_cfg else None, sm0["cfg"], dt, dt_rows_per_item=S)
         for r, a in enumerate(group):
             a.state["lat"] = lat[r * S:(r + 1) * S]

@@ -201,17 +201,19 @@ def cfg_euler_step_(latents, pos, neg, true_cfg_scale: float, dt: torch.Tensor, 
     return latents
 
 
-def vae_conv2d(x, w, bias=None, *, gamma=None, silu=True, res=None, upsample2x=False, clamp=None, out=None):
-    """NHWC bf16 conv (3x3 pad 1 or 1x1): x [B,H,W,Cin], w [Cout,ks,ks,Cin]."""
+def vae_conv2d(x, w, bias=None, *, gamma=None, silu=True, res=None, upsample2x=False, downsample2x=False, clamp=None,
+               out=None):
+    """NHWC bf16 conv (3x3 pad 1 or 1x1): x [B,H,W,Cin], w [Cout,ks,ks,Cin].  downsample2x: the encoder's zero-pad
+    (right/bottom) + stride-2 3x3 conv."""
     B, Hin, Win, Cin = x.shape
     Cout, ks = w.shape[0], w.shape[1]
-    Hout, Wout = (2 * Hin, 2 * Win) if upsample2x else (Hin, Win)
+    Hout, Wout = (2 * Hin, 2 * Win) if upsample2x else ((Hin // 2, Win // 2) if downsample2x else (Hin, Win))
     y = torch.empty(B, Hout, Wout, Cout, dtype=BF16, device=x.device) if out is None else out
     p = N.ConvParams()
     p.x, p.w, p.bias, p.gamma = _p(x.contiguous(), name="x"), _p(w, name="w"), _p(bias, name="bias"), _p(gamma)
     p.res, p.y = _p(res, name="res"), _p(y, name="y")
     p.B, p.Hin, p.Win, p.Cin, p.Cout, p.ksize = B, Hin, Win, Cin, Cout, ks
-    p.upsample2x, p.silu = int(upsample2x), int(silu)
+    p.upsample2x, p.silu, p.downsample2x = int(upsample2x), int(silu), int(downsample2x)
     p.clamp_lo, p.clamp_hi = clamp if clamp else (0.0, 0.0)
     N.check(N.lib().omni_vae_conv2d(C.byref(p), _stream()), "omni_vae_conv2d")
     return y
