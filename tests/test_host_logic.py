@@ -184,6 +184,19 @@ def test_vae_param_names_match_oracle():
     assert ours == theirs
 
 
+def test_registry_resolves_pipelines_by_arch_name():
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.registry import get_diffusion_post_process_func, resolve_model_cls
+
+    assert resolve_model_cls("QwenImagePipeline").__name__ == "QwenImagePipeline"
+    assert resolve_model_cls("QwenImageEditPipeline").__name__ == "QwenImageEditPipeline"
+    with pytest.raises(ValueError):
+        resolve_model_cls("WanPipeline")
+    post = get_diffusion_post_process_func(OmniDiffusionConfig(model_class_name="QwenImageEditPipeline"))
+    imgs = post(torch.zeros(2, 3, 16, 16))
+    assert len(imgs) == 2 and imgs[0].size == (16, 16) and imgs[0].getpixel((0, 0)) == (128, 128, 128)
+
+
 def test_shard_requests_balanced_and_deterministic():
     from vllm_omni_amd.diffusion.distributed.data_parallel import shard_requests, unshard
 

@@ -39,10 +39,12 @@ class DiffusionEngine:
                  post_process_func: Callable | None | str = "default", pre_process_func: Callable | None = None,
                  start_timeout_s: float = 600.0):
         self.od_config = od_config
-        if post_process_func == "default":              # registry role of get_diffusion_post_process_func (registry.py:135-146)
-            from .models.qwen_image.pipeline_qwen_image import get_qwen_image_post_process_func
+        from .registry import get_diffusion_post_process_func, get_diffusion_pre_process_func
 
-            post_process_func = get_qwen_image_post_process_func(od_config)
+        if post_process_func == "default":              # reference diffusion_engine.py:68-69 / registry.py:135-146
+            post_process_func = get_diffusion_post_process_func(od_config)
+        if pre_process_func is None:
+            pre_process_func = get_diffusion_pre_process_func(od_config)
         self.post_process_func, self.pre_process_func = post_process_func, pre_process_func
         self.num_gpus = int(od_config.num_gpus or 1)
         self._ctx = mp.get_context("spawn")

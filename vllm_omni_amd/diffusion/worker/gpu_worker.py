@@ -33,10 +33,10 @@ class GPUWorker:
         self.rank, self.world, _ = dp.init_distributed(timeout_s=self.od_config.dist_timeout)
         if self.pipeline is None:
             if pipeline_factory is None:
-                from ..models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+                from ..registry import initialize_model      # arch name -> pipeline class (reference registry.py:81-94)
 
-                pipeline_factory = lambda: QwenImagePipeline(od_config=self.od_config,  # noqa: E731
-                                                             device=torch.device("cuda", self.local_rank))
+                pipeline_factory = lambda: initialize_model(self.od_config,  # noqa: E731
+                                                            device=torch.device("cuda", self.local_rank))
             self.pipeline = pipeline_factory()
 
     def is_ready(self) -> bool:
