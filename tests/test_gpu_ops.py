@@ -136,8 +136,10 @@ def _set_gemm_variant(v):
 @pytest.mark.parametrize("K", [64, 128, 192, 3072])
 @pytest.mark.parametrize("blocked", [False, True])
 def test_gemm_pingpong_kernel_is_bit_identical_to_ring_kernel(K, blocked):
-    """The ping-pong kernel (3, default) and the ring kernel (1, its fallback) accumulate every output element in the same k order with the
-    same MFMA: identical bits, for 1 / 2 / 3 / many K-tiles (prologue, steady state and drain of the 6-phase DMA lead),
+    """The ping-pong kernel (3, default; v_mfma_f32_16x16x32_bf16) and the ring kernel (1, its fallback; 32x32x16) accumulate
+    every output element in the same k order; on gfx950 both MFMA shapes add their products to the fp32 accumulator in
+    8-k groups in ascending k (measured: identical bits, here and at the bench shapes in tools/bench_ab.py), so the two
+    kernels agree bit for bit — for 1 / 2 / 3 / many K-tiles (prologue, steady state and drain of the 6-phase DMA lead),
     ragged M in both groups, gathered A rows, both operand layouts, all epilogues that have a coalesced form."""
     from vllm_omni_amd import ops
 

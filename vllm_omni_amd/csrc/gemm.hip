@@ -245,9 +245,9 @@ OMNI_DEVINL void gemm_epilogue(const omni_gemm_params& P, const omni_gemm_group&
 constexpr int EPI_LDS_STRIDE = BN * 2 + 16;              // 528 B per C row in LDS
 constexpr int EPI_LDS_BYTES = BM * EPI_LDS_STRIDE;       // 132 KiB
 
-template <int EPI>
-OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_group& G, f32x16_t (&acc)[2][4], int m0,
-                                   int n0, int wm, int wn, int l31, int hi, char* smem, int tid) {
+template <int EPI, typename WriteTile>
+OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_gemm_group& G, int m0, int n0, char* smem,
+                                        int tid, WriteTile write_tile) {
   const int M = G.M, N = P.N;
   // Phase 2 moves rows in batches of 4 per thread: batch b = tile rows (4b+j)*16 + rsub.  Its pipeline is
   //   row-map loads (b+2)  |  residual/gate/LDS loads (b+1)  |  math + stores (b)
@@ -295,29 +295,7 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
   load_maps(1, x1);
 
   __builtin_amdgcn_s_barrier();          // every wave has finished reading the operand ring
-  {
-    const int ncol = wn * 64 + hi * 4;   // tile-local column of this lane's first value
-    // (the bias is already in the accumulators: see the ring kernel's accumulator initialisation)
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      char* rowp = smem + (wm * 128 + mb * 32 + l31) * EPI_LDS_STRIDE + ncol * 2;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[j] = acc[nb][mb][q * 4 + j];
-            if (EPI == OMNI_EPI_BIAS_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
-          }
-          u32x2_t o;
-          o[0] = pack_bf16x2(v[0], v[1]);
-          o[1] = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<u32x2_t*>(rowp + (nb * 32 + q * 8) * 2) = o;
-        }
-    }
-  }
+  write_tile();                          // accumulators (+ GELU) -> bf16 C tile in LDS, layout-specific
   __syncthreads();
   const int chunk = tid & 31;
   const int n = n0 + chunk * 8;
@@ -394,6 +372,62 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
     }
     d0 = d1;
   }
+}
+
+// 32x32x16 accumulator layout: acc[nb][mb][4q+j] = C[wm*128 + mb*32 + l31][wn*64 + nb*32 + 8q + 4hi + j]
+template <int EPI>
+OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_group& G, f32x16_t (&acc)[2][4], int m0,
+                                   int n0, int wm, int wn, int l31, int hi, char* smem, int tid) {
+  gemm_epilogue_lds_impl<EPI>(P, G, m0, n0, smem, tid, [&]() {
+    const int ncol = wn * 64 + hi * 4;   // tile-local column of this lane's first value
+    // (the bias is already in the accumulators: see the ring kernel's accumulator initialisation)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      char* rowp = smem + (wm * 128 + mb * 32 + l31) * EPI_LDS_STRIDE + ncol * 2;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = acc[nb][mb][q * 4 + j];
+            if (EPI == OMNI_EPI_BIAS_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
+          }
+          u32x2_t o;
+          o[0] = pack_bf16x2(v[0], v[1]);
+          o[1] = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<u32x2_t*>(rowp + (nb * 32 + q * 8) * 2) = o;
+        }
+    }
+  });
+}
+// 16x16x32 accumulator layout: acc[nb][mb][j] = C[wm*128 + mb*16 + l15][wn*64 + nb*16 + 4g + j], l15 = lane & 15, g = lane >> 4.
+// A ds_write_b64 of the wave covers 16 rows x 4 column groups: bank = (4*l15 + 2*g + {0,1}) mod 64 -> 2-way = the minimum
+// for 512 B per instruction.
+template <int EPI>
+OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_group& G, f32x4_t (&acc)[4][8], int m0,
+                                   int n0, int wm, int wn, int l15, int g, char* smem, int tid) {
+  gemm_epilogue_lds_impl<EPI>(P, G, m0, n0, smem, tid, [&]() {
+    const int ncol = wn * 64 + g * 4;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      char* rowp = smem + (wm * 128 + mb * 16 + l15) * EPI_LDS_STRIDE + ncol * 2;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[nb][mb][j];
+          if (EPI == OMNI_EPI_BIAS_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
+        }
+        u32x2_t o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2_t*>(rowp + nb * 32) = o;
+      }
+    }
+  });
 }
 
 #ifdef OMNI_DEV   // dev-only kernel family (OMNI_GEMM_VARIANT=0): built with -DOMNI_DEV, not part of the product library
@@ -795,6 +829,21 @@ OMNI_DEVINL void pp_mfma(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 #endif
 }
+// MFMA shape of the ping-pong kernel.  1: v_mfma_f32_16x16x32_bf16 — the same flops per matrix-pipe cycle as 32x32x16, but
+// an instruction carries 32 k instead of 16: half the accumulator read-modify-write traffic per flop.  On this power-limited
+// part that is clock: swapping only the instruction shape (same loads, same barriers) measured 1127 -> 1194 TF/s (+6 %,
+// profiles/r02_gemm_mfma_shape.log).  Both shapes add their products to the fp32 accumulator in 8-k groups in ascending k:
+// the results are bit-identical to the 32x32x16 build and to the ring kernel (tests/test_gpu_ops.py asserts it).
+#ifndef OMNI_PP_MFMA16
+#define OMNI_PP_MFMA16 1
+#endif
+OMNI_DEVINL void pp_mfma16(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
+#if OMNI_PP_ABL == 1
+  asm volatile("" : "+v"(acc) : "v"(a), "v"(b));
+#else
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#endif
+}
 constexpr int PBK = 64;
 constexpr int PSLOT_BYTES = 128 * PBK * 2;    // 16 KiB per half-tile
 constexpr int PLDS_BYTES = 8 * PSLOT_BYTES;   // 128 KiB ring
@@ -864,6 +913,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
     OMNI_PP_ISSUE_PIECE(h, tile, 1);                                                                        \
   } while (0)
 
+#if OMNI_PP_MFMA16
+  // ---- per-lane fragment read offsets (16x16x32: lane = row l15 of a 16-row block, k = 32*ks + 8*g .. +8):
+  //      row * 128 + ((ks*4 + g) ^ swz) * 16, swz = (row >> 1) & 7 = (l15 >> 1) & 7; 16-row blocks via the offset immediate.
+  //      Every 16-lane group reads 16 consecutive rows at one logical chunk: (row & 1) * 8 + (chunk ^ swz) covers all 16
+  //      16-B bank groups -> conflict-free, like the 32x32 pattern.
+  const int l15 = lane & 15, g4 = lane >> 4;
+  uint32_t a_rd[2], w_rd[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const uint32_t chunk = ((uint32_t)(ks * 4 + g4) ^ ((l15 >> 1) & 7)) << 4;
+    a_rd[ks] = lds0 + (wm * 64 + l15) * 128 + chunk;
+    w_rd[ks] = lds0 + (wn * 32 + l15) * 128 + chunk;
+  }
+#else
   // ---- per-lane fragment read offsets: row * 128 + ((ks*2 + hi) ^ swz) * 16, swz = (row >> 1) & 7 = (l31 >> 1) & 7 ----
   uint32_t a_rd[4], w_rd[4];
 #pragma unroll
@@ -872,12 +935,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
     a_rd[ks] = lds0 + (wm * 64 + l31) * 128 + chunk;
     w_rd[ks] = lds0 + (wn * 32 + l31) * 128 + chunk;
   }
+#endif
 
   // ---- prologue: half-tiles 0..5 in flight; 0 and 1 landed before the first read ---------------------------------
   OMNI_PP_ISSUE(0, 0); OMNI_PP_ISSUE(1, 0); OMNI_PP_ISSUE(2, 0); OMNI_PP_ISSUE(3, 0);
   if (nkt > 1) { OMNI_PP_ISSUE(0, 1); OMNI_PP_ISSUE(1, 1); }
   // accumulators start at the bias.  The bias loads sit BEHIND the prologue's DMA issue: hipcc retires them with vmcnt(0)
   // (it cannot see the asm DMAs), which placed between the DMA issues would drain the first pieces before the rest is sent.
+#if OMNI_PP_MFMA16
+  f32x4_t acc[4][8];                               // [16-column block][16-row block]: C[mb*16 + l15][nb*16 + 4*g4 + j]
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int n = n0 + wn * 64 + nb * 16 + g4 * 4;
+    u32x2_t b = {0u, 0u};
+    if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
+    const f32x4_t bini = {bf16_lo(b[0]), bf16_hi(b[0]), bf16_lo(b[1]), bf16_hi(b[1])};
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = bini;
+  }
+#else
   f32x16_t acc[2][4];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
@@ -895,6 +971,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][mb][i] = bini[i];
   }
+#endif
   if (nkt > 1) {
     asm volatile(OMNI_PP_VMCNT ::: "memory");
   } else {
@@ -908,6 +985,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   // wf[nq][ks]; afx[mb][ks] holds the A rows of mq 0, afy[mb][ks] those of mq 1 (OMNI_PP_BALANCED: two register sets, so
   // that the 8 reads of the NEXT K-tile's mq-0 rows move from phase 0 into phase 3, which reads nothing otherwise: the
   // phases then read 4 / 4 / 8 / 8 fragments instead of 12 / 4 / 8 / 0; without it afy aliases afx)
+#if OMNI_PP_MFMA16
+  static_assert(!OMNI_PP_BALANCED && !OMNI_PP_DMA_IN_MMA, "the placement experiments exist for the 32x32x16 build only");
+  // wf[nq][16-row block of the 32 W rows][ks]; afx[16-row block of the 64 A rows][ks] (mq 0 and mq 1 share the registers)
+  bf16x8_t wf[2][2][2], afx[4][2];
+  bf16x8_t (&afy)[4][2] = afx;
+#define OMNI_PP_READ_A(AF, sb)                                                             \
+  do {                                                                                     \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                  \
+      AF[0][ks_] = lds_read16<0, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));                      \
+      AF[1][ks_] = lds_read16<16 * 128, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));               \
+      AF[2][ks_] = lds_read16<32 * 128, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));               \
+      AF[3][ks_] = lds_read16<48 * 128, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));               \
+    }                                                                                      \
+  } while (0)
+#define OMNI_PP_READ_W(nq, sb)                                                             \
+  do {                                                                                     \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                  \
+      wf[nq][0][ks_] = lds_read16<0, OMNI_PP_ABL == 7>(w_rd[ks_] + (sb));                  \
+      wf[nq][1][ks_] = lds_read16<16 * 128, OMNI_PP_ABL == 7>(w_rd[ks_] + (sb));           \
+    }                                                                                      \
+  } while (0)
+// the quadrant's 16 MFMAs: 8 accumulators round-robin, each touched again 8 instructions (128 pipe cycles) later
+#define OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1)                                                            \
+  _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                      \
+    _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_) {                                                  \
+      pp_mfma16(acc[2 * (nq)][4 * (mq) + mb_], wf[nq][0][ks_], AF[mb_][ks_]);                              \
+      pp_mfma16(acc[2 * (nq) + 1][4 * (mq) + mb_], wf[nq][1][ks_], AF[mb_][ks_]);                          \
+    }
+#else
   bf16x8_t wf[2][4], afx[2][4];
 #if OMNI_PP_BALANCED
   bf16x8_t afy[2][4];
@@ -925,6 +1031,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   do {                                                                                     \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) wf[nq][ks_] = lds_read16<0, OMNI_PP_ABL == 7>(w_rd[ks_] + (sb)); \
   } while (0)
+#define OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1)                                                            \
+  _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                    \
+    pp_mfma(acc[nq][2 * (mq)], wf[nq][ks_], AF[0][ks_]);                                                   \
+    pp_mfma(acc[nq][2 * (mq) + 1], wf[nq][ks_], AF[1][ks_]);                                               \
+    if (OMNI_PP_DMA_IN_MMA && ks_ == 0) { DMA0; }                                                          \
+    if (OMNI_PP_DMA_IN_MMA && ks_ == 2) { DMA1; }                                                          \
+  }
+#endif
 // end of a load section: counted DMA wait, barrier, fragments arrived; then the MFMA cluster and the second barrier.
 // `landed_ok`: the counted wait is valid (enough younger pieces were issued behind the ones that must have landed).
 // DMA0 / DMA1: with OMNI_PP_DMA_IN_MMA the phase's two DMA pieces are issued INSIDE the cluster (behind MFMA 2 and 6): a
@@ -940,12 +1054,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                    \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                  \
-      pp_mfma(acc[nq][2 * (mq)], wf[nq][ks_], AF[0][ks_]);                                                 \
-      pp_mfma(acc[nq][2 * (mq) + 1], wf[nq][ks_], AF[1][ks_]);                                             \
-      if (OMNI_PP_DMA_IN_MMA && ks_ == 0) { DMA0; }                                                        \
-      if (OMNI_PP_DMA_IN_MMA && ks_ == 2) { DMA1; }                                                        \
-    }                                                                                                      \
+    OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1)                                                                \
     if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                                \
@@ -992,12 +1101,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // asm MFMA results -> first compiler-visible VALU read
 #undef OMNI_PP_PHASE
 #undef OMNI_PP_MMA
+#undef OMNI_PP_CLUSTER
 #undef OMNI_PP_READ_W
 #undef OMNI_PP_READ_A
 #undef OMNI_PP_ISSUE
 #undef OMNI_PP_ISSUE_PIECE
 
+#if OMNI_PP_MFMA16
+  gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l15, g4, smem, tid);
+#else
   gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi, smem, tid);
+#endif
 }
 
 
