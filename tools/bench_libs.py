@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """dev tool: time ONE kernel of several library builds (tools/build_variants.sh) in interleaved subprocess rounds.
-   python tools/bench_libs.py attention|gemm lib1.so lib2.so ...   (each lib is run AB_ROUNDS times, round-robin)"""
+   python tools/bench_libs.py attention|gemm lib1.so lib2.so ...   (each lib is run AB_ROUNDS times, round-robin)
+   a lib may carry environment knobs: path/lib.so@OMNI_ATTN_MFMA=32@OTHER=1"""
 import os
 import statistics
 import subprocess
@@ -45,8 +46,9 @@ print("RESULT", 2.0 * (Mi + Mt) * N * K / t / 1e12, 0.0)
 res = {l: [] for l in libs}
 for _ in range(rounds):
     for l in libs:
-        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMNI_CDNA4_LIB=os.path.abspath(l)),
-                             capture_output=True, text=True)
+        path, *knobs = l.split("@")
+        env = dict(os.environ, OMNI_CDNA4_LIB=os.path.abspath(path), **dict(kv.split("=", 1) for kv in knobs))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         line = [x for x in out.stdout.splitlines() if x.startswith("RESULT")]
         if not line:
             print(l, "FAILED", out.stderr[-400:])

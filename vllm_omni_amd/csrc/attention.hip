@@ -381,7 +381,19 @@ OMNI_DEVINL float xhalf_sum(float x) {
 // resources the ablations show this loop to be limited by.  The accumulators then live in AGPRs (an inline
 // asm with an "a" constraint switches hipcc to the AGPR form of the MFMAs; without it the second half of the register file
 // is only used as spill space).
-template <int NW, int NQ = 1>
+// PP = 1 (8 waves, NQ = 1): the two waves of every SIMD run HALF AN ITERATION APART.  An iteration has a VALU-heavy half
+// (H1: QK^T(t+1) MFMAs with the 32 exp / 32 fma / pack of softmax(t) between them: ~52 VALU cycles per 32-cycle MFMA) and an
+// MFMA-bound half (H2: P.V(t), two v_max3 per MFMA).  With all 8 waves in the same half (PP = 0) a SIMD's two waves ask for
+// ~104 VALU cycles per 64 matrix-pipe cycles in H1 and leave the VALU idle in H2: the matrix pipe is busy 49 % (measured).
+// With wave group B (waves 4..7, the SIMD partners of waves 0..3) one half behind, every half-phase pairs one wave's H1
+// with its partner's H2.  A barrier ends every half-phase; DMA pieces are issued by wall-clock half-phase h (K(h/2 + 2) at the
+// start of even h, V((h+1)/2) at odd h, by all waves: group A from H1 / H2 of its iteration t = h/2, group B from H2 / H1),
+// and retired with a counted vmcnt at the end of the NEXT half-phase:
+//   RAW: K(t+1) is read in H1(t) (A: h = 2t, B: 2t+1), issued at h = 2t-2, waited (vmcnt <= the pieces of h = 2t-1) at the
+//        end of h = 2t-1;  V(t) is read in H2(t) (h = 2t+1 / 2t+2), issued at h = 2t-1, waited at the end of h = 2t.
+//   WAR: K(t+2) overwrites K(t) (last read by B at h = 2t-1) at h = 2t;  V(t+1) overwrites V(t-1) (last read by B at h = 2t)
+//        at h = 2t+1.
+template <int NW, int NQ = 1, int PP = 0>
 __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash_attn_fwd_pipe_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
@@ -415,6 +427,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
   const int seq_len = cu_seqlens[b + 1] - seq_start;
   constexpr int QBLK = 32 * NW * NQ;
   constexpr int NPIECE = 16 / NW;   // DMA pieces (1 KiB) per wave per operand per tile
+  static_assert(!PP || (NW == 8 && NQ == 1), "ping-pong: 8 waves (2 DMA pieces per wave and operand: the counted vmcnt(2))");
   if (qb * QBLK >= seq_len) return;
 
   const char* kbase = reinterpret_cast<const char*>(k + (int64_t)seq_start * ldk + h * DH);
@@ -482,8 +495,10 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
 
   uint32_t k_addr[8];
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) k_addr[ks] = l31 * 256 + ((((uint32_t)(ks * 2 + hi)) ^ (l31 & 15)) << 4);
-  const uint32_t v_lane_off = K_TILE_BYTES + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + hi * 256;
+  for (int ks = 0; ks < 8; ++ks) k_addr[ks] = lds0 + l31 * 256 + ((((uint32_t)(ks * 2 + hi)) ^ (l31 & 15)) << 4);
+  // absolute LDS addresses; the stage (a compile-time constant per call site: the loop is unrolled by two) and the fragment
+  // index go into the 16-bit offset immediate of the ds_reads, so the loop has no address arithmetic at all
+  const uint32_t v_addr = lds0 + K_TILE_BYTES + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + hi * 256;
 
   f32x16_t o[NQ][4];
   float m_run[NQ], l_run[NQ];
@@ -498,10 +513,10 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
   }
 
   bf16x8_t kf[4];
-#define OMNI_KREAD(i, kst)                                                                                          \
+#define OMNI_KREAD(i, kst)   /* kst = LDS stage (compile-time 0 / 1) */                                              \
   do {                                                                                                              \
-    if (OMNI_ATTN_ABL & 16) asm volatile("" : "=v"(kf[(i) & 3]) : "v"(k_addr[(i) & 7] + (kst)));                     \
-    else kf[(i) & 3] = (((i) >> 3) ? lds_read16<32 * 256>(k_addr[(i) & 7] + (kst)) : lds_read16<0>(k_addr[(i) & 7] + (kst))); \
+    if (OMNI_ATTN_ABL & 16) asm volatile("" : "=v"(kf[(i) & 3]) : "v"(k_addr[(i) & 7]));                             \
+    else kf[(i) & 3] = lds_read16<((i) >> 3) * 32 * 256 + (kst) * STAGE_BYTES>(k_addr[(i) & 7]);                    \
   } while (0)
 #define OMNI_QK_STEP(i, SN, kst, CHUNK)                                                          \
   do {                                                                                           \
@@ -515,7 +530,6 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     __builtin_amdgcn_sched_barrier(0);                                                           \
     if ((i) + 4 < 16) OMNI_KREAD((i) + 4, kst);                                                  \
     CHUNK;                                                                                       \
-    OMNI_QK_DMA(i);                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                           \
   } while (0)
 #define OMNI_QK_ALL(SN, kst, CH)                                                                                     \
@@ -529,7 +543,6 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     OMNI_QK_STEP(15, SN, kst, CH(15));                                                                               \
   } while (0)
 #define OMNI_NOCHUNK(i) (void)0
-#define OMNI_QK_DMA(i) (void)0
 
   auto mask_tail = [&](f32x16_t (&S)[NQ][2], int kv0) {
 #pragma unroll
@@ -561,7 +574,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
   f32x16_t sA[NQ][2], sB[NQ][2];
   float mxA[NQ], mxB[NQ];
   zero_s(sA);
-  OMNI_QK_ALL(sA, lds0, OMNI_NOCHUNK);
+  OMNI_QK_ALL(sA, 0, OMNI_NOCHUNK);
   if (KVBLK > seq_len) mask_tail(sA, 0);
 #pragma unroll
   for (int bq = 0; bq < NQ; ++bq) {
@@ -573,14 +586,26 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     mxA[bq] = xhalf_max(mx);
     mxB[bq] = 0.0f;
   }
+  const bool grpB = PP && wave >= NW / 2;
+  if (PP) {
+    __syncthreads();                               // every wave has read K(0): its stage can take K(2)
+    if (ntiles > 2) issue_K(2, 0);
+    if (grpB) __builtin_amdgcn_s_barrier();        // group B sits out half-phase 0
+  }
 
   // One iteration; SC = S(t) (complete, row max mxc known), SN receives S(t+1).
   // has_next is a compile-time constant: a run-time flag puts a branch between every two MFMAs of the P.V phase.
-  auto iteration = [&](auto has_next_c, int t, f32x16_t (&SC)[NQ][2], f32x16_t (&SN)[NQ][2], float (&mxc)[NQ],
+  // par_c = t & 1 as a compile-time constant (tile j lives in stage j & 1)
+  auto iteration = [&](auto has_next_c, auto par_c, int t, f32x16_t (&SC)[NQ][2], f32x16_t (&SN)[NQ][2], float (&mxc)[NQ],
                        float (&mxn)[NQ]) {
     constexpr bool has_next = decltype(has_next_c)::value;
+    constexpr int PAR = decltype(par_c)::value;
     const bool dma_k = !(OMNI_ATTN_ABL & 4) && t + 2 < ntiles, dma_v = !(OMNI_ATTN_ABL & 4) && has_next;
-    if (OMNI_ATTN_DMA_BURST == 1 || (OMNI_ATTN_DMA_BURST == 2 && (NW != 8 || !has_next))) {
+    bool issued1 = false, issued2 = false;         // PP: pieces issued at the start of this wave's H1 / H2
+    if (PP) {
+      if (!grpB) { if (t >= 1 && dma_k) { issue_K(t + 2, t & 1); issued1 = true; } }
+      else if (dma_v) { issue_V(t + 1, (t + 1) & 1); issued1 = true; }
+    } else if (OMNI_ATTN_DMA_BURST == 1) {
       if (dma_k) issue_K(t + 2, t & 1);
       if (dma_v) issue_V(t + 1, (t + 1) & 1);
     }
@@ -607,55 +632,72 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
       mneg2[bq][0] = mneg; mneg2[bq][1] = mneg;
       psum2[bq][0] = 0.0f; psum2[bq][1] = 0.0f;
     }
-    // exp chunk i: S elements (flat index over j, r) 2i and 2i+1 -> one packed bf16 pair of P
-#define OMNI_EXP_CHUNK(i)                                                                                        \
+    // exp chunk i: S elements (flat index over j, r) 2i and 2i+1 -> one packed bf16 pair of P.  The sum / pack of chunk i
+    // is issued in chunk i+1, behind that chunk's exps: a v_exp result needs a wait state before a VALU may read it, and
+    // with the consumer right behind hipcc fills it with an s_nop (one issue slot per chunk)
+    f32x2_t pend[NQ];
+#define OMNI_EXP_FINISH(i)                                                                                       \
   do {                                                                                                           \
     _Pragma("unroll") for (int bq_ = 0; bq_ < NQ; ++bq_) {                                                        \
-      if (OMNI_ATTN_ABL & 8) { pfu[bq_][(i) >> 3][((i) >> 2) & 1][(i) & 3] = 0x3c003c00u; continue; }              \
-      /* packed fp32 (v_pk_add_f32): S elements 2i, 2i+1 are an aligned register pair */                         \
-      const f32x2_t x_ = {SC[bq_][(i) >> 3][(2 * (i)) & 15], SC[bq_][(i) >> 3][((2 * (i)) & 15) + 1]};             \
-      f32x2_t y_;                                                                                                \
-      if (OMNI_ATTN_PKFMA) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y_) : "v"(x_), "v"(scale2), "v"(mneg2[bq_])); \
-      else y_ = __builtin_elementwise_fma(x_, scale2, mneg2[bq_]);                                               \
-      const float p0_ = __builtin_amdgcn_exp2f(y_[0]), p1_ = __builtin_amdgcn_exp2f(y_[1]);                       \
-      const f32x2_t pp_ = {p0_, p1_};                                                                            \
-      psum2[bq_] += pp_;                                                                                         \
-      uint32_t pk_ = pack_bf16x2(p0_, p1_);                                                                      \
+      psum2[bq_] += pend[bq_];                                                                                   \
+      uint32_t pk_ = pack_bf16x2(pend[bq_][0], pend[bq_][1]);                                                    \
       asm volatile("" : "+v"(pk_), "+v"(psum2[bq_])); /* pin: pure arithmetic is otherwise sunk below the MFMA run */ \
       pfu[bq_][(i) >> 3][((i) >> 2) & 1][(i) & 3] = pk_;                                                         \
     }                                                                                                            \
   } while (0)
-#undef OMNI_QK_DMA
-// OMNI_ATTN_DMA_BURST == 2: ONE piece per wave per slot, waves staggered over the slots (wave w: K pieces at QK steps w and
-// w + 8): at most one global_load_lds per CU is being issued at a time instead of a burst of 32 into a queue that holds ~8
-#define OMNI_QK_DMA(i)                                                                              \
-  do {                                                                                              \
-    if (OMNI_ATTN_DMA_BURST == 2 && NW == 8 && has_next && dma_k && ((i) & 7) == wave)               \
-      issue_K_piece(t + 2, t & 1, (i) >> 3);                                                         \
+#define OMNI_EXP_CHUNK(i)                                                                                        \
+  do {                                                                                                           \
+    if (OMNI_ATTN_ABL & 8) {                                                                                     \
+      _Pragma("unroll") for (int bq_ = 0; bq_ < NQ; ++bq_) pfu[bq_][(i) >> 3][((i) >> 2) & 1][(i) & 3] = 0x3c003c00u; \
+      break;                                                                                                     \
+    }                                                                                                            \
+    f32x2_t e_[NQ];                                                                                              \
+    _Pragma("unroll") for (int bq_ = 0; bq_ < NQ; ++bq_) {                                                        \
+      /* packed fp32: S elements 2i, 2i+1 are an aligned register pair */                                        \
+      const f32x2_t x_ = {SC[bq_][(i) >> 3][(2 * (i)) & 15], SC[bq_][(i) >> 3][((2 * (i)) & 15) + 1]};             \
+      f32x2_t y_;                                                                                                \
+      if (OMNI_ATTN_PKFMA) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y_) : "v"(x_), "v"(scale2), "v"(mneg2[bq_])); \
+      else y_ = __builtin_elementwise_fma(x_, scale2, mneg2[bq_]);                                               \
+      e_[bq_][0] = __builtin_amdgcn_exp2f(y_[0]);                                                                \
+      e_[bq_][1] = __builtin_amdgcn_exp2f(y_[1]);                                                                \
+      asm volatile("" : "+v"(e_[bq_]));                                                                          \
+    }                                                                                                            \
+    if ((i) > 0) OMNI_EXP_FINISH(((i) + 15) & 15);                                                               \
+    _Pragma("unroll") for (int bq_ = 0; bq_ < NQ; ++bq_) pend[bq_] = e_[bq_];                                     \
   } while (0)
     if (has_next) {
-      const uint32_t kst = lds0 + ((t + 1) & 1) * STAGE_BYTES;
       zero_s(SN);
       if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(1);
-      OMNI_QK_ALL(SN, kst, OMNI_EXP_CHUNK);
+      OMNI_QK_ALL(SN, (PAR ^ 1), OMNI_EXP_CHUNK);      // K(t+1) lives in stage (t+1) & 1
       if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(0);
     } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) OMNI_EXP_CHUNK(i);
+      OMNI_EXP_CHUNK(0);  OMNI_EXP_CHUNK(1);  OMNI_EXP_CHUNK(2);  OMNI_EXP_CHUNK(3);  OMNI_EXP_CHUNK(4);  OMNI_EXP_CHUNK(5);
+      OMNI_EXP_CHUNK(6);  OMNI_EXP_CHUNK(7);  OMNI_EXP_CHUNK(8);  OMNI_EXP_CHUNK(9);  OMNI_EXP_CHUNK(10); OMNI_EXP_CHUNK(11);
+      OMNI_EXP_CHUNK(12); OMNI_EXP_CHUNK(13); OMNI_EXP_CHUNK(14); OMNI_EXP_CHUNK(15);
     }
+    if (!(OMNI_ATTN_ABL & 8)) OMNI_EXP_FINISH(15);
 #undef OMNI_EXP_CHUNK
+#undef OMNI_EXP_FINISH
 #pragma unroll
     for (int bq = 0; bq < NQ; ++bq) l_run[bq] += psum2[bq][0] + psum2[bq][1];
     if (has_next && (t + 2) * KVBLK > seq_len) mask_tail(SN, (t + 1) * KVBLK);
+
+    if (PP) {                                      // ---- end of H1: the pieces of the previous half-phase have landed
+      if (issued1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (!grpB) { if (dma_v) { issue_V(t + 1, (t + 1) & 1); issued2 = true; } }
+      else if (!(OMNI_ATTN_ABL & 4) && t + 3 < ntiles) { issue_K(t + 3, (t + 1) & 1); issued2 = true; }
+    }
 
     // ---- O^T += V^T P^T (tile t), with the row max of S(t+1) in the MFMA shadows
     float mx[NQ];
 #pragma unroll
     for (int bq = 0; bq < NQ; ++bq) mx[bq] = has_next ? SN[bq][0][0] : 0.0f;
     {
-      const uint32_t vb = lds0 + (t & 1) * STAGE_BYTES + v_lane_off;
+      const uint32_t vb = v_addr;                 // V(t) lives in stage t & 1 = PAR: folded into the offset immediates
       u32x2_t vlo[4], vhi[4];
-#define OMNI_VOFF(i) (((i) & 3) * 4096 + ((((i) >> 3) * 8 + (((i) >> 2) & 1) * 4) * 256))
+#define OMNI_VOFF(i) (PAR * STAGE_BYTES + ((i) & 3) * 4096 + ((((i) >> 3) * 8 + (((i) >> 2) & 1) * 4) * 256))
 #define OMNI_VREAD(i)                                                                      \
   do {                                                                                     \
     if (OMNI_ATTN_ABL & 16) {                                                              \
@@ -696,11 +738,6 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
 // DMA slot j (0 .. 2*NPIECE-1): K(t+2) pieces first (needed one iteration from now), then V(t+1) pieces
 #define OMNI_DMA_SLOT(j)                                                                  \
   do {                                                                                    \
-    if (OMNI_ATTN_DMA_BURST == 2 && NW == 8 && has_next) {                                 \
-      /* staggered: slots 0..3 = P.V steps 0..3 (piece 0), slots 4..7 are not used; waves 2s, 2s+1 issue in slot s */ \
-      if ((j) < 4 && dma_v && (wave >> 1) == (j)) { issue_V_piece(t + 1, (t + 1) & 1, 0); issue_V_piece(t + 1, (t + 1) & 1, 1); } \
-      __builtin_amdgcn_sched_barrier(0);                                                  \
-    } else                                                                                \
     if (!OMNI_ATTN_DMA_BURST && (j) < 2 * NPIECE) {                                       \
       if ((j) < NPIECE) { if (dma_k) issue_K_piece(t + 2, t & 1, (j) % NPIECE); }         \
       else { if (dma_v) issue_V_piece(t + 1, (t + 1) & 1, (j) % NPIECE); }                \
@@ -728,25 +765,34 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
 #pragma unroll
       for (int bq = 0; bq < NQ; ++bq) mxn[bq] = xhalf_max(mx[bq]);
     }
-    if (!(OMNI_ATTN_ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this iteration's DMA has landed
-    if (!(OMNI_ATTN_ABL & 2)) __syncthreads();          // ... for every wave; and every wave is done with K(t+1), V(t)
+    if (PP) {                                      // ---- end of H2
+      if (issued2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    } else {
+      if (!(OMNI_ATTN_ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this iteration's DMA has landed
+      if (!(OMNI_ATTN_ABL & 2)) __syncthreads();          // ... for every wave; and every wave is done with K(t+1), V(t)
+    }
   };
 
   {
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
-    int t = 0;
+    using even = std::integral_constant<int, 0>;
+    using odd = std::integral_constant<int, 1>;
+    int t = 0;                                     // even at every call site below
     for (; t + 2 < ntiles; t += 2) {
-      iteration(yes{}, t, sA, sB, mxA, mxB);
-      iteration(yes{}, t + 1, sB, sA, mxB, mxA);
+      iteration(yes{}, even{}, t, sA, sB, mxA, mxB);
+      iteration(yes{}, odd{}, t + 1, sB, sA, mxB, mxA);
     }
     if (t + 1 < ntiles) {
-      iteration(yes{}, t, sA, sB, mxA, mxB);
-      iteration(no{}, t + 1, sB, sA, mxB, mxA);
+      iteration(yes{}, even{}, t, sA, sB, mxA, mxB);
+      iteration(no{}, odd{}, t + 1, sB, sA, mxB, mxA);
     } else {
-      iteration(no{}, t, sA, sB, mxA, mxB);
+      iteration(no{}, even{}, t, sA, sB, mxA, mxB);
     }
   }
+  if (PP && !grpB) __builtin_amdgcn_s_barrier();   // group A waits out group B's last half-phase
 #undef OMNI_QK_ALL
 #undef OMNI_QK_STEP
 #undef OMNI_KREAD
@@ -774,6 +820,426 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     }
   }
 }
+
+
+#ifdef OMNI_DEV
+// ------------------------------------------------------------------------------------------------
+// 16x16x32 MFMA form of the software-pipelined kernel (dev builds, OMNI_ATTN_MFMA=16; measured -2.4 %: see below).  The same tile stream, K image, skewed loop, DMA and
+// barrier structure as flash_attn_fwd_pipe_kernel<NW, 1>; what changes is the instruction shape and the layouts that follow
+// from it.  v_mfma_f32_16x16x32_bf16 does the same flops per matrix-pipe cycle as 32x32x16 with 32 k per instruction: half
+// the accumulator read-modify-write traffic per flop.  On this power-limited part that is clock: swapping only the
+// instruction in the 32x32 kernel (results wrong) measured 900 -> 997 TF/s at B=6, S=4160 (profiles/r02_attention_mfma_shape.log).
+//   A wave owns 32 queries as TWO 16-query blocks (qb): lane = (q = lane & 15, g = lane >> 4).
+//   Sᵀ = K·Qᵀ: A = K fragment (16 keys x 32 d: key l15, d 32*ks + 8g..), B = Q fragment in registers (d 32*ks + 8g.. of query
+//        l15).  Each K fragment feeds both query blocks.  C layout: S[qb][kb][i] = key kb*16 + 4g + i of query qb*16 + l15:
+//        softmax max / sum are lane-local over 16 keys, then reduced over the four g groups with two permlane swaps.
+//   Oᵀ = Vᵀ·Pᵀ: B = Pᵀ taken straight from the S registers of TWO key blocks: k slots 0..3 = keys 4g + i of block 2c, slots
+//        4..7 = the same of block 2c+1 (the MFMA k order is simply defined that way); A = Vᵀ fragment (16 d x those 32 keys)
+//        from two ds_read_b64_tr_b16 (keys 4g.. of key group c*8 + g, and of c*8 + g + 4).
+//   V image: [d/32 (4)][key-group pair (8)][d-block parity (2)][key-group parity (2)][key & 3 (4)][16 d] — the 32 lanes of a
+//        tr-read half cover 256 contiguous bytes (conflict-free), and a 1-KiB DMA piece still fetches 16 keys x 64 B.
+// The rescale decision is taken per wave over both query blocks, i.e. over the same 32 queries as in the 32x32 kernel.
+// MEASURED (B=6, S=4160, same box, profiles/r02_attention_mfma_shape.log): 883 TF/s against 904 for the 32x32x16 kernel.
+// PMC: the clock does rise (GRBM_GUI_ACTIVE / duration: 1.74 -> 1.96 GHz) but the kernel needs 17 % more cycles: SQ_INSTS_VALU
+// 208 M -> 265 M (the MFMA count doubles: 32 more issues per wave and tile, +13 other VALU), and with two waves per SIMD this
+// loop is bound by its per-wave instruction issue (~8 cycles per instruction), not by the matrix pipe (busy 42-49 %).
+// ------------------------------------------------------------------------------------------------
+OMNI_DEVINL float xquad_max(float x) {   // max over the four 16-lane groups
+  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return xhalf_max(fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)));
+}
+OMNI_DEVINL float xquad_sum(float x) {
+  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return xhalf_sum(__builtin_bit_cast(float, a) + __builtin_bit_cast(float, b));
+}
+
+// max of TWO per-lane values over the four 16-lane groups in three swaps (the plain form needs four): after the 16-swap of
+// (x0, x1) lane groups hold [x0 g0, x1 g0, x0 g2, x1 g2] / [x0 g1, x1 g1, x0 g3, x1 g3]; their max, 32-swapped with itself,
+// gives the full max of x0 in groups 0 / 2 and of x1 in groups 1 / 3; a last 16-swap of that with itself spreads both to
+// every lane.  v_max_f32 from asm: fmaxf() adds two canonicalising v_max x, x, x per call.
+OMNI_DEVINL float vmaxf(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+OMNI_DEVINL void xquad_max2(float x0, float x1, float& r0, float& r1) {
+  uint32_t a = __builtin_bit_cast(uint32_t, x0), b = __builtin_bit_cast(uint32_t, x1);
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  const float y = vmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+  uint32_t c = __builtin_bit_cast(uint32_t, y), d = c;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));
+  const float z = vmaxf(__builtin_bit_cast(float, c), __builtin_bit_cast(float, d));
+  uint32_t e = __builtin_bit_cast(uint32_t, z), f = e;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(e), "+v"(f));
+  r0 = __builtin_bit_cast(float, e);
+  r1 = __builtin_bit_cast(float, f);
+}
+#ifndef OMNI_ATTN16_VIMG
+#define OMNI_ATTN16_VIMG 1   // V image: 1 = [d/32][key group][key & 3][32 d] with the two 16-d halves XOR (key group & 1):
+                             // four CONSECUTIVE lanes of a DMA piece fetch one key's 64 contiguous bytes; 0 = paired image
+#endif
+#ifndef OMNI_ATTN16_RED2
+#define OMNI_ATTN16_RED2 1   // 1 = xquad_max2 (three swaps for both query blocks), 0 = two xquad_max
+#endif
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pipe16_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+    const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e, int out_k32_rows,
+    int block_order, const int32_t* __restrict__ item_skip) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+
+  int hb, qblk;                                  // block -> (item*head, q-block): see flash_attn_fwd_pipe_kernel
+  if (block_order == 1) {
+    const int nwg = gridDim.x, bid = blockIdx.x, qblocks = nwg / n_heads_total;
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    hb = lid / qblocks;
+    qblk = lid - hb * qblocks;
+  } else {
+    hb = blockIdx.x % n_heads_total;
+    qblk = blockIdx.x / n_heads_total;
+  }
+  const int b = hb / H, h = hb - b * H;
+  if (item_skip && item_skip[b]) return;          // device-side predicate: this item's block stack is skipped (omni_teacache)
+  const int seq_start = cu_seqlens[b];
+  const int seq_len = cu_seqlens[b + 1] - seq_start;
+  constexpr int QBLK = 32 * NW;
+  constexpr int NPIECE = 16 / NW;                 // DMA pieces (1 KiB) per wave per operand per tile
+  if (qblk * QBLK >= seq_len) return;
+
+  const char* kbase = reinterpret_cast<const char*>(k + (int64_t)seq_start * ldk + h * DH);
+  const char* vbase = reinterpret_cast<const char*>(v + (int64_t)seq_start * ldv + h * DH);
+
+  // ---- Q fragments (B operand): qf[qb][ks] = d 32*ks + 8g .. +8 of query qb*16 + l15 ----------------------------
+  bf16x8_t qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = min(qblk * QBLK + wave * 32 + qb * 16 + l15, seq_len - 1);
+    const uint16_t* qp = q + (int64_t)(seq_start + qrow) * ldq + h * DH + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qb][ks]));   // no rematerialisation of the loads inside the loop
+  }
+
+  // ---- DMA sources.  One wave-instruction = 1 KiB of the LDS image, lane L -> byte 16*L of the piece.
+  //  K piece P (keys 4P .. 4P+3): key = 4P + (L>>4), LDS chunk L&15 holds logical chunk (L&15)^(key&15)
+  //  V piece P = (d/32 = P>>2, 16-key group = P&3): L = [key-group pair 1][d-block parity 1][key-group parity 1][key&3 2][8-d half 1]
+  auto k_key_of = [&](int i) { return 4 * (wave + NW * i) + (lane >> 4); };
+  auto k_col_of = [&](int i) { return (uint32_t)(((lane & 15) ^ (k_key_of(i) & 15)) * 16); };
+#if OMNI_ATTN16_VIMG
+  //  V piece P = (d/32 = P>>2, 16-key group = P&3): L = [key group & 3 (2)][key & 3 (2)][16-B chunk of the 64-B row (2)]; the
+  //  chunk's 16-d half is XORed with the key group's parity (= (L>>4) & 1) so that a tr-read's even and odd lane groups
+  //  (key groups g, g+1) fall into different bank halves
+  auto v_key_of = [&](int i) { return 16 * ((wave + NW * i) & 3) + 4 * (lane >> 4) + ((lane >> 2) & 3); };
+  auto v_col_of = [&](int i) { return (uint32_t)((4 * ((wave + NW * i) >> 2) + ((lane & 3) ^ (2 * ((lane >> 4) & 1)))) * 16); };
+#else
+  auto v_key_of = [&](int i) { return 16 * ((wave + NW * i) & 3) + 8 * (lane >> 5) + 4 * ((lane >> 3) & 1) + ((lane >> 1) & 3); };
+  auto v_col_of = [&](int i) { return (uint32_t)(((wave + NW * i) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 1) * 16); };
+#endif
+  uint32_t k_src[NPIECE], v_src[NPIECE];
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) {
+    k_src[i] = (uint32_t)(k_key_of(i) * ldk * 2) + k_col_of(i);
+    v_src[i] = (uint32_t)(v_key_of(i) * ldv * 2) + v_col_of(i);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int ntiles = (seq_len + KVBLK - 1) / KVBLK;
+  const int last_valid = seq_len - (ntiles - 1) * KVBLK;          // keys in the last tile (1..64)
+  auto issue_K = [&](int t, int stage) {
+    const char* tb = kbase + (int64_t)t * KVBLK * ldk * 2;          // uniform
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const uint32_t dst = lds0 + stage * STAGE_BYTES + (wave + NW * i) * 1024;
+      if (t == ntiles - 1 && last_valid < KVBLK)                    // ragged tail: re-read the last valid row
+        attn_glds16(tb, (uint32_t)(min(k_key_of(i), last_valid - 1) * ldk * 2) + k_col_of(i), dst);
+      else
+        attn_glds16(tb, k_src[i], dst);
+    }
+  };
+  auto issue_V = [&](int t, int stage) {
+    const char* tb = vbase + (int64_t)t * KVBLK * ldv * 2;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const uint32_t dst = lds0 + stage * STAGE_BYTES + K_TILE_BYTES + (wave + NW * i) * 1024;
+      if (t == ntiles - 1 && last_valid < KVBLK)
+        attn_glds16(tb, (uint32_t)(min(v_key_of(i), last_valid - 1) * ldv * 2) + v_col_of(i), dst);
+      else
+        attn_glds16(tb, v_src[i], dst);
+    }
+  };
+
+  // K fragment (kb, ks): key kb*16 + l15 (256-B rows), logical 16-B chunk 4*ks + g, XOR key & 15 = l15
+  uint32_t k_addr[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_addr[ks] = l15 * 256 + ((((uint32_t)(ks * 4 + g)) ^ (uint32_t)l15) << 4);
+  // V^T fragment: 16-lane group g transposes the 4 keys x 16 d block of key group c*8 + g (+4 for the upper k slots)
+#if OMNI_ATTN16_VIMG
+  // key group c*8 + g (256 B each), key l15 >> 2 (64 B), 16-d half (db & 1) ^ (g & 1) (32 B): one lane offset per d-block parity
+  const uint32_t v_lane_off0 = K_TILE_BYTES + g * 256 + (l15 >> 2) * 64 + (g & 1) * 32 + (l15 & 3) * 8;
+  const uint32_t v_lane_off1 = K_TILE_BYTES + g * 256 + (l15 >> 2) * 64 + ((g & 1) ^ 1) * 32 + (l15 & 3) * 8;
+#else
+  const uint32_t v_lane_off = K_TILE_BYTES + (g >> 1) * 512 + (g & 1) * 128 + (l15 >> 2) * 32 + (l15 & 3) * 8;
+#endif
+
+  f32x4_t o[2][8];                               // O^T[qb][d block]: d = db*16 + 4g + i of query qb*16 + l15
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o[qb][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    m_run[qb] = -INFINITY;
+    l_run[qb] = 0.0f;
+  }
+
+  bf16x8_t kf[4];
+// QK step i (0..15): key block i & 3, k-step i >> 2: consecutive MFMAs never share an accumulator
+#define OMNI_KREAD(i, kst) kf[(i) & 3] = lds_read16<((i) & 3) * 4096>(k_addr[((i) >> 2) & 3] + (kst))
+#define OMNI_QK_STEP(i, SN, kst, CHUNK)                                                          \
+  do {                                                                                           \
+    if ((i) <= 12) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                            \
+    else if ((i) == 13) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                       \
+    else if ((i) == 14) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");                       \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    SN[0][(i) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[(i) & 3], qf[0][(i) >> 2], SN[0][(i) & 3], 0, 0, 0); \
+    SN[1][(i) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[(i) & 3], qf[1][(i) >> 2], SN[1][(i) & 3], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    if ((i) + 4 < 16) OMNI_KREAD((i) + 4, kst);                                                  \
+    CHUNK;                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
+#define OMNI_QK_ALL(SN, kst, CH)                                                                                     \
+  do {                                                                                                               \
+    OMNI_KREAD(0, kst); OMNI_KREAD(1, kst); OMNI_KREAD(2, kst); OMNI_KREAD(3, kst);                                  \
+    OMNI_QK_STEP(0, SN, kst, CH(0));   OMNI_QK_STEP(1, SN, kst, CH(1));   OMNI_QK_STEP(2, SN, kst, CH(2));           \
+    OMNI_QK_STEP(3, SN, kst, CH(3));   OMNI_QK_STEP(4, SN, kst, CH(4));   OMNI_QK_STEP(5, SN, kst, CH(5));           \
+    OMNI_QK_STEP(6, SN, kst, CH(6));   OMNI_QK_STEP(7, SN, kst, CH(7));   OMNI_QK_STEP(8, SN, kst, CH(8));           \
+    OMNI_QK_STEP(9, SN, kst, CH(9));   OMNI_QK_STEP(10, SN, kst, CH(10)); OMNI_QK_STEP(11, SN, kst, CH(11));         \
+    OMNI_QK_STEP(12, SN, kst, CH(12)); OMNI_QK_STEP(13, SN, kst, CH(13)); OMNI_QK_STEP(14, SN, kst, CH(14));         \
+    OMNI_QK_STEP(15, SN, kst, CH(15));                                                                               \
+  } while (0)
+#define OMNI_NOCHUNK(i) (void)0
+
+  auto mask_tail = [&](f32x4_t (&S)[2][4], int kv0) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (kv0 + kb * 16 + 4 * g + i >= seq_len) { S[0][kb][i] = -INFINITY; S[1][kb][i] = -INFINITY; }
+  };
+  auto zero_s = [&](f32x4_t (&S)[2][4]) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) S[qb][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ---- prologue: tiles 0 (K, V) and 1 (K) in flight, S(0) and its row max -------------------------------------
+  issue_K(0, 0);
+  issue_V(0, 0);
+  if (ntiles > 1) issue_K(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x4_t sA[2][4], sB[2][4];
+  float mxA[2], mxB[2];
+  zero_s(sA);
+  OMNI_QK_ALL(sA, lds0, OMNI_NOCHUNK);
+  if (KVBLK > seq_len) mask_tail(sA, 0);
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float mx = sA[qb][0][0];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sA[qb][kb][i]);
+    mxA[qb] = mx;
+    mxB[qb] = 0.0f;
+  }
+  xquad_max2(mxA[0], mxA[1], mxA[0], mxA[1]);
+
+  // One iteration; SC = S(t) (complete, row max mxc known), SN receives S(t+1).
+  auto iteration = [&](auto has_next_c, int t, f32x4_t (&SC)[2][4], f32x4_t (&SN)[2][4], float (&mxc)[2], float (&mxn)[2]) {
+    constexpr bool has_next = decltype(has_next_c)::value;
+    if (t + 2 < ntiles) issue_K(t + 2, t & 1);
+    if (has_next) issue_V(t + 1, (t + 1) & 1);
+
+    // defer-max: rescale only when some query's new tile max exceeds its running max by more than 2^DEFER
+    constexpr float DEFER = 6.0f;
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t scale2 = {scale_log2e, scale_log2e};
+    f32x2_t mneg2[2], psum2[2];
+    uint32_t pfu[2][2][4];                        // [qb][32-key chunk c][k-slot pair]: bf16 pairs of P^T
+    if (!__all((mxc[0] - m_run[0]) * scale_log2e <= DEFER && (mxc[1] - m_run[1]) * scale_log2e <= DEFER)) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const float m_new = fmaxf(m_run[qb], mxc[qb]);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * scale_log2e);
+        m_run[qb] = m_new;
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[qb][d] *= alpha;
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const float mneg = -m_run[qb] * scale_log2e;
+      mneg2[qb][0] = mneg; mneg2[qb][1] = mneg;
+      psum2[qb][0] = 0.0f; psum2[qb][1] = 0.0f;
+    }
+    // exp chunk i (0..15): query block i >> 3, key block (i >> 1) & 3, register pair i & 1 -> one packed bf16 pair of P
+#define OMNI_EXP_CHUNK(i)                                                                                        \
+  do {                                                                                                           \
+    const f32x2_t x_ = {SC[(i) >> 3][((i) >> 1) & 3][2 * ((i) & 1)], SC[(i) >> 3][((i) >> 1) & 3][2 * ((i) & 1) + 1]}; \
+    const f32x2_t y_ = __builtin_elementwise_fma(x_, scale2, mneg2[(i) >> 3]);                                   \
+    const float p0_ = __builtin_amdgcn_exp2f(y_[0]), p1_ = __builtin_amdgcn_exp2f(y_[1]);                         \
+    const f32x2_t pp_ = {p0_, p1_};                                                                              \
+    psum2[(i) >> 3] += pp_;                                                                                      \
+    uint32_t pk_ = pack_bf16x2(p0_, p1_);                                                                        \
+    asm volatile("" : "+v"(pk_), "+v"(psum2[(i) >> 3])); /* pin: pure arithmetic is otherwise sunk below the MFMA run */ \
+    pfu[(i) >> 3][((i) >> 2) & 1][(((i) >> 1) & 1) * 2 + ((i) & 1)] = pk_;                                       \
+  } while (0)
+    if (has_next) {
+      const uint32_t kst = lds0 + ((t + 1) & 1) * STAGE_BYTES;
+      zero_s(SN);
+      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(1);
+      OMNI_QK_ALL(SN, kst, OMNI_EXP_CHUNK);
+      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) OMNI_EXP_CHUNK(i);
+    }
+#undef OMNI_EXP_CHUNK
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) l_run[qb] += psum2[qb][0] + psum2[qb][1];
+    if (has_next && (t + 2) * KVBLK > seq_len) mask_tail(SN, (t + 1) * KVBLK);
+
+    // ---- O^T += V^T P^T (tile t), with the row max of S(t+1) in the MFMA shadows
+    float mx[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) mx[qb] = has_next ? SN[qb][0][0] : 0.0f;
+    {
+      u32x2_t vlo[4], vhi[4];
+// PV step i (0..15): 32-key chunk c = i >> 3, d block db = i & 7
+#if OMNI_ATTN16_VIMG
+      const uint32_t vb0 = lds0 + (t & 1) * STAGE_BYTES + v_lane_off0, vb1 = lds0 + (t & 1) * STAGE_BYTES + v_lane_off1;
+#define OMNI_VOFF(i) ((((i) & 7) >> 1) * 4096 + ((i) >> 3) * 2048)
+#define OMNI_VREAD(i)                                                                      \
+  do {                                                                                     \
+    vlo[(i) & 3] = lds_tr_read8<OMNI_VOFF(i)>(((i) & 1) ? vb1 : vb0);                      \
+    vhi[(i) & 3] = lds_tr_read8<OMNI_VOFF(i) + 1024>(((i) & 1) ? vb1 : vb0);               \
+  } while (0)
+#else
+      const uint32_t vb = lds0 + (t & 1) * STAGE_BYTES + v_lane_off;
+#define OMNI_VOFF(i) ((((i) & 7) >> 1) * 4096 + ((i) >> 3) * 2048 + ((i) & 1) * 256)
+#define OMNI_VREAD(i)                                                                      \
+  do {                                                                                     \
+    vlo[(i) & 3] = lds_tr_read8<OMNI_VOFF(i)>(vb);                                         \
+    vhi[(i) & 3] = lds_tr_read8<OMNI_VOFF(i) + 1024>(vb);                                  \
+  } while (0)
+#endif
+#define OMNI_PV(i)                                                                                             \
+  do {                                                                                                         \
+    if ((i) <= 13) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                          \
+    else if ((i) == 14) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                                     \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    {                                                                                                          \
+      const u32x4_t w_ = {vlo[(i) & 3][0], vlo[(i) & 3][1], vhi[(i) & 3][0], vhi[(i) & 3][1]};                 \
+      _Pragma("unroll") for (int qb_ = 0; qb_ < 2; ++qb_) {                                                     \
+        const u32x4_t p_ = {pfu[qb_][(i) >> 3][0], pfu[qb_][(i) >> 3][1], pfu[qb_][(i) >> 3][2], pfu[qb_][(i) >> 3][3]}; \
+        o[qb_][(i) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w_),            \
+                                                    __builtin_bit_cast(bf16x8_t, p_), o[qb_][(i) & 7], 0, 0, 0); \
+      }                                                                                                        \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+// max chunk c (0..7): query block c >> 2, key block c & 3
+#define OMNI_MAX_CHUNK(c)                                                                                       \
+  do {                                                                                                          \
+    if (has_next) {                                                                                             \
+      mx[(c) >> 2] = fmaxf(fmaxf(mx[(c) >> 2], SN[(c) >> 2][(c) & 3][0]), SN[(c) >> 2][(c) & 3][1]);              \
+      mx[(c) >> 2] = fmaxf(fmaxf(mx[(c) >> 2], SN[(c) >> 2][(c) & 3][2]), SN[(c) >> 2][(c) & 3][3]);              \
+      asm volatile("" : "+v"(mx[(c) >> 2]));                                                                    \
+    }                                                                                                           \
+  } while (0)
+      OMNI_VREAD(0); OMNI_VREAD(1); OMNI_VREAD(2);
+      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(1);
+      OMNI_PV(0);  OMNI_VREAD(3);  OMNI_PV(1);  OMNI_VREAD(4);
+      OMNI_PV(2);  OMNI_VREAD(5);  OMNI_PV(3);  OMNI_VREAD(6);
+      OMNI_PV(4);  OMNI_VREAD(7);  OMNI_MAX_CHUNK(0); OMNI_PV(5);  OMNI_VREAD(8);  OMNI_MAX_CHUNK(1);
+      OMNI_PV(6);  OMNI_VREAD(9);  OMNI_MAX_CHUNK(2); OMNI_PV(7);  OMNI_VREAD(10); OMNI_MAX_CHUNK(3);
+      OMNI_PV(8);  OMNI_VREAD(11); OMNI_MAX_CHUNK(4); OMNI_PV(9);  OMNI_VREAD(12); OMNI_MAX_CHUNK(5);
+      OMNI_PV(10); OMNI_VREAD(13); OMNI_MAX_CHUNK(6); OMNI_PV(11); OMNI_VREAD(14); OMNI_MAX_CHUNK(7);
+      OMNI_PV(12); OMNI_VREAD(15); OMNI_PV(13); OMNI_PV(14); OMNI_PV(15);
+      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(0);
+#undef OMNI_MAX_CHUNK
+#undef OMNI_PV
+#undef OMNI_VREAD
+#undef OMNI_VOFF
+    }
+    if (has_next) {
+      if (OMNI_ATTN16_RED2) {
+        xquad_max2(mx[0], mx[1], mxn[0], mxn[1]);
+      } else {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) mxn[qb] = xquad_max(mx[qb]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this iteration's DMA has landed
+    __syncthreads();                                  // ... for every wave; and every wave is done with K(t+1), V(t)
+  };
+
+  {
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    int t = 0;
+    for (; t + 2 < ntiles; t += 2) {
+      iteration(yes{}, t, sA, sB, mxA, mxB);
+      iteration(yes{}, t + 1, sB, sA, mxB, mxA);
+    }
+    if (t + 1 < ntiles) {
+      iteration(yes{}, t, sA, sB, mxA, mxB);
+      iteration(no{}, t + 1, sB, sA, mxB, mxA);
+    } else {
+      iteration(no{}, t, sA, sB, mxA, mxB);
+    }
+  }
+#undef OMNI_QK_ALL
+#undef OMNI_QK_STEP
+#undef OMNI_KREAD
+#undef OMNI_NOCHUNK
+
+  // ---- epilogue: a wave-instruction stores 16 rows x 32 contiguous bytes ------------------------------------------
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float inv = 1.0f / xquad_sum(l_run[qb]);
+    const int qrow = qblk * QBLK + wave * 32 + qb * 16 + l15;
+    if (qrow < seq_len) {
+      // row-major: out[row][h*128 + db*16 + 4g ..];  K32-blocked: slab h*4 + db/2, [slab][row][(db&1)*16 + 4g ..]
+#pragma unroll
+      for (int db = 0; db < 8; ++db) {
+        uint16_t* op = out_k32_rows
+                           ? out + ((int64_t)(h * 4 + (db >> 1)) * out_k32_rows + seq_start + qrow) * 32 + (db & 1) * 16 + g * 4
+                           : out + (int64_t)(seq_start + qrow) * ldo + h * DH + db * 16 + g * 4;
+        u32x2_t w;
+        w[0] = pack_bf16x2(o[qb][db][0] * inv, o[qb][db][1] * inv);
+        w[1] = pack_bf16x2(o[qb][db][2] * inv, o[qb][db][3] * inv);
+        *reinterpret_cast<u32x2_t*>(op) = w;
+      }
+    }
+  }
+}
+
+#endif  // OMNI_DEV
 
 }  // namespace
 
@@ -821,24 +1287,63 @@ int attn_pipe_waves(int n_heads_total, int max_seqlen) {
   const long wgs8 = (long)n_heads_total * ((max_seqlen + 255) / 256);
   return wgs8 >= 6 * 256 ? 8 : 4;
 }
-template <int NW, int NQ = 1>
+template <int NW, int NQ = 1, int PP = 0>
 int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
                 int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
                 float softmax_scale, int out_k32_rows, hipStream_t s, const int32_t* item_skip = nullptr) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe_kernel<NW, NQ>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe_kernel<NW, NQ, PP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
     attr_set = true;
   }
   const int qblocks = (max_seqlen + 32 * NW * NQ - 1) / (32 * NW * NQ);
   const int nh = B * H;
-  hipLaunchKernelGGL((flash_attn_fwd_pipe_kernel<NW, NQ>), dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
+  hipLaunchKernelGGL((flash_attn_fwd_pipe_kernel<NW, NQ, PP>), dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
                      ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows, attn_block_order(), item_skip);
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }
+#ifdef OMNI_DEV
+int attn_mfma_shape() {
+  // dev knob: OMNI_ATTN_MFMA = 32 (default: flash_attn_fwd_pipe_kernel, 32x32x16) | 16 (flash_attn_fwd_pipe16_kernel, 16x16x32)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OMNI_ATTN_MFMA");
+    v = e ? atoi(e) : 32;
+    if (v != 16) v = 32;
+  }
+  return v;
+}
+int attn_pingpong() {
+  // dev knob: OMNI_ATTN_PP = 0 (default) | 1 (wave groups half an iteration apart in the 8-wave kernel: measured 878 vs 912 TF/s)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OMNI_ATTN_PP");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+template <int NW>
+int launch_pipe16(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
+                  int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
+                  float softmax_scale, int out_k32_rows, hipStream_t s, const int32_t* item_skip) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe16_kernel<NW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return OMNI_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int qblocks = (max_seqlen + 32 * NW - 1) / (32 * NW);
+  const int nh = B * H;
+  hipLaunchKernelGGL((flash_attn_fwd_pipe16_kernel<NW>), dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
+                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows, attn_block_order(), item_skip);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+#endif  // OMNI_DEV
 #ifdef OMNI_DEV
 template <int NQ>
 int launch_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
@@ -885,6 +1390,13 @@ int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_
   }
   if (attn_variant() == 2)   // OMNI_ATTN_NQ=2: 4 waves x 64 queries, one wave per SIMD (spills as compiled by hipcc)
     return launch_pipe<4, 2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
+  if (attn_mfma_shape() == 16) {
+    if (attn_pipe_waves(B * H, max_seqlen) == 8)
+      return launch_pipe16<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
+    return launch_pipe16<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
+  }
+  if (attn_pipe_waves(B * H, max_seqlen) == 8 && attn_pingpong())
+    return launch_pipe<8, 1, 1>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
 #endif
   if (attn_pipe_waves(B * H, max_seqlen) == 8)
     return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
