@@ -207,6 +207,20 @@ def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
     t = timed(lambda: [pipe.decode_latents(o.output, 256, 256) for o in pipe.generate(many, output_type="latent")], n=2)
     pipe.od_config.max_step_batch = old_cap
     out["config1_256px_4step_stepbatched16_images_per_sec"] = 16 / t
+    # BASELINE config 5 geometry in bf16: 2048x2048 (16384 image tokens per item: attention is 47 % of the FLOPs), one
+    # request with true-CFG.  3 denoise steps are timed and scaled to the config's 50; the VAE decode (2048^2) is timed once.
+    big = reqs(1, 2048, 3, cfg=True)
+    t3 = timed(lambda: pipe.generate(big, output_type="latent"))
+    lat = pipe.generate(big, output_type="latent")[0].output
+    tv = timed(lambda: pipe.decode_latents(lat, 2048, 2048))
+    flop_step = 2 * 423.01e12                       # 423.01 TFLOP per forward at 2048^2, two forwards per step
+    out["res2048_bf16_ms_per_denoise_step"] = t3 / 3 * 1e3
+    out["res2048_bf16_vae_decode_ms"] = tv * 1e3
+    out["res2048_bf16_50step_images_per_sec_extrapolated"] = 1.0 / (50 * t3 / 3 + tv)
+    out["res2048_bf16_dit_mfma_roofline_frac"] = flop_step / (t3 / 3) / 2.5e15
+    out["res2048_note"] = ("2048x2048, true-CFG, batch 1, bf16 (the fp8-weight variant of BASELINE config 5 is not built): 3 steps "
+                           "timed, images/s extrapolated to 50 steps + one measured VAE decode")
+    del lat
     # TeaCache (device-side decisions, no host sync) on the headline workload
     try:
         from vllm_omni_amd.diffusion.cache.teacache.config import TeaCacheConfig
