@@ -29,8 +29,8 @@ if which.startswith("gemm"):
     oi, ot = torch.empty(Mi, N, dtype=BF16, device=dev), torch.empty(Mt, N, dtype=BF16, device=dev)
     fn = lambda: ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi), ops.GemmGroupArgs(xt, wt, b, ot)], epi)  # noqa: E731
 elif which == "roofline":
-    # exactly bench.py's roofline launch: MLP-up + GELU at the step-batch shape (R=3), production layouts
-    R = 3
+    # exactly bench.py's roofline launch: MLP-up + GELU at the step-batch shape (R = bench.py's default 5), production layouts
+    R = int(os.environ.get("BENCH_R", "5"))
     Mi, Mt, N, K = 2 * R * 4096, 2 * R * 64, 4 * D, D
     xi, xt = ops.w_to_k32_blocked(rn(Mi, K)), ops.w_to_k32_blocked(rn(Mt, K))
     wi, wt, b = ops.w_to_k32_blocked(rn(N, K, s=0.02)), ops.w_to_k32_blocked(rn(N, K, s=0.02)), rn(N)

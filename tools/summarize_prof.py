@@ -53,7 +53,9 @@ for f in sorted(glob.glob(f"{root}/pmc_{tag}_roofline_*/*.db")):
     except Exception:  # noqa: BLE001
         pass
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-    out = {"kernel": "gemm_bf16_pp_kernel<GELU> M=24576+384 N=12288 K=3072 (bench.py roofline launch)",
+    import os
+    R = int(os.environ.get("BENCH_R", "5"))
+    out = {"kernel": f"gemm_bf16_pp_kernel<GELU> M={2 * R * 4096}+{2 * R * 64} N=12288 K=3072 (bench.py roofline launch, R={R})",
            "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
            "traffic_bytes": 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024,
            "note": "fabric-side bytes per launch = 2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE; "

@@ -88,7 +88,8 @@ class OmniDiffusionConfig:
     num_gpus: int | None = None
     master_port: int | None = None
     output_type: str = "pil"
-    max_step_batch: int = 4          # NEW (not in the reference): requests whose steps share one DiT forward
+    max_step_batch: int = 5          # NEW (not in the reference): requests whose steps share one DiT forward (5 x 2 CFG
+                                     # items x 4160 rows fills the 256 CUs' tile rounds best at 1024^2: DESIGN.md 7)
     dist_timeout: int | None = None
     use_hip_graph: bool | None = None   # NEW: capture one denoise step as a hipGraph (None = automatic by size)
 
