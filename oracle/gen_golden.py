@@ -263,6 +263,60 @@ def run_diffuse_case():
     print(f"pipe_diffuse_cfg_256: final std {final.std():.4f}, steps {len(traj)}")
 
 
+def run_edit_plus_case():
+    """(a) Reference DiT forward over a THREE-image sequence (target + two condition images of different sizes), the way
+    the Edit-Plus pipeline calls it (pipeline_qwen_image_edit_plus.py:543-556,729-738).  (b) The Edit-Plus pre-process
+    arithmetic and prompt template, taken from the unmodified reference sources by executing ONLY their constant
+    assignments and the `calculate_dimensions` function (the module itself imports PIL / transformers / diffusers)."""
+    import ast
+
+    case = dict(layers=2, heads=2, joint=128, grids=[(1, 8, 8), (1, 6, 10), (1, 4, 4)], T=9, B=1, bias_std=0.02, jitter=0.1,
+                dtype="float32", sigma=[0.37])
+    P = O.make_dit_params(case["layers"], seed=1234, bias_std=case["bias_std"], norm_jitter=case["jitter"],
+                          num_heads=case["heads"], joint_dim=case["joint"])
+    model, cfg = ref_shims.build_reference_model(case["layers"], num_attention_heads=case["heads"],
+                                                 joint_attention_dim=case["joint"], dtype=torch.float32)
+    model.load_state_dict(P, strict=True)
+    S = sum(f * h * w for f, h, w in case["grids"])
+    g = torch.Generator().manual_seed(43)
+    lat = torch.randn(1, S, 64, generator=g)
+    txt = torch.randn(1, case["T"], case["joint"], generator=g)
+    sig = torch.tensor(case["sigma"])
+    out = ref_shims.reference_forward(
+        model, cfg, hidden_states=lat, encoder_hidden_states=txt,
+        encoder_hidden_states_mask=torch.ones(1, case["T"], dtype=torch.long), timestep=sig,
+        img_shapes=[[tuple(gr) for gr in case["grids"]]], txt_seq_lens=[case["T"]])
+    # --- constants / helpers of the reference Edit(-Plus) modules
+    rdir = os.path.join(ref_shims.REFERENCE_ROOT, "vllm_omni", "diffusion", "models", "qwen_image")
+    ns: dict = {"math": __import__("math")}
+    tree = ast.parse(open(os.path.join(rdir, "pipeline_qwen_image_edit.py")).read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == "calculate_dimensions":
+            exec(compile(ast.Module([node], []), "ref_edit", "exec"), ns)
+    tree = ast.parse(open(os.path.join(rdir, "pipeline_qwen_image_edit_plus.py")).read())
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") in ("CONDITION_IMAGE_SIZE", "VAE_IMAGE_SIZE"):
+            exec(compile(ast.Module([node], []), "ref_edit_plus", "exec"), ns)
+    template = img_template = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Attribute) and node.targets[0].attr == "prompt_template_encode":
+            template = ast.literal_eval(node.value)
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == "img_prompt_template":
+            img_template = ast.literal_eval(node.value)
+    assert template and img_template
+    sizes = [(1920, 1080), (640, 480), (512, 512), (300, 900)]
+    helpers = dict(CONDITION_IMAGE_SIZE=ns["CONDITION_IMAGE_SIZE"], VAE_IMAGE_SIZE=ns["VAE_IMAGE_SIZE"], sizes=sizes,
+                   condition=[list(ns["calculate_dimensions"](ns["CONDITION_IMAGE_SIZE"], w / h)) for w, h in sizes],
+                   vae=[list(ns["calculate_dimensions"](ns["VAE_IMAGE_SIZE"], w / h)) for w, h in sizes],
+                   prompt_2_images=template.format("".join(img_template.format(i + 1) for i in range(2)) + "make it snow"))
+    meta = dict(case=case, params_sha256=params_checksum(P), param_seed=1234, helpers=helpers,
+                reference="qwen_image_transformer.py:692-802 with a three-entry img_shapes via oracle/ref_shims.py; "
+                          "pipeline_qwen_image_edit.py:124-132 and pipeline_qwen_image_edit_plus.py:44-45,203-209,286-299 via ast")
+    np.savez_compressed(os.path.join(OUT, "dit_edit_plus_three_images_fp32.npz"), latents=lat.numpy(), prompt_embeds=txt.numpy(),
+                        sigma=sig.numpy(), noise_pred=out.float().numpy(), meta=json.dumps(meta))
+    print(f"dit_edit_plus_three_images_fp32: out {tuple(out.shape)} std {out.std():.4f}; helpers {helpers['vae']}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -280,6 +334,8 @@ def main():
         run_vae_encode_case()
     if only is None or "edit" in only:
         run_edit_case()
+    if only is None or "editplus" in only:
+        run_edit_plus_case()
 
 
 if __name__ == "__main__":

@@ -86,3 +86,67 @@ def test_edit_pipeline_matches_oracle_loop():
     img = pipe.generate([OmniDiffusionRequest(height=128, width=128, num_inference_steps=2, seed=3, prompt_embeds=pos.to(BF16),
                                               extra={"image": image})])[0].output
     assert img.shape == (1, 3, 128, 128) and torch.isfinite(img.float()).all()
+
+
+def test_three_image_sequence_forward_matches_reference_golden():
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+
+    z, meta, c = load_golden("dit_edit_plus_three_images_fp32")
+    P = golden_params(c)
+    m = QwenImageTransformer2DModel(num_layers=c["layers"], num_attention_heads=c["heads"], joint_attention_dim=c["joint"],
+                                    device=DEV)
+    m.load_weights(P.items())
+    out = m(hidden_states=torch.from_numpy(z["latents"]).to(DEV, BF16), encoder_hidden_states=torch.from_numpy(z["prompt_embeds"]).to(DEV, BF16),
+            timestep=torch.from_numpy(z["sigma"]).to(DEV), img_shapes=[[tuple(g) for g in c["grids"]]], txt_seq_lens=[c["T"]],
+            return_dict=False)[0]
+    torch.cuda.synchronize()
+    r = rel_l2(out, torch.from_numpy(z["noise_pred"]))
+    print(f"three-image sequence forward vs reference golden: {r:.3e}")
+    assert r <= 1.5e-2 and cosine(out, torch.from_numpy(z["noise_pred"])) >= 0.9995
+
+
+def test_edit_plus_pipeline_two_condition_images_matches_oracle_loop():
+    """Edit-Plus: two condition images of DIFFERENT sizes, each VAE-encoded and packed on its own, concatenated behind the
+    noise latents with their own RoPE frames (pipeline_qwen_image_edit_plus.py:440-464,729-738); two requests step-batched."""
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import AutoencoderKLQwenImage
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image_edit_plus import QwenImageEditPlusPipeline
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    heads, joint, layers = 2, 128, 2
+    P = O.make_dit_params(layers, seed=1234, bias_std=0.02, norm_jitter=0.1, num_heads=heads, joint_dim=joint)
+    m = QwenImageTransformer2DModel(num_layers=layers, num_attention_heads=heads, joint_attention_dim=joint, device=DEV)
+    m.load_weights(P.items())
+    vae = AutoencoderKLQwenImage(device=DEV, with_encoder=True)
+    Pe, Pd = O.make_vae_encoder_params(), O.make_vae_params()
+    vae.load_weights(list(Pe.items()) + list(Pd.items()))
+    pipe = QwenImageEditPlusPipeline(device=DEV, transformer=m, vae=vae)
+    g = torch.Generator().manual_seed(6)
+    images = [bf16_round(torch.rand(1, 3, 64, 96, generator=g) * 2 - 1),          # -> 4 x 6 tokens
+              bf16_round(torch.rand(1, 3, 96, 32, generator=g) * 2 - 1)]          # -> 6 x 2 tokens
+    Peb = {k: bf16_round(v) for k, v in Pe.items()}
+    cond = torch.cat([bf16_round(O.image_to_latents(Peb, im.unsqueeze(2))) for im in images], dim=1)     # [1, 24 + 12, 64]
+    grids = [(1, 8, 8), (1, 4, 6), (1, 6, 2)]
+    Pb = {k: bf16_round(v) for k, v in P.items()}
+    reqs, refs = [], []
+    for r_ in range(2):
+        lat = bf16_round(torch.randn(1, 64, 64, generator=g))
+        pos, neg = bf16_round(torch.randn(1, 9 + r_, joint, generator=g)), bf16_round(torch.randn(1, 5, joint, generator=g))
+        reqs.append(OmniDiffusionRequest(height=128, width=128, num_inference_steps=3, true_cfg_scale=4.0, latents=lat.to(BF16),
+                                         prompt_embeds=pos.to(BF16), negative_prompt_embeds=neg.to(BF16), output_type="latent",
+                                         extra={"image": images}))
+        ts, sig = O.flow_match_sigmas(3, 64)
+        x = lat.float()
+        for i, t in enumerate(ts):
+            s_in = (t.bfloat16() / 1000).bfloat16().float().expand(1)
+            inp = torch.cat([x, cond], dim=1)
+            p = O.dit_forward(Pb, inp, pos.float(), s_in, grids, num_heads=heads)[:, :64]
+            n = O.dit_forward(Pb, inp, neg.float(), s_in, grids, num_heads=heads)[:, :64]
+            x = bf16_round(O.euler_step(x, O.cfg_combine(p, n, 4.0), float(sig[i]), float(sig[i + 1])))
+        refs.append(x[0])
+    outs = pipe.generate(reqs, output_type="latent")
+    torch.cuda.synchronize()
+    for o, ref in zip(outs, refs):
+        r = rel_l2(o.output[0], ref)
+        print(f"edit-plus loop (2 condition images) final latent vs oracle: rel_l2 {r:.3e}")
+        assert r <= 2e-2

@@ -347,3 +347,22 @@ def test_transformer_weight_layout_switch_is_lossless_on_cpu_tensors():
     m._set_weight_layout(True)
     m.load_weights([(n, t) for n, t in before.items()])
     assert not m._w_blocked and all(torch.equal(p, before[n]) for n, p in m.named_parameters())
+
+
+def test_edit_plus_preprocess_arithmetic_and_prompt_template_match_reference():
+    """plan_image_sizes / edit_plus_prompt against values taken from the unmodified reference sources
+    (pipeline_qwen_image_edit.py:124-132, pipeline_qwen_image_edit_plus.py:44-45,203-209,286-299; oracle/gen_golden.py editplus)."""
+    from _util import load_golden
+    from vllm_omni_amd.diffusion.models.qwen_image import pipeline_qwen_image_edit_plus as EP
+    from vllm_omni_amd.diffusion.registry import resolve_model_cls
+
+    _, meta, _ = load_golden("dit_edit_plus_three_images_fp32")
+    h = meta["helpers"]
+    assert EP.CONDITION_IMAGE_SIZE == h["CONDITION_IMAGE_SIZE"] and EP.VAE_IMAGE_SIZE == h["VAE_IMAGE_SIZE"]
+    sizes = [tuple(s) for s in h["sizes"]]
+    plan = EP.plan_image_sizes(sizes)
+    assert [list(x) for x in plan["condition_image_sizes"]] == h["condition"]
+    assert [list(x) for x in plan["vae_image_sizes"]] == h["vae"]
+    assert [plan["width"], plan["height"]] == h["vae"][0]              # the output takes the first image's aspect ratio
+    assert EP.edit_plus_prompt("make it snow", 2) == h["prompt_2_images"]
+    assert resolve_model_cls("QwenImageEditPlusPipeline") is EP.QwenImageEditPlusPipeline

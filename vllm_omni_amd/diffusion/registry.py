@@ -12,9 +12,11 @@ _PKG = "vllm_omni_amd.diffusion.models"
 _DIFFUSION_MODELS = {
     "QwenImagePipeline": ("qwen_image", "pipeline_qwen_image", "QwenImagePipeline"),
     "QwenImageEditPipeline": ("qwen_image", "pipeline_qwen_image_edit", "QwenImageEditPipeline"),
+    "QwenImageEditPlusPipeline": ("qwen_image", "pipeline_qwen_image_edit_plus", "QwenImageEditPlusPipeline"),
 }
 _POST_PROCESS = {"QwenImagePipeline": "get_qwen_image_post_process_func",
-                 "QwenImageEditPipeline": "get_qwen_image_post_process_func"}
+                 "QwenImageEditPipeline": "get_qwen_image_post_process_func",
+                 "QwenImageEditPlusPipeline": "get_qwen_image_post_process_func"}
 _PRE_PROCESS: dict[str, str] = {}
 
 
