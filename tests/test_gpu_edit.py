@@ -150,3 +150,24 @@ def test_edit_plus_pipeline_two_condition_images_matches_oracle_loop():
         r = rel_l2(o.output[0], ref)
         print(f"edit-plus loop (2 condition images) final latent vs oracle: rel_l2 {r:.3e}")
         assert r <= 2e-2
+
+
+def test_vae_mid_attention_handles_token_counts_that_are_not_multiples_of_32():
+    """A 48 x 80 image has a 6 x 10 latent: 60 mid-block tokens (pad keys are masked: score -inf, V column 0)."""
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import AutoencoderKLQwenImage
+
+    vae = AutoencoderKLQwenImage(device=DEV, with_encoder=True)
+    Pe, Pd = O.make_vae_encoder_params(), O.make_vae_params()
+    vae.load_weights(list(Pe.items()) + list(Pd.items()))
+    g = torch.Generator().manual_seed(8)
+    image = bf16_round(torch.rand(1, 3, 1, 48, 80, generator=g) * 2 - 1)
+    mean = vae.encode(image.to(DEV, BF16))
+    ref = O.vae_encode({k: bf16_round(v) for k, v in Pe.items()}, image)
+    r_e = rel_l2(mean, ref)
+    z = bf16_round(torch.randn(1, 16, 1, 6, 10, generator=g) * 1.5)
+    img = vae.decode(z.to(DEV, BF16))[0]
+    torch.cuda.synchronize()
+    ref_d = O.vae_decode({k: bf16_round(v) for k, v in Pd.items()}, z)
+    r_d = rel_l2(img, ref_d)
+    print(f"60-token mid attention: encode rel_l2 {r_e:.3e}, decode rel_l2 {r_d:.3e}")
+    assert mean.shape == (1, 16, 1, 6, 10) and r_e <= 3e-2 and r_d <= 3e-2

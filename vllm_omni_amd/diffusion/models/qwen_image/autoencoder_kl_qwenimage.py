@@ -213,23 +213,30 @@ class AutoencoderKLQwenImage(nn.Module):
     def _attn_block(self, W, pre, x):
         B, H, Wd, Cc = x.shape
         tok = H * Wd
-        if tok % 32 or Cc % 64:
-            raise NotImplementedError("mid-block attention needs h*w to be a multiple of 32 and channels of 64")
+        if Cc % 64:
+            raise NotImplementedError("mid-block attention needs the channel count to be a multiple of 64")
+        # the P.V product contracts over the keys: its K dimension must be a multiple of 64 for the GEMM kernels.  Token
+        # counts that are not (e.g. a 352 x 352 image: 44 x 44 latent) get masked pad keys: score -inf, V^T column 0.
+        tokp = (tok + 63) // 64 * 64
         xn = ops.vae_rmsnorm_silu(x, W[pre + ".norm.gamma"], silu=False)
         wqkv = W[pre + ".to_qkv.weight"].reshape(3 * Cc, Cc)
         bqkv = W[pre + ".to_qkv.bias"]
         outs = []
         for b in range(B):
             t = xn[b].reshape(tok, Cc)
+            if tokp != tok:                                             # zero pad rows: V^T pad columns come out 0
+                t = torch.nn.functional.pad(t, (0, 0, 0, tokp - tok)).contiguous()
             q = ops.linear(t, wqkv[:Cc], bqkv[:Cc])
             k = ops.linear(t, wqkv[Cc:2 * Cc], bqkv[Cc:2 * Cc])
-            vt = ops.linear(wqkv[2 * Cc:].contiguous(), t)              # V^T [C, tok] (bias folded below)
+            vt = ops.linear(wqkv[2 * Cc:].contiguous(), t)              # V^T [C, tokp] (bias folded below)
             # query rows in chunks: the score buffer is [chunk, tok] bf16 (256 MiB at 1024^2, 1 GiB at 2048^2) instead
             # of [tok, tok] (512 MiB / 8.6 GB)
             o_b = torch.empty(tok, Cc, dtype=BF16, device=x.device)
             for r0 in range(0, tok, self.ATTN_Q_CHUNK):
                 r1 = min(tok, r0 + self.ATTN_Q_CHUNK)
-                s = ops.linear(q[r0:r1], k)                             # [chunk, tok] scores
+                s = ops.linear(q[r0:r1], k)                             # [chunk, tokp] scores
+                if tokp != tok:
+                    s[:, tok:] = float("-inf")                          # pad keys get probability 0
                 ops.softmax_rows_(s, 1.0 / math.sqrt(Cc))
                 ops.gemm([ops.GemmGroupArgs(s, vt, bqkv[2 * Cc:], o_b[r0:r1])])   # P V + b_v  (rows of P sum to 1)
             outs.append(o_b)
