@@ -366,3 +366,70 @@ def test_edit_plus_preprocess_arithmetic_and_prompt_template_match_reference():
     assert [plan["width"], plan["height"]] == h["vae"][0]              # the output takes the first image's aspect ratio
     assert EP.edit_plus_prompt("make it snow", 2) == h["prompt_2_images"]
     assert resolve_model_cls("QwenImageEditPlusPipeline") is EP.QwenImageEditPlusPipeline
+
+
+def test_diffusers_checkpoint_directory_loader(tmp_path):
+    """DiffusersPipelineLoader (role of reference model_loader/diffusers_loader.py:35-260) on a diffusers-layout directory:
+    sharded safetensors with an index, HF split q/k/v names stacked into the fused parameters, VAE from vae/, the scheduler
+    config applied, extra checkpoint tensors ignored, a missing tensor reported."""
+    import json
+
+    import qwen_image_oracle as O
+    from safetensors.torch import save_file
+
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.model_loader import DiffusersPipelineLoader
+
+    heads, joint, layers = 2, 128, 2
+    P = O.make_dit_params(layers, seed=7, bias_std=0.02, norm_jitter=0.1, num_heads=heads, joint_dim=joint)
+    D = heads * 128
+    hf = {}
+    for n, w in P.items():                                   # HF checkpoints store q / k / v separately
+        if ".to_qkv." in n:
+            for i, s_ in enumerate(("to_q", "to_k", "to_v")):
+                hf[n.replace("to_qkv", s_)] = w[i * D:(i + 1) * D].clone()
+        elif ".add_kv_proj." in n:
+            for i, s_ in enumerate(("add_q_proj", "add_k_proj", "add_v_proj")):
+                hf[n.replace("add_kv_proj", s_)] = w[i * D:(i + 1) * D].clone()
+        else:
+            hf[n] = w.clone()
+    names = sorted(hf)
+    root = tmp_path / "ckpt"
+    (root / "transformer").mkdir(parents=True)
+    (root / "vae").mkdir()
+    (root / "scheduler").mkdir()
+    shards = {"diffusion_pytorch_model-00001-of-00002.safetensors": names[: len(names) // 2],
+              "diffusion_pytorch_model-00002-of-00002.safetensors": names[len(names) // 2:]}
+    for f, ns in shards.items():
+        save_file({n: hf[n].to(torch.bfloat16) for n in ns}, str(root / "transformer" / f))
+    save_file({"stale": torch.zeros(1)}, str(root / "transformer" / "old_export.safetensors"))   # not named by the index
+    (root / "transformer" / "diffusion_pytorch_model.safetensors.index.json").write_text(
+        json.dumps({"weight_map": {n: f for f, ns in shards.items() for n in ns}}))
+    Pv = O.make_vae_params()
+    vae_sd = {n: w.to(torch.bfloat16) for n, w in Pv.items()}
+    assert any("time_conv" in n for n in vae_sd)             # 3-D-only tensors of the checkpoint: skipped by the 2-D VAE
+    save_file(vae_sd, str(root / "vae" / "diffusion_pytorch_model.safetensors"))
+    (root / "scheduler" / "scheduler_config.json").write_text(json.dumps(
+        {"base_shift": 0.5, "max_shift": 0.9, "base_image_seq_len": 256, "max_image_seq_len": 8192, "shift_terminal": 0.02,
+         "use_dynamic_shifting": True, "time_shift_type": "exponential", "num_train_timesteps": 1000}))
+    (root / "model_index.json").write_text(json.dumps({"_class_name": "QwenImagePipeline"}))
+
+    cfg = OmniDiffusionConfig(model=str(root))
+    kw = dict(transformer_kwargs=dict(num_layers=layers, num_attention_heads=heads, joint_attention_dim=joint))
+    pipe = DiffusersPipelineLoader().load_model(cfg, "cpu", **kw)
+    got = dict(pipe.transformer.named_parameters())
+    for n, w in P.items():
+        assert torch.equal(got[n].float(), w.to(torch.bfloat16).float()), n
+    for n in pipe.vae._shapes:
+        assert torch.equal(pipe.vae.params[pipe.vae._names[n]].float().cpu(), Pv[n].to(torch.bfloat16).float()), n
+    assert pipe.scheduler.config.max_image_seq_len == 8192 and pipe.scheduler.config.shift_terminal == 0.02
+    # a checkpoint that lacks a tensor is reported by name
+    os.remove(root / "transformer" / "diffusion_pytorch_model-00002-of-00002.safetensors")
+    (root / "transformer" / "diffusion_pytorch_model.safetensors.index.json").unlink()
+    with pytest.raises(KeyError, match="unexpected weight stale"):      # without the index the stray export is read too
+        DiffusersPipelineLoader().load_model(cfg, "cpu", **kw)
+    os.remove(root / "transformer" / "old_export.safetensors")
+    with pytest.raises(ValueError, match="not initialized from checkpoint"):
+        DiffusersPipelineLoader().load_model(cfg, "cpu", **kw)
+    with pytest.raises(FileNotFoundError):
+        DiffusersPipelineLoader().load_model(OmniDiffusionConfig(model="Qwen/Qwen-Image"), "cpu", **kw)

@@ -441,6 +441,13 @@ class QwenImagePipeline(nn.Module):
         """Reference entry point (:588-750): one request in, DiffusionOutput out."""
         return self.generate([req])[0]
 
+    def expected_weight_names(self) -> set[str]:
+        """Checkpoint names `load_weights` must see for a complete load (the loader's "weights not initialized" check,
+        reference diffusers_loader.py:247-258): the DiT's parameters under their fused names, the VAE's under the names of
+        the diffusers / vendored state dict."""
+        names = {"transformer." + n for n, _ in self.transformer.named_parameters()}
+        return names | {"vae." + n for n in self.vae._shapes}
+
     def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]) -> set[str]:
         """Names prefixed `transformer.` / `vae.` are routed to the sub-models (AutoWeightsLoader role, :752-754)."""
         tw, vw = [], []

@@ -33,10 +33,19 @@ class GPUWorker:
         self.rank, self.world, _ = dp.init_distributed(timeout_s=self.od_config.dist_timeout)
         if self.pipeline is None:
             if pipeline_factory is None:
-                from ..registry import initialize_model      # arch name -> pipeline class (reference registry.py:81-94)
+                import os
 
-                pipeline_factory = lambda: initialize_model(self.od_config,  # noqa: E731
-                                                            device=torch.device("cuda", self.local_rank))
+                dev = torch.device("cuda", self.local_rank)
+                if self.od_config.model and os.path.isdir(self.od_config.model):
+                    # a diffusers-layout checkpoint directory: registry class + weights from transformer/ and vae/
+                    # (reference gpu_worker.py:100-113 -> DiffusersPipelineLoader.load_model)
+                    from ..model_loader import DiffusersPipelineLoader
+
+                    pipeline_factory = lambda: DiffusersPipelineLoader().load_model(self.od_config, dev)  # noqa: E731
+                else:
+                    from ..registry import initialize_model  # arch name -> pipeline class (reference registry.py:81-94)
+
+                    pipeline_factory = lambda: initialize_model(self.od_config, device=dev)  # noqa: E731
             self.pipeline = pipeline_factory()
 
     def is_ready(self) -> bool:
