@@ -259,6 +259,7 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
   struct RowIdx { int ro[BATCH], im[BATCH], ps[BATCH]; };
   struct RowData { u32x4_t c[BATCH], g[BATCH], r[BATCH]; u32x2_t cw[BATCH], sw[BATCH]; int ro[BATCH]; };
   const int rsub = tid >> 5;
+  const bool v_tile = QKROPE && n0 >= 2 * P.split_n;      // the V third of the fused QKV output: no norm, no RoPE
   const float inv_rpi = 1.0f / (float)max(G.rows_per_item, 1);
   auto load_maps = [&](int b, RowIdx& x) {
     int mc[BATCH];
@@ -271,7 +272,7 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) x.ro[j] = G.out_row_map[mc[j]];
     }
-    if (QKROPE) {
+    if (QKROPE && !v_tile) {
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) x.ps[j] = G.qk_row_pos[mc[j]];     // RoPE table row of the LOGICAL row
     }
@@ -321,7 +322,8 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
         d.r[j] = *reinterpret_cast<const u32x4_t*>(G.res + (int64_t)x.ro[j] * G.ldres + n);
       }
       d.c[j] = *reinterpret_cast<const u32x4_t*>(lds_row + (b * BATCH + j) * 16 * EPI_LDS_STRIDE);
-      if (QKROPE) {       // cos / sin of the 4 rotation pairs this lane holds (sub = lane's 16-B chunk within its head)
+      if (QKROPE && which < 2) {   // cos / sin of the 4 rotation pairs this lane holds (sub = lane's 16-B chunk within its head);
+                                   // `which` is uniform over the workgroup (split_n is a multiple of the tile width): V tiles skip
         d.cw[j] = *reinterpret_cast<const u32x2_t*>(G.qk_rope_cos + (int64_t)x.ps[j] * 64 + (chunk & 15) * 4);
         d.sw[j] = *reinterpret_cast<const u32x2_t*>(G.qk_rope_sin + (int64_t)x.ps[j] * 64 + (chunk & 15) * 4);
       }
@@ -343,7 +345,7 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
       u32x4_t o = d0.c[j];
-      if (QKROPE) {
+      if (QKROPE && which < 2) {
         // identical arithmetic (and order) to qk_norm_rope_kernel on the bf16-rounded linear output
         float f[8], r8[8];
 #pragma unroll
@@ -351,10 +353,8 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
         const float cc[4] = {bf16_lo(d0.cw[j][0]), bf16_hi(d0.cw[j][0]), bf16_lo(d0.cw[j][1]), bf16_hi(d0.cw[j][1])};
         const float sn[4] = {bf16_lo(d0.sw[j][0]), bf16_hi(d0.sw[j][0]), bf16_lo(d0.sw[j][1]), bf16_hi(d0.sw[j][1])};
         qk_norm_rope_lane(f, qkw, cc, sn, G.qk_eps, r8);
-        if (which < 2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(r8[2 * e], r8[2 * e + 1]);
-        }
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(r8[2 * e], r8[2 * e + 1]);
       }
       if (EPI == OMNI_EPI_BIAS_GATE_RES) {
 #pragma unroll
