@@ -115,6 +115,13 @@ typedef struct {
                           * fetches whole 128-B lines instead of 16 half lines (the L1 request-slot limit).
                           * A one-time re-layout at weight-load time; occupies the struct's former padding. */
   omni_gemm_group g[2];
+  /* ABI v4 — optional split-K workspace (DEVICE, 16-byte aligned, caller-owned; NULL = never split).  When the launch has so
+   * few tiles that at least half of the CUs would idle (<= 128 tiles in <= 10 row tiles: a forward over one or two small images
+   * streams its N = 3072 weight panels through 36 workgroups), the K loop is split s ways (s <= 8), the fp32 partial tiles go to
+   * splitk_ws[s][M0 + M1][N] and a second kernel sums them in split order and runs the epilogue.  Needs
+   * s * (M0 + M1) * N <= splitk_ws_floats; results agree with the unsplit kernel to fp32 summation order. */
+  float* splitk_ws;
+  int64_t splitk_ws_floats;
 } omni_gemm_params;
 
 int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream);

@@ -449,3 +449,48 @@ def test_cfg_euler_step(with_neg):
     ops.cfg_euler_step_(ld, g_(pos), g_(neg) if with_neg else None, 4.0, dt.to(dev()), dt_rows_per_item=rows // 2)
     torch.cuda.synchronize()
     elem_close(ld, ref, "cfg_euler")
+
+
+@pytest.mark.parametrize("K,N", [(3072, 3072), (12288, 3072), (1024, 256)])
+def test_gemm_split_k_matches_the_unsplit_kernel(K, N):
+    """ABI v4 split-K (small grids: <= 64 tiles in <= 4 row tiles): fp32 partial tiles + a finishing kernel that sums them in
+    split order and runs the same row-coalesced epilogue.  Same products, different fp32 summation order than the single
+    pass: equal up to isolated one-ulp bf16 flips; deterministic from run to run.  Two groups, ragged M, gathered blocked A,
+    bias / GELU / in-place gated residual."""
+    from vllm_omni_amd import ops
+
+    Mi, Mt, R = 512, 75, 700
+    a = rnd((R, K), 31)
+    wi, wt, b = rnd((N, K), 32, 0.03), rnd((N, K), 33, 0.03), rnd((N,), 34, 0.5)
+    gate = g_(rnd((3, N), 35))
+    gi = torch.Generator().manual_seed(6)
+    map_i = torch.randperm(R, generator=gi)[:Mi].to(torch.int32).to(dev())
+    map_t = torch.randperm(R, generator=gi)[:Mt].to(torch.int32).to(dev())
+    item_i = (torch.arange(Mi) % 3).to(torch.int32).to(dev())
+    item_t = (torch.arange(Mt) % 3).to(torch.int32).to(dev())
+    A, Wi, Wt = ops.w_to_k32_blocked(g_(a)), ops.w_to_k32_blocked(g_(wi)), ops.w_to_k32_blocked(g_(wt))
+    ws = torch.empty(8 * (Mi + Mt) * N, dtype=torch.float32, device=dev())
+    res_i, res_t = g_(rnd((Mi, N), 36)), g_(rnd((Mt, N), 37))
+
+    def run(epi, splitk):
+        oi = res_i.clone() if epi == ops.EPI_BIAS_GATE_RES else torch.zeros(Mi, N, dtype=BF16, device=dev())
+        ot = res_t.clone() if epi == ops.EPI_BIAS_GATE_RES else torch.zeros(Mt, N, dtype=BF16, device=dev())
+        kw_i = dict(res=oi, gate=gate, gate_item_stride=N, row_item_map=item_i) if epi == ops.EPI_BIAS_GATE_RES else {}
+        kw_t = dict(res=ot, gate=gate, gate_item_stride=N, row_item_map=item_t) if epi == ops.EPI_BIAS_GATE_RES else {}
+        ops.gemm([ops.GemmGroupArgs(A, Wi, g_(b), oi, a_row_map=map_i, a_k32_blocked=True, **kw_i),
+                  ops.GemmGroupArgs(A, Wt, g_(b), ot, a_row_map=map_t, a_k32_blocked=True, **kw_t)], epi, w_k32_blocked=True,
+                 splitk_ws=ws if splitk else None)
+        torch.cuda.synchronize()
+        return oi, ot
+
+    for epi in (ops.EPI_BIAS, ops.EPI_BIAS_GELU_TANH, ops.EPI_BIAS_GATE_RES):
+        ws.fill_(float("nan"))                                  # every partial the finish reads must have been written
+        plain, split, again = run(epi, False), run(epi, True), run(epi, True)
+        for x, y, z in zip(plain, split, again):
+            assert torch.equal(y, z), "split-K is not deterministic"
+            d = (x.float() - y.float()).abs()
+            assert torch.isfinite(y.float()).all()
+            assert float((d > 0).float().mean()) <= 0.15 and float(d.norm() / x.float().norm()) <= 2e-3
+    ref = a[map_i.long().cpu()] @ wi.t() + b
+    assert rel_l2(run(ops.EPI_BIAS, True)[0], ref) <= 4e-3
+    assert not bool(torch.isnan(ws[: 2 * (Mi + Mt) * N]).any())   # at least two splits were written: the split path did run

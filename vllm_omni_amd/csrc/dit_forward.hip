@@ -18,6 +18,8 @@ struct Workspace {
   omni_bf16 *tproj, *th, *temb, *mod_img, *mod_txt, *emb_out;
   omni_bf16 *hidden_img, *hidden_txt, *xn, *txt_normed, *q, *k, *v, *attn, *mlp_h, *h_in;
   int32_t *img_pos, *txt_pos;   // RoPE table row of every image / text stream row (joint_pos gathered through the joint-row maps)
+  float* splitk;                // fp32 partial tiles of the split-K GEMMs (small batches only; include/omni_cdna4.h splitk_ws)
+  int64_t splitk_floats;
   size_t total;
 };
 
@@ -52,6 +54,11 @@ Workspace carve(void* base, const omni_dit_weights* w, int64_t Ri, int64_t Rt, i
   ws.h_in = take(Ri * D);           // image stream at block-stack entry (TeaCache residual / skip path)
   ws.img_pos = reinterpret_cast<int32_t*>(take(Ri * 2));
   ws.txt_pos = reinterpret_cast<int32_t*>(take(Rt * 2));
+  // split-K workspace of the GEMMs whose grid would leave half of the chip idle (include/omni_cdna4.h splitk_ws): up to 8
+  // splits x rows x D fp32 for a batch of at most four row tiles (63 MB for a CFG pair of 256x256 images), 2 splits up to ten
+  // row tiles (a CFG pair at 512x512: 53 MB); larger batches fill the chip without it
+  ws.splitk_floats = Rj <= 4 * 256 ? 8 * Rj * D : (Rj <= 10 * 256 ? 2 * Rj * D : 0);
+  ws.splitk = reinterpret_cast<float*>(take(ws.splitk_floats * 2));
   ws.total = off;
   return ws;
 }
@@ -141,6 +148,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.add_qkv_w; p.g[1].bias = L.add_qkv_b;
     p.g[1].out = ws.q; p.g[1].out1 = ws.k; p.g[1].out2 = ws.v; p.g[1].ldo = D; p.g[1].out_row_map = b->txt_joint_row;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
+    p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
   // per-head RMSNorm + RoPE on q and k (reference :397-410)
@@ -171,6 +179,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].res = hidden_txt; p.g[1].ldres = D; p.g[1].gate = ws.mod_txt + 2 * D; p.g[1].gate_item_stride = 6 * D;
     p.g[1].row_item_map = b->txt_item;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
+    p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
   // norm2 + modulate (reference :590, :595)
@@ -202,6 +211,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].out = hidden_txt; p.g[1].ldo = D; p.g[1].res = hidden_txt; p.g[1].ldres = D;
     p.g[1].gate = ws.mod_txt + 5 * D; p.g[1].gate_item_stride = 6 * D; p.g[1].row_item_map = b->txt_item;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
+    p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
   return OMNI_OK;
@@ -218,7 +228,7 @@ int prepare_positions(const omni_dit_batch* b, const Workspace& ws, omni_stream 
 }
 }  // namespace
 
-extern "C" int omni_abi_version(void) { return 3; }
+extern "C" int omni_abi_version(void) { return 4; }
 extern "C" const char* omni_build_arch(void) { return "gfx950"; }
 extern "C" const char* omni_status_string(int status) {
   switch (status) {
@@ -267,6 +277,7 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     p.ngroups = 1; p.N = D; p.K = w->joint_dim; p.epilogue = OMNI_EPI_BIAS;
     p.g[0].A = ws.txt_normed; p.g[0].lda = w->joint_dim; p.g[0].M = Rt;
     p.g[0].W = w->txt_in_w; p.g[0].bias = w->txt_in_b; p.g[0].out = ws.hidden_txt; p.g[0].ldo = D;
+    p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
 
@@ -307,6 +318,7 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     p.ngroups = 1; p.N = w->out_channels_packed; p.K = D; p.epilogue = OMNI_EPI_BIAS;
     p.g[0].A = xn_img; p.g[0].lda = D; p.g[0].M = Ri; p.g[0].W = w->proj_out_w; p.g[0].bias = w->proj_out_b;
     p.g[0].out = b->noise_pred; p.g[0].ldo = w->out_channels_packed;
+    p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
   return OMNI_OK;

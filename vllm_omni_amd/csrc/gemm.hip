@@ -245,9 +245,22 @@ OMNI_DEVINL void gemm_epilogue(const omni_gemm_params& P, const omni_gemm_group&
 constexpr int EPI_LDS_STRIDE = BN * 2 + 16;              // 528 B per C row in LDS
 constexpr int EPI_LDS_BYTES = BM * EPI_LDS_STRIDE;       // 132 KiB
 
-template <int EPI, typename WriteTile>
+// tag: phase 2 reads the bf16 C tile that phase 1 staged in LDS
+struct EpiFromLds {};
+// split-K finish (gemm_splitk_finish_kernel): phase 2 forms C = sum over the K-splits of the fp32 partial tiles (in split
+// order: deterministic) + bias (+ GELU), rounded to bf16 exactly where the fused kernel rounds (acc + bias -> bf16 in LDS)
+struct EpiFromPartials {
+  const float* ws;          // [nsplit][Mtot][N] fp32
+  int64_t split_stride;     // Mtot * N
+  int64_t row_base;         // first row of this group inside the Mtot rows
+  int nsplit;
+  int b_begin, b_end;       // row batches (64 rows each) of the tile this workgroup finishes
+};
+
+template <int EPI, typename WriteTile, typename CSrc = EpiFromLds>
 OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_gemm_group& G, int m0, int n0, char* smem,
-                                        int tid, WriteTile write_tile) {
+                                        int tid, WriteTile write_tile, CSrc csrc = CSrc{}) {
+  constexpr bool FROM_PARTIALS = std::is_same<CSrc, EpiFromPartials>::value;
   const int M = G.M, N = P.N;
   // Phase 2 moves rows in batches of 4 per thread: batch b = tile rows (4b+j)*16 + rsub.  Its pipeline is
   //   row-map loads (b+2)  |  residual/gate/LDS loads (b+1)  |  math + stores (b)
@@ -292,12 +305,16 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
     }
   };
   RowIdx x0, x1;
-  load_maps(0, x0);                      // in flight under phase 1
-  load_maps(1, x1);
+  int bb = 0, be = NBATCH;               // row batches of this workgroup (all four, except in the split-K finish)
+  if constexpr (FROM_PARTIALS) { bb = csrc.b_begin; be = csrc.b_end; }
+  load_maps(bb, x0);                     // in flight under phase 1
+  if (bb + 1 < be) load_maps(bb + 1, x1);
 
-  __builtin_amdgcn_s_barrier();          // every wave has finished reading the operand ring
-  write_tile();                          // accumulators (+ GELU) -> bf16 C tile in LDS, layout-specific
-  __syncthreads();
+  if (!FROM_PARTIALS) {
+    __builtin_amdgcn_s_barrier();        // every wave has finished reading the operand ring
+    write_tile();                        // accumulators (+ GELU) -> bf16 C tile in LDS, layout-specific
+    __syncthreads();
+  }
   const int chunk = tid & 31;
   const int n = n0 + chunk * 8;
   if (n >= N) return;
@@ -321,7 +338,29 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
         d.g[j] = *reinterpret_cast<const u32x4_t*>(G.gate + (int64_t)x.im[j] * G.gate_item_stride + n);
         d.r[j] = *reinterpret_cast<const u32x4_t*>(G.res + (int64_t)x.ro[j] * G.ldres + n);
       }
-      d.c[j] = *reinterpret_cast<const u32x4_t*>(lds_row + (b * BATCH + j) * 16 * EPI_LDS_STRIDE);
+      if constexpr (FROM_PARTIALS) {
+        const int64_t row = csrc.row_base + min(m0 + (b * BATCH + j) * 16 + rsub, M - 1);
+        const float* src = csrc.ws + row * N + n;
+        f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+        for (int sp = 0; sp < csrc.nsplit; ++sp) {
+          lo += *reinterpret_cast<const f32x4_t*>(src + sp * csrc.split_stride);
+          hi += *reinterpret_cast<const f32x4_t*>(src + sp * csrc.split_stride + 4);
+        }
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (G.bias) {
+          const u32x4_t bb = *reinterpret_cast<const u32x4_t*>(G.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_lo(bb[e]); v[2 * e + 1] += bf16_hi(bb[e]); }
+        }
+        if (EPI == OMNI_EPI_BIAS_GELU_TANH) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d.c[j][e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+      } else {
+        d.c[j] = *reinterpret_cast<const u32x4_t*>(lds_row + (b * BATCH + j) * 16 * EPI_LDS_STRIDE);
+      }
       if (QKROPE && which < 2) {   // cos / sin of the 4 rotation pairs this lane holds (sub = lane's 16-B chunk within its head);
                                    // `which` is uniform over the workgroup (split_n is a multiple of the tile width): V tiles skip
         d.cw[j] = *reinterpret_cast<const u32x2_t*>(G.qk_rope_cos + (int64_t)x.ps[j] * 64 + (chunk & 15) * 4);
@@ -337,11 +376,11 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
     for (int e = 0; e < 4; ++e) { qkw[2 * e] = bf16_lo(wv[e]); qkw[2 * e + 1] = bf16_hi(wv[e]); }
   }
   RowData d0, d1;
-  load_data(0, x0, d0);
+  load_data(bb, x0, d0);
 #pragma unroll 1
-  for (int b = 0; b < NBATCH; ++b) {
-    if (b + 1 < NBATCH) load_data(b + 1, x1, d1);
-    if (b + 2 < NBATCH) load_maps(b + 2, x1);
+  for (int b = bb; b < be; ++b) {
+    if (b + 1 < be) load_data(b + 1, x1, d1);
+    if (b + 2 < be) load_maps(b + 2, x1);
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
       u32x4_t o = d0.c[j];
@@ -848,15 +887,20 @@ constexpr int PBK = 64;
 constexpr int PSLOT_BYTES = 128 * PBK * 2;    // 16 KiB per half-tile
 constexpr int PLDS_BYTES = 8 * PSLOT_BYTES;   // 128 KiB ring
 
-template <int EPI>
+// NSPLIT > 1 (host: small grids, see launch()): split-K.  Workgroup b computes K-tiles [split * nkt, (split+1) * nkt) of
+// tile b / nsplit with split = b % nsplit and stores its fp32 accumulators to P.splitk_ws[split][row][col]; the epilogue runs
+// in gemm_splitk_finish_kernel.  A DiT forward over one or two 256x256 images has 36 workgroups in its N = 3072 GEMMs, each
+// streaming its 256 x K weight panel at the pace of one CU's k-loop (~1.2 us per K-tile): the weights arrive at ~1 TB/s.
+template <int EPI, int SPLITK = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
-                                                                     int tiles_n, int GROUP_M) {
+                                                                     int tiles_n, int GROUP_M, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
+  const int split = SPLITK ? (int)blockIdx.x % nsplit : 0;
+  const int bid = SPLITK ? (int)blockIdx.x / nsplit : (int)blockIdx.x;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   const int band_sz = GROUP_M * tiles_n;
@@ -896,9 +940,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   const int64_t astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * 128 : 128;
   const int64_t wstep = P.w_k32_blocked ? (int64_t)N * 128 : 128;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const int nkt = K / PBK;
-  const char* const Ab = reinterpret_cast<const char*>(G.A);
-  const char* const Wb = reinterpret_cast<const char*>(G.W);
+  const int nkt = SPLITK ? K / PBK / nsplit : K / PBK;             // K-tiles of this workgroup
+  const char* const Ab = reinterpret_cast<const char*>(G.A) + (SPLITK ? (int64_t)split * nkt * astep : 0);
+  const char* const Wb = reinterpret_cast<const char*>(G.W) + (SPLITK ? (int64_t)split * nkt * wstep : 0);
   // piece i (0 / 1) of half-tile h (compile time) of K-tile `tile`
 #define OMNI_PP_ISSUE_PIECE(h, tile, i)                                                                     \
   do {                                                                                                      \
@@ -948,7 +992,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   for (int nb = 0; nb < 4; ++nb) {
     const int n = n0 + wn * 64 + nb * 16 + g4 * 4;
     u32x2_t b = {0u, 0u};
-    if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
+    if (!SPLITK && G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);   // split-K: the finish adds the bias
     const f32x4_t bini = {bf16_lo(b[0]), bf16_hi(b[0]), bf16_lo(b[1]), bf16_hi(b[1])};
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = bini;
@@ -1108,12 +1152,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 #undef OMNI_PP_ISSUE_PIECE
 
 #if OMNI_PP_MFMA16
+  if (SPLITK) {
+    // fp32 partial tile: lane (l15, g4) holds C[mb*16 + l15][nb*16 + 4*g4 .. +4]: 16-B stores, 64 contiguous bytes per row
+    float* const wsp = P.splitk_ws + ((int64_t)split * (P.g[0].M + (P.ngroups > 1 ? P.g[1].M : 0)) + (gi ? P.g[0].M : 0)) * N;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const int row = m0 + wm * 128 + mb * 16 + l15;
+      if (row >= M) continue;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int col = n0 + wn * 64 + nb * 16 + g4 * 4;
+        if (col < N) *reinterpret_cast<f32x4_t*>(wsp + (int64_t)row * N + col) = acc[nb][mb];
+      }
+    }
+    return;
+  }
   gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l15, g4, smem, tid);
 #else
+  static_assert(!SPLITK, "split-K is built for the 16x16x32 accumulator layout");
   gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi, smem, tid);
 #endif
 }
 
+
+// Split-K finish: one workgroup per output tile (the same workgroup -> tile map as the ping-pong kernel), phase 2 of the
+// row-coalesced epilogue with C taken from the fp32 partials.
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_splitk_finish_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
+                                                                       int tiles_n, int GROUP_M, int nsplit) {
+  const int bid = blockIdx.x >> 2, quarter = blockIdx.x & 3;      // four workgroups per tile: 64 rows (one row batch) each
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int band_sz = GROUP_M * tiles_n;
+  const int band = lid / band_sz, in_band = lid - band * band_sz;
+  const int first_m = band * GROUP_M;
+  const int gm = min(GROUP_M, tiles_m - first_m);
+  const int mt = first_m + in_band % gm;
+  const int nt = in_band / gm;
+  const int gi = (mt >= mtiles0) ? 1 : 0;
+  const omni_gemm_group G = pick_group(P, gi);
+  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
+  const int n0 = nt * BN;
+  if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;
+  if (m0 + quarter * 64 >= G.M) return;
+  const int64_t mtot = P.g[0].M + (P.ngroups > 1 ? P.g[1].M : 0);
+  const EpiFromPartials src = {P.splitk_ws, mtot * P.N, gi ? (int64_t)P.g[0].M : 0, nsplit, quarter, quarter + 1};
+  gemm_epilogue_lds_impl<EPI>(P, G, m0, n0, nullptr, (int)threadIdx.x, []() {}, src);
+}
 
 #ifdef OMNI_DEV   // dev-only kernel families: two-phase ping-pong (variants 5 / 6: measured <= the four-phase kernel) and
                   // 4 waves x 128x128 (variant 2)
@@ -1583,6 +1669,29 @@ bool gemm_persistent() {
   return v != 0;
 }
 
+// Split-K factor for a launch of the ping-pong kernel, 1 = off.  On when the caller gave a workspace and the grid would leave
+// at least half of the chip idle (<= 128 tiles in <= 10 row tiles: a forward over one or two small images): the
+// largest s in {8, 6, 4, 3, 2} that divides the K-tile count, keeps tiles * s within one round of the CUs and fits the
+// workspace.  s depends on the TILE COUNTS only, so a batch and its sequence-parallel shards (fewer rows, same N and K)
+// take the same decision whenever both stay under the limits.
+int splitk_factor(const omni_gemm_params* p, int tiles_m, int tiles_n) {
+  static int knob = -1;                       // dev knob: OMNI_GEMM_SPLITK=0 disables
+  if (knob < 0) {
+    const char* e = getenv("OMNI_GEMM_SPLITK");
+    knob = e ? atoi(e) : 1;
+  }
+  if (!knob || !p->splitk_ws || p->splitk_ws_floats <= 0 || !OMNI_PP_MFMA16) return 1;
+  const int tiles = tiles_m * tiles_n;
+  if (tiles > 128 || tiles_m > 10 || (p->N % 4) != 0 || (reinterpret_cast<uintptr_t>(p->splitk_ws) & 15)) return 1;
+  const int nkt = p->K / PBK;
+  const int64_t mtot = p->g[0].M + (p->ngroups > 1 ? p->g[1].M : 0);
+  const int cus = gemm_num_cus();
+  for (int s : {8, 6, 4, 3, 2}) {
+    if (nkt % s == 0 && nkt / s >= 4 && tiles * s <= cus && (int64_t)s * mtot * p->N <= p->splitk_ws_floats) return s;
+  }
+  return 1;
+}
+
 template <int EPI>
 int launch(const omni_gemm_params* p, hipStream_t s) {
   const int mt0 = (p->g[0].M + BM - 1) / BM;
@@ -1608,6 +1717,8 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI, 0, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
     attr_set = true;
@@ -1638,9 +1749,19 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
 #endif
   if (false) {
   }
-  else if (gemm_variant() == 3 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p))
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
-                       tiles_n, gemm_group_m());
+  else if (gemm_variant() == 3 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
+    const int nsplit = splitk_factor(p, tiles_m, tiles_n);
+    if (nsplit > 1) {
+      hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, 1>), dim3(tiles_m * tiles_n * nsplit), dim3(NTHREADS), RLDS_BYTES, s, *p,
+                         mt0, tiles_m, tiles_n, gemm_group_m(), nsplit);
+      OMNI_CHECK_LAUNCH();
+      hipLaunchKernelGGL((gemm_splitk_finish_kernel<EPI>), dim3(tiles_m * tiles_n * 4), dim3(NTHREADS), 0, s, *p, mt0,
+                         tiles_m, tiles_n, gemm_group_m(), nsplit);
+    } else {
+      hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
+                         tiles_n, gemm_group_m(), 1);
+    }
+  }
   else if (epilogue_rows_coalescable(p)) {
     int grid = tiles_m * tiles_n;
     if (gemm_persistent() && grid > gemm_num_cus()) grid = gemm_num_cus() & ~7;

@@ -65,9 +65,14 @@ def w_to_k32_blocked(w: torch.Tensor) -> torch.Tensor:
 
 
 def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0, m_override: list[int] | None = None,
-         w_k32_blocked: bool = False):
-    """Y_g = epilogue(A_g @ W_g.T + bias_g) for up to two groups sharing N, K (omni_gemm_bf16)."""
+         w_k32_blocked: bool = False, splitk_ws: torch.Tensor | None = None):
+    """Y_g = epilogue(A_g @ W_g.T + bias_g) for up to two groups sharing N, K (omni_gemm_bf16).  `splitk_ws`: optional fp32
+    device workspace; with it, launches of at most 128 tiles in at most 10 row tiles split their K loop (ABI v4)."""
     p = N.GemmParams()
+    if splitk_ws is not None:
+        if splitk_ws.dtype != torch.float32 or not splitk_ws.is_cuda or not splitk_ws.is_contiguous():
+            raise N.OmniNativeError("splitk_ws must be a contiguous float32 GPU tensor")
+        p.splitk_ws, p.splitk_ws_floats = splitk_ws.data_ptr(), splitk_ws.numel()
     p.ngroups = len(groups)
     p.epilogue = epilogue
     p.split_n = split_n
