@@ -329,7 +329,7 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
     obase = reinterpret_cast<uint16_t*>(ob);
     ncol_out = n - which * P.split_n;
   }
-  const char* lds_row = smem + rsub * EPI_LDS_STRIDE + chunk * 16;
+  const char* lds_row = FROM_PARTIALS ? nullptr : smem + rsub * EPI_LDS_STRIDE + chunk * 16;
   auto load_data = [&](int b, const RowIdx& x, RowData& d) {
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
