@@ -193,6 +193,10 @@ def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
     pipe.od_config.max_step_batch = old_cap
     out["no_cfg_images_per_sec"] = 2 * R / t
     out["no_cfg_note"] = f"1024^2, 20 steps, 1 forward/step, {2 * R} requests step-batched, incl. VAE decode"
+    # latency of ONE 1024^2 request (true-CFG: a 2-item forward, 33 row tiles: the N = 3072 GEMMs fill 1.55 -> 2 rounds)
+    single = reqs(1, HEIGHT, STEPS_DENOISE, cfg=True)
+    t = timed(lambda: pipe.decode_latents(pipe.generate(single, output_type="latent")[0].output, HEIGHT, WIDTH))
+    out["single_request_1024px_seconds_per_image"] = t
     # BASELINE config 1 at real depth: 256x256, 4 steps, batch 1, true-CFG; eager launches vs hipGraph replay
     one = reqs(1, 256, 4, cfg=True)
     for name, flag in (("eager", False), ("hipgraph", True)):
