@@ -99,6 +99,10 @@ typedef struct {
                              * omni_gemm_params.w_k32_blocked, for activations produced by this library's own kernels */
   int32_t out_k32_rows;     /* 0: out is row-major [*, ldo].  R > 0: out is written K32-blocked [N/32][R][32] (ldo
                              * ignored; BIAS / BIAS_GELU_TANH epilogues only) so that the next GEMM can read it blocked */
+  float qk_q_scale;         /* SPLIT3_QKNORM_ROPE only, ABI v5 (occupies former padding): 0 or 1 = off; otherwise the q block is
+                             * additionally multiplied by this factor in fp32 BEFORE its single bf16 rounding (folded into the
+                             * RMSNorm weight).  omni_dit_forward passes softmax_scale * log2(e), so that the attention kernel's
+                             * QK^T accumulator is the exp2 argument directly (csrc/attention.hip OMNI_ATTN_BAKE) */
   const int32_t* tile_skip; /* nullable DEVICE array, one int32 per 256-row tile of this group: non-zero = the workgroups of
                              * that row tile return at once (its rows belong to items whose block stack is skipped this
                              * forward, omni_teacache).  A device-side predicate: no host round trip.  ABI v3. */

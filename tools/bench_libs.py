@@ -16,7 +16,7 @@ sys.path.insert(0, os.getcwd())
 from vllm_omni_amd import ops
 from tools.bench_kernels import timeit
 dev = torch.device("cuda:0"); g = torch.Generator(device=dev).manual_seed(0)
-H, S, B = 24, 4160, 6
+H, S, B = 24, 4160, int(os.environ.get("AB_ATTN_B", "6"))
 q, k, v = ((torch.randn(B * S, H * 128, device=dev, generator=g)).to(torch.bfloat16) for _ in range(3))
 cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
 o = ops.flash_attn_varlen(q, k, v, cu, H, S, 1 / math.sqrt(128))

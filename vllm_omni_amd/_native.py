@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OMNI_CDNA4_LIB", os.path.join(_HERE, "libomni_cdna4.so"))   # env override: dev sweeps
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_bf16_p = C.c_void_p  # device pointer to uint16_t bf16 bits
 c_i32_p = C.c_void_p
@@ -34,7 +34,7 @@ class GemmGroup(C.Structure):
         ("row_item_map", c_i32_p), ("rows_per_item", C.c_int32),
         ("qk_norm_q_w", c_bf16_p), ("qk_norm_k_w", c_bf16_p), ("qk_rope_cos", c_bf16_p), ("qk_rope_sin", c_bf16_p),
         ("qk_row_pos", c_i32_p), ("qk_eps", C.c_float),
-        ("a_k32_rows", C.c_int32), ("out_k32_rows", C.c_int32),
+        ("a_k32_rows", C.c_int32), ("out_k32_rows", C.c_int32), ("qk_q_scale", C.c_float),      # qk_q_scale: ABI v5
         ("tile_skip", c_i32_p),
     ]
 

@@ -371,6 +371,12 @@ OMNI_DEVINL float xhalf_sum(float x) {
 #ifndef OMNI_ATTN_PKFMA
 #define OMNI_ATTN_PKFMA 0   // 1: v_pk_fma_f32 from inline asm for the exponent argument (measured -3 %: pair set-up moves)
 #endif
+#ifndef OMNI_ATTN_BAKE
+#define OMNI_ATTN_BAKE 1  // 1: Q is pre-scaled by softmax_scale*log2(e) (by the QKV GEMM epilogue, or in this kernel's prologue)
+                          // and the first MFMA of every S chain takes C = -m_run (a 16-register splat, rewritten only on the
+                          // rare rescale path) instead of 0: the accumulator then IS the exp2 argument s~ - m~, and the 32
+                          // v_fma per wave and tile that formed it are gone (the loop is bound by per-wave instruction issue)
+#endif
 #ifndef OMNI_ATTN_ABL
 #define OMNI_ATTN_ABL 0   // dev-only timing ablations (wrong results): 1 no DMA wait, 2 no barrier, 4 no DMA, 8 no exp, 16 no LDS reads
 #endif
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
     const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e, int out_k32_rows,
-    int block_order, const int32_t* __restrict__ item_skip) {
+    int block_order, const int32_t* __restrict__ item_skip, int q_prescaled) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -444,6 +450,17 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     const uint16_t* qp = q + (int64_t)(seq_start + qrow) * ldq + h * DH + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[bq][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+    if (OMNI_ATTN_BAKE && !q_prescaled) {
+      // callers outside the fused DiT block hand over the reference's un-scaled q: Q~ = bf16(q * scale * log2 e) here (one
+      // extra bf16 rounding of q; the fused QKV epilogue folds the factor into its fp32 RMSNorm weight instead)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        u32x4_t w = __builtin_bit_cast(u32x4_t, qf[bq][ks]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(bf16_lo(w[e]) * scale_log2e, bf16_hi(w[e]) * scale_log2e);
+        qf[bq][ks] = __builtin_bit_cast(bf16x8_t, w);
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[bq][ks]));   // see flash_attn_fwd_kernel: no rematerialisation
   }
@@ -502,14 +519,17 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
 
   f32x16_t o[NQ][4];
   float m_run[NQ], l_run[NQ];
+  f32x16_t negm16[NQ];       // OMNI_ATTN_BAKE: -m_run (exp2 domain) in all 16 registers = the C operand that opens an S chain
 #pragma unroll
   for (int bq = 0; bq < NQ; ++bq) {
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[bq][d][i] = 0.0f;
-    m_run[bq] = -INFINITY;
+    m_run[bq] = OMNI_ATTN_BAKE ? 0.0f : -INFINITY;     // BAKE: m_run holds -m~ (what negm16 is a splat of); tile 0 always rescales
     l_run[bq] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm16[bq][i] = 0.0f;
   }
 
   bf16x8_t kf[4];
@@ -526,7 +546,8 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     _Pragma("unroll") for (int bq_ = 0; bq_ < NQ; ++bq_)                                          \
-      SN[bq_][(i) >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[(i) & 3], qf[bq_][(i) & 7], SN[bq_][(i) >> 3], 0, 0, 0); \
+      SN[bq_][(i) >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[(i) & 3], qf[bq_][(i) & 7],               \
+                              (OMNI_ATTN_BAKE && ((i) & 7) == 0) ? negm16[bq_] : SN[bq_][(i) >> 3], 0, 0, 0);          \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     if ((i) + 4 < 16) OMNI_KREAD((i) + 4, kst);                                                  \
     CHUNK;                                                                                       \
@@ -573,7 +594,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
   __syncthreads();
   f32x16_t sA[NQ][2], sB[NQ][2];
   float mxA[NQ], mxB[NQ];
-  zero_s(sA);
+  if (!OMNI_ATTN_BAKE) zero_s(sA);
   OMNI_QK_ALL(sA, 0, OMNI_NOCHUNK);
   if (KVBLK > seq_len) mask_tail(sA, 0);
 #pragma unroll
@@ -618,6 +639,27 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     uint32_t pfu[NQ][2][2][4];
 #pragma unroll
     for (int bq = 0; bq < NQ; ++bq) {
+      if (OMNI_ATTN_BAKE) {
+        // SC already holds s~ - m~ (m~ = the running max when its chain was opened) and mxc is its row max: the rescale is
+        // needed only when that exceeds the defer threshold.  Tile 0 opened its chain with C = 0: it always "rescales"
+        // (o = l = 0), which sets the first max — also when every score of the tile is far below zero.
+        if (t == 0 || !__all(mxc[bq] <= DEFER)) {
+          const float d = t == 0 ? mxc[bq] : fmaxf(mxc[bq], 0.0f);
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          l_run[bq] *= alpha;
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[bq][dd][i] *= alpha;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) SC[bq][j][i] -= d;
+          m_run[bq] -= d;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) negm16[bq][i] = m_run[bq];
+        }
+      } else {
       if (!__all((mxc[bq] - m_run[bq]) * scale_log2e <= DEFER)) {
         const float m_new = fmaxf(m_run[bq], mxc[bq]);
         const float alpha = __builtin_amdgcn_exp2f((m_run[bq] - m_new) * scale_log2e);
@@ -630,6 +672,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
       }
       const float mneg = -m_run[bq] * scale_log2e;
       mneg2[bq][0] = mneg; mneg2[bq][1] = mneg;
+      }
       psum2[bq][0] = 0.0f; psum2[bq][1] = 0.0f;
     }
     // exp chunk i: S elements (flat index over j, r) 2i and 2i+1 -> one packed bf16 pair of P.  The sum / pack of chunk i
@@ -656,7 +699,8 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
       /* packed fp32: S elements 2i, 2i+1 are an aligned register pair */                                        \
       const f32x2_t x_ = {SC[bq_][(i) >> 3][(2 * (i)) & 15], SC[bq_][(i) >> 3][((2 * (i)) & 15) + 1]};             \
       f32x2_t y_;                                                                                                \
-      if (OMNI_ATTN_PKFMA) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y_) : "v"(x_), "v"(scale2), "v"(mneg2[bq_])); \
+      if (OMNI_ATTN_BAKE) y_ = x_;                                                                               \
+      else if (OMNI_ATTN_PKFMA) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y_) : "v"(x_), "v"(scale2), "v"(mneg2[bq_])); \
       else y_ = __builtin_elementwise_fma(x_, scale2, mneg2[bq_]);                                               \
       e_[bq_][0] = __builtin_amdgcn_exp2f(y_[0]);                                                                \
       e_[bq_][1] = __builtin_amdgcn_exp2f(y_[1]);                                                                \
@@ -666,7 +710,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
     _Pragma("unroll") for (int bq_ = 0; bq_ < NQ; ++bq_) pend[bq_] = e_[bq_];                                     \
   } while (0)
     if (has_next) {
-      zero_s(SN);
+      if (!OMNI_ATTN_BAKE) zero_s(SN);
       if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(1);
       OMNI_QK_ALL(SN, (PAR ^ 1), OMNI_EXP_CHUNK);      // K(t+1) lives in stage (t+1) & 1
       if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(0);
@@ -1290,7 +1334,7 @@ int attn_pipe_waves(int n_heads_total, int max_seqlen) {
 template <int NW, int NQ = 1, int PP = 0>
 int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
                 int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
-                float softmax_scale, int out_k32_rows, hipStream_t s, const int32_t* item_skip = nullptr) {
+                float softmax_scale, int out_k32_rows, hipStream_t s, const int32_t* item_skip = nullptr, int q_prescaled = 0) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe_kernel<NW, NQ, PP>),
@@ -1301,7 +1345,8 @@ int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
   const int qblocks = (max_seqlen + 32 * NW * NQ - 1) / (32 * NW * NQ);
   const int nh = B * H;
   hipLaunchKernelGGL((flash_attn_fwd_pipe_kernel<NW, NQ, PP>), dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
-                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows, attn_block_order(), item_skip);
+                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows, attn_block_order(), item_skip,
+                     q_prescaled);
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }
@@ -1373,7 +1418,7 @@ extern "C" void omni_dev_attn_set_block_order(int v) { g_attn_block_order = v; }
 int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq,
                              int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H,
                              int32_t head_dim, int32_t max_seqlen, float softmax_scale, int32_t out_k32_rows,
-                             const int32_t* item_skip, void* stream) {
+                             const int32_t* item_skip, int32_t q_prescaled, void* stream) {
   if (!q || !k || !v || !out || !cu_seqlens || B <= 0 || H <= 0 || max_seqlen <= 0 || out_k32_rows < 0)
     return OMNI_ERR_BAD_ARG;
   if (head_dim != DH) return OMNI_ERR_UNSUPPORTED;
@@ -1382,6 +1427,7 @@ int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_
     return OMNI_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
 #ifdef OMNI_DEV
+  if (q_prescaled && (!attn_pipelined() || attn_mfma_shape() == 16 || !OMNI_ATTN_BAKE)) return OMNI_ERR_UNSUPPORTED;
   if (!attn_pipelined()) {
     if (out_k32_rows) return OMNI_ERR_UNSUPPORTED;   // only the pipelined kernel writes the blocked layout
     if (attn_variant() == 1)
@@ -1389,18 +1435,20 @@ int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_
     return launch_attn<2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
   }
   if (attn_variant() == 2)   // OMNI_ATTN_NQ=2: 4 waves x 64 queries, one wave per SIMD (spills as compiled by hipcc)
-    return launch_pipe<4, 2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
+    return launch_pipe<4, 2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip, q_prescaled);
   if (attn_mfma_shape() == 16) {
     if (attn_pipe_waves(B * H, max_seqlen) == 8)
       return launch_pipe16<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
     return launch_pipe16<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
   }
   if (attn_pipe_waves(B * H, max_seqlen) == 8 && attn_pingpong())
-    return launch_pipe<8, 1, 1>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
+    return launch_pipe<8, 1, 1>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip, q_prescaled);
 #endif
   if (attn_pipe_waves(B * H, max_seqlen) == 8)
-    return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
-  return launch_pipe<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
+    return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip,
+                          q_prescaled);
+  return launch_pipe<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip,
+                        q_prescaled);
 }
 
 extern "C" int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
@@ -1408,7 +1456,7 @@ extern "C" int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, co
                                       int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
                                       int32_t out_k32_rows, omni_stream stream) {
   return omni_internal_flash_attn(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, head_dim, max_seqlen, softmax_scale,
-                                  out_k32_rows, nullptr, stream);
+                                  out_k32_rows, nullptr, 0, stream);
 }
 
 extern "C" int omni_flash_attn_fwd(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,

@@ -102,11 +102,12 @@ static inline bool omni_aligned16(const void* p) { return (reinterpret_cast<uint
 // internal (not part of the C-ABI): dst[i] = src[idx[i]] for int32 maps; used by omni_dit_forward
 int omni_internal_gather_i32(int32_t* dst, const int32_t* src, const int32_t* idx, int32_t n, void* stream);
 
-// internal: flash attention with a per-item device predicate (item_skip[b] != 0 -> the item's blocks return at once)
+// internal: flash attention with a per-item device predicate (item_skip[b] != 0 -> the item's blocks return at once);
+// q_prescaled = 1: q already carries softmax_scale * log2(e) (omni_gemm_group.qk_q_scale of the fused QKV epilogue)
 int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq,
                              int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H,
                              int32_t head_dim, int32_t max_seqlen, float softmax_scale, int32_t out_k32_rows,
-                             const int32_t* item_skip, void* stream);
+                             const int32_t* item_skip, int32_t q_prescaled, void* stream);
 // internal: TeaCache device-side decision / residual kernels (elementwise.hip), used by omni_dit_forward
 int omni_internal_teacache_decide(const omni_teacache* tc, const omni_bf16* mod, int32_t n_items, int32_t rows_per_item,
                                   int32_t n_img_rows, int32_t n_txt_rows, int32_t D, int32_t blocked, void* stream);

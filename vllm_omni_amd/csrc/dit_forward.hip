@@ -116,6 +116,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   omni_bf16* h_txt = ws.mlp_h + (int64_t)Ri * 4 * D;
   const float sm_scale = 1.0f / sqrtf((float)w->head_dim);
   const bool fuse_qkrope = dit_fuse_qkrope();
+  const bool q_prescale = fuse_qkrope && phase == BLOCK_ALL;
   const bool blk = dit_act_blocked() && (D % 32 == 0);
   const int32_t bRi = blk ? Ri : 0, bRt = blk ? Rt : 0, bRj = blk ? Ri + Rt : 0;
   // modulation vectors [shift1|scale1|gate1|shift2|scale2|gate2]  (reference :552-561)
@@ -140,6 +141,9 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
       p.g[1].qk_norm_q_w = L.norm_added_q_w; p.g[1].qk_norm_k_w = L.norm_added_k_w; p.g[1].qk_row_pos = ws.txt_pos;
       for (int g = 0; g < 2; ++g) {
         p.g[g].qk_rope_cos = b->rope_cos; p.g[g].qk_rope_sin = b->rope_sin; p.g[g].qk_eps = eps;
+        // the whole-block path hands q to the attention kernel pre-multiplied by softmax_scale * log2(e) (one rounding, as
+        // before); a sequence-parallel caller (BLOCK_QKV) gets the reference's un-scaled q back
+        if (q_prescale) p.g[g].qk_q_scale = sm_scale * 1.4426950408889634f;
       }
     }
     p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt;
@@ -161,7 +165,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   if (phase == BLOCK_QKV) return OMNI_OK;
   // joint attention (reference :437-443 -> attention/backends/sdpa.py:46-66)
   OMNI_TRY(omni_internal_flash_attn(ws.q, ws.k, ws.v, ws.attn, D, D, D, D, b->cu_seqlens, b->n_items, w->num_heads,
-                                    w->head_dim, b->max_seqlen, sm_scale, bRj, pr.item, stream));
+                                    w->head_dim, b->max_seqlen, sm_scale, bRj, pr.item, q_prescale ? 1 : 0, stream));
   }  // phase != BLOCK_POST
   const omni_bf16* attn_src = phase == BLOCK_POST ? attn_in : ws.attn;
   const int32_t attn_k32 = phase == BLOCK_POST ? 0 : bRj;       // a caller-provided attention output is row-major
@@ -228,7 +232,7 @@ int prepare_positions(const omni_dit_batch* b, const Workspace& ws, omni_stream 
 }
 }  // namespace
 
-extern "C" int omni_abi_version(void) { return 4; }
+extern "C" int omni_abi_version(void) { return 5; }
 extern "C" const char* omni_build_arch(void) { return "gfx950"; }
 extern "C" const char* omni_status_string(int status) {
   switch (status) {

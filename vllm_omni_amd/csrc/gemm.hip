@@ -154,7 +154,7 @@ OMNI_DEVINL omni_gemm_group pick_group(const omni_gemm_params& P, int gi) {
   OMNI_PICK(gate); OMNI_PICK(gate_item_stride); OMNI_PICK(row_item_map); OMNI_PICK(rows_per_item);
   OMNI_PICK(a_k32_rows); OMNI_PICK(out_k32_rows);
   OMNI_PICK(qk_norm_q_w); OMNI_PICK(qk_norm_k_w); OMNI_PICK(qk_rope_cos); OMNI_PICK(qk_rope_sin); OMNI_PICK(qk_row_pos);
-  OMNI_PICK(qk_eps); OMNI_PICK(tile_skip);
+  OMNI_PICK(qk_eps); OMNI_PICK(qk_q_scale); OMNI_PICK(tile_skip);
 #undef OMNI_PICK
   return G;
 }
@@ -374,6 +374,10 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
     const u32x4_t wv = *reinterpret_cast<const u32x4_t*>((which == 1 ? G.qk_norm_k_w : G.qk_norm_q_w) + (chunk & 15) * 8);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { qkw[2 * e] = bf16_lo(wv[e]); qkw[2 * e + 1] = bf16_hi(wv[e]); }
+    if (which == 0 && G.qk_q_scale != 0.0f) {      // q pre-multiplied for the attention kernel (omni_gemm_group.qk_q_scale)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qkw[e] *= G.qk_q_scale;
+    }
   }
   RowData d0, d1;
   load_data(bb, x0, d0);

@@ -113,6 +113,12 @@ class DiffusersPipelineLoader:
         if os.path.isfile(sched) and hasattr(model, "scheduler"):
             with open(sched) as fh:
                 apply_scheduler_config(model.scheduler, json.load(fh))
+        # prompt encoder: built when the checkpoint carries one (the reference always loads it, pipeline_qwen_image.py:
+        # 225-228); without it requests must bring prompt_embeds
+        if hasattr(model, "load_text_encoder") and getattr(model, "text_encoder", None) is None and \
+                os.path.isdir(os.path.join(od_config.model, "text_encoder")) and \
+                os.path.isdir(os.path.join(od_config.model, "tokenizer")):
+            model.load_text_encoder(od_config.model, device=load_device)
         return model.eval() if hasattr(model, "eval") else model
 
 

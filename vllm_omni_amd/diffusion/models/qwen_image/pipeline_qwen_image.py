@@ -214,6 +214,7 @@ class QwenImagePipeline(nn.Module):
             for i in range(len(timesteps)):
                 step(sig_in[i:i + 1], dt_dev[i:i + 1])
             return list(lat.clone().view(R, S, -1).unbind(0))
+        tr._native_weights()      # (re)build the pointer table NOW: `_native_gen` then names the storages a replay would read
         if st["graph"] is None or st.get("gen") != tr._native_gen:
             # warm-up on a side stream (lazy initialisation inside the native library: function attributes, workspace),
             # then capture; the warm-up step advances `lat`, so the real inputs are restored afterwards
@@ -266,24 +267,43 @@ class QwenImagePipeline(nn.Module):
         width = req.width or self.default_sample_size * self.vae_scale_factor
         steps = req.num_inference_steps or 50
         cfg = req.true_cfg_scale or 4.0
-        if req.prompt is not None and req.prompt_embeds is not None:
-            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one of the two.")
+        # A request that carries BOTH a prompt string and pre-computed embeddings is served from the embeddings (the prompt
+        # is then metadata for the output record): the entry point `OmniDiffusion.generate(prompt, prompt_embeds=...)` always
+        # sets `prompt`, so the reference's either-or check (:300-307) would make embeddings unusable through it.
         if req.prompt is None and req.prompt_embeds is None:
             raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
         if req.prompt is not None and not isinstance(req.prompt, (str, list)):
             raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(req.prompt)}")
         if req.negative_prompt is not None and req.negative_prompt_embeds is not None:
             raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`.")
-        if req.prompt is not None and self.text_encoder is None:
-            raise NotImplementedError("this pipeline was built without a text encoder: pass prompt_embeds, or construct it "
-                                      "with text_encoder= / load one with load_text_encoder()")
+        if req.prompt is not None and req.prompt_embeds is None and self.text_encoder is None:
+            raise NotImplementedError("this pipeline was built without a text encoder: pass prompt_embeds, construct it with "
+                                      "text_encoder=, or call load_text_encoder(checkpoint_dir)")
         if (req.num_outputs_per_prompt or 1) < 1:
             raise ValueError("num_outputs_per_prompt must be >= 1")
-        if req.prompt is not None:
+        if req.prompt is not None and req.prompt_embeds is None:
             has_neg = True                       # negative_prompt defaults to "" in the reference's forward (:591-592)
         else:
             has_neg = req.negative_prompt_embeds is not None or req.negative_prompt is not None
         return height, width, steps, cfg, (cfg > 1 and has_neg)
+
+    def load_text_encoder(self, model_dir: str, device=None) -> None:
+        """Build the prompt encoder from the `text_encoder/` + `tokenizer/` folders of a diffusers-layout checkpoint
+        (reference :225-228,261: `Qwen2_5_VLForConditionalGeneration.from_pretrained(model, subfolder="text_encoder")`,
+        `Qwen2Tokenizer.from_pretrained(model, subfolder="tokenizer")`), local files only."""
+        import os
+
+        from transformers import AutoTokenizer, Qwen2_5_VLForConditionalGeneration
+
+        from .text_encoder import QwenPromptEncoder
+
+        te_dir, tok_dir = os.path.join(model_dir, "text_encoder"), os.path.join(model_dir, "tokenizer")
+        if not (os.path.isdir(te_dir) and os.path.isdir(tok_dir)):
+            raise FileNotFoundError(f"{model_dir!r} has no text_encoder/ + tokenizer/ folders")
+        dev = torch.device(device if device is not None else self.device)
+        model = Qwen2_5_VLForConditionalGeneration.from_pretrained(te_dir, torch_dtype=BF16, local_files_only=True).to(dev).eval()
+        tok = AutoTokenizer.from_pretrained(tok_dir, local_files_only=True)
+        self.text_encoder = QwenPromptEncoder(model, tok, dtype=BF16)
 
     def encode_prompt(self, prompt, num_images_per_prompt: int = 1, prompt_embeds=None, prompt_embeds_mask=None,
                       max_sequence_length: int = 1024):
@@ -305,6 +325,10 @@ class QwenImagePipeline(nn.Module):
                                                                     device=self.device)
         if embeds.dim() == 2:
             embeds = embeds.unsqueeze(0)
+        if mask is not None:
+            mask = mask.reshape(embeds.shape[0], -1)         # [T] with [T, D] / [1, T, D] embeds -> [1, T]
+            if mask.shape[1] != embeds.shape[1]:
+                raise ValueError(f"prompt_embeds_mask {tuple(mask.shape)} does not match prompt_embeds {tuple(embeds.shape)}")
         rows = []
         for b in range(embeds.shape[0]):
             t = int(mask[b].sum()) if mask is not None else embeds.shape[1]
@@ -319,6 +343,8 @@ class QwenImagePipeline(nn.Module):
         pos = self._rows_of(req.prompt_embeds, req.prompt_embeds_mask, req.prompt, n)
         neg = None
         if do_cfg:
+            if req.negative_prompt_embeds is None and self.text_encoder is None:
+                raise NotImplementedError("true-CFG needs negative_prompt_embeds (no text encoder is loaded)")
             neg_prompt = req.negative_prompt if req.negative_prompt is not None else ""
             if isinstance(neg_prompt, str) and req.negative_prompt_embeds is None:
                 neg_prompt = [neg_prompt] * (len(pos) // n)

@@ -15,7 +15,6 @@ There is no eager/PyTorch fallback: without libomni_cdna4.so or off-GPU, forward
 from __future__ import annotations
 
 import ctypes as C
-import os
 from collections.abc import Iterable
 
 import torch
@@ -280,7 +279,7 @@ class QwenImageTransformer2DModel(nn.Module):
             blk.layer_idx, blk._model_ref = i, weakref.ref(self)
         self.teacache = None         # TeaCacheConfig when the native TeaCache path is enabled (cache/teacache/backend.py)
         self._native = None        # (DitWeights struct, keep-alive list)
-        self._native_gen = 0       # bumped whenever the pointer table is rebuilt (captured hipGraphs must be re-captured)
+        self._native_gen = 0       # bumped whenever the pointer table is invalidated (captured hipGraphs must be re-captured)
         self._w_blocked = False    # the 8 big matrices per layer currently hold the K32-blocked re-layout
         self._workspace = None
         self._batch_cache: dict = {}
@@ -298,6 +297,13 @@ class QwenImageTransformer2DModel(nn.Module):
                         blk.img_mlp.net[0].proj.weight, blk.img_mlp.net[2].weight,
                         blk.txt_mlp.net[0].proj.weight, blk.txt_mlp.net[2].weight)
 
+    def _invalidate_native(self) -> None:
+        """Drop the cached raw-pointer table.  The generation counter moves NOW (not when the table is lazily rebuilt), so
+        that anything holding device addresses of the old storages — a captured hipGraph in the pipeline — is seen as stale
+        before it can be replayed."""
+        self._native = None
+        self._native_gen += 1
+
     def _set_weight_layout(self, blocked: bool) -> None:
         """In-place (one matrix of scratch) switch between the reference's row-major [out, in] and the K32-blocked order
         [in/32][out][32] the ring GEMM's LDS-DMA reads in whole cache lines (include/omni_cdna4.h).  Parameters are in
@@ -312,7 +318,7 @@ class QwenImageTransformer2DModel(nn.Module):
             else:
                 p.data = p.data.view(k // 32, n, 32).transpose(0, 1).contiguous().view(n, k)
         self._w_blocked = blocked
-        self._native = None
+        self._invalidate_native()
 
     def unblock_weights(self) -> None:
         """Put every parameter back into the reference's row-major layout (e.g. before `state_dict()` / saving: after the
@@ -329,13 +335,14 @@ class QwenImageTransformer2DModel(nn.Module):
     def load_state_dict(self, state_dict, *args, **kwargs):
         self.unblock_weights()
         out = super().load_state_dict(state_dict, *args, **kwargs)
-        self._native = None
+        self._invalidate_native()
         return out
 
     def _apply(self, fn, *args, **kwargs):
         """.to() / .cuda() / .half() move or replace parameter storage: drop every cached device pointer first."""
         self.unblock_weights()
-        self._native, self._workspace = None, None
+        self._invalidate_native()
+        self._workspace = None
         self._batch_cache.clear()
         return super()._apply(fn, *args, **kwargs)
 
@@ -350,7 +357,7 @@ class QwenImageTransformer2DModel(nn.Module):
                 p.data.fill_(1.0)
             else:
                 p.data.zero_()
-        self._native = None
+        self._invalidate_native()
         return self
 
     def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]) -> set[str]:
@@ -381,13 +388,13 @@ class QwenImageTransformer2DModel(nn.Module):
                     raise ValueError(f"{name}: expected {tuple(params[name].shape)}, got {tuple(w.shape)}")
                 params[name].data.copy_(w)
             loaded.add(name)
-        self._native = None  # derived pointer tables must be rebuilt after loading (SURVEY.md §8b Ownership)
+        self._invalidate_native()  # derived pointer tables must be rebuilt after loading (SURVEY.md §8b Ownership)
         return loaded
 
     def _native_weights(self) -> N.DitWeights:
         if self._native is not None:
             return self._native[0]
-        self._set_weight_layout(os.environ.get("OMNI_GEMM_W_BLOCKED", "1") != "0")
+        self._set_weight_layout(True)
         for n, p in self.named_parameters():
             if not p.is_cuda or p.dtype != BF16 or not p.is_contiguous():
                 raise N.OmniNativeError(f"parameter {n} must be a contiguous bf16 GPU tensor (got {p.device}, {p.dtype})")
@@ -424,7 +431,6 @@ class QwenImageTransformer2DModel(nn.Module):
         w.proj_out_w, w.proj_out_b = self.proj_out.weight.data_ptr(), self.proj_out.bias.data_ptr()
         w.layers = C.cast(layers, C.POINTER(N.DitLayerWeights))
         self._native = (w, layers)
-        self._native_gen += 1
         return w
 
     # ------------------------------------------------------------------ batches
