@@ -27,6 +27,7 @@ import hashlib
 import json
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -317,6 +318,160 @@ def run_edit_plus_case():
     print(f"dit_edit_plus_three_images_fp32: out {tuple(out.shape)} std {out.std():.4f}; helpers {helpers['vae']}")
 
 
+def run_teacache_case():
+    """The reference's OWN TeaCache (cache/teacache/hook.py:82-217 `TeaCacheHook.new_forward` +
+    `_should_compute_full_transformer`, extractors.py:145-261 `extract_qwen_context`, state.py, config.py, hooks.py — all
+    torch/numpy only) applied with `apply_teacache_hook` to the reference DiT and driven by the reference `diffuse` loop
+    (true-CFG: the hook alternates positive / negative states).  Stored: the compute / skip decision of every forward per
+    branch, the rel-L1 distances behind them, the trajectory and the final latent."""
+    import importlib
+
+    import ref_shims_pipeline as RP
+    from ref_shims import _pkg
+
+    case = dict(layers=2, heads=2, joint=128, grid=(16, 16), T=9, Tneg=5, steps=10, cfg=4.0, bias_std=0.02, jitter=0.1,
+                rel_l1_thresh=0.15, dtype="float32")
+    P = O.make_dit_params(case["layers"], seed=1234, bias_std=case["bias_std"], norm_jitter=case["jitter"],
+                          num_heads=case["heads"], joint_dim=case["joint"])
+    model, cfg = ref_shims.build_reference_model(case["layers"], num_attention_heads=case["heads"],
+                                                 joint_attention_dim=case["joint"], dtype=torch.float32)
+    model.load_state_dict(P, strict=True)
+    RP.install()
+    _pkg("vllm_omni.diffusion.cache.teacache", os.path.join(ref_shims.REFERENCE_ROOT, "vllm_omni", "diffusion", "cache", "teacache"))
+    hookmod = importlib.import_module("vllm_omni.diffusion.cache.teacache.hook")
+    cfgmod = importlib.import_module("vllm_omni.diffusion.cache.teacache.config")
+    tcfg = cfgmod.TeaCacheConfig(transformer_type="QwenImageTransformer2DModel", rel_l1_thresh=case["rel_l1_thresh"])
+    hookmod.apply_teacache_hook(model, tcfg)
+    hook = model._hook_registry.get_hook("teacache")
+    decisions = {"positive": [], "negative": []}
+    rels = {"positive": [], "negative": []}
+    orig = hook._should_compute_full_transformer
+
+    def tap(state, modulated):
+        branch = hook.state_manager._context.split("_")[-1]
+        rel = float("nan")
+        if state.cnt > 0 and state.previous_modulated_input is not None:
+            rel = float(((modulated - state.previous_modulated_input).abs().mean()
+                         / (state.previous_modulated_input.abs().mean() + 1e-8)).item())
+        r = orig(state, modulated)
+        decisions[branch].append(bool(r))
+        rels[branch].append(rel)
+        return r
+
+    hook._should_compute_full_transformer = tap
+    pipe, mod = RP.reference_pipeline_shell(model, cfg)
+    model.do_true_cfg = True                       # what the reference pipeline sets before diffuse (:729-731)
+    gh, gw = case["grid"]
+    g = torch.Generator().manual_seed(42)
+    lat = torch.randn(1, gh * gw, 64, generator=g)
+    pos = torch.randn(1, case["T"], case["joint"], generator=g)
+    neg = torch.randn(1, case["Tneg"], case["joint"], generator=g)
+    timesteps, _ = mod.QwenImagePipeline.prepare_timesteps(pipe, case["steps"], None, gh * gw)
+    traj = []
+    orig_step = pipe.scheduler.step
+
+    def step_tap(*a, **k):
+        r = orig_step(*a, **k)
+        traj.append(r[0].clone())
+        return r
+
+    pipe.scheduler.step = step_tap
+    final = RP.reference_diffuse(
+        pipe, cfg, prompt_embeds=pos, prompt_embeds_mask=torch.ones(1, case["T"], dtype=torch.long),
+        negative_prompt_embeds=neg, negative_prompt_embeds_mask=torch.ones(1, case["Tneg"], dtype=torch.long),
+        latents=lat, img_shapes=[[(1, gh, gw)]], txt_seq_lens=[case["T"]], negative_txt_seq_lens=[case["Tneg"]],
+        timesteps=timesteps, do_true_cfg=True, guidance=None, true_cfg_scale=case["cfg"])
+    meta = dict(case=case, params_sha256=params_checksum(P), param_seed=1234, coefficients=list(tcfg.coefficients),
+                reference="cache/teacache/hook.py:82-217 + extractors.py:145-261 + state.py + hooks.py over "
+                          "qwen_image_transformer.py and pipeline_qwen_image.py:530-586 via oracle/ref_shims*.py")
+    np.savez_compressed(os.path.join(OUT, "teacache_diffuse_cfg_256.npz"), latents=lat.numpy(), pos=pos.numpy(), neg=neg.numpy(),
+                        timesteps=timesteps.numpy(), trajectory=torch.stack(traj).numpy(), final=final.numpy(),
+                        compute_pos=np.array(decisions["positive"]), compute_neg=np.array(decisions["negative"]),
+                        rel_pos=np.array(rels["positive"]), rel_neg=np.array(rels["negative"]), meta=json.dumps(meta))
+    print("teacache_diffuse_cfg_256: compute pattern pos", "".join("C" if d else "s" for d in decisions["positive"]),
+          "neg", "".join("C" if d else "s" for d in decisions["negative"]))
+    print("   rel pos", np.round(rels["positive"], 4).tolist())
+    print("   rel neg", np.round(rels["negative"], 4).tolist())
+
+
+class _RefTokenizerStub:
+    """Tokenizer stand-in for the prompt-encoding fixture: whitespace words -> ids, with the reference template's prefix
+    ("<|im_start|>system ... <|im_start|>user\n") mapped to EXACTLY 34 ids, which is what the Qwen2 tokenizer produces and
+    what `prompt_template_encode_start_idx = 34` (pipeline_qwen_image.py:282) relies on; the template's suffix
+    ("<|im_end|>\n<|im_start|>assistant\n") is 5 ids as under Qwen2.  Deterministic, no vocabulary file."""
+
+    PREFIX_IDS, SUFFIX_IDS, vocab_size, pad_token_id = 34, 5, 512, 0
+
+    def __init__(self, template: str):
+        self.prefix, self.suffix = template.split("{}")
+
+    def _ids(self, text: str):
+        assert text.startswith(self.prefix) and text.endswith(self.suffix), "prompt was not wrapped in the reference template"
+        body = text[len(self.prefix): len(text) - len(self.suffix)]
+        words = body.split()
+        mid = [3 + (sum(w.encode()) * 7 + len(w)) % 400 for w in words]
+        return [410 + i for i in range(self.PREFIX_IDS)] + mid + [460 + i for i in range(self.SUFFIX_IDS)]
+
+    def __call__(self, text, max_length=None, padding=True, truncation=True, return_tensors="pt"):
+        ids = [self._ids(t) for t in ([text] if isinstance(text, str) else text)]
+        if truncation and max_length:
+            ids = [x[:max_length] for x in ids]
+        L = max(len(x) for x in ids)
+        out = types.SimpleNamespace(
+            input_ids=torch.tensor([x + [0] * (L - len(x)) for x in ids], dtype=torch.long),
+            attention_mask=torch.tensor([[1] * len(x) + [0] * (L - len(x)) for x in ids], dtype=torch.long))
+        out.to = lambda device: out
+        return out
+
+
+def run_prompt_encode_case():
+    """The reference's `_extract_masked_hidden` / `_get_qwen_prompt_embeds` / `encode_prompt` (pipeline_qwen_image.py:
+    351-433) called UNBOUND on a bare pipeline object whose `text_encoder` is a seeded random HF `Qwen2_5_VLTextModel`
+    (real width 3584, 2 layers) and whose tokenizer is `_RefTokenizerStub`.  Stored: token ids, embeddings, masks."""
+    import ref_shims_pipeline as RP
+    from transformers import Qwen2_5_VLTextConfig, Qwen2_5_VLTextModel
+
+    pipe, mod = RP.reference_pipeline_shell(None, None)
+    torch.manual_seed(7)
+    tcfg = Qwen2_5_VLTextConfig(vocab_size=_RefTokenizerStub.vocab_size, hidden_size=3584, num_hidden_layers=2,
+                                num_attention_heads=28, num_key_value_heads=4, intermediate_size=512,
+                                max_position_embeddings=4096, bos_token_id=1, eos_token_id=2, pad_token_id=0,
+                                rope_scaling={"type": "default", "mrope_section": [16, 24, 24], "rope_type": "default"})
+    te = Qwen2_5_VLTextModel(tcfg).float().eval()
+    pipe.text_encoder = te
+    pipe.tokenizer_max_length = 1024
+    pipe.prompt_template_encode = ("<|im_start|>system\nDescribe the image by detailing the color, shape, size, texture, quantity, "
+                                   "text, spatial relationships of the objects and background:<|im_end|>\n<|im_start|>user\n{}"
+                                   "<|im_end|>\n<|im_start|>assistant\n")
+    # take template + start index from the reference SOURCE (its __init__, :280-282), not from this file
+    import ast
+    src = open(os.path.join(ref_shims.REFERENCE_ROOT, "vllm_omni", "diffusion", "models", "qwen_image", "pipeline_qwen_image.py")).read()
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Attribute):
+            if node.targets[0].attr == "prompt_template_encode":
+                pipe.prompt_template_encode = ast.literal_eval(node.value)
+            if node.targets[0].attr == "prompt_template_encode_start_idx":
+                pipe.prompt_template_encode_start_idx = ast.literal_eval(node.value)
+            if node.targets[0].attr == "tokenizer_max_length":
+                pipe.tokenizer_max_length = ast.literal_eval(node.value)
+    assert pipe.prompt_template_encode_start_idx == 34
+    pipe.tokenizer = _RefTokenizerStub(pipe.prompt_template_encode)
+    pipe.device = torch.device("cpu")
+    prompts = ["a red fox jumping over a frozen lake at dawn", "two cats", ""]
+    with torch.no_grad():
+        emb, msk = mod.QwenImagePipeline._get_qwen_prompt_embeds(pipe, prompts, dtype=torch.float32)
+        emb2, msk2 = mod.QwenImagePipeline.encode_prompt(pipe, prompts[:2], num_images_per_prompt=2, max_sequence_length=6)
+    toks = pipe.tokenizer([pipe.prompt_template_encode.format(e) for e in prompts])
+    sd = {k: v.numpy() for k, v in te.state_dict().items()}
+    meta = dict(prompts=prompts, drop_idx=34, text_config=tcfg.to_dict(), seed=7, template=pipe.prompt_template_encode,
+                reference="pipeline_qwen_image.py:351-433 (unbound) over HF Qwen2_5_VLTextModel via oracle/ref_shims_pipeline.py")
+    np.savez_compressed(os.path.join(OUT, "prompt_encode.npz"), input_ids=toks.input_ids.numpy(),
+                        attention_mask=toks.attention_mask.numpy(), prompt_embeds=emb.numpy(), prompt_embeds_mask=msk.numpy(),
+                        encode_prompt_embeds=emb2.numpy(), encode_prompt_mask=msk2.numpy(),
+                        te_checksum=np.array([float(sum(float(np.abs(v).sum()) for v in sd.values()))]), meta=json.dumps(meta, default=str))
+    print(f"prompt_encode: embeds {tuple(emb.shape)} mask rows {msk.sum(1).tolist()}; encode_prompt {tuple(emb2.shape)}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -336,6 +491,10 @@ def main():
         run_edit_case()
     if only is None or "editplus" in only:
         run_edit_plus_case()
+    if only is None or "teacache" in only:
+        run_teacache_case()
+    if only is None or "prompt" in only:
+        run_prompt_encode_case()
 
 
 if __name__ == "__main__":

@@ -347,6 +347,105 @@ def diffuse(P: Params, latents: torch.Tensor, prompt_embeds: torch.Tensor, negat
     return latents
 
 
+# =============================================================================== TeaCache (optional cache accelerator)
+TEACACHE_QWEN_COEFFICIENTS = [-4.5e02, 2.8e02, -4.5e01, 3.2e00, -2.0e-02]   # cache/teacache/config.py:18-27
+
+
+class TeaCacheBranchState:
+    """cache/teacache/state.py:13-37."""
+
+    def __init__(self):
+        self.cnt, self.acc = 0, 0.0
+        self.prev_mod = self.prev_res = None
+
+
+def teacache_forward(P: Params, st: TeaCacheBranchState, hidden_states, encoder_hidden_states, timestep, img_shape,
+                     num_heads: int, rel_l1_thresh: float, coefficients=TEACACHE_QWEN_COEFFICIENTS, log: list | None = None):
+    """ONE hooked transformer forward: TeaCacheHook.new_forward (cache/teacache/hook.py:82-157) over extract_qwen_context
+    (extractors.py:145-261) with the decision rule of _should_compute_full_transformer (hook.py:170-217).  `st` is the
+    state of the CFG branch this forward belongs to (hook.py:113-121)."""
+    import numpy as np
+
+    T = encoder_hidden_states.shape[1]
+    hidden = F.linear(hidden_states, P["img_in.weight"], P["img_in.bias"])                        # extractors.py:189-193
+    timestep = timestep.to(hidden.dtype)
+    enc = F.linear(rms_norm(encoder_hidden_states, P["txt_norm.weight"]), P["txt_in.weight"], P["txt_in.bias"])
+    temb = timestep_embedding(P, timestep, hidden.dtype)
+    vid_cs, txt_cs = rope_tables(*img_shape, T)
+    img_mod = F.linear(F.silu(temb), P["transformer_blocks.0.img_mod.1.weight"], P["transformer_blocks.0.img_mod.1.bias"])
+    modulated, _ = ada_layer_norm(hidden, img_mod.chunk(2, dim=-1)[0])                            # extractors.py:208-211
+    # --- decision (hook.py:188-217)
+    if st.cnt == 0:
+        st.acc, compute = 0.0, True
+    elif st.prev_mod is None:
+        compute = True
+    else:
+        rel = float(((modulated - st.prev_mod).abs().mean() / (st.prev_mod.abs().mean() + 1e-8)).item())
+        st.acc += abs(float(np.poly1d(coefficients)(rel)))
+        if st.acc < rel_l1_thresh:
+            compute = False
+        else:
+            st.acc, compute = 0.0, True
+    if log is not None:
+        log.append(compute)
+    if not compute and st.prev_res is not None:                                                   # hook.py:127-134
+        out = hidden + st.prev_res
+    else:                                                                                         # hook.py:135-157
+        h, e = hidden, enc
+        for i in range(num_layers_of(P)):
+            e, h = dit_block(P, i, h, e, temb, vid_cs, txt_cs, num_heads)
+        st.prev_res = h - hidden
+        out = h
+    st.prev_mod = modulated
+    st.cnt += 1
+    emb = F.linear(F.silu(temb).to(out.dtype), P["norm_out.linear.weight"], P["norm_out.linear.bias"])   # postprocess
+    scale, shift = emb.chunk(2, dim=1)
+    out = layer_norm_noaffine(out) * (1 + scale)[:, None, :] + shift[:, None, :]
+    return F.linear(out, P["proj_out.weight"], P["proj_out.bias"])
+
+
+def teacache_diffuse(P: Params, latents, prompt_embeds, negative_prompt_embeds, img_shape, num_inference_steps: int,
+                     rel_l1_thresh: float, true_cfg_scale: float = 4.0, num_heads: int = 24,
+                     sched: SchedulerConfig = SchedulerConfig(), trajectory: list | None = None):
+    """The reference `diffuse` loop (pipeline_qwen_image.py:530-586) over the TeaCache-hooked transformer: forwards
+    alternate positive / negative, each branch with its own state.  Returns (final latents, compute log per branch)."""
+    timesteps, sigmas = flow_match_sigmas(num_inference_steps, latents.shape[1], sched)
+    pos_st, neg_st = TeaCacheBranchState(), TeaCacheBranchState()
+    log_p, log_n = [], []
+    for i, t in enumerate(timesteps):
+        ts = t.expand(latents.shape[0]).to(latents.dtype)
+        p = teacache_forward(P, pos_st, latents, prompt_embeds, ts / 1000, img_shape, num_heads, rel_l1_thresh, log=log_p)
+        n = teacache_forward(P, neg_st, latents, negative_prompt_embeds, ts / 1000, img_shape, num_heads, rel_l1_thresh, log=log_n)
+        latents = euler_step(latents, cfg_combine(p, n, true_cfg_scale), float(sigmas[i]), float(sigmas[i + 1]))
+        if trajectory is not None:
+            trajectory.append(latents.clone())
+    return latents, (log_p, log_n)
+
+
+# =============================================================================== prompt encoding (request-side boundary)
+def qwen_prompt_embeds(hidden: torch.Tensor, attention_mask: torch.Tensor, drop_idx: int = 34):
+    """`_extract_masked_hidden` + the rest of `_get_qwen_prompt_embeds` after the text-encoder call
+    (pipeline_qwen_image.py:351-357, 378-392): per-sample valid rows, minus the `drop_idx` template tokens, zero-padded to
+    the longest, with the matching mask.  hidden [B, L, D] = text_encoder(...).hidden_states[-1]."""
+    mask = attention_mask.bool()
+    lens = mask.sum(dim=1).tolist()
+    split = [e[drop_idx:] for e in torch.split(hidden[mask], lens, dim=0)]
+    T = max(e.size(0) for e in split)
+    emb = torch.stack([torch.cat([u, u.new_zeros(T - u.size(0), u.size(1))]) for u in split])
+    msk = torch.stack([torch.cat([torch.ones(u.size(0), dtype=torch.long), torch.zeros(T - u.size(0), dtype=torch.long)])
+                       for u in split])
+    return emb, msk
+
+
+def encode_prompt_postprocess(emb: torch.Tensor, msk: torch.Tensor, num_images_per_prompt: int, max_sequence_length: int):
+    """encode_prompt after `_get_qwen_prompt_embeds` (pipeline_qwen_image.py:423-433): truncate, repeat per image."""
+    emb, msk = emb[:, :max_sequence_length], msk[:, :max_sequence_length]
+    B, T, _ = emb.shape
+    emb = emb.repeat(1, num_images_per_prompt, 1).view(B * num_images_per_prompt, T, -1)
+    msk = msk.repeat(1, num_images_per_prompt, 1).view(B * num_images_per_prompt, T)
+    return emb, msk
+
+
 # =============================================================================== VAE decode (T = 1)
 LATENTS_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
                 0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]

@@ -4,8 +4,10 @@ The CPU oracle cannot finish these sizes in seconds, but it is plain torch: on t
 (rocBLAS fp32 GEMMs, materialised softmax) next to the product's HIP path and is compared on identical bf16-rounded
 weights and inputs.  The oracle itself is pinned to reference-run fixtures on CPU (tests/test_oracle_golden.py).
 
-  * two full-width layers at the bench step-batch: 6 items x (4096 image + 64 text) rows (bench.py: R = 3 requests x 2
-    CFG branches), D = 3072, 24 heads — the exact shapes BENCH times;
+  * two full-width layers at the bench step-batch: 10 items x (4096 image + 64 text) rows (bench.py: R = 5 requests x 2
+    CFG branches = 163 row tiles), D = 3072, 24 heads — the exact shapes BENCH times;
+  * the HEADLINE config at real depth: 60 full-width layers over ONE 1024x1024 item (4096 + 64 rows): one forward and a
+    4-step true-CFG loop, per-step drift of the product and of the bf16-eager reference algorithm printed side by side;
   * BASELINE config 1 at REAL DEPTH: 60 layers, full width, 256x256 (16x16 tokens), 4 steps, true-CFG on.  Besides the
     fp32 oracle, the same oracle is run in bf16 (= the reference's algorithm in the reference's dtype, one rounding
     per eager op) to calibrate how much drift 60 blocks x 8 forwards produce by themselves;
@@ -53,7 +55,7 @@ def test_two_fullwidth_layers_at_bench_step_batch():
     torch.backends.cuda.matmul.allow_tf32 = False
     m = _perturbed_random_model(2, seed=77)
     P = _oracle_params(m)
-    B, S, T = 6, 4096, 64
+    B, S, T = 10, 4096, 64                                                 # bench.py default: R = 5 requests x 2 CFG branches
     g = torch.Generator(device=DEV).manual_seed(5)
     lat = torch.randn(B, S, 64, device=DEV, generator=g).to(BF16)
     txt = torch.randn(B, T, 3584, device=DEV, generator=g).to(BF16)
@@ -68,11 +70,11 @@ def test_two_fullwidth_layers_at_bench_step_batch():
             r, c = rel_l2(out[i:i + 1], ref), cosine(out[i:i + 1], ref)
             worst, wc = max(worst, r), min(wc, c)
             del ref
-    print(f"2 full-width layers @ 6 x (4096+64): worst rel_l2 {worst:.3e}, worst cosine {wc:.6f}")
+    print(f"2 full-width layers @ 10 x (4096+64): worst rel_l2 {worst:.3e}, worst cosine {wc:.6f}")
     assert worst <= 1e-2 and wc >= 0.9995
 
 
-def _oracle_denoise(P, lat, pos, neg, grid, steps, cfg, dtype):
+def _oracle_denoise(P, lat, pos, neg, grid, steps, cfg, dtype, trajectory=None):
     """reference diffuse() (pipeline_qwen_image.py:530-586) with the oracle DiT in `dtype`; latents kept in bf16 (:585)."""
     ts, sig = O.flow_match_sigmas(steps, lat.shape[1])
     x = lat.float()
@@ -84,7 +86,76 @@ def _oracle_denoise(P, lat, pos, neg, grid, steps, cfg, dtype):
         if first is None:
             first = p.clone()
         x = O.euler_step(x, O.cfg_combine(p, n, cfg), float(sig[i]), float(sig[i + 1])).bfloat16().float()
+        if trajectory is not None:
+            trajectory.append(x.clone())
     return x, first
+
+
+def _product_trajectory(pipe, req):
+    """pipe.generate with the latents recorded after every fused CFG + Euler update."""
+    from vllm_omni_amd import ops
+
+    traj, orig = [], ops.cfg_euler_step_
+
+    def tap(lat, *a, **k):
+        r = orig(lat, *a, **k)
+        traj.append(lat.clone())
+        return r
+
+    ops.cfg_euler_step_ = tap
+    try:
+        out = pipe.generate([req], output_type="latent")[0].output
+    finally:
+        ops.cfg_euler_step_ = orig
+    torch.cuda.synchronize()
+    return out, traj
+
+
+def test_headline_1024px_at_real_depth_60_layers():
+    """BASELINE config 2's model and shape — 60 full-width layers, ONE 1024x1024 item (4096 image + 64 / 48 text rows),
+    true-CFG — for one forward and a 4-step loop (the 20-step schedule's step size would need 40 fp32-oracle forwards; 4
+    steps cover the same per-step arithmetic at 5x the step size).  Checker: the fp32 oracle on the GPU; calibration: the
+    same oracle in bf16 (the dtype the reference runs in).  The drift after every step is printed for both."""
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    m = _perturbed_random_model(60, seed=1234)
+    grid, S, steps = (1, 64, 64), 4096, 4
+    g = torch.Generator(device=DEV).manual_seed(42)
+    lat = torch.randn(1, S, 64, device=DEV, generator=g).to(BF16)
+    pos = torch.randn(1, 64, 3584, device=DEV, generator=g).to(BF16)
+    neg = torch.randn(1, 48, 3584, device=DEV, generator=g).to(BF16)
+    t32, tb = [], []
+    with torch.no_grad():
+        P32 = _oracle_params(m)
+        ref, ref_first = _oracle_denoise(P32, lat, pos, neg, grid, steps, 4.0, torch.float32, t32)
+        del P32
+        torch.cuda.empty_cache()
+        Pb = _oracle_params(m, BF16)
+        eager, eager_first = _oracle_denoise(Pb, lat, pos, neg, grid, steps, 4.0, BF16, tb)
+        del Pb
+        torch.cuda.empty_cache()
+    pipe = QwenImagePipeline(od_config=OmniDiffusionConfig(use_hip_graph=False), device=DEV, transformer=m)
+    sig0 = pipe.scheduler.model_timestep(pipe.scheduler.set_timesteps(steps, S))[:1].to(DEV)
+    fwd = m(hidden_states=lat, encoder_hidden_states=pos, timestep=sig0, img_shapes=[[grid]], txt_seq_lens=[64],
+            return_dict=False)[0]
+    req = OmniDiffusionRequest(height=1024, width=1024, num_inference_steps=steps, true_cfg_scale=4.0, latents=lat,
+                               prompt_embeds=pos, negative_prompt_embeds=neg, output_type="latent")
+    out, tp = _product_trajectory(pipe, req)
+    r_f, r_f_eager = rel_l2(fwd, ref_first), rel_l2(eager_first, ref_first)
+    print(f"60 layers @ 1024^2 (4096+64 rows), one forward: product vs fp32 oracle {r_f:.3e} cos {cosine(fwd, ref_first):.6f} "
+          f"(bf16-eager oracle vs fp32 oracle {r_f_eager:.3e})")
+    assert len(tp) == steps
+    for i in range(steps):
+        print(f"   step {i + 1}/{steps}: latent drift vs fp32 oracle — product {rel_l2(tp[i].view(1, S, 64), t32[i]):.3e}, "
+              f"bf16-eager reference algorithm {rel_l2(tb[i], t32[i]):.3e}")
+    r, c, r_eager = rel_l2(out, ref), cosine(out, ref), rel_l2(eager, ref)
+    print(f"   final: product {r:.3e} cos {c:.6f}; bf16-eager {r_eager:.3e}; product vs bf16-eager {rel_l2(out, eager):.3e}")
+    assert torch.isfinite(out.float()).all()
+    assert r_f <= max(1e-2, 1.1 * r_f_eager)
+    assert r <= max(2e-2, 1.1 * r_eager) and c >= 0.997
 
 
 def test_config1_256px_4steps_at_real_depth_60_layers():

@@ -157,3 +157,34 @@ def test_diffuse_matches_reference_golden():
     r, cs = rel_l2(out, ref), cosine(out, ref)
     print(f"diffuse vs reference-run golden: final latent rel_l2 {r:.3e} cos {cs:.6f}")
     assert r <= 2e-2 and cs >= 0.9995
+
+
+def test_hip_graph_is_recaptured_after_the_weights_change():
+    """A captured denoise-step graph bakes in the device addresses and the K32-blocked layout flag of the weights.
+    `state_dict()` / `load_weights()` undo the blocked re-layout (new storages, old ones freed): the next generate with the
+    same batch key must NOT replay the stale graph (round-2 advisor finding: silently wrong images + a device use-after-free)."""
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    pipe0, _ = make(2, 128, 2)
+    tr = pipe0.transformer
+    g = torch.Generator().manual_seed(7)
+    lat = torch.randn(1, 256, 64, generator=g).to(BF16)
+    pos, neg = torch.randn(1, 9, 128, generator=g).to(BF16), torch.randn(1, 4, 128, generator=g).to(BF16)
+    req = lambda: OmniDiffusionRequest(height=256, width=256, num_inference_steps=3, true_cfg_scale=4.0, latents=lat,  # noqa: E731
+                                       prompt_embeds=pos, negative_prompt_embeds=neg, output_type="latent")
+    eager = QwenImagePipeline(od_config=OmniDiffusionConfig(use_hip_graph=False), device=DEV, transformer=tr)
+    graph = QwenImagePipeline(od_config=OmniDiffusionConfig(use_hip_graph=True), device=DEV, transformer=tr)
+    want = eager.generate([req()], output_type="latent")[0].output
+    a = graph.generate([req()], output_type="latent")[0].output                # captures
+    gen0 = tr._native_gen
+    sd = {k: v.clone() for k, v in tr.state_dict().items()}                      # un-blocks the weights: storages replaced
+    assert tr._native_gen != gen0 and tr._native is None
+    junk = [torch.full((1 << 20,), 7.0, device=DEV) for _ in range(8)]           # recycle the freed blocks with garbage
+    b = graph.generate([req()], output_type="latent")[0].output                # must re-capture, not replay
+    tr.load_state_dict(sd)
+    c = graph.generate([req()], output_type="latent")[0].output
+    torch.cuda.synchronize()
+    del junk
+    assert torch.equal(a, want) and torch.equal(b, want) and torch.equal(c, want)

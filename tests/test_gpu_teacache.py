@@ -165,3 +165,48 @@ def test_step_batched_teacache_keeps_per_request_decisions():
         assert s == [skips_b[i], skips_b[2 + i]]
         assert rel_l2(both[i].output, solo) <= 5e-3
     m.teacache = None
+
+
+def test_device_teacache_reproduces_the_reference_run_pattern():
+    """tests/golden/teacache_diffuse_cfg_256.npz = the reference's OWN TeaCacheHook + extract_qwen_context over the reference
+    DiT, driven by the reference diffuse loop (fp32, 10 steps, true-CFG, rel_l1_thresh 0.15: a mixed compute / skip pattern).
+    The device-side TeaCache inside omni_dit_forward must take the SAME decision at every forward of both branches, and land
+    on the same final latent within the 4-step bf16 tolerance."""
+    from _util import golden_params, load_golden
+    from vllm_omni_amd import ops
+    from vllm_omni_amd.diffusion.cache.teacache.config import TeaCacheConfig
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    z, meta, c = load_golden("teacache_diffuse_cfg_256")
+    P = golden_params(c)
+    m = QwenImageTransformer2DModel(num_layers=c["layers"], num_attention_heads=c["heads"], joint_attention_dim=c["joint"], device=DEV)
+    m.load_weights(P.items())
+    m.teacache = TeaCacheConfig(rel_l1_thresh=c["rel_l1_thresh"])
+    assert list(m.teacache.coefficients) == list(meta["coefficients"])
+    pipe = QwenImagePipeline(od_config=OmniDiffusionConfig(use_hip_graph=False), device=DEV, transformer=m)
+    gh, gw = c["grid"]
+    req = OmniDiffusionRequest(height=16 * gh, width=16 * gw, num_inference_steps=c["steps"], true_cfg_scale=c["cfg"],
+                               latents=torch.from_numpy(z["latents"]).to(BF16), prompt_embeds=torch.from_numpy(z["pos"]).to(BF16),
+                               negative_prompt_embeds=torch.from_numpy(z["neg"]).to(BF16), output_type="latent")
+    pattern, orig = [], ops.cfg_euler_step_
+
+    def tap(*a, **k):                                   # test-only host read of this forward's per-item decisions
+        pattern.append(pipe.last_teacache_state.skip.tolist())
+        return orig(*a, **k)
+
+    ops.cfg_euler_step_ = tap
+    try:
+        out = pipe.generate([req], output_type="latent")[0].output
+    finally:
+        ops.cfg_euler_step_ = orig
+        m.teacache = None
+    torch.cuda.synchronize()
+    got_pos, got_neg = [not bool(s[0]) for s in pattern], [not bool(s[1]) for s in pattern]
+    show = lambda d: "".join("C" if x else "s" for x in d)  # noqa: E731
+    print(f"device pattern pos {show(got_pos)} neg {show(got_neg)}; reference run pos {show(z['compute_pos'])} neg {show(z['compute_neg'])}; "
+          f"final latent vs reference run {rel_l2(out, torch.from_numpy(z['final'])):.3e}")
+    assert got_pos == z["compute_pos"].tolist() and got_neg == z["compute_neg"].tolist()
+    assert rel_l2(out, torch.from_numpy(z["final"])) <= 1e-2
