@@ -400,6 +400,45 @@ def test_flash_attention_forced_rescale_spike():
     assert rel_l2(got, ref) <= 4e-3
 
 
+@pytest.mark.parametrize("lens,H", [([1100, 300, 257, 65, 1, 647], 24), ([2100], 64), ([256, 512, 1000, 64, 63], 32)])
+def test_flash_attention_w64_kernel_varlen(lens, H):
+    """Grids of >= 512 workgroups run the 64-queries-per-wave kernel (csrc/attention_w64.hip): ragged items, tails that are
+    not a multiple of 64 keys / 256 queries, items shorter than one tile."""
+    from vllm_omni_amd import ops
+
+    assert len(lens) * H * ((max(lens) + 255) // 256) >= 512
+    rows = sum(lens)
+    q, k, v = rnd((rows, H * 128), 1), rnd((rows, H * 128), 2), rnd((rows, H * 128), 3)
+    ref = attn_ref(q, k, v, lens, H)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev())
+    got = ops.flash_attn_varlen(g_(q), g_(k), g_(v), cu, H, max(lens), 1 / math.sqrt(128))
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got, ref) <= 4e-3
+    assert (got.float().cpu() - ref).abs().max() <= 2e-2
+
+
+def test_flash_attention_w64_forced_rescale_spike():
+    """The rare O-rescale path of the 64-queries-per-wave kernel (O lives in AGPRs there): spiked keys late in the sequence
+    for queries of both 32-query blocks of a wave, and a row whose every score is far below zero (first-tile reference)."""
+    from vllm_omni_amd import ops
+
+    H, L = 64, 2100
+    q, k, v = rnd((L, H * 128), 1, 0.3), rnd((L, H * 128), 2, 0.3), rnd((L, H * 128), 3)
+    for hh, (kr, qr, f) in enumerate([(1400, 17, 40.0), (70, 300, 25.0), (2050, 40, 30.0), (900, 2099, 35.0)]):
+        k[kr, hh * 128:(hh + 1) * 128] = bf16_round(q[qr, hh * 128:(hh + 1) * 128] * f)
+    q[5, 4 * 128:5 * 128] = bf16_round(-k[:, 4 * 128:5 * 128].mean(0) * 200.0)      # head 4, query 5: all scores << 0
+    ref = attn_ref(q, k, v, [L], H)
+    cu = torch.tensor([0, L], dtype=torch.int32, device=dev())
+    got = ops.flash_attn_varlen(g_(q), g_(k), g_(v), cu, H, L, 1 / math.sqrt(128))
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got, ref) <= 4e-3
+    for hh in range(5):
+        sl = slice(hh * 128, (hh + 1) * 128)
+        assert rel_l2(got[:, sl], ref[:, sl]) <= 6e-3, hh
+
+
 def test_attention_backend_plugin_surface():
     from vllm_omni_amd.diffusion.attention.selector import get_attn_backend
 

@@ -10,10 +10,10 @@ tu=$1; shift
 mkdir -p $B/abl
 while [ $# -ge 2 ]; do
   n=$1; f=$2; shift 2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DOMNI_DEV -Iinclude -Ivllm_omni_amd/csrc $f \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -fno-gpu-rdc -DOMNI_DEV -Iinclude -Ivllm_omni_amd/csrc $f \
       -c vllm_omni_amd/csrc/$tu.hip -o $B/abl/${tu}_$n.o 2>/dev/null
   objs=""
-  for t in gemm attention elementwise vae dit_forward; do
+  for t in gemm attention attention_w64 elementwise vae dit_forward; do
     if [ $t = $tu ]; then objs="$objs $B/abl/${tu}_$n.o"; else objs="$objs $B/$t.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $B/abl/libomni_$n.so

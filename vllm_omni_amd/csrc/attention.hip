@@ -377,6 +377,9 @@ OMNI_DEVINL float xhalf_sum(float x) {
                           // rare rescale path) instead of 0: the accumulator then IS the exp2 argument s~ - m~, and the 32
                           // v_fma per wave and tile that formed it are gone (the loop is bound by per-wave instruction issue)
 #endif
+#ifndef OMNI_ATTN_W64
+#define OMNI_ATTN_W64 1   // large grids run flash_attn_fwd_w64_kernel (attention_w64.hip)
+#endif
 #ifndef OMNI_ATTN_ABL
 #define OMNI_ATTN_ABL 0   // dev-only timing ablations (wrong results): 1 no DMA wait, 2 no barrier, 4 no DMA, 8 no exp, 16 no LDS reads
 #endif
@@ -1426,6 +1429,13 @@ int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_
       (ldq % 8) || (ldk % 8) || (ldv % 8) || (!out_k32_rows && (ldo % 4)))
     return OMNI_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
+#if OMNI_ATTN_W64
+  // >= 2 rounds of 256-query workgroups over the 256 CUs: the 64-queries-per-wave kernel (attention_w64.hip); smaller grids
+  // keep the finer 128 / 256-query blocks of the two-waves-per-SIMD kernel below
+  if ((long)B * H * ((max_seqlen + 255) / 256) >= 512)
+    return omni_internal_flash_attn_w64(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale,
+                                        out_k32_rows, item_skip, q_prescaled, stream);
+#endif
 #ifdef OMNI_DEV
   if (q_prescaled && (!attn_pipelined() || attn_mfma_shape() == 16 || !OMNI_ATTN_BAKE)) return OMNI_ERR_UNSUPPORTED;
   if (!attn_pipelined()) {

@@ -1,0 +1,547 @@
+// Flash attention forward, 64 queries per wave, ONE wave per SIMD: the large-batch production kernel (gfx950 only).
+//
+// flash_attn_fwd_pipe_kernel (attention.hip) gives each wave 32 queries and runs two waves per SIMD; it is bound by per-wave
+// instruction issue (~370 issued instructions per wave and KV tile around 32 MFMAs).  Here a workgroup is 4 waves
+// = one 256-query block of one (item, head); a wave owns 64 queries (two 32-query blocks) and the whole 512-entry register
+// file of its SIMD, so every K / V^T fragment read from LDS feeds TWO MFMAs and the LDS-DMA per query halves:
+//
+//   AGPRs (named literally in the asm statements, never touched by the compiler):
+//     a[0:127]    O^T accumulators  o[bq][d]  (bq = query block 0/1, d = 32-wide slice of head_dim)  = 8 x 16
+//     a[128:191]  Q~ fragments      qf[bq][ks] (ks = 16-wide k-step of head_dim)                     = 16 x 4
+//     a[192:255]  K fragments of ONE whole tile, kf[j][ks] (j = 32-key block)                        = 16 x 4
+//   arch VGPRs (compiler-allocated): two S tiles (2 x 64), the packed P tile (32), the -max splats (32), V^T fragments in
+//   flight (16), addresses.
+//
+// MFMA operands: S^T = K Q~^T takes A and B from AGPRs and C / D in VGPRs (the first MFMA of a chain takes C = -m_run, so the
+// accumulator IS the exp2 argument: OMNI_ATTN_BAKE of attention.hip); O^T += V^T P^T takes A (V^T fragment, tr-read from LDS)
+// and B (P^T = the exp'ed S registers, packed) from VGPRs and C / D in AGPRs.
+//
+// Per KV tile t a wave runs two phases of 32 MFMAs:
+//   P1:  S(t+1) = K(t+1) Q~^T  ||  exp2 / pack / row-sum of S(t)  ||  LDS-DMA issue for K(t+3), V(t+1)
+//   P2:  O += V(t)^T P(t)^T    ||  row max of S(t+1)  ||  V(t) tr-reads (3 fragments ahead)  ||  K(t+2) fragments -> AGPRs
+// and ONE barrier.  LDS: 2 K slots + 2 V slots of 16 KiB (images as in attention.hip: K rows XOR-swizzled, V in tr-read blocks).
+//   K(j) lives in K slot j & 1: DMA'd during iteration j-3, waited + barrier'd at its end, read into AGPRs in P2 of iteration
+//        j-2, multiplied in P1 of iteration j-1; its slot is re-filled with K(j+2) during iteration j-1.
+//   V(j) lives in V slot j & 1: DMA'd during iteration j-1, read in P2 of iteration j; re-filled with V(j+2) in iteration j+1.
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 128;
+constexpr int KVBLK = 64;
+constexpr int TILE_BYTES = KVBLK * DH * 2;        // 16 KiB
+constexpr int K_SLOT0 = 0, V_SLOT0 = 2 * TILE_BYTES;
+constexpr int LDS_BYTES = 4 * TILE_BYTES;         // 64 KiB
+constexpr int QBLK = 256;                         // queries per workgroup
+
+// every AGPR, as a clobber list: makes the kernel descriptor allocate the accumulator half of the register file and tells the
+// compiler that nothing of its own survives there
+#define OMNI_A1(x) "a" #x
+#define OMNI_A10(d) OMNI_A1(d##0), OMNI_A1(d##1), OMNI_A1(d##2), OMNI_A1(d##3), OMNI_A1(d##4), OMNI_A1(d##5), OMNI_A1(d##6), \
+                    OMNI_A1(d##7), OMNI_A1(d##8), OMNI_A1(d##9)
+#define OMNI_ALL_AGPRS                                                                                                        \
+  OMNI_A1(0), OMNI_A1(1), OMNI_A1(2), OMNI_A1(3), OMNI_A1(4), OMNI_A1(5), OMNI_A1(6), OMNI_A1(7), OMNI_A1(8), OMNI_A1(9),      \
+  OMNI_A10(1), OMNI_A10(2), OMNI_A10(3), OMNI_A10(4), OMNI_A10(5), OMNI_A10(6), OMNI_A10(7), OMNI_A10(8), OMNI_A10(9),          \
+  OMNI_A10(10), OMNI_A10(11), OMNI_A10(12), OMNI_A10(13), OMNI_A10(14), OMNI_A10(15), OMNI_A10(16), OMNI_A10(17),               \
+  OMNI_A10(18), OMNI_A10(19), OMNI_A10(20), OMNI_A10(21), OMNI_A10(22), OMNI_A10(23), OMNI_A10(24), OMNI_A1(250),               \
+  OMNI_A1(251), OMNI_A1(252), OMNI_A1(253), OMNI_A1(254), OMNI_A1(255)
+
+constexpr int A_O = 0, A_Q = 128, A_K = 192;
+
+#ifndef OMNI_W64_P2SPLIT
+#define OMNI_W64_P2SPLIT 1      // P2: the fillers of a step are split between its two MFMAs (0: both MFMAs back to back)
+#endif
+#ifndef OMNI_W64_KREAD_STEPS
+#define OMNI_W64_KREAD_STEPS 8  // the 16 K(t+2) fragment reads are spread over the first N PV steps of P2 (16, 8 or 4)
+#endif
+#ifndef OMNI_W64_ABL
+#define OMNI_W64_ABL 0          // dev-only timing ablations (WRONG results): 1 no DMA, 2 no end-of-tile wait + barrier, 4 no exp,
+#endif                          // 8 no LDS fragment reads, 16 no row max, 32 no MFMA
+
+// LDS issue order of P2 (LDS operations return in order, so a counted lgkmcnt retires exactly the reads a step needs):
+//   VREAD(0) VREAD(1) VREAD(2) | step f: [wait] MFMAs, VREAD(f+3) (2 ops), KREADs of step f (16 / KREAD_STEPS ops, f < KREAD_STEPS)
+constexpr int kreads_at(int f) { return f < OMNI_W64_KREAD_STEPS ? 16 / OMNI_W64_KREAD_STEPS : 0; }
+constexpr int lds_ops_allowed_at(int f) {   // operations issued after VREAD(f) and before step f's wait
+  int issued = 6, after_vf = f < 3 ? 2 * (f + 1) : 0;
+  for (int s = 0; s < f; ++s) {
+    if (s + 3 < 16) { issued += 2; if (s + 3 == f) after_vf = issued; }
+    issued += kreads_at(s);
+  }
+  const int n = issued - after_vf;
+  return n > 15 ? 15 : n;                   // lgkmcnt is a 4-bit counter; waiting for fewer is only conservative
+}
+static_assert(lds_ops_allowed_at(0) == 4, "VREAD(1), VREAD(2) may stay in flight at step 0");
+
+// ---- asm statements.  hipcc schedules each as one opaque instruction and inserts no hazard padding inside: every wait state
+// a statement needs is written in its string (cdna_hip_programming.md 5.7).
+template <int KA, int QA>   // first MFMA of an S chain: D <- A(K frag) x B(Q frag) + C, C = the -max splat (VGPRs written by VALU)
+OMNI_DEVINL void mfma_qk_first(f32x16_t& d, const f32x16_t& c) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c2:%c3], a[%c4:%c5], %1"
+               : "=&v"(d) : "v"(c), "i"(KA), "i"(KA + 3), "i"(QA), "i"(QA + 3));
+}
+template <int KA, int QA>
+OMNI_DEVINL void mfma_qk_acc(f32x16_t& d) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(d) : "i"(KA), "i"(KA + 3), "i"(QA), "i"(QA + 3));
+}
+template <int OA>           // O^T[bq][d] += V^T frag x P^T frag   (accumulator in AGPRs)
+OMNI_DEVINL void mfma_pv(const u32x4_t& vf, const u32x4_t& pf) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vf), "v"(pf), "i"(OA), "i"(OA + 15));
+}
+template <int KA, int OFF>  // one K fragment (16 B per lane) LDS -> AGPRs
+OMNI_DEVINL void kread(uint32_t addr) {
+  asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "i"(KA), "i"(KA + 3), "i"(OFF));
+}
+template <int OFF>
+OMNI_DEVINL u32x2_t vread8(uint32_t addr) {   // ds_read_b64_tr_b16: hardware 4x4 transpose read (half of a V^T fragment)
+  u32x2_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+template <int A>
+OMNI_DEVINL void agpr_write(uint32_t v) { asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "i"(A)); }
+template <int A>
+OMNI_DEVINL void agpr_zero() { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(A)); }
+template <int A>
+OMNI_DEVINL float agpr_read() {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(A));
+  return v;
+}
+template <int A>
+OMNI_DEVINL void agpr_scale(float alpha) {
+  float t;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a[%c2], %0"
+               : "=&v"(t) : "v"(alpha), "i"(A));
+}
+template <int BASE, int... I>
+OMNI_DEVINL void agpr_zero_range(std::integer_sequence<int, I...>) { (agpr_zero<BASE + I>(), ...); }
+template <int BASE, int... I>
+OMNI_DEVINL void agpr_scale_range(float alpha, std::integer_sequence<int, I...>) { (agpr_scale<BASE + I>(alpha), ...); }
+// a PV MFMA's D reaches a non-MFMA reader only after its passes have drained: software wait states, no interlock
+OMNI_DEVINL void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// the same, pinned in front of plain VALU code that touches an S tile right behind the MFMAs that produced it
+OMNI_DEVINL void mfma_drain_s(f32x16_t (&S)[2][2]) {
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[1][0]), "+v"(S[1][1]));
+}
+
+OMNI_DEVINL float max3(float a, float b, float c) {   // one instruction; fmaxf() on asm outputs gets a canonicalising v_max first
+  float r;
+  asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+OMNI_DEVINL float xhalf_max(float x) {
+  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+OMNI_DEVINL float xhalf_sum(float x) {
+  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+// LDS-DMA through a buffer descriptor: per-lane byte offset (offen) + uniform soffset; M0 = LDS byte address of the 1-KiB
+// piece (the hardware adds lane * 16).  Rows past the end of the sequence are outside the descriptor's range and land as
+// ZEROS: no clamp, no branch (those keys are masked to -inf, their V rows meet P = 0).  No instruction offset: it would
+// also move the LDS address.
+OMNI_DEVINL void dma16(const u32x4_t& srd, uint32_t lane_off, uint32_t soff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               ::"s"(lds_addr), "v"(lane_off), "s"(srd), "s"(soff) : "memory");
+}
+OMNI_DEVINL u32x4_t make_srd(const void* base, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  u32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);     // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+
+template <int N>
+using ic = std::integral_constant<int, N>;
+
+__global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+    const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e, int out_k32_rows,
+    const int32_t* __restrict__ item_skip, int q_prescaled) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // XCD-aware head-major block order (attention.hip): block b runs on XCD b % 8; every XCD gets a contiguous range of the
+  // (item*head, q-block) list, so the workgroups resident on an XCD stream the same few heads' K / V through its L2
+  int hb, qb;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x, qblocks = nwg / n_heads_total;
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    hb = lid / qblocks;
+    qb = lid - hb * qblocks;
+  }
+  const int b = hb / H, h = hb - b * H;
+  if (item_skip && item_skip[b]) return;
+  const int seq_start = cu_seqlens[b];
+  const int seq_len = cu_seqlens[b + 1] - seq_start;
+  if (qb * QBLK >= seq_len) return;
+
+  asm volatile("" ::: OMNI_ALL_AGPRS);   // allocate a[0:255]
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int ntiles = (seq_len + KVBLK - 1) / KVBLK;
+
+  // ---- LDS-DMA sources.  Piece P = wave + 4i (1 KiB of a tile image), lane L -> byte 16 L of the piece.
+  //  K piece P: key = 4P + (L>>4) = [4 wave + (L>>4)] + 16 i; LDS chunk L&15 holds logical chunk (L&15) ^ (key&15) — the same
+  //             for every i, so the four pieces differ by a uniform 16-row stride in soffset;
+  //  V piece P = (dblk = i, key group = wave): key = 16 wave + 4 (L>>4) + ((L>>2)&3), logical chunk 4i + (L&3): the four
+  //             pieces differ by 64 B in soffset.
+  const u32x4_t k_srd = make_srd(k + (int64_t)seq_start * ldk + h * DH, (uint32_t)((int64_t)(seq_len - 1) * ldk * 2 + DH * 2));
+  const u32x4_t v_srd = make_srd(v + (int64_t)seq_start * ldv + h * DH, (uint32_t)((int64_t)(seq_len - 1) * ldv * 2 + DH * 2));
+  const int k_key0 = 4 * wave + (lane >> 4);
+  const int v_key = 16 * wave + 4 * (lane >> 4) + ((lane >> 2) & 3);
+  const uint32_t k_src = (uint32_t)(k_key0 * ldk * 2) + (uint32_t)(((lane & 15) ^ (k_key0 & 15)) * 16);
+  const uint32_t v_src = (uint32_t)(v_key * ldv * 2) + (uint32_t)((lane & 3) * 16);
+  const uint32_t k_tile_stride = (uint32_t)(KVBLK * ldk * 2), v_tile_stride = (uint32_t)(KVBLK * ldv * 2);
+  const uint32_t k_piece_stride = (uint32_t)(16 * ldk * 2);
+  // a tile index past the last tile is fine: every row of it is out of the descriptor's range (zeros)
+  auto issue_K_piece = [&](int t, int slot, auto ii) {
+    constexpr int i = decltype(ii)::value;
+    dma16(k_srd, k_src, (uint32_t)t * k_tile_stride + i * k_piece_stride, lds0 + K_SLOT0 + slot * TILE_BYTES + (wave + 4 * i) * 1024);
+  };
+  auto issue_V_piece = [&](int t, int slot, auto ii) {
+    constexpr int i = decltype(ii)::value;
+    dma16(v_srd, v_src, (uint32_t)t * v_tile_stride + i * 64, lds0 + V_SLOT0 + slot * TILE_BYTES + (wave + 4 * i) * 1024);
+  };
+  auto issue_K = [&](int t, int slot) {
+    issue_K_piece(t, slot, ic<0>{}); issue_K_piece(t, slot, ic<1>{}); issue_K_piece(t, slot, ic<2>{}); issue_K_piece(t, slot, ic<3>{});
+  };
+  auto issue_V = [&](int t, int slot) {
+    issue_V_piece(t, slot, ic<0>{}); issue_V_piece(t, slot, ic<1>{}); issue_V_piece(t, slot, ic<2>{}); issue_V_piece(t, slot, ic<3>{});
+  };
+
+  // ---- prologue DMA first (it flies while Q is fetched)
+  issue_K(0, 0);
+  issue_K(1, 1);
+  issue_V(0, 0);
+
+  // ---- Q~ fragments (B operand: lane holds query l31, d = ks*16 + hi*8 .. +8) -> a[128:191]; O <- 0
+  {
+    bf16x8_t qf[2][8];
+    const float qs = q_prescaled ? 1.0f : scale_log2e;
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq) {
+      const int qrow = min(qb * QBLK + wave * 64 + bq * 32 + l31, seq_len - 1);
+      const uint16_t* qp = q + (int64_t)(seq_start + qrow) * ldq + h * DH + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) qf[bq][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+    }
+    uint32_t qw[64];
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        u32x4_t w = __builtin_bit_cast(u32x4_t, qf[bq][ks]);
+        // the reference's un-scaled q: Q~ = bf16(q * scale * log2 e) (one extra rounding; attention.hip); a pre-scaled q is
+        // multiplied by 1.0f (exact)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(bf16_lo(w[e]) * qs, bf16_hi(w[e]) * qs);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qw[(bq * 8 + ks) * 4 + e] = w[e];
+      }
+    [&]<int... I>(std::integer_sequence<int, I...>) { (agpr_write<A_Q + I>(qw[I]), ...); }(std::make_integer_sequence<int, 64>{});
+    agpr_zero_range<A_O>(std::make_integer_sequence<int, 128>{});
+  }
+
+  // ---- fragment read addresses (attention.hip).  K: row key = j*32 + l31, chunk (ks*2 + hi) ^ (key & 15)
+  uint32_t k_addr[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_addr[ks] = lds0 + K_SLOT0 + l31 * 256 + ((((uint32_t)(ks * 2 + hi)) ^ (l31 & 15)) << 4);
+  const uint32_t v_addr = lds0 + V_SLOT0 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + hi * 256;
+
+  float negm[2], l_run[2] = {0.0f, 0.0f};
+  f32x16_t negm16[2];
+#pragma unroll
+  for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm16[bq][i] = 0.0f;
+
+  // all 16 K fragments of the tile in K slot `slot` -> a[192:255]   (fragment f = j*8 + ks)
+  auto kread_one = [&](auto ff, auto slot_c) {
+    constexpr int f = decltype(ff)::value, slot = decltype(slot_c)::value;
+    kread<A_K + f * 4, slot * TILE_BYTES + (f >> 3) * 32 * 256>(k_addr[f & 7]);
+  };
+  auto kread_all = [&](auto slot_c) {
+    [&]<int... F>(std::integer_sequence<int, F...>) { (kread_one(ic<F>{}, slot_c), ...); }(std::make_integer_sequence<int, 16>{});
+  };
+
+  // one QK^T MFMA step i = 0..31: j = i >> 4, ks = (i >> 1) & 7, bq = i & 1
+  auto qk_step = [&](auto ii, f32x16_t (&SN)[2][2]) {
+    constexpr int i = decltype(ii)::value, j = i >> 4, ks = (i >> 1) & 7, bq = i & 1;
+    if constexpr (OMNI_W64_ABL & 32) { if constexpr (ks == 0) SN[bq][j] = negm16[bq]; asm volatile("" : "+v"(SN[bq][j])); }
+    else if constexpr (ks == 0) mfma_qk_first<A_K + (j * 8 + ks) * 4, A_Q + (bq * 8 + ks) * 4>(SN[bq][j], negm16[bq]);
+    else mfma_qk_acc<A_K + (j * 8 + ks) * 4, A_Q + (bq * 8 + ks) * 4>(SN[bq][j]);
+  };
+  auto mask_tail = [&](f32x16_t (&S)[2][2], int kv0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (key >= seq_len) { S[0][j][r] = -INFINITY; S[1][j][r] = -INFINITY; }
+      }
+  };
+  auto row_max = [&](f32x16_t (&S)[2][2], float (&mx)[2]) {
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq) {
+      float m = S[bq][0][0];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        m = max3(m, S[bq][c >> 2][(c & 3) * 4 + 0], S[bq][c >> 2][(c & 3) * 4 + 1]);
+        m = max3(m, S[bq][c >> 2][(c & 3) * 4 + 2], S[bq][c >> 2][(c & 3) * 4 + 3]);
+      }
+      mx[bq] = xhalf_max(m);
+    }
+  };
+
+  // ---- prologue: K(0) -> AGPRs, S(0), K(2) into the freed slot, K(1) -> AGPRs, row max of S(0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  kread_all(ic<0>{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();                                  // every wave has K(0) in registers: its slot can take K(2)
+  issue_K(2, 0);
+  f32x16_t sA[2][2], sB[2][2];
+  float mxA[2], mxB[2] = {0.0f, 0.0f};
+  [&]<int... I>(std::integer_sequence<int, I...>) { (qk_step(ic<I>{}, sA), ...); }(std::make_integer_sequence<int, 32>{});
+  __builtin_amdgcn_sched_barrier(0);
+  kread_all(ic<1>{});
+  mfma_drain_s(sA);                                 // S(0) is read by VALU right away here (in the loop it is not)
+  if (KVBLK > seq_len) mask_tail(sA, 0);
+  row_max(sA, mxA);
+  // tile 0 opened its chains with C = 0: its row max becomes the first running max here (O = l = 0: nothing to rescale), also
+  // when every score of the tile is far below zero; the loop then sees a tile whose max is exactly at the reference point
+#pragma unroll
+  for (int bq = 0; bq < 2; ++bq) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sA[bq][j][i] -= mxA[bq];
+    negm[bq] = -mxA[bq];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm16[bq][i] = negm[bq];
+    mxA[bq] = 0.0f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+
+  // One iteration.  SC = S(t) (complete; row max mxc), SN receives S(t+1).  HAS_NEXT and PAR = t & 1 are compile-time: the
+  // LDS slots sit in the ds_read offset immediates and the last tile's body has no QK^T.
+  auto iteration = [&](auto has_next_c, auto par_c, int t, f32x16_t (&SC)[2][2], f32x16_t (&SN)[2][2], float (&mxc)[2],
+                       float (&mxn)[2]) {
+    constexpr bool HAS_NEXT = decltype(has_next_c)::value;
+    constexpr int PAR = decltype(par_c)::value;
+
+    // ---- defer-max decision (attention.hip OMNI_ATTN_BAKE): SC already is s~ - m~; rescale only when its row max exceeds
+    // the threshold (rare after the first tiles).
+    constexpr float DEFER = 6.0f;
+    float psum[2][2];
+    u32x4_t pf[2][2][2];                            // packed P^T: [bq][j][16-key half] = one MFMA B operand
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq) {
+      if (!__all(mxc[bq] <= DEFER)) {
+        const float d = fmaxf(mxc[bq], 0.0f);
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        l_run[bq] *= alpha;
+        mfma_drain();
+        if (bq == 0) agpr_scale_range<A_O>(alpha, std::make_integer_sequence<int, 64>{});
+        else agpr_scale_range<A_O + 64>(alpha, std::make_integer_sequence<int, 64>{});
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) SC[bq][j][i] -= d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm16[bq][i] -= d;
+      }
+      psum[bq][0] = 0.0f; psum[bq][1] = 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- P1: exp chunk c = 0..31 <-> (bq = c & 1, e = c >> 1): S elements 2e, 2e+1 of SC[bq] -> one packed word of P.
+    // The pack / sum of chunk c is issued behind the exps of chunk c+1 (a v_exp result needs a wait state before a VALU read).
+    float pend0[2], pend1[2];
+    auto exp_finish = [&](auto cc) {
+      constexpr int c = decltype(cc)::value, bq = c & 1, e = c >> 1;
+      psum[bq][0] += pend0[bq];
+      psum[bq][1] += pend1[bq];
+      uint32_t pk = pack_bf16x2(pend0[bq], pend1[bq]);
+      asm volatile("" : "+v"(pk), "+v"(psum[bq][0]), "+v"(psum[bq][1]));      // pin: keep it between these two MFMAs
+      pf[bq][e >> 3][(e >> 2) & 1][e & 3] = pk;
+    };
+    auto exp_chunk = [&](auto cc) {
+      constexpr int c = decltype(cc)::value, bq = c & 1, e = c >> 1;
+      float e0 = (OMNI_W64_ABL & 4) ? SC[bq][e >> 3][(2 * e) & 15] : __builtin_amdgcn_exp2f(SC[bq][e >> 3][(2 * e) & 15]);
+      float e1 = (OMNI_W64_ABL & 4) ? SC[bq][e >> 3][((2 * e) & 15) + 1] : __builtin_amdgcn_exp2f(SC[bq][e >> 3][((2 * e) & 15) + 1]);
+      asm volatile("" : "+v"(e0), "+v"(e1));
+      if constexpr (c >= 2) exp_finish(ic<c - 2>{});
+      pend0[bq] = e0; pend1[bq] = e1;
+    };
+    auto p1_step = [&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      if constexpr (HAS_NEXT) {
+        qk_step(ii, SN);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (!(OMNI_W64_ABL & 1)) {
+        if constexpr (i < 4) issue_V_piece(t + 1, PAR ^ 1, ic<i>{});
+        else if constexpr (i < 8) issue_K_piece(t + 3, PAR ^ 1, ic<i - 4>{});
+      }
+      exp_chunk(ii);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    __builtin_amdgcn_s_setprio(1);
+    [&]<int... I>(std::integer_sequence<int, I...>) { (p1_step(ic<I>{}), ...); }(std::make_integer_sequence<int, 32>{});
+    exp_finish(ic<30>{});
+    exp_finish(ic<31>{});
+    l_run[0] += psum[0][0] + psum[0][1];
+    l_run[1] += psum[1][0] + psum[1][1];
+    if (HAS_NEXT && (t + 2) * KVBLK > seq_len) { mfma_drain_s(SN); mask_tail(SN, (t + 1) * KVBLK); }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- P2: O^T += V(t)^T P(t)^T.  PV step f = 0..15 <-> (j = f >> 3, half = (f >> 2) & 1, d = f & 3): ONE V^T fragment
+    // (two tr-reads), two MFMAs (bq = 0, 1).  V fragments are read 3 ahead; K(t+2) fragment f goes to the AGPRs behind step f
+    // (after P1 nothing reads a[192:255] any more); the row max of S(t+1) fills steps 4..11.
+    // LDS ops return in order: at step f the reads issued after VREAD(f) are VREAD(f+1), VREAD(f+2) and up to three KREADs.
+    u32x2_t vlo[4], vhi[4];
+    float mx[2] = {HAS_NEXT ? SN[0][0][0] : 0.0f, HAS_NEXT ? SN[1][0][0] : 0.0f};
+    auto vread = [&](auto ff) {
+      constexpr int f = decltype(ff)::value;
+      constexpr int off = PAR * TILE_BYTES + (f & 3) * 4096 + (((f >> 3) * 8 + ((f >> 2) & 1) * 4) * 256);
+      if constexpr (OMNI_W64_ABL & 8) {
+        asm volatile("" : "=v"(vlo[f & 3]) : "v"(v_addr));
+        asm volatile("" : "=v"(vhi[f & 3]) : "v"(v_addr));
+      } else {
+        vlo[f & 3] = vread8<off>(v_addr);
+        vhi[f & 3] = vread8<off + 512>(v_addr);
+      }
+    };
+    auto max_half = [&](auto cc, auto bq_c) {       // row-max chunk c (4 S values) of query block bq
+      constexpr int c = decltype(cc)::value, bq = decltype(bq_c)::value;
+      if constexpr (HAS_NEXT && !(OMNI_W64_ABL & 16) && c >= 0 && c < 8) {
+        mx[bq] = max3(mx[bq], SN[bq][c >> 2][(c & 3) * 4 + 0], SN[bq][c >> 2][(c & 3) * 4 + 1]);
+        mx[bq] = max3(mx[bq], SN[bq][c >> 2][(c & 3) * 4 + 2], SN[bq][c >> 2][(c & 3) * 4 + 3]);
+      }
+    };
+    auto kreads_of = [&](auto ff) {                 // K(t+2) lives in K slot t & 1 (stale bytes past the last tile: unused)
+      constexpr int f = decltype(ff)::value, n = kreads_at(f);
+      if constexpr (!(OMNI_W64_ABL & 8))
+        [&]<int... J>(std::integer_sequence<int, J...>) { (kread_one(ic<f * n + J>{}, ic<PAR>{}), ...); }(std::make_integer_sequence<int, n>{});
+    };
+    auto p2_step = [&](auto ff) {
+      constexpr int f = decltype(ff)::value;
+      if constexpr (!(OMNI_W64_ABL & 8)) asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(lds_ops_allowed_at(f)) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4_t w = {vlo[f & 3][0], vlo[f & 3][1], vhi[f & 3][0], vhi[f & 3][1]};
+      if constexpr (!(OMNI_W64_ABL & 32)) mfma_pv<A_O + (0 * 4 + (f & 3)) * 16>(w, pf[0][f >> 3][(f >> 2) & 1]);
+      else asm volatile("" ::"v"(w), "v"(pf[0][f >> 3][(f >> 2) & 1]));
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (OMNI_W64_P2SPLIT) {             // fillers behind the FIRST MFMA: nothing here may overwrite `w`
+        max_half(ic<f - 4>{}, ic<0>{});
+        max_half(ic<f - 4>{}, ic<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (!(OMNI_W64_ABL & 32)) mfma_pv<A_O + (1 * 4 + (f & 3)) * 16>(w, pf[1][f >> 3][(f >> 2) & 1]);
+      else asm volatile("" ::"v"(w), "v"(pf[1][f >> 3][(f >> 2) & 1]));
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (f + 3 < 16) vread(ic<f + 3>{});
+      kreads_of(ff);
+      if constexpr (!OMNI_W64_P2SPLIT) {
+        max_half(ic<f - 4>{}, ic<0>{});
+        max_half(ic<f - 4>{}, ic<1>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    vread(ic<0>{}); vread(ic<1>{}); vread(ic<2>{});
+    [&]<int... F>(std::integer_sequence<int, F...>) { (p2_step(ic<F>{}), ...); }(std::make_integer_sequence<int, 16>{});
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (HAS_NEXT) {
+      mxn[0] = xhalf_max(mx[0]);
+      mxn[1] = xhalf_max(mx[1]);
+    }
+    if constexpr (!(OMNI_W64_ABL & 2)) {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // this iteration's DMA landed; K(t+2) in AGPRs
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+    }
+  };
+
+  {
+    using yes = std::true_type;
+    using no = std::false_type;
+    int t = 0;
+    for (; t + 2 < ntiles; t += 2) {
+      iteration(yes{}, ic<0>{}, t, sA, sB, mxA, mxB);
+      iteration(yes{}, ic<1>{}, t + 1, sB, sA, mxB, mxA);
+    }
+    if (t + 1 < ntiles) {
+      iteration(yes{}, ic<0>{}, t, sA, sB, mxA, mxB);
+      iteration(no{}, ic<1>{}, t + 1, sB, sA, mxB, mxA);
+    } else {
+      iteration(no{}, ic<0>{}, t, sA, sB, mxA, mxB);
+    }
+  }
+
+  // ---- epilogue: O / l -> out.  o[bq][d][4 qd + j] = O[q][d*32 + qd*8 + hi*4 + j]
+  mfma_drain();
+#pragma unroll
+  for (int bq = 0; bq < 2; ++bq) {
+    const float inv = 1.0f / xhalf_sum(l_run[bq]);
+    const int qrow = qb * QBLK + wave * 64 + bq * 32 + l31;
+    float o[64];
+    if (bq == 0) [&]<int... I>(std::integer_sequence<int, I...>) { ((o[I] = agpr_read<A_O + I>()), ...); }(std::make_integer_sequence<int, 64>{});
+    else [&]<int... I>(std::integer_sequence<int, I...>) { ((o[I] = agpr_read<A_O + 64 + I>()), ...); }(std::make_integer_sequence<int, 64>{});
+    if (qrow < seq_len) {
+      uint16_t* op = out_k32_rows ? out + ((int64_t)(h * 4) * out_k32_rows + seq_start + qrow) * 32 + hi * 4
+                                  : out + (int64_t)(seq_start + qrow) * ldo + h * DH + hi * 4;
+      const int64_t dstep = out_k32_rows ? (int64_t)out_k32_rows * 32 : 32;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          u32x2_t w;
+          w[0] = pack_bf16x2(o[d * 16 + qd * 4 + 0] * inv, o[d * 16 + qd * 4 + 1] * inv);
+          w[1] = pack_bf16x2(o[d * 16 + qd * 4 + 2] * inv, o[d * 16 + qd * 4 + 3] * inv);
+          *reinterpret_cast<u32x2_t*>(op + d * dstep + qd * 8) = w;
+        }
+    }
+  }
+}
+
+}  // namespace
+
+// internal: the 64-queries-per-wave kernel (same contract as omni_internal_flash_attn; picked by it for large grids)
+int omni_internal_flash_attn_w64(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq,
+                                 int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H,
+                                 int32_t max_seqlen, float softmax_scale, int32_t out_k32_rows, const int32_t* item_skip,
+                                 int32_t q_prescaled, void* stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_w64_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return OMNI_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int qblocks = (max_seqlen + QBLK - 1) / QBLK;
+  const int nh = B * H;
+  hipLaunchKernelGGL(flash_attn_fwd_w64_kernel, dim3(nh * qblocks), dim3(256), LDS_BYTES, static_cast<hipStream_t>(stream), q,
+                     k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows,
+                     item_skip, q_prescaled);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}

@@ -99,6 +99,12 @@ OMNI_DEVINL void qk_norm_rope_lane(const float (&f)[8], const float (&w)[8], con
 
 static inline bool omni_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// internal: the 64-queries-per-wave attention kernel (attention_w64.hip); same contract as omni_internal_flash_attn
+int omni_internal_flash_attn_w64(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq,
+                                 int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H,
+                                 int32_t max_seqlen, float softmax_scale, int32_t out_k32_rows, const int32_t* item_skip,
+                                 int32_t q_prescaled, void* stream);
+
 // internal (not part of the C-ABI): dst[i] = src[idx[i]] for int32 maps; used by omni_dit_forward
 int omni_internal_gather_i32(int32_t* dst, const int32_t* src, const int32_t* idx, int32_t n, void* stream);
 

@@ -91,6 +91,19 @@ bool dit_fuse_qkrope() {
   return v;
 }
 
+// omni_linear_smallbatch takes at most 8 rows (one weight stream shared by 8 activations): more conditioning rows (a
+// reference-shaped forward over B > 8 items with their own timesteps) run in chunks of 8, each re-streaming the weights
+int linear_rows(const omni_bf16* x, int64_t ldx, int32_t B, const omni_bf16* W, const omni_bf16* bias, int64_t N, int32_t K,
+                omni_bf16* y, int64_t ldy, int32_t act_in, int32_t act_out, omni_stream stream) {
+  for (int32_t b0 = 0; b0 < B; b0 += 8) {
+    const int32_t nb = B - b0 < 8 ? B - b0 : 8;
+    const int st = omni_linear_smallbatch(x + (int64_t)b0 * ldx, ldx, nb, W, bias, N, K, y + (int64_t)b0 * ldy, ldy, act_in,
+                                          act_out, stream);
+    if (st != OMNI_OK) return st;
+  }
+  return OMNI_OK;
+}
+
 struct BlockPred { const int32_t *tile_img, *tile_txt, *item; };
 
 // One dual-stream block (reference QwenImageTransformerBlock.forward, qwen_image_transformer.py:541-605) on the residual
@@ -120,9 +133,9 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   const bool blk = dit_act_blocked() && (D % 32 == 0);
   const int32_t bRi = blk ? Ri : 0, bRt = blk ? Rt : 0, bRj = blk ? Ri + Rt : 0;
   // modulation vectors [shift1|scale1|gate1|shift2|scale2|gate2]  (reference :552-561)
-  OMNI_TRY(omni_linear_smallbatch(temb, D, nT, L.img_mod_w, L.img_mod_b, 6 * (int64_t)D, D, ws.mod_img, 6 * D, 1,
+  OMNI_TRY(linear_rows(temb, D, nT, L.img_mod_w, L.img_mod_b, 6 * (int64_t)D, D, ws.mod_img, 6 * D, 1,
                                   0, stream));
-  OMNI_TRY(omni_linear_smallbatch(temb, D, nT, L.txt_mod_w, L.txt_mod_b, 6 * (int64_t)D, D, ws.mod_txt, 6 * D, 1,
+  OMNI_TRY(linear_rows(temb, D, nT, L.txt_mod_w, L.txt_mod_b, 6 * (int64_t)D, D, ws.mod_txt, 6 * D, 1,
                                   0, stream));
   if (phase != BLOCK_POST) {
   // norm1 + modulate (reference :564-567)
@@ -263,8 +276,8 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
 
   // --- conditioning: sinusoid -> Linear -> SiLU -> Linear   (reference :50-62) ---------------------------
   OMNI_TRY(omni_timestep_sinusoid(b->timestep, nT, 256, 1000.0f, ws.tproj, stream));
-  OMNI_TRY(omni_linear_smallbatch(ws.tproj, 256, nT, w->t_lin1_w, w->t_lin1_b, D, 256, ws.th, D, 0, 1, stream));
-  OMNI_TRY(omni_linear_smallbatch(ws.th, D, nT, w->t_lin2_w, w->t_lin2_b, D, D, ws.temb, D, 0, 0, stream));
+  OMNI_TRY(linear_rows(ws.tproj, 256, nT, w->t_lin1_w, w->t_lin1_b, D, 256, ws.th, D, 0, 1, stream));
+  OMNI_TRY(linear_rows(ws.th, D, nT, w->t_lin2_w, w->t_lin2_b, D, D, ws.temb, D, 0, 0, stream));
 
   // --- input projections (reference :743, :758-759) -------------------------------------------------------
   {
@@ -313,7 +326,7 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
 
   omni_bf16* xn_img = ws.xn;
   // --- output head: AdaLayerNormContinuous (scale first, then shift) + proj_out (reference :797-798) -------
-  OMNI_TRY(omni_linear_smallbatch(ws.temb, D, nT, w->norm_out_w, w->norm_out_b, 2 * (int64_t)D, D, ws.emb_out, 2 * D, 1,
+  OMNI_TRY(linear_rows(ws.temb, D, nT, w->norm_out_w, w->norm_out_b, 2 * (int64_t)D, D, ws.emb_out, 2 * D, 1,
                                   0, stream));
   OMNI_TRY(omni_adaln_modulate(ws.hidden_img, D, xn_img, D, Ri, D, ws.emb_out, ws.emb_out + D, 2 * D, b->img_item, 0,
                                eps, stream));

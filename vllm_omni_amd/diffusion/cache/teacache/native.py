@@ -45,6 +45,34 @@ class TeaCacheDeviceState:
         s.txt_cu = self.txt_cu.data_ptr()
         self._struct = s
 
+    # ---- per-item state hand-over (continuous step batching: a sample keeps its TeaCache history when the batch it runs in
+    # is re-composed).  prev_mod has the layout the first AdaLN writes: K32-blocked [D/32][rows][32] when D % 32 == 0.
+    def _item_views(self, i: int):
+        Ri = self.rows[0]
+        S = Ri // self.n_items
+        D = self.prev_res.numel() // Ri
+        res = self.prev_res.view(Ri, D)[i * S:(i + 1) * S]
+        mod = self.prev_mod.view(D // 32, Ri, 32)[:, i * S:(i + 1) * S] if D % 32 == 0 else self.prev_mod.view(Ri, D)[i * S:(i + 1) * S]
+        return mod, res
+
+    def export_item(self, i: int) -> dict:
+        mod, res = self._item_views(i)
+        return dict(mod=mod.clone(), res=res.clone(), acc=self.acc[i:i + 1].clone(), cnt=self.cnt[i:i + 1].clone(),
+                    skip_total=self.skip_total[i:i + 1].clone())
+
+    def import_item(self, i: int, saved: dict | None) -> None:
+        """Load a sample's history into slot i; None = a fresh sample (cnt = 0 forces a full compute first)."""
+        if saved is None:
+            for t in (self.acc, self.cnt, self.skip_total, self.skip):
+                t[i:i + 1].zero_()
+            return
+        mod, res = self._item_views(i)
+        mod.copy_(saved["mod"])
+        res.copy_(saved["res"])
+        self.acc[i:i + 1].copy_(saved["acc"])
+        self.cnt[i:i + 1].copy_(saved["cnt"])
+        self.skip_total[i:i + 1].copy_(saved["skip_total"])
+
     def struct_for(self, rb: RaggedBatch) -> N.TeaCache:
         if (rb.n_img_rows, rb.n_txt_rows) != self.rows or rb.n_items != self.n_items:
             raise ValueError("TeaCache state was built for a different batch")

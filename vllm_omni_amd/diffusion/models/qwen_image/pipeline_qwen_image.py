@@ -67,6 +67,7 @@ class QwenImagePipeline(nn.Module):
         self._latents_std = torch.tensor(self.vae.config.latents_std).view(1, -1, 1, 1, 1)
         self.weights_sources: list = []
         self._step_state: dict = {}     # hipGraph + static buffers per step-batch shape
+        self._serve_states: dict = {}   # the same for the continuous step batcher (denoise_one_step)
         self.last_teacache_state = None
         self.cache_backend = None
         name = getattr(self.od_config, "cache_backend", "none")
@@ -407,54 +408,181 @@ class QwenImagePipeline(nn.Module):
 
     # ------------------------------------------------------------------ continuous step batching (step_batcher.py)
     def begin_sample(self, a) -> None:
-        """Schedule tensors of one sample: per-step model timestep (bf16-rounded t/1000) and dt, on the device."""
+        """Schedule of one sample: per-step model timestep (bf16-rounded t/1000) and dt, kept on the HOST (a step uploads one
+        small pinned vector for the whole group instead of gathering R device scalars)."""
         sm = a.sample
         sch = FlowMatchEulerSchedule(self.scheduler.config)
         ts = sch.set_timesteps(sm["steps"], sm["lat"].shape[0])
         a.n_steps = len(ts)
-        a.state = dict(sig=sch.model_timestep(ts).to(self.device), dt=sch.dt().to(self.device, torch.float32),
+        a.state = dict(sig_h=sch.model_timestep(ts).float().tolist(), dt_h=sch.dt().float().tolist(),
                        lat=sm["lat"].to(self.device, BF16).clone(), pos=sm["pos"].to(self.device, BF16),
                        neg=None if sm["neg"] is None else sm["neg"].to(self.device, BF16),
-                       cond=None if sm.get("cond") is None else sm["cond"].to(self.device, BF16))
+                       cond=None if sm.get("cond") is None else sm["cond"].to(self.device, BF16),
+                       home=None, tc=None)
 
     @staticmethod
     def batch_key(a):
         sm = a.sample
         return (sm["grid"], sm["do_cfg"], sm["cfg"])
 
+    # A "serve state" = everything one composition of a running batch needs, allocated ONCE: the static input / output
+    # buffers of the forward, the ragged-batch descriptor, the per-request timestep / dt vectors, the TeaCache device state
+    # and (for short forwards) the captured hipGraph of one step.  A sample lives in one slot of one state ("home"): its
+    # latents and its TeaCache history stay there from step to step, and are copied out / in only when the batch is
+    # re-composed (a request joined or left) — never per step.  Item order: pos_0..pos_{R-1}, neg_0..neg_{R-1}.
+    def _serve_state(self, group: list) -> dict:
+        tr, dev = self.transformer, self.device
+        sm0 = group[0].sample
+        R, do_cfg = len(group), sm0["do_cfg"]
+        S = int(group[0].state["lat"].shape[0])
+        cond0 = group[0].state.get("cond")
+        S_c = 0 if cond0 is None else int(cond0.shape[0])
+        lens = [int(a.state["pos"].shape[0]) for a in group] + ([int(a.state["neg"].shape[0]) for a in group] if do_cfg else [])
+        tcfg = getattr(tr, "teacache", None)
+        key = (tuple(lens), tuple(sm0["grid"]), do_cfg, float(sm0["cfg"]), R, S_c,
+               None if tcfg is None else (tcfg.rel_l1_thresh, tuple(tcfg.coefficients)))
+        st = self._serve_states.get(key)
+        if st is not None:
+            return st
+        n_items, S_tot, Cl = (2 if do_cfg else 1) * R, S + S_c, tr.in_channels
+        rb = build_ragged_batch(lens, sm0["grid"], temb_rows=list(range(R)) * (2 if do_cfg else 1))
+        offs = [0]
+        for t in lens:
+            offs.append(offs[-1] + t)
+        st = dict(key=key, R=R, S=S, S_c=S_c, do_cfg=do_cfg, cfg=float(sm0["cfg"]), n_items=n_items, rb=rb, txt_off=offs,
+                  prepared=tr.prepare_batch(rb), members=[None] * R, graph=None, gen=None,
+                  lat=torch.zeros(R * S, Cl, dtype=BF16, device=dev),
+                  lat_in=torch.zeros(n_items * S_tot, Cl, dtype=BF16, device=dev),
+                  pred=torch.empty(n_items * S_tot, Cl, dtype=BF16, device=dev),
+                  pred_c=torch.empty(n_items * S, Cl, dtype=BF16, device=dev) if S_c else None,
+                  prompt=torch.zeros(sum(lens), tr.joint_attention_dim, dtype=BF16, device=dev),
+                  sig=torch.zeros(R, dtype=torch.float32, device=dev), dt=torch.zeros(R, dtype=torch.float32, device=dev),
+                  sig_h=torch.zeros(R, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(R),
+                  dt_h=torch.zeros(R, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(R), tc=None)
+        if tcfg is not None:
+            from ...cache.teacache.native import TeaCacheDeviceState
+
+            st["tc"] = TeaCacheDeviceState(tcfg, rb, tr.inner_dim, dev)
+        if len(self._serve_states) >= 8:                      # evict: every resident sample goes back to its own tensors
+            for old in self._serve_states.values():
+                for occ in old["members"]:
+                    if occ is not None:
+                        self._export_sample(occ)
+            self._serve_states.clear()
+        self._serve_states[key] = st
+        return st
+
+    def _export_sample(self, a) -> None:
+        """Copy a sample's latents (and TeaCache history) out of its home slot; the slot becomes free."""
+        home = a.state.get("home")
+        if home is None:
+            return
+        st, r = home
+        S, R = st["S"], st["R"]
+        a.state["lat"] = st["lat"][r * S:(r + 1) * S].clone()
+        if st["tc"] is not None:
+            a.state["tc"] = [st["tc"].export_item(r)] + ([st["tc"].export_item(R + r)] if st["do_cfg"] else [])
+        st["members"][r] = None
+        a.state["home"] = None
+
+    def _import_sample(self, a, st: dict, r: int) -> None:
+        home = a.state.get("home")
+        if home is not None and home[0] is st and home[1] == r:
+            return
+        self._export_sample(a)
+        occ = st["members"][r]
+        if occ is not None and occ is not a:
+            self._export_sample(occ)
+        S, S_c, R, do_cfg = st["S"], st["S_c"], st["R"], st["do_cfg"]
+        st["lat"][r * S:(r + 1) * S].copy_(a.state["lat"])
+        off = st["txt_off"]
+        st["prompt"][off[r]:off[r + 1]].copy_(a.state["pos"])
+        if do_cfg:
+            st["prompt"][off[R + r]:off[R + r + 1]].copy_(a.state["neg"])
+        if S_c:                                              # Edit: the condition rows of this sample's item(s) never change
+            li = st["lat_in"].view(st["n_items"], S + S_c, -1)
+            li[r, S:].copy_(a.state["cond"])
+            if do_cfg:
+                li[R + r, S:].copy_(a.state["cond"])
+        if st["tc"] is not None:
+            saved = a.state.get("tc")
+            st["tc"].import_item(r, saved[0] if saved else None)
+            if do_cfg:
+                st["tc"].import_item(R + r, saved[1] if saved else None)
+        st["members"][r] = a
+        a.state["home"] = (st, r)
+
+    def _serve_step_body(self, st: dict) -> None:
+        tr = self.transformer
+        R, S, S_c, do_cfg, n_items = st["R"], st["S"], st["S_c"], st["do_cfg"], st["n_items"]
+        lat, lat_in, pred = st["lat"], st["lat_in"], st["pred"]
+        Cl = lat.shape[1]
+        if S_c:
+            li = lat_in.view(n_items, S + S_c, Cl)
+            li[:R, :S].copy_(lat.view(R, S, Cl))
+            if do_cfg:
+                li[R:, :S].copy_(lat.view(R, S, Cl))
+        else:
+            lat_in[: R * S].copy_(lat)
+            if do_cfg:
+                lat_in[R * S:].copy_(lat)
+        tr.forward_ragged(st["prepared"], lat_in, st["prompt"], st["sig"], out=pred, teacache=st["tc"])
+        pr = pred
+        if S_c:                                              # noise_pred[:, :latents.size(1)] (edit pipeline :632)
+            st["pred_c"].view(n_items, S, Cl).copy_(pred.view(n_items, S + S_c, Cl)[:, :S])
+            pr = st["pred_c"]
+        ops.cfg_euler_step_(lat, pr[: R * S], pr[R * S:] if do_cfg else None, st["cfg"], st["dt"], dt_rows_per_item=S)
+
     @torch.no_grad()
     def denoise_one_step(self, group: list) -> None:
         """ONE ragged DiT forward for samples that may sit at different step indices: sample r owns temb row r (its CFG
-        pair shares it); the fused CFG + Euler kernel reads a per-sample dt."""
+        pair shares it); the fused CFG + Euler kernel reads a per-sample dt.  Static buffers, no per-step concatenation;
+        TeaCache decisions per item on the device; the step is a hipGraph replay when the forward is short (reference loop
+        shape: vllm_omni/diffusion/worker/gpu_worker.py:226-290 runs one request to completion per iteration)."""
         tr, dev = self.transformer, self.device
-        if getattr(tr, "teacache", None) is not None:
-            raise NotImplementedError("TeaCache state is kept per static step-batch; use generate() with it")
-        R = len(group)
-        sm0 = group[0].sample
-        S, do_cfg = group[0].state["lat"].shape[0], sm0["do_cfg"]
-        txt = [a.state["pos"] for a in group] + ([a.state["neg"] for a in group] if do_cfg else [])
-        lens = [int(t.shape[0]) for t in txt]
-        rb = build_ragged_batch(lens, sm0["grid"], temb_rows=list(range(R)) * (2 if do_cfg else 1))
-        prepared = tr.prepare_batch(rb)
-        lat = torch.cat([a.state["lat"] for a in group])
-        if group[0].state.get("cond") is not None:           # Edit: [latents ; condition-image latents] per item
-            per = torch.cat([torch.cat([a.state["lat"], a.state["cond"]]) for a in group])
-            lat_in = torch.cat([per, per]) if do_cfg else per
-        else:
-            lat_in = torch.cat([lat, lat]) if do_cfg else lat
-        sig = torch.stack([a.state["sig"][a.step] for a in group]).contiguous()
-        dt = torch.stack([a.state["dt"][a.step] for a in group]).contiguous()
-        tr.do_true_cfg = do_cfg
-        pred = tr.forward_ragged(prepared, lat_in.contiguous(), torch.cat(txt).contiguous(), sig)
-        if group[0].state.get("cond") is not None:
-            n_it = (2 if do_cfg else 1) * R
-            pred = pred.view(n_it, -1, pred.shape[-1])[:, :S].reshape(n_it * S, -1).contiguous()
-        ops.cfg_euler_step_(lat, pred[: R * S], pred[R * S:] if do_cfg else None, sm0["cfg"], dt, dt_rows_per_item=S)
+        st = self._serve_state(group)
         for r, a in enumerate(group):
-            a.state["lat"] = lat[r * S:(r + 1) * S]
+            self._import_sample(a, st, r)
+        for r, a in enumerate(group):
+            st["sig_h"][r] = a.state["sig_h"][a.step]
+            st["dt_h"][r] = a.state["dt_h"][a.step]
+        st["sig"].copy_(st["sig_h"], non_blocking=True)
+        st["dt"].copy_(st["dt_h"], non_blocking=True)
+        tr.do_true_cfg = st["do_cfg"]
+        self.last_teacache_state = st["tc"]
+        if not self._use_graph(st["n_items"] * st["S"]):
+            self._serve_step_body(st)
+            return
+        tr._native_weights()
+        if st["graph"] is None or st["gen"] != tr._native_gen:
+            # warm-up on a side stream, then capture (see _denoise); both advance `lat` and the TeaCache state of the resident
+            # samples, so those are saved and restored around them
+            saved_lat = st["lat"].clone()
+            saved_tc = None
+            if st["tc"] is not None:
+                saved_tc = [st["tc"].export_item(i) for i in range(st["n_items"])]
+            st["dt"].zero_()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._serve_step_body(st)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._serve_step_body(st)
+            st["graph"], st["gen"] = g, tr._native_gen
+            st["keepalive"] = (st["prepared"], tr._workspace, tr._native)
+            st["lat"].copy_(saved_lat)
+            if saved_tc is not None:
+                for i, sv in enumerate(saved_tc):
+                    st["tc"].import_item(i, sv)
+            st["dt"].copy_(st["dt_h"], non_blocking=True)
+        st["graph"].replay()
 
     def sample_result(self, a) -> torch.Tensor:
-        return a.state["lat"].clone()
+        """Final latents of a finished sample; its slot is released."""
+        self._export_sample(a)
+        return a.state["lat"]
 
     def finish_request(self, req: OmniDiffusionRequest, latents: list[torch.Tensor], sample: dict) -> DiffusionOutput:
         lat = torch.stack(latents)

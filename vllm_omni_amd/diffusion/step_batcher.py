@@ -62,7 +62,10 @@ class ContinuousStepBatcher:
         head = self.active[0]
         key = self.pipeline.batch_key(head)
         group = [a for a in self.active if self.pipeline.batch_key(a) == key][: self.max_samples]
-        self.pipeline.denoise_one_step(group)
+        try:
+            self.pipeline.denoise_one_step(group)
+        except Exception as e:  # noqa: BLE001 — a failing step aborts the REQUESTS that were in it, nothing else
+            return self.abort({a.tag for a in group}, f"{type(e).__name__}: {e}")
         finished = []
         for a in group:
             a.step += 1
@@ -76,6 +79,24 @@ class ContinuousStepBatcher:
                     finished.append((a.tag, self.pipeline.finish_request(p["req"], [p["done"][k] for k in range(p["n"])],
                                                                          a.sample)))
         return finished
+
+    def abort(self, tags, error: str) -> list[tuple[Any, Any]]:
+        """Drop every sample of the given requests (all samples of a request succeed together or not at all) and report ONE
+        error output per request."""
+        from .data import DiffusionOutput
+
+        tags = set(tags)
+        for a in [a for a in self.active if a.tag in tags]:
+            self.active.remove(a)
+            release = getattr(self.pipeline, "_export_sample", None)
+            if release is not None:
+                try:
+                    release(a)
+                except Exception:  # noqa: BLE001
+                    pass
+        for t in tags:
+            self._pending.pop(t, None)
+        return [(t, DiffusionOutput(error=error)) for t in sorted(tags, key=str)]
 
     def drain(self) -> list[tuple[Any, Any]]:
         out = []

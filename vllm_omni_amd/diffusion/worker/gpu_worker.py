@@ -162,11 +162,10 @@ class WorkerProc:
             except queue.Empty:
                 pass
             try:
-                finished = self.batcher.step()
-            except Exception as e:  # a failing step aborts the samples that were in it, not the worker
-                finished = [(a.tag, DiffusionOutput(error=f"{type(e).__name__}: {e}")) for a in list(self.batcher.active)]
-                self.batcher.active.clear()
-                self.batcher._pending.clear()
+                finished = self.batcher.step()              # a failing step aborts only the requests that were in it
+            except Exception as e:  # noqa: BLE001 — scheduler bug: abort everything once per request, keep the worker alive
+                finished = self.batcher.abort({a.tag for a in self.batcher.active} | set(self.batcher._pending),
+                                              f"{type(e).__name__}: {e}")
             for tag, out in finished:
                 self.outbox.put({"type": "done", "id": tag, "rank": self.rank, "output": _to_cpu(out),
                                  "outstanding_steps": self.batcher.outstanding_steps()})
