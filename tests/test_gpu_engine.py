@@ -65,3 +65,68 @@ def test_continuous_step_batching_equals_solo_runs():
         solo = pipe.generate([r], output_type="latent")[0].output
         e = rel_l2(done[k].output, solo)
         assert e <= 5e-3, (k, e)                            # B=1 semantics; only GEMM tile grouping differs
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_continuous_step_batching_with_teacache_keeps_per_sample_history(graph):
+    """TeaCache in the SERVING path: a sample's device-side history (previous modulated input, cached residual, accumulated
+    distance, counters) moves with it when the running batch is re-composed, so staggered requests take the same
+    compute / reuse decision at every step as their solo runs and end at the same latents (round-2 advisor finding: the
+    engine path raised NotImplementedError with tea_cache on)."""
+    import _gpu_factory
+    from vllm_omni_amd.diffusion.cache.teacache.config import TeaCacheConfig
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+    from vllm_omni_amd.diffusion.step_batcher import ContinuousStepBatcher
+
+    pipe = _gpu_factory.make_small_pipeline()
+    pipe.od_config.use_hip_graph = graph
+    pipe.transformer.teacache = TeaCacheConfig(rel_l1_thresh=0.6)
+    g = torch.Generator().manual_seed(9)
+
+    def req(steps, T, Tn):
+        return OmniDiffusionRequest(height=128, width=128, num_inference_steps=steps, true_cfg_scale=4.0, output_type="latent",
+                                    latents=torch.randn(1, 64, 64, generator=g).to(BF16),
+                                    prompt_embeds=torch.randn(1, T, 128, generator=g).to(BF16),
+                                    negative_prompt_embeds=torch.randn(1, Tn, 128, generator=g).to(BF16))
+
+    reqs = {"a": req(8, 7, 3), "b": req(6, 19, 12), "c": req(7, 4, 4)}
+
+    def run(plan, max_items):
+        """plan: list of ("add", tag) / ("step",) / ("drain",); returns outputs and, per tag, the (pos, neg) decision of every step."""
+        b = ContinuousStepBatcher(pipe, max_items=max_items)
+        done, pattern = {}, {}
+
+        def one_step():
+            out = b.step()
+            tc = pipe.last_teacache_state
+            st = next(s for s in pipe._serve_states.values() if s["tc"] is tc)
+            flags = tc.skip.tolist()
+            for r, a in enumerate(st["members"]):
+                if a is not None:
+                    pattern.setdefault(a.tag, []).append((flags[r], flags[st["R"] + r]))
+            done.update(out)
+
+        for op in plan:
+            if op[0] == "add":
+                b.add(reqs[op[1]], op[1])
+            elif op[0] == "step":
+                one_step()
+            else:
+                while b.has_work():
+                    one_step()
+        return done, pattern
+
+    done, pat = run([("add", "a"), ("step",), ("step",), ("add", "b"), ("step",), ("add", "c"), ("drain",)], 3)
+    torch.cuda.synchronize()
+    assert set(done) == set(reqs) and all(o.error is None for o in done.values())
+    for k, r in reqs.items():
+        solo, solo_pat = run([("add", k), ("drain",)], 1)
+        static = pipe.generate([r], output_type="latent")[0].output           # the bench's static loop
+        static_skips = tuple(pipe.last_teacache_state.skipped_forwards())
+        e, e2 = rel_l2(done[k].output, solo[k].output), rel_l2(solo[k].output, static)
+        print(f"graph={graph} request {k}: decisions batched {pat[k]} solo {solo_pat[k]}; static-loop reuse counts {static_skips}; "
+              f"batched vs solo rel_l2 {e:.2e}, solo vs static loop {e2:.2e}")
+        assert pat[k] == solo_pat[k] and sum(map(sum, solo_pat[k])) > 0
+        assert tuple(map(sum, zip(*solo_pat[k]))) == static_skips
+        assert e <= 5e-3 and e2 <= 5e-3, (k, e, e2)
+    pipe.transformer.teacache = None

@@ -92,3 +92,130 @@ def test_ulysses_collectives_and_strategy_on_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert all(v == "ok" for v in res.values()), res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sp_driver: generators that yield their collectives, software-pipelined over a process group (round 3)
+def _toy_forward_gen(rank, P, x, scale):
+    """Three segments with two exchanges: out = all_gather(all_to_all(x * scale) + rank) — every value is checkable."""
+    send = (x * scale).reshape(P, -1).contiguous()
+    got = yield ("all_to_all", send)                       # got[j] = what rank j sent to me
+    y = got + float(rank)
+    full = yield ("all_gather", y.reshape(-1).contiguous())
+    return full.reshape(-1)
+
+
+def _driver_rank(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from vllm_omni_amd.diffusion.distributed.sp_driver import drive
+
+    dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+    base = torch.arange(world * 3, dtype=torch.float32) + 100.0 * rank
+    gens = [_toy_forward_gen(rank, world, base, s) for s in (1.0, 2.0, -1.0)]      # three pipelined "forwards"
+    outs = drive(gens, None)
+    solo = [drive([_toy_forward_gen(rank, world, base, s)], None)[0] for s in (1.0, 2.0, -1.0)]
+    q.put((rank, [o.tolist() for o in outs], [o.tolist() for o in solo]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sp_driver_pipelines_generators_over_gloo(world):
+    from test_host_logic import _free_port
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, outs, solo = q.get(timeout=120)
+        res[rank] = (outs, solo)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for s_i, s in enumerate((1.0, 2.0, -1.0)):
+        # expected: rank r receives chunk r of every rank j's (base_j * s), adds r; the gather concatenates ranks
+        want = []
+        for r in range(world):
+            for j in range(world):
+                bj = torch.arange(world * 3, dtype=torch.float32) + 100.0 * j
+                want += (bj * s).reshape(world, -1)[r].add(float(r)).tolist()
+        for r in range(world):
+            assert res[r][0][s_i] == want, (world, s, r)
+            assert res[r][1][s_i] == want                  # pipelined == one at a time
+
+
+def _sp_worker_rank(rank, world, port, q, degree):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from vllm_omni_amd.diffusion.data import DiffusionOutput, DiffusionParallelConfig, OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+    from vllm_omni_amd.diffusion.worker.gpu_worker import GPUWorker
+
+    class FakeSPPipeline:
+        """'Denoised latent' = seed + 1000 * (sum of the SP group's ranks, exchanged over the group the worker handed in): a
+        wrong group, a rank that skips its share or a gather from the wrong rank all show."""
+        device = torch.device("cpu")
+        sp_group, sp_degree = None, 1
+        ran = []
+
+        def _req_params(self, r):
+            return (r.height, r.width, r.num_inference_steps, 4.0, False)
+
+        def generate(self, reqs, output_type="latent"):
+            t = torch.tensor([float(rank)])
+            dist.all_reduce(t, group=self.sp_group)
+            self.ran += [r.seed for r in reqs]
+            return [DiffusionOutput(output=torch.full((1, 16, 64), float(r.seed) + 1000.0 * float(t), dtype=torch.float32).bfloat16())
+                    for r in reqs]
+
+        def decode_latents(self, lat, h, w):
+            return lat
+
+    cfg = OmniDiffusionConfig(dist_timeout=60, parallel_config=DiffusionParallelConfig(ulysses_degree=degree, data_parallel_size=world // degree))
+    pipe = FakeSPPipeline()
+    w = GPUWorker(rank, rank, cfg, pipeline=pipe)
+    w.init_device_and_model()
+    assert pipe.sp_degree == degree and (w.dp_rank, w.dp_world) == (rank // degree, world // degree)
+    reqs = [OmniDiffusionRequest(height=64, width=64, num_inference_steps=s, seed=i, prompt_embeds=torch.zeros(1, 1, 8))
+            for i, s in enumerate([4, 20, 4, 4])]
+    out = w.execute_model(reqs, decode=False)
+    q.put((rank, out.error, None if out.output is None else out.output[:, 0, 0].float().tolist(), sorted(pipe.ran)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,degree", [(2, 2), (4, 2)])
+def test_worker_shards_requests_over_sp_groups_on_gloo(world, degree):
+    """world = data-parallel groups x ulysses_degree: every rank of a group runs the group's share in lockstep (its pipeline's
+    collectives run over THAT group), only the group's first rank contributes rows to the latent gather."""
+    from test_host_logic import _free_port
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sp_worker_rank, args=(r, world, port, q, degree)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, err, vals, ran = q.get(timeout=180)
+        res[rank] = (err, vals, ran)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res[r][0] is None for r in range(world)), res
+    for g in range(world // degree):
+        shares = {tuple(res[r][2]) for r in range(g * degree, (g + 1) * degree)}
+        assert len(shares) == 1                              # the ranks of a group ran the same requests
+    assert sorted(s for g in range(world // degree) for s in res[g * degree][2]) == [0, 1, 2, 3]
+    got = res[0][1]
+    for i, v in enumerate(got):                              # value = seed + 1000 * sum(ranks of the group that ran it)
+        g = next(g for g in range(world // degree) if i in res[g * degree][2])
+        assert v == pytest.approx(i + 1000.0 * sum(range(g * degree, (g + 1) * degree)), rel=1e-2)

@@ -1432,7 +1432,8 @@ int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_
 #if OMNI_ATTN_W64
   // >= 2 rounds of 256-query workgroups over the 256 CUs: the 64-queries-per-wave kernel (attention_w64.hip); smaller grids
   // keep the finer 128 / 256-query blocks of the two-waves-per-SIMD kernel below
-  if ((long)B * H * ((max_seqlen + 255) / 256) >= 512)
+  if ((long)B * H * ((max_seqlen + 255) / 256) >= 512 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+      (out_k32_rows || ldo % 8 == 0))                       // its epilogue stores whole 16-byte pieces
     return omni_internal_flash_attn_w64(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale,
                                         out_k32_rows, item_skip, q_prescaled, stream);
 #endif

@@ -17,12 +17,18 @@
 // and B (P^T = the exp'ed S registers, packed) from VGPRs and C / D in AGPRs.
 //
 // Per KV tile t a wave runs two phases of 32 MFMAs:
-//   P1:  S(t+1) = K(t+1) Q~^T  ||  exp2 / pack / row-sum of S(t)  ||  LDS-DMA issue for K(t+3), V(t+1)
+//   P1:  S(t+1) = K(t+1) Q~^T  ||  exp2 / pack / row-sum of S(t)                       (5 VALU per MFMA: the loaded phase)
 //   P2:  O += V(t)^T P(t)^T    ||  row max of S(t+1)  ||  V(t) tr-reads (3 fragments ahead)  ||  K(t+2) fragments -> AGPRs
-// and ONE barrier.  LDS: 2 K slots + 2 V slots of 16 KiB (images as in attention.hip: K rows XOR-swizzled, V in tr-read blocks).
-//   K(j) lives in K slot j & 1: DMA'd during iteration j-3, waited + barrier'd at its end, read into AGPRs in P2 of iteration
-//        j-2, multiplied in P1 of iteration j-1; its slot is re-filled with K(j+2) during iteration j-1.
-//   V(j) lives in V slot j & 1: DMA'd during iteration j-1, read in P2 of iteration j; re-filled with V(j+2) in iteration j+1.
+//                              ||  LDS-DMA issue for K(t+4), V(t+2)   (a piece costs its wave ~50 issue cycles: measured 11 %
+//                                  of the kernel when issued inside P1, whose MFMA gaps are already full)
+// and ONE barrier.  LDS: 3 K slots + 3 V slots of 16 KiB (images as in attention.hip: K rows XOR-swizzled, V in tr-read blocks).
+//   K(j) lives in K slot j % 3: DMA'd in P2 of iteration j-4, retired by the COUNTED vmcnt(8) at the end of iteration j-3 (the 8
+//        pieces of iteration j-3 stay in flight across the barrier), read into AGPRs in P2 of iteration j-2, multiplied in P1 of
+//        iteration j-1; its slot takes K(j+3) in P2 of iteration j-1.
+//   V(j) lives in V slot j % 3: DMA'd in P2 of iteration j-2, retired at the end of iteration j-1, read in P2 of iteration j; its
+//        slot takes V(j+3) in P2 of iteration j+1.
+// The slot of a tile is a run-time value (a period of 3 against the S ping-pong's period of 2 would need a 6-fold unroll):
+// the nine fragment base addresses are re-based once per tile (9 VALU).
 #include <type_traits>
 #include <utility>
 
@@ -33,8 +39,9 @@ namespace {
 constexpr int DH = 128;
 constexpr int KVBLK = 64;
 constexpr int TILE_BYTES = KVBLK * DH * 2;        // 16 KiB
-constexpr int K_SLOT0 = 0, V_SLOT0 = 2 * TILE_BYTES;
-constexpr int LDS_BYTES = 4 * TILE_BYTES;         // 64 KiB
+constexpr int NSLOT = 3;                          // K ring and V ring: 3 slots of 16 KiB each
+constexpr int K_SLOT0 = 0, V_SLOT0 = NSLOT * TILE_BYTES;
+constexpr int LDS_BYTES = 2 * NSLOT * TILE_BYTES; // 96 KiB
 constexpr int QBLK = 256;                         // queries per workgroup
 
 // every AGPR, as a clobber list: makes the kernel descriptor allocate the accumulator half of the register file and tells the
@@ -57,6 +64,27 @@ constexpr int A_O = 0, A_Q = 128, A_K = 192;
 #ifndef OMNI_W64_KREAD_STEPS
 #define OMNI_W64_KREAD_STEPS 8  // the 16 K(t+2) fragment reads are spread over the first N PV steps of P2 (16, 8 or 4)
 #endif
+#ifndef OMNI_W64_DMA_STEP0
+#define OMNI_W64_DMA_STEP0 0    // the 8 LDS-DMA pieces of a tile are issued behind PV steps STEP0 .. STEP0+7 of P2
+#endif
+#ifndef OMNI_W64_HOISTV
+#define OMNI_W64_HOISTV 1       // dev bisect knobs (all 1 in production)
+#endif
+#ifndef OMNI_W64_NEWDMA
+#define OMNI_W64_NEWDMA 1
+#endif
+#ifndef OMNI_W64_FUSEDMAX
+#define OMNI_W64_FUSEDMAX 1
+#endif
+#ifndef OMNI_W64_FINP2
+#define OMNI_W64_FINP2 1
+#endif
+#ifndef OMNI_W64_EARLYDEC
+#define OMNI_W64_EARLYDEC 1
+#endif
+#ifndef OMNI_W64_XHALF_IN_P2
+#define OMNI_W64_XHALF_IN_P2 1
+#endif
 #ifndef OMNI_W64_ABL
 #define OMNI_W64_ABL 0          // dev-only timing ablations (WRONG results): 1 no DMA, 2 no end-of-tile wait + barrier, 4 no exp,
 #endif                          // 8 no LDS fragment reads, 16 no row max, 32 no MFMA
@@ -77,10 +105,17 @@ static_assert(lds_ops_allowed_at(0) == 4, "VREAD(1), VREAD(2) may stay in flight
 
 // ---- asm statements.  hipcc schedules each as one opaque instruction and inserts no hazard padding inside: every wait state
 // a statement needs is written in its string (cdna_hip_programming.md 5.7).
-template <int KA, int QA>   // first MFMA of an S chain: D <- A(K frag) x B(Q frag) + C, C = the -max splat (VGPRs written by VALU)
+template <int KA, int QA, bool FRESH_C>   // first MFMA of an S chain: D <- A(K frag) x B(Q frag) + C, C = the -max splat.
 OMNI_DEVINL void mfma_qk_first(f32x16_t& d, const f32x16_t& c) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c2:%c3], a[%c4:%c5], %1"
-               : "=&v"(d) : "v"(c), "i"(KA), "i"(KA + 3), "i"(QA), "i"(QA + 3));
+  // FRESH_C: the splat may have been (re)materialised by VALU moves right in front of this statement (prologue: the compiler
+  // places the zero splat of tile 0 there) — a VALU-written SrcC needs wait states and they must sit INSIDE the statement.
+  // In the loop the splat is long-lived (rewritten only by the rescale path, which pads itself): no wait state, no issue slot.
+  if constexpr (FRESH_C)
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c2:%c3], a[%c4:%c5], %1"
+                 : "=&v"(d) : "v"(c), "i"(KA), "i"(KA + 3), "i"(QA), "i"(QA + 3));
+  else
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c2:%c3], a[%c4:%c5], %1"
+                 : "=&v"(d) : "v"(c), "i"(KA), "i"(KA + 3), "i"(QA), "i"(QA + 3));
 }
 template <int KA, int QA>
 OMNI_DEVINL void mfma_qk_acc(f32x16_t& d) {
@@ -132,10 +167,20 @@ OMNI_DEVINL float max3(float a, float b, float c) {   // one instruction; fmaxf(
   asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-OMNI_DEVINL float xhalf_max(float x) {
-  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+// four v_max3 of the two row-max chains, interleaved, in ONE statement: the compiler pads back-to-back dependent asm VALU
+// statements with s_nop (6 issue slots for 4 instructions); inside a statement nothing is inserted and none is needed
+OMNI_DEVINL void max3x4(float& m0, float& m1, float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
+  asm volatile("v_max3_f32 %0, %0, %2, %3\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %8, %9"
+               : "+v"(m0), "+v"(m1) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+OMNI_DEVINL void max3x4_first(float& m0, float& m1, float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
+  asm volatile("v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %6, %7, %8\n\tv_max_f32 %0, %0, %5\n\tv_max_f32 %1, %1, %9"
+               : "=&v"(m0), "=&v"(m1) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+OMNI_DEVINL float xhalf_max(float x) {          // max(x, x of the lane 32 away): one statement, 5 issue slots
+  float a = x, b;
+  asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "=&v"(b));
+  return a;
 }
 OMNI_DEVINL float xhalf_sum(float x) {
   uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
@@ -149,6 +194,20 @@ OMNI_DEVINL float xhalf_sum(float x) {
 OMNI_DEVINL void dma16(const u32x4_t& srd, uint32_t lane_off, uint32_t soff, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                ::"s"(lds_addr), "v"(lane_off), "s"(srd), "s"(soff) : "memory");
+}
+// the in-loop form: M0 and the source offset are formed by two SALU adds inside the statement (the second one is the wait
+// state the M0 write needs before the DMA): 3 issue slots per piece instead of 5
+template <int LDS_IMM, int SOFF_IMM>
+OMNI_DEVINL void dma16_at(const u32x4_t& srd, uint32_t lane_off, uint32_t soff_base, uint32_t lds_base) {
+  uint32_t tmp;
+  asm volatile("s_add_u32 m0, %1, %c5\n\ts_add_u32 %0, %2, %c6\n\tbuffer_load_dwordx4 %3, %4, %0 offen lds"
+               : "=&s"(tmp) : "s"(lds_base), "s"(soff_base), "v"(lane_off), "s"(srd), "i"(LDS_IMM), "i"(SOFF_IMM) : "memory", "scc");
+}
+template <int LDS_IMM>      // the same with a run-time (uniform) source addend
+OMNI_DEVINL void dma16_at(const u32x4_t& srd, uint32_t lane_off, uint32_t soff_base, uint32_t soff_add, uint32_t lds_base) {
+  uint32_t tmp;
+  asm volatile("s_add_u32 m0, %1, %c6\n\ts_add_u32 %0, %2, %5\n\tbuffer_load_dwordx4 %3, %4, %0 offen lds"
+               : "=&s"(tmp) : "s"(lds_base), "s"(soff_base), "v"(lane_off), "s"(srd), "s"(soff_add), "i"(LDS_IMM) : "memory", "scc");
 }
 OMNI_DEVINL u32x4_t make_srd(const void* base, uint32_t bytes) {
   const uint64_t a = reinterpret_cast<uint64_t>(base);
@@ -227,7 +286,9 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
   // ---- prologue DMA first (it flies while Q is fetched)
   issue_K(0, 0);
   issue_K(1, 1);
+  issue_K(2, 2);
   issue_V(0, 0);
+  issue_V(1, 1);
 
   // ---- Q~ fragments (B operand: lane holds query l31, d = ks*16 + hi*8 .. +8) -> a[128:191]; O <- 0
   {
@@ -263,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
   for (int ks = 0; ks < 8; ++ks) k_addr[ks] = lds0 + K_SLOT0 + l31 * 256 + ((((uint32_t)(ks * 2 + hi)) ^ (l31 & 15)) << 4);
   const uint32_t v_addr = lds0 + V_SLOT0 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + hi * 256;
 
-  float negm[2], l_run[2] = {0.0f, 0.0f};
+  float negm[2];
   f32x16_t negm16[2];
 #pragma unroll
   for (int bq = 0; bq < 2; ++bq)
@@ -271,19 +332,27 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
     for (int i = 0; i < 16; ++i) negm16[bq][i] = 0.0f;
 
   // all 16 K fragments of the tile in K slot `slot` -> a[192:255]   (fragment f = j*8 + ks)
-  auto kread_one = [&](auto ff, auto slot_c) {
-    constexpr int f = decltype(ff)::value, slot = decltype(slot_c)::value;
-    kread<A_K + f * 4, slot * TILE_BYTES + (f >> 3) * 32 * 256>(k_addr[f & 7]);
+  auto kread_one = [&](auto ff, const uint32_t (&ka)[8]) {
+    constexpr int f = decltype(ff)::value;
+    kread<A_K + f * 4, (f >> 3) * 32 * 256>(ka[f & 7]);
   };
-  auto kread_all = [&](auto slot_c) {
-    [&]<int... F>(std::integer_sequence<int, F...>) { (kread_one(ic<F>{}, slot_c), ...); }(std::make_integer_sequence<int, 16>{});
+  auto kread_all = [&](int slot) {
+    uint32_t ka[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) ka[ks] = k_addr[ks] + slot * TILE_BYTES;
+    [&]<int... F>(std::integer_sequence<int, F...>) { (kread_one(ic<F>{}, ka), ...); }(std::make_integer_sequence<int, 16>{});
   };
 
   // one QK^T MFMA step i = 0..31: j = i >> 4, ks = (i >> 1) & 7, bq = i & 1
-  auto qk_step = [&](auto ii, f32x16_t (&SN)[2][2]) {
+  auto qk_step = [&](auto ii, f32x16_t (&SN)[2][2], auto fresh_c) {
     constexpr int i = decltype(ii)::value, j = i >> 4, ks = (i >> 1) & 7, bq = i & 1;
-    if constexpr (OMNI_W64_ABL & 32) { if constexpr (ks == 0) SN[bq][j] = negm16[bq]; asm volatile("" : "+v"(SN[bq][j])); }
-    else if constexpr (ks == 0) mfma_qk_first<A_K + (j * 8 + ks) * 4, A_Q + (bq * 8 + ks) * 4>(SN[bq][j], negm16[bq]);
+    constexpr bool FRESH = decltype(fresh_c)::value;
+    if constexpr (OMNI_W64_ABL & 32) {
+      if constexpr (ks == 0) SN[bq][j] = negm16[bq];
+      f32x16_t& sref = SN[bq][j];
+      asm volatile("" : "+v"(sref));
+    }
+    else if constexpr (ks == 0) mfma_qk_first<A_K + (j * 8 + ks) * 4, A_Q + (bq * 8 + ks) * 4, FRESH>(SN[bq][j], negm16[bq]);
     else mfma_qk_acc<A_K + (j * 8 + ks) * 4, A_Q + (bq * 8 + ks) * 4>(SN[bq][j]);
   };
   auto mask_tail = [&](f32x16_t (&S)[2][2], int kv0) {
@@ -311,16 +380,16 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
   // ---- prologue: K(0) -> AGPRs, S(0), K(2) into the freed slot, K(1) -> AGPRs, row max of S(0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  kread_all(ic<0>{});
+  kread_all(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();                                  // every wave has K(0) in registers: its slot can take K(2)
-  issue_K(2, 0);
+  __syncthreads();                                  // every wave has K(0) in registers: its slot can take K(3)
+  issue_K(3, 0);
   f32x16_t sA[2][2], sB[2][2];
   float mxA[2], mxB[2] = {0.0f, 0.0f};
-  [&]<int... I>(std::integer_sequence<int, I...>) { (qk_step(ic<I>{}, sA), ...); }(std::make_integer_sequence<int, 32>{});
+  [&]<int... I>(std::integer_sequence<int, I...>) { (qk_step(ic<I>{}, sA, std::true_type{}), ...); }(std::make_integer_sequence<int, 32>{});
   __builtin_amdgcn_sched_barrier(0);
-  kread_all(ic<1>{});
+  kread_all(1);
   mfma_drain_s(sA);                                 // S(0) is read by VALU right away here (in the loop it is not)
   if (KVBLK > seq_len) mask_tail(sA, 0);
   row_max(sA, mxA);
@@ -337,39 +406,82 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
     for (int i = 0; i < 16; ++i) negm16[bq][i] = negm[bq];
     mxA[bq] = 0.0f;
   }
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // K(1) in AGPRs (K(3) may stay in flight: retired in iteration 0)
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
 
-  // One iteration.  SC = S(t) (complete; row max mxc), SN receives S(t+1).  HAS_NEXT and PAR = t & 1 are compile-time: the
-  // LDS slots sit in the ds_read offset immediates and the last tile's body has no QK^T.
-  auto iteration = [&](auto has_next_c, auto par_c, int t, f32x16_t (&SC)[2][2], f32x16_t (&SN)[2][2], float (&mxc)[2],
+  // One iteration.  SC = S(t) (complete; row max mxc), SN receives S(t+1).  HAS_NEXT is compile-time (the last tile's body has
+  // no QK^T).  Everything that is not an MFMA sits in an MFMA's shadow; what used to run between the phases and between the
+  // iterations (round-3 timeline: ~45 + ~30 issue slots with the matrix pipe idle, plus an exposed LDS read latency) is now
+  // loop-carried and produced inside P2:
+  //   * the first three V(t) fragments are read right behind the barrier that published the tile (before P1), not at P2's door;
+  //   * the fragment base addresses of the NEXT tile's slots are formed in P2's last steps;
+  //   * the row max of S(t+1) is complete by step 9, its cross-half exchange and the rescale decision follow in steps 10-12:
+  //     the next iteration opens with one scalar branch;
+  //   * the row sums are two persistent accumulator pairs (no per-tile zeroing / folding), the last two pack/sum chunks of P1
+  //     ride in P2's first two gaps (their P words are first used by step 12).
+  int slot_t = 0;                                   // t % 3, maintained by the loop
+  float lsum[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};  // row sums: two interleaved chains per query block, never reset
+  uint32_t va = v_addr;                             // V(t) fragment base:   V slot t % 3
+  uint32_t ka[8];                                   // K(t+2) fragment bases: K slot (t+2) % 3
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) ka[ks] = k_addr[ks] + 2 * TILE_BYTES;
+  u32x2_t vlo[4], vhi[4];                           // V^T fragments in flight
+  bool rescale = false;                             // decided in P2 of the previous iteration (tile 0 is at its own max)
+  uint32_t kps[4];                                  // K piece strides as uniform values
+#pragma unroll
+  for (int i = 0; i < 4; ++i) kps[i] = __builtin_amdgcn_readfirstlane(i * k_piece_stride);
+
+  auto vread = [&](auto ff) {
+    constexpr int f = decltype(ff)::value;
+    constexpr int off = (f & 3) * 4096 + (((f >> 3) * 8 + ((f >> 2) & 1) * 4) * 256);
+    if constexpr (OMNI_W64_ABL & 8) {
+      const uint32_t va_ = va;
+      u32x2_t a_, b_;
+      asm volatile("" : "=v"(a_) : "v"(va_));
+      asm volatile("" : "=v"(b_) : "v"(va_));
+      vlo[f & 3] = a_; vhi[f & 3] = b_;
+    } else {
+      vlo[f & 3] = vread8<off>(va);
+      vhi[f & 3] = vread8<off + 512>(va);
+    }
+  };
+
+  auto iteration = [&](auto has_next_c, int t, f32x16_t (&SC)[2][2], f32x16_t (&SN)[2][2], float (&mxc)[2],
                        float (&mxn)[2]) {
     constexpr bool HAS_NEXT = decltype(has_next_c)::value;
-    constexpr int PAR = decltype(par_c)::value;
+    const int s1 = slot_t == 2 ? 0 : slot_t + 1, s2 = slot_t == 0 ? 2 : slot_t - 1;   // (t+1) % 3, (t+2) % 3
+    // DMA targets of this iteration: V(t+2) -> V slot (t+2) % 3 [held V(t-1)], K(t+4) -> K slot (t+1) % 3 [held K(t+1)]
+    const uint32_t v_lds = lds0 + V_SLOT0 + s2 * TILE_BYTES + wave * 1024, k_lds = lds0 + K_SLOT0 + s1 * TILE_BYTES + wave * 1024;
+    const uint32_t v_soff = (uint32_t)(t + 2) * v_tile_stride, k_soff = (uint32_t)(t + 4) * k_tile_stride;
 
-    // ---- defer-max decision (attention.hip OMNI_ATTN_BAKE): SC already is s~ - m~; rescale only when its row max exceeds
-    // the threshold (rare after the first tiles).
+    if constexpr (OMNI_W64_HOISTV) { vread(ic<0>{}); vread(ic<1>{}); vread(ic<2>{}); }   // V(t) landed before the barrier behind us
+
+    // ---- defer-max (attention.hip OMNI_ATTN_BAKE): SC already is s~ - m~; rescale only when a row max exceeds the threshold
+    // (rare after the first tiles; the wave-uniform decision was taken in P2 of the previous iteration)
     constexpr float DEFER = 6.0f;
-    float psum[2][2];
     u32x4_t pf[2][2][2];                            // packed P^T: [bq][j][16-key half] = one MFMA B operand
+    if constexpr (!OMNI_W64_EARLYDEC) rescale = !__all(max3(mxc[0], mxc[0], mxc[1]) <= DEFER);
+    if (rescale) {
 #pragma unroll
-    for (int bq = 0; bq < 2; ++bq) {
-      if (!__all(mxc[bq] <= DEFER)) {
-        const float d = fmaxf(mxc[bq], 0.0f);
-        const float alpha = __builtin_amdgcn_exp2f(-d);
-        l_run[bq] *= alpha;
-        mfma_drain();
-        if (bq == 0) agpr_scale_range<A_O>(alpha, std::make_integer_sequence<int, 64>{});
-        else agpr_scale_range<A_O + 64>(alpha, std::make_integer_sequence<int, 64>{});
+      for (int bq = 0; bq < 2; ++bq) {
+        if (!__all(mxc[bq] <= DEFER)) {
+          const float d = fmaxf(mxc[bq], 0.0f);
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          lsum[bq][0] *= alpha;
+          lsum[bq][1] *= alpha;
+          mfma_drain();
+          if (bq == 0) agpr_scale_range<A_O>(alpha, std::make_integer_sequence<int, 64>{});
+          else agpr_scale_range<A_O + 64>(alpha, std::make_integer_sequence<int, 64>{});
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) SC[bq][j][i] -= d;
+            for (int i = 0; i < 16; ++i) SC[bq][j][i] -= d;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) negm16[bq][i] -= d;
+          for (int i = 0; i < 16; ++i) negm16[bq][i] -= d;
+        }
       }
-      psum[bq][0] = 0.0f; psum[bq][1] = 0.0f;
+      asm volatile("s_nop 4" ::: "memory");         // the -max splats were just written by VALU: wait states before an MFMA reads them as C
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -378,10 +490,10 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
     float pend0[2], pend1[2];
     auto exp_finish = [&](auto cc) {
       constexpr int c = decltype(cc)::value, bq = c & 1, e = c >> 1;
-      psum[bq][0] += pend0[bq];
-      psum[bq][1] += pend1[bq];
+      lsum[bq][0] += pend0[bq];
+      lsum[bq][1] += pend1[bq];
       uint32_t pk = pack_bf16x2(pend0[bq], pend1[bq]);
-      asm volatile("" : "+v"(pk), "+v"(psum[bq][0]), "+v"(psum[bq][1]));      // pin: keep it between these two MFMAs
+      asm volatile("" : "+v"(pk), "+v"(lsum[bq][0]), "+v"(lsum[bq][1]));      // pin: keep it between these two MFMAs
       pf[bq][e >> 3][(e >> 2) & 1][e & 3] = pk;
     };
     auto exp_chunk = [&](auto cc) {
@@ -393,89 +505,101 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
       pend0[bq] = e0; pend1[bq] = e1;
     };
     auto p1_step = [&](auto ii) {
-      constexpr int i = decltype(ii)::value;
       if constexpr (HAS_NEXT) {
-        qk_step(ii, SN);
+        qk_step(ii, SN, std::false_type{});
         __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (!(OMNI_W64_ABL & 1)) {
-        if constexpr (i < 4) issue_V_piece(t + 1, PAR ^ 1, ic<i>{});
-        else if constexpr (i < 8) issue_K_piece(t + 3, PAR ^ 1, ic<i - 4>{});
       }
       exp_chunk(ii);
       __builtin_amdgcn_sched_barrier(0);
     };
     __builtin_amdgcn_s_setprio(1);
     [&]<int... I>(std::integer_sequence<int, I...>) { (p1_step(ic<I>{}), ...); }(std::make_integer_sequence<int, 32>{});
-    exp_finish(ic<30>{});
-    exp_finish(ic<31>{});
-    l_run[0] += psum[0][0] + psum[0][1];
-    l_run[1] += psum[1][0] + psum[1][1];
+    if constexpr (!OMNI_W64_FINP2) { exp_finish(ic<30>{}); exp_finish(ic<31>{}); }
     if (HAS_NEXT && (t + 2) * KVBLK > seq_len) { mfma_drain_s(SN); mask_tail(SN, (t + 1) * KVBLK); }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- P2: O^T += V(t)^T P(t)^T.  PV step f = 0..15 <-> (j = f >> 3, half = (f >> 2) & 1, d = f & 3): ONE V^T fragment
-    // (two tr-reads), two MFMAs (bq = 0, 1).  V fragments are read 3 ahead; K(t+2) fragment f goes to the AGPRs behind step f
-    // (after P1 nothing reads a[192:255] any more); the row max of S(t+1) fills steps 4..11.
+    // (two tr-reads), two MFMAs (bq = 0, 1).  Behind the FIRST MFMA of a step (nothing there may overwrite its V fragment):
+    // steps 0-1 the last two pack/sum chunks, 2-9 the row max of S(t+1), 10-11 its cross-half exchange, 12 the decision.
+    // Behind the SECOND: V fragment f+3, K(t+2) fragments -> AGPRs (after P1 nothing reads a[192:255]), one LDS-DMA piece, and
+    // in steps 13-15 the next tile's fragment bases.
     // LDS ops return in order: at step f the reads issued after VREAD(f) are VREAD(f+1), VREAD(f+2) and up to three KREADs.
-    u32x2_t vlo[4], vhi[4];
-    float mx[2] = {HAS_NEXT ? SN[0][0][0] : 0.0f, HAS_NEXT ? SN[1][0][0] : 0.0f};
-    auto vread = [&](auto ff) {
-      constexpr int f = decltype(ff)::value;
-      constexpr int off = PAR * TILE_BYTES + (f & 3) * 4096 + (((f >> 3) * 8 + ((f >> 2) & 1) * 4) * 256);
-      if constexpr (OMNI_W64_ABL & 8) {
-        asm volatile("" : "=v"(vlo[f & 3]) : "v"(v_addr));
-        asm volatile("" : "=v"(vhi[f & 3]) : "v"(v_addr));
-      } else {
-        vlo[f & 3] = vread8<off>(v_addr);
-        vhi[f & 3] = vread8<off + 512>(v_addr);
+    if constexpr (!OMNI_W64_HOISTV) { vread(ic<0>{}); vread(ic<1>{}); vread(ic<2>{}); }
+    float mx[2] = {0.0f, 0.0f};
+    auto first_gap = [&](auto ff) {
+      constexpr int f = decltype(ff)::value, c = f - 2;
+      if constexpr (f == 0 && OMNI_W64_FINP2) exp_finish(ic<30>{});
+      if constexpr (f == 1 && OMNI_W64_FINP2) exp_finish(ic<31>{});
+      if constexpr (HAS_NEXT && !(OMNI_W64_ABL & 16)) {
+        if constexpr (!OMNI_W64_FUSEDMAX) {
+          if constexpr (c == 0) { mx[0] = SN[0][0][0]; mx[1] = SN[1][0][0]; }
+          if constexpr (c >= 0 && c < 8) {
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq) {
+              mx[bq] = max3(mx[bq], SN[bq][c >> 2][(c & 3) * 4 + 0], SN[bq][c >> 2][(c & 3) * 4 + 1]);
+              mx[bq] = max3(mx[bq], SN[bq][c >> 2][(c & 3) * 4 + 2], SN[bq][c >> 2][(c & 3) * 4 + 3]);
+            }
+          }
+        } else if constexpr (c == 0)
+          max3x4_first(mx[0], mx[1], SN[0][0][0], SN[0][0][1], SN[0][0][2], SN[0][0][3], SN[1][0][0], SN[1][0][1], SN[1][0][2], SN[1][0][3]);
+        else if constexpr (c > 0 && c < 8)
+          max3x4(mx[0], mx[1], SN[0][c >> 2][(c & 3) * 4 + 0], SN[0][c >> 2][(c & 3) * 4 + 1], SN[0][c >> 2][(c & 3) * 4 + 2],
+                 SN[0][c >> 2][(c & 3) * 4 + 3], SN[1][c >> 2][(c & 3) * 4 + 0], SN[1][c >> 2][(c & 3) * 4 + 1],
+                 SN[1][c >> 2][(c & 3) * 4 + 2], SN[1][c >> 2][(c & 3) * 4 + 3]);
+        if constexpr (f == 10 && OMNI_W64_XHALF_IN_P2) mxn[0] = xhalf_max(mx[0]);
+        if constexpr (f == 11 && OMNI_W64_XHALF_IN_P2) mxn[1] = xhalf_max(mx[1]);
+        if constexpr (f == 12 && OMNI_W64_XHALF_IN_P2 && OMNI_W64_EARLYDEC) rescale = !__all(max3(mxn[0], mxn[0], mxn[1]) <= DEFER);
       }
     };
-    auto max_half = [&](auto cc, auto bq_c) {       // row-max chunk c (4 S values) of query block bq
-      constexpr int c = decltype(cc)::value, bq = decltype(bq_c)::value;
-      if constexpr (HAS_NEXT && !(OMNI_W64_ABL & 16) && c >= 0 && c < 8) {
-        mx[bq] = max3(mx[bq], SN[bq][c >> 2][(c & 3) * 4 + 0], SN[bq][c >> 2][(c & 3) * 4 + 1]);
-        mx[bq] = max3(mx[bq], SN[bq][c >> 2][(c & 3) * 4 + 2], SN[bq][c >> 2][(c & 3) * 4 + 3]);
-      }
-    };
-    auto kreads_of = [&](auto ff) {                 // K(t+2) lives in K slot t & 1 (stale bytes past the last tile: unused)
+    auto kreads_of = [&](auto ff) {                 // K(t+2) (zeros past the last tile: unused)
       constexpr int f = decltype(ff)::value, n = kreads_at(f);
       if constexpr (!(OMNI_W64_ABL & 8))
-        [&]<int... J>(std::integer_sequence<int, J...>) { (kread_one(ic<f * n + J>{}, ic<PAR>{}), ...); }(std::make_integer_sequence<int, n>{});
+        [&]<int... J>(std::integer_sequence<int, J...>) { (kread_one(ic<f * n + J>{}, ka), ...); }(std::make_integer_sequence<int, n>{});
     };
     auto p2_step = [&](auto ff) {
       constexpr int f = decltype(ff)::value;
       if constexpr (!(OMNI_W64_ABL & 8)) asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(lds_ops_allowed_at(f)) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       const u32x4_t w = {vlo[f & 3][0], vlo[f & 3][1], vhi[f & 3][0], vhi[f & 3][1]};
-      if constexpr (!(OMNI_W64_ABL & 32)) mfma_pv<A_O + (0 * 4 + (f & 3)) * 16>(w, pf[0][f >> 3][(f >> 2) & 1]);
-      else asm volatile("" ::"v"(w), "v"(pf[0][f >> 3][(f >> 2) & 1]));
+      const u32x4_t p0 = pf[0][f >> 3][(f >> 2) & 1], p1 = pf[1][f >> 3][(f >> 2) & 1];
+      if constexpr (!(OMNI_W64_ABL & 32)) mfma_pv<A_O + (0 * 4 + (f & 3)) * 16>(w, p0);
+      else asm volatile("" ::"v"(w), "v"(p0));
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (OMNI_W64_P2SPLIT) {             // fillers behind the FIRST MFMA: nothing here may overwrite `w`
-        max_half(ic<f - 4>{}, ic<0>{});
-        max_half(ic<f - 4>{}, ic<1>{});
-        __builtin_amdgcn_sched_barrier(0);
+      first_gap(ff);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(OMNI_W64_ABL & 32)) mfma_pv<A_O + (1 * 4 + (f & 3)) * 16>(w, p1);
+      else asm volatile("" ::"v"(w), "v"(p1));
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(OMNI_W64_ABL & 1) && f >= OMNI_W64_DMA_STEP0 && f < OMNI_W64_DMA_STEP0 + 8) {
+        constexpr int pc = f - OMNI_W64_DMA_STEP0;
+        if constexpr (!OMNI_W64_NEWDMA) {
+          if constexpr (pc < 4) issue_V_piece(t + 2, s2, ic<pc>{});
+          else issue_K_piece(t + 4, s1, ic<pc - 4>{});
+        } else if constexpr (pc < 4) dma16_at<pc * 4096, pc * 64>(v_srd, v_src, v_soff, v_lds);
+        else dma16_at<(pc - 4) * 4096>(k_srd, k_src, k_soff, kps[pc - 4], k_lds);
       }
-      if constexpr (!(OMNI_W64_ABL & 32)) mfma_pv<A_O + (1 * 4 + (f & 3)) * 16>(w, pf[1][f >> 3][(f >> 2) & 1]);
-      else asm volatile("" ::"v"(w), "v"(pf[1][f >> 3][(f >> 2) & 1]));
-      __builtin_amdgcn_sched_barrier(0);
       if constexpr (f + 3 < 16) vread(ic<f + 3>{});
       kreads_of(ff);
-      if constexpr (!OMNI_W64_P2SPLIT) {
-        max_half(ic<f - 4>{}, ic<0>{});
-        max_half(ic<f - 4>{}, ic<1>{});
+      if constexpr (HAS_NEXT) {                     // next tile: V(t+1) in V slot (t+1) % 3, K(t+3) in K slot t % 3
+        if constexpr (f == 13) va = v_addr + s1 * TILE_BYTES;     // (the last V(t) read was issued in step 12)
+        if constexpr (f >= 13) {
+          constexpr int k0 = (f - 13) * 3;
+#pragma unroll
+          for (int ks = k0; ks < (k0 + 3 < 8 ? k0 + 3 : 8); ++ks) ka[ks] = k_addr[ks] + slot_t * TILE_BYTES;
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    vread(ic<0>{}); vread(ic<1>{}); vread(ic<2>{});
     [&]<int... F>(std::integer_sequence<int, F...>) { (p2_step(ic<F>{}), ...); }(std::make_integer_sequence<int, 16>{});
     __builtin_amdgcn_s_setprio(0);
-    if constexpr (HAS_NEXT) {
+    if constexpr (HAS_NEXT && !OMNI_W64_XHALF_IN_P2) {
       mxn[0] = xhalf_max(mx[0]);
       mxn[1] = xhalf_max(mx[1]);
+      if constexpr (OMNI_W64_EARLYDEC) rescale = !__all(max3(mxn[0], mxn[0], mxn[1]) <= DEFER);
     }
     if constexpr (!(OMNI_W64_ABL & 2)) {
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // this iteration's DMA landed; K(t+2) in AGPRs
+      // everything but this iteration's 8 pieces has landed: K(t+3), V(t+1) (issued one iteration ago); K(t+2) is in AGPRs
+      asm volatile("s_waitcnt vmcnt(%c0)\n\ts_waitcnt lgkmcnt(0)" ::"i"((OMNI_W64_ABL & 1) ? 0 : 8) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
     }
@@ -484,42 +608,50 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
   {
     using yes = std::true_type;
     using no = std::false_type;
+    auto bump = [&] { slot_t = slot_t == 2 ? 0 : slot_t + 1; };
     int t = 0;
     for (; t + 2 < ntiles; t += 2) {
-      iteration(yes{}, ic<0>{}, t, sA, sB, mxA, mxB);
-      iteration(yes{}, ic<1>{}, t + 1, sB, sA, mxB, mxA);
+      iteration(yes{}, t, sA, sB, mxA, mxB); bump();
+      iteration(yes{}, t + 1, sB, sA, mxB, mxA); bump();
     }
     if (t + 1 < ntiles) {
-      iteration(yes{}, ic<0>{}, t, sA, sB, mxA, mxB);
-      iteration(no{}, ic<1>{}, t + 1, sB, sA, mxB, mxA);
+      iteration(yes{}, t, sA, sB, mxA, mxB); bump();
+      iteration(no{}, t + 1, sB, sA, mxB, mxA);
     } else {
-      iteration(no{}, ic<0>{}, t, sA, sB, mxA, mxB);
+      iteration(no{}, t, sA, sB, mxA, mxB);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // DMA pieces of tiles past the end (zeros) still target this block's LDS
 
   // ---- epilogue: O / l -> out.  o[bq][d][4 qd + j] = O[q][d*32 + qd*8 + hi*4 + j]
   mfma_drain();
 #pragma unroll
   for (int bq = 0; bq < 2; ++bq) {
-    const float inv = 1.0f / xhalf_sum(l_run[bq]);
+    const float inv = 1.0f / xhalf_sum(lsum[bq][0] + lsum[bq][1]);
     const int qrow = qb * QBLK + wave * 64 + bq * 32 + l31;
     float o[64];
     if (bq == 0) [&]<int... I>(std::integer_sequence<int, I...>) { ((o[I] = agpr_read<A_O + I>()), ...); }(std::make_integer_sequence<int, 64>{});
     else [&]<int... I>(std::integer_sequence<int, I...>) { ((o[I] = agpr_read<A_O + 64 + I>()), ...); }(std::make_integer_sequence<int, 64>{});
-    if (qrow < seq_len) {
-      uint16_t* op = out_k32_rows ? out + ((int64_t)(h * 4) * out_k32_rows + seq_start + qrow) * 32 + hi * 4
-                                  : out + (int64_t)(seq_start + qrow) * ldo + h * DH + hi * 4;
-      const int64_t dstep = out_k32_rows ? (int64_t)out_k32_rows * 32 : 32;
+    // A lane holds columns 8 qd + 4 hi .. +3 of its row, the other half-wave the neighbouring four: one v_permlane32_swap per
+    // dword pairs (qd, qd+1) so that every lane owns 16 contiguous bytes — lanes 0-31 columns 16k .. 16k+7, lanes 32-63 columns
+    // 16k+8 .. 16k+15 — and the row goes out as 8 x 16-B stores instead of 16 x 8-B (the store tail is issue-bound:
+    // cdna_hip_programming.md T21).  All 64 lanes take part in the swaps; only the store is predicated.
+    uint16_t* op = out_k32_rows ? out + ((int64_t)(h * 4) * out_k32_rows + seq_start + qrow) * 32 + hi * 8
+                                : out + (int64_t)(seq_start + qrow) * ldo + h * DH + hi * 8;
+    const int64_t dstep = out_k32_rows ? (int64_t)out_k32_rows * 32 : 32;
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < 4; ++d)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          u32x2_t w;
-          w[0] = pack_bf16x2(o[d * 16 + qd * 4 + 0] * inv, o[d * 16 + qd * 4 + 1] * inv);
-          w[1] = pack_bf16x2(o[d * 16 + qd * 4 + 2] * inv, o[d * 16 + qd * 4 + 3] * inv);
-          *reinterpret_cast<u32x2_t*>(op + d * dstep + qd * 8) = w;
-        }
-    }
+      for (int kk = 0; kk < 2; ++kk) {
+        const int q0 = d * 16 + (2 * kk) * 4, q1 = q0 + 4;
+        uint32_t a0 = pack_bf16x2(o[q0 + 0] * inv, o[q0 + 1] * inv), a1 = pack_bf16x2(o[q0 + 2] * inv, o[q0 + 3] * inv);
+        uint32_t b0 = pack_bf16x2(o[q1 + 0] * inv, o[q1 + 1] * inv), b1 = pack_bf16x2(o[q1 + 2] * inv, o[q1 + 3] * inv);
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                     : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+        // lanes 0-31: a = [own cols 16kk..+3 | upper half's cols 16kk+4..+7]; lanes 32-63: b = [lower's 16kk+8.. | own 16kk+12..]
+        const u32x4_t w = {a0, a1, b0, b1};
+        if (qrow < seq_len) *reinterpret_cast<u32x4_t*>(op + d * dstep + kk * 16) = w;
+      }
   }
 }
 

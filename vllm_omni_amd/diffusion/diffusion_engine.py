@@ -47,12 +47,16 @@ class DiffusionEngine:
             pre_process_func = get_diffusion_pre_process_func(od_config)
         self.post_process_func, self.pre_process_func = post_process_func, pre_process_func
         self.num_gpus = int(od_config.num_gpus or 1)
+        self.sp_degree = int(getattr(od_config.parallel_config, "ulysses_degree", 1) or 1)
+        if self.num_gpus % self.sp_degree:
+            raise ValueError(f"num_gpus {self.num_gpus} is not a multiple of ulysses_degree {self.sp_degree}")
+        self.num_groups = self.num_gpus // self.sp_degree    # dispatch units: one data-parallel group = sp_degree ranks
         self._ctx = mp.get_context("spawn")
         self._inbox = [self._ctx.Queue() for _ in range(self.num_gpus)]
         self._outbox = self._ctx.Queue()
         self._ready = self._ctx.Queue()
         self._ids = itertools.count()
-        self._load = [0.0] * self.num_gpus              # outstanding steps x tokens per rank
+        self._load = [0.0] * self.num_groups            # outstanding steps x tokens per data-parallel group
         self._cost: dict[int, tuple[int, float]] = {}   # request id -> (rank, cost)
         self._results: dict[int, DiffusionOutput] = {}
         self._rpc_results: dict[int, dict[int, Any]] = {}
@@ -91,11 +95,13 @@ class DiffusionEngine:
     def submit(self, req: OmniDiffusionRequest) -> int:
         """Hand one request to the least-loaded rank; returns its ticket."""
         rid = next(self._ids)
-        rank = min(range(self.num_gpus), key=lambda r: (self._load[r], r))
+        grp = min(range(self.num_groups), key=lambda r: (self._load[r], r))
         cost = self._request_cost(req)
-        self._load[rank] += cost
-        self._cost[rid] = (rank, cost)
-        self._inbox[rank].put({"type": "add", "id": rid, "request": _request_to_cpu(req)})
+        self._load[grp] += cost
+        self._cost[rid] = (grp, cost)
+        msg = {"type": "add", "id": rid, "request": _request_to_cpu(req)}
+        for r in range(grp * self.sp_degree, (grp + 1) * self.sp_degree):       # every rank of a sequence-parallel group
+            self._inbox[r].put(msg)
         return rid
 
     def _pump(self, timeout: float | None) -> bool:
@@ -104,8 +110,8 @@ class DiffusionEngine:
         except queue.Empty:
             return False
         if m["type"] == "done":
-            rank, cost = self._cost.pop(m["id"], (m["rank"], 0.0))
-            self._load[rank] = max(0.0, self._load[rank] - cost)
+            grp, cost = self._cost.pop(m["id"], (m["rank"] // self.sp_degree, 0.0))
+            self._load[grp] = max(0.0, self._load[grp] - cost)
             self._results[m["id"]] = m["output"]
         elif m["type"] == "rpc_result":
             self._rpc_results.setdefault(m["id"], {})[m["rank"]] = m["result"]

@@ -39,6 +39,23 @@ def init_distributed(backend: str | None = None, timeout_s: int | None = None) -
     return rank, world, local
 
 
+def init_sp_groups(world: int, degree: int, rank: int):
+    """Partition the world into world/degree sequence-parallel groups of CONSECUTIVE ranks (rank r: group r // degree,
+    position r % degree — neighbours on the xGMI mesh) and return (this rank's group, dp_rank, dp_world).  Every rank must
+    call this (dist.new_group is collective over the world)."""
+    if degree <= 1:
+        return None, rank, world
+    if world % degree:
+        raise ValueError(f"world size {world} is not divisible by ulysses_degree {degree}")
+    mine = None
+    for g in range(world // degree):
+        ranks = list(range(g * degree, (g + 1) * degree))
+        grp = dist.new_group(ranks=ranks) if dist.is_initialized() and world > 1 else None
+        if rank in ranks:
+            mine = grp
+    return mine, rank // degree, world // degree
+
+
 def shard_requests(costs: list[float], world: int) -> list[list[int]]:
     """Greedy least-loaded assignment of request indices to ranks (cost = denoise steps x tokens).
     Deterministic on every rank, so no coordination message is needed."""

@@ -68,6 +68,9 @@ class QwenImagePipeline(nn.Module):
         self.weights_sources: list = []
         self._step_state: dict = {}     # hipGraph + static buffers per step-batch shape
         self._serve_states: dict = {}   # the same for the continuous step batcher (denoise_one_step)
+        # Ulysses sequence parallelism: set by the worker when parallel_config.ulysses_degree > 1 — the
+        # process group of this rank's SP group; every rank of the group then runs the SAME requests in lockstep
+        self.sp_group, self.sp_degree = None, 1
         self.last_teacache_state = None
         self.cache_backend = None
         name = getattr(self.od_config, "cache_backend", "none")
@@ -142,6 +145,8 @@ class QwenImagePipeline(nn.Module):
         axis in every forward and sliced off the prediction (pipeline_qwen_image_edit.py:600-632); `grid` is then the
         sequence of token grids ((1, h, w), (1, h_c, w_c), ...)."""
         tr, dev = self.transformer, self.device
+        if self.sp_degree > 1 or getattr(self, "_force_sp_path", False):
+            return self._denoise_sp(latents, pos, neg, grid, timesteps, dts, cfg_scales, cond)
         R = len(latents)
         S = latents[0].shape[0]
         S_c = 0 if cond is None else int(cond[0].shape[0])
@@ -240,6 +245,38 @@ class QwenImagePipeline(nn.Module):
             st["dt"].copy_(dt_dev[i:i + 1], non_blocking=True)
             st["graph"].replay()
         return list(lat.clone().view(R, S, -1).unbind(0))
+
+    @torch.no_grad()
+    def _denoise_sp(self, latents, pos, neg, grid, timesteps, dts, cfg_scales, cond=None) -> list[torch.Tensor]:
+        """The same loop with every DiT forward SEQUENCE-PARALLEL over `self.sp_group` (reference wiring:
+        qwen_image_transformer.py:735-742,776-781,800-801 + attention/parallel/ulysses.py:59-135; end-to-end contract
+        tests/e2e/offline_inference/test_sequence_parallel.py:68-71,128-147): each rank holds S_img / P image rows of an
+        item through the block stack, attention runs on H / P heads over the whole sequence.  The items of a step (requests
+        x CFG branches) are independent forwards: they are software-pipelined so that one item's all-to-all flies while the
+        next item's GEMMs run (distributed/sp_driver.py).  Every rank ends with the full latents."""
+        tr, dev = self.transformer, self.device
+        if cond is not None:
+            raise NotImplementedError("sequence parallelism with condition images (Edit pipelines) is not built")
+        if getattr(tr, "teacache", None) is not None:
+            raise NotImplementedError("TeaCache with sequence parallelism is not built (per-rank residual slices)")
+        do_cfg = neg is not None
+        if do_cfg and len(set(cfg_scales)) != 1:
+            raise NotImplementedError("step-batched requests must share true_cfg_scale")
+        R, S = len(latents), int(latents[0].shape[0])
+        lat = torch.stack([x.to(dev, BF16) for x in latents]).contiguous()                  # [R, S, 64]
+        pe = [p.to(dev, BF16) for p in pos] + ([n.to(dev, BF16) for n in neg] if do_cfg else [])
+        sig_in = self.scheduler.model_timestep(timesteps).to(dev)
+        dt_dev = dts.to(dev, torch.float32).contiguous()
+        tr.do_true_cfg = do_cfg
+        flat = lat.view(R * S, -1)
+        for i in range(len(timesteps)):
+            sg = sig_in[i:i + 1]
+            items = [(lat[r % R], pe[j], sg) for j, r in enumerate(list(range(R)) * (2 if do_cfg else 1))]
+            preds = tr.forward_sp_multi(items, grid, self.sp_group)
+            p = torch.cat(preds[:R]).contiguous()
+            n = torch.cat(preds[R:]).contiguous() if do_cfg else None
+            ops.cfg_euler_step_(flat, p, n, cfg_scales[0], dt_dev[i:i + 1])
+        return list(lat.clone().unbind(0))
 
     def _use_graph(self, img_rows: int) -> bool:
         """`od_config.use_hip_graph`: True / False, or None = automatic (on while a forward is short enough for the host's
@@ -540,6 +577,8 @@ class QwenImagePipeline(nn.Module):
         TeaCache decisions per item on the device; the step is a hipGraph replay when the forward is short (reference loop
         shape: vllm_omni/diffusion/worker/gpu_worker.py:226-290 runs one request to completion per iteration)."""
         tr, dev = self.transformer, self.device
+        if self.sp_degree > 1:
+            raise NotImplementedError("sequence-parallel workers run requests to completion (generate), not step-batched")
         st = self._serve_state(group)
         for r, a in enumerate(group):
             self._import_sample(a, st, r)

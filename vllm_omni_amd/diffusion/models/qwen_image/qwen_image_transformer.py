@@ -572,32 +572,21 @@ class QwenImageTransformer2DModel(nn.Module):
                    grid: tuple[int, int, int], group=None) -> torch.Tensor:
         """Ulysses sequence-parallel forward over `group` (RCCL): every rank passes the same full `latents` / prompt and
         receives the full noise prediction [S_img, 64].  240 all-to-alls + 1 all-gather per 60-layer forward."""
+        return self.forward_sp_multi([(latents, prompt_embeds, sigma)], grid, group)[0]
+
+    @torch.no_grad()
+    def forward_sp_multi(self, items: list[tuple[torch.Tensor, torch.Tensor, torch.Tensor]], grid, group=None) -> list[torch.Tensor]:
+        """Several sequence-parallel forwards over the same grid — the two true-CFG branches of a request, or several
+        requests — software-pipelined: while one forward's all-to-all is in flight the next forward's GEMMs run
+        (distributed/sp_driver.py).  items[i] = (latents [S_img, 64], prompt_embeds [T_i, joint], sigma fp32 [1])."""
         import torch.distributed as dist
+
+        from ...distributed.sp_driver import drive
 
         P = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
-        gen = self._sp_forward_gen(rank, P, latents, prompt_embeds, sigma, grid)
-        msg = next(gen)
-        while True:
-            kind, t = msg
-            if kind == "all_to_all":
-                out = torch.empty_like(t)
-                if P > 1:
-                    dist.all_to_all_single(out, t, group=group)
-                else:
-                    out = t
-            elif kind == "all_gather":
-                out = torch.empty((P,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-                if P > 1:
-                    dist.all_gather_into_tensor(out, t, group=group)
-                else:
-                    out[0] = t
-            else:
-                raise RuntimeError(f"unknown collective {kind}")
-            try:
-                msg = gen.send(out)
-            except StopIteration as e:
-                return e.value
+        gens = [self._sp_forward_gen(rank, P, lat, pe, sg, grid) for lat, pe, sg in items]
+        return drive(gens, group)
 
     # ------------------------------------------------------------------ reference-shaped forward
     @torch.no_grad()

@@ -26,11 +26,17 @@ class GPUWorker:
         self.local_rank, self.rank, self.od_config = local_rank, rank, od_config
         self.pipeline = pipeline
         self.world = 1
+        self.sp_degree, self.sp_group, self.dp_rank, self.dp_world = 1, None, rank, 1
 
     def init_device_and_model(self, pipeline_factory=None) -> None:
         if torch.cuda.is_available():
             torch.cuda.set_device(self.local_rank)
         self.rank, self.world, _ = dp.init_distributed(timeout_s=self.od_config.dist_timeout)
+        # world = data-parallel groups x ulysses_degree (reference DiffusionParallelConfig); consecutive ranks form an SP group
+        self.sp_degree = int(getattr(self.od_config.parallel_config, "ulysses_degree", 1) or 1)
+        if self.sp_degree > 1 and self.world % self.sp_degree:
+            raise ValueError(f"{self.world} ranks cannot form groups of ulysses_degree {self.sp_degree}")
+        self.sp_group, self.dp_rank, self.dp_world = dp.init_sp_groups(self.world, self.sp_degree, self.rank)
         if self.pipeline is None:
             if pipeline_factory is None:
                 import os
@@ -47,6 +53,10 @@ class GPUWorker:
 
                     pipeline_factory = lambda: initialize_model(self.od_config, device=dev)  # noqa: E731
             self.pipeline = pipeline_factory()
+        if self.sp_degree > 1:
+            if not hasattr(self.pipeline, "sp_degree"):
+                raise NotImplementedError(f"{type(self.pipeline).__name__} has no sequence-parallel denoise loop")
+            self.pipeline.sp_group, self.pipeline.sp_degree = self.sp_group, self.sp_degree
 
     def is_ready(self) -> bool:
         return self.pipeline is not None
@@ -69,10 +79,14 @@ class GPUWorker:
                 raise NotImplementedError("a DP batch must share one resolution (one gather shape)")
             costs = [float((r.num_inference_steps or 50) * ((r.height or 1024) // 16) * ((r.width or 1024) // 16))
                      for r in reqs]
-            assign = dp.shard_requests(costs, self.world)
+            # requests are sharded over the data-parallel GROUPS; the ranks of a sequence-parallel group run the same share in
+            # lockstep and only the group's first rank contributes rows to the gather
+            dp_assign = dp.shard_requests(costs, self.dp_world)
+            P = self.sp_degree
+            assign = [dp_assign[r // P] if r % P == 0 else [] for r in range(self.world)]
         except Exception as e:  # same policy as the reference busy loop: report, do not kill the worker
             return DiffusionOutput(error=f"{type(e).__name__}: {e}")
-        mine = [reqs[i] for i in assign[self.rank]]
+        mine = [reqs[i] for i in dp_assign[self.dp_rank]]
         err, outs = None, []
         try:
             outs = self.pipeline.generate(mine, output_type="latent") if mine else []
@@ -85,6 +99,8 @@ class GPUWorker:
             h, w = next(iter(shapes))
             S = (h // 16) * (w // 16)
             dev = self.pipeline.device
+            if self.rank % self.sp_degree:
+                outs = []                                    # not the group's first rank: nothing to contribute
             local = torch.cat([o.output for o in outs]) if outs else torch.empty((0, S, 64), dtype=torch.bfloat16, device=dev)
             gathered = dp.gather_latents(local.contiguous(), [len(a) for a in assign])
             lat = torch.stack(dp.unshard(gathered, assign))
@@ -132,7 +148,18 @@ class WorkerProc:
         kind = msg.get("type")
         if kind == "shutdown":
             return False
-        if kind == "add":
+        if kind == "add" and self.worker.sp_degree > 1:
+            # sequence-parallel group: every rank of the group receives the same requests in the same order and runs each to
+            # completion in lockstep (a continuous batcher would have to agree on every step's composition across ranks);
+            # the group's first rank answers
+            try:
+                out = self.worker.pipeline.generate([msg["request"]])[0]
+            except Exception as e:  # noqa: BLE001
+                out = DiffusionOutput(error=f"{type(e).__name__}: {e}")
+            if self.rank % self.worker.sp_degree == 0:
+                self.outbox.put({"type": "done", "id": msg["id"], "rank": self.rank, "output": _to_cpu(out),
+                                 "outstanding_steps": 0})
+        elif kind == "add":
             try:
                 self.batcher.add(msg["request"], tag=msg["id"])
             except Exception as e:  # admission errors are per request: report, keep serving (reference :266-274)
