@@ -126,7 +126,16 @@ typedef struct {
    * s * (M0 + M1) * N <= splitk_ws_floats; results agree with the unsplit kernel to fp32 summation order. */
   float* splitk_ws;
   int64_t splitk_ws_floats;
+  /* ABI v6 — kernel choice, normally 0 = automatic (the ping-pong kernel where its preconditions hold, else the ring kernel).
+   * OMNI_GEMM_KERNEL_RING forces the ring kernel (the fallback family): the two accumulate every output element in the same
+   * k order and must agree bit for bit, which is how callers (and tests/) cross-check one against the other.  Values
+   * >= 16 select development families and are honoured only by libraries built with -DOMNI_DEV; the product library ignores
+   * them.  The library itself has no switches: no environment variable and no process-global setter changes what a call does. */
+  int32_t kernel_hint;
+  int32_t reserved0;
 } omni_gemm_params;
+#define OMNI_GEMM_KERNEL_AUTO 0
+#define OMNI_GEMM_KERNEL_RING 1
 
 int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream);
 

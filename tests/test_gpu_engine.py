@@ -96,15 +96,21 @@ def test_continuous_step_batching_with_teacache_keeps_per_sample_history(graph):
         b = ContinuousStepBatcher(pipe, max_items=max_items)
         done, pattern = {}, {}
 
-        def one_step():
-            out = b.step()
+        orig = pipe.denoise_one_step
+
+        def tapped(group):                                   # the decisions of this forward, per member of its group
+            orig(group)
             tc = pipe.last_teacache_state
-            st = next(s for s in pipe._serve_states.values() if s["tc"] is tc)
-            flags = tc.skip.tolist()
-            for r, a in enumerate(st["members"]):
-                if a is not None:
-                    pattern.setdefault(a.tag, []).append((flags[r], flags[st["R"] + r]))
-            done.update(out)
+            flags, R = tc.skip.tolist(), len(group)
+            for r, a in enumerate(group):
+                pattern.setdefault(a.tag, []).append((flags[r], flags[R + r]))
+
+        def one_step():
+            pipe.denoise_one_step = tapped
+            try:
+                done.update(b.step())
+            finally:
+                pipe.denoise_one_step = orig
 
         for op in plan:
             if op[0] == "add":

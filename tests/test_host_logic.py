@@ -30,12 +30,27 @@ def test_library_exports_every_declared_symbol():
     assert dll.omni_abi_version() == _native.ABI_VERSION
 
 
+def test_product_library_has_no_switches():
+    """Round-2 verdict: dev state in the product .so.  The library exports exactly the header's symbols (no omni_dev_* setters)
+    and does not import getenv: tuning knobs and development kernel families exist only in -DOMNI_DEV builds."""
+    import subprocess
+
+    from vllm_omni_amd import _native as N
+
+    dyn = subprocess.run(["nm", "-D", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in dyn.splitlines() if " T " in ln}
+    assert not [s for s in exported if s.startswith("omni_dev_")], exported
+    assert {s for s in exported if s.startswith("omni_") and not s.startswith("omni_internal_")} == set(N.PROTOTYPES)
+    undefined = {ln.split()[-1].split("@")[0] for ln in dyn.splitlines() if " U " in ln}
+    assert "getenv" not in undefined and "secure_getenv" not in undefined
+
+
 def test_ctypes_struct_layout_matches_c():
     # sizes the C compiler produces for the ABI structs (computed with the same alignment rules)
     from vllm_omni_amd import _native as N
 
-    assert ctypes.sizeof(N.GemmGroup) == 200 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 200 + 16  # ABI v3: + tile_skip; v4: + split-K workspace
-    assert N.GemmParams.splitk_ws.offset == 24 + 2 * 200
+    assert ctypes.sizeof(N.GemmGroup) == 200 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 200 + 16 + 8  # ABI v3: + tile_skip; v4: + split-K workspace; v6: + kernel_hint
+    assert N.GemmParams.splitk_ws.offset == 24 + 2 * 200 and N.GemmParams.kernel_hint.offset == 24 + 2 * 200 + 16
     assert ctypes.sizeof(N.TeaCache) == 24 + 10 * 8 and N.DitBatch.teacache.offset == ctypes.sizeof(N.DitBatch) - 8
     assert ctypes.sizeof(N.DitLayerWeights) == 24 * 8
     assert N.GemmParams.g.offset == 24 and N.DitWeights.t_lin1_w.offset == 32   # w_k32_blocked flags live in padding / ABI v2

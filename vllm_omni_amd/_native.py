@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OMNI_CDNA4_LIB", os.path.join(_HERE, "libomni_cdna4.so"))   # env override: dev sweeps
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_bf16_p = C.c_void_p  # device pointer to uint16_t bf16 bits
 c_i32_p = C.c_void_p
@@ -44,6 +44,7 @@ class GemmParams(C.Structure):
         ("ngroups", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("epilogue", C.c_int32),
         ("split_n", C.c_int32), ("w_k32_blocked", C.c_int32), ("g", GemmGroup * 2),
         ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_int64),          # ABI v4
+        ("kernel_hint", C.c_int32), ("reserved0", C.c_int32),                # ABI v6: 0 auto, 1 = ring (fallback) kernel
     ]
 
 

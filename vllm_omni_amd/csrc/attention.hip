@@ -1297,8 +1297,7 @@ int attn_variant() {
   // and VGPR halves every tile and spills 19 — it needs hand-placed registers before it can pay off.
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("OMNI_ATTN_NQ");
-    v = e ? atoi(e) : 1;
+    v = omni_dev_env_int("OMNI_ATTN_NQ", 1);
     if (v != 1 && v != 2) v = 1;
   }
   return v;
@@ -1307,27 +1306,21 @@ bool attn_pipelined() {
   // dev knob: OMNI_ATTN_PIPE=0 selects the unskewed register-staged kernels (then OMNI_ATTN_NQ picks 32/64 queries per wave)
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("OMNI_ATTN_PIPE");
-    v = e ? atoi(e) : 1;
+    v = omni_dev_env_int("OMNI_ATTN_PIPE", 1);
   }
   return v != 0;
 }
-int g_attn_block_order = -1;
 int attn_block_order() {
   // dev knob: OMNI_ATTN_BLOCK_ORDER = 1 (default, XCD-aware head-major) | 0 (heads fastest)
-  if (g_attn_block_order < 0) {
-    const char* e = getenv("OMNI_ATTN_BLOCK_ORDER");
-    g_attn_block_order = e ? atoi(e) : 1;
-  }
-  return g_attn_block_order;
+  static const int v = omni_dev_env_int("OMNI_ATTN_BLOCK_ORDER", 1);
+  return v;
 }
 int attn_pipe_waves(int n_heads_total, int max_seqlen) {
   // 8 waves per workgroup (256 queries, half the DMA per query: +3.7 % at B=6) once the grid is at least 6 rounds of 256
   // CUs deep; 4 waves (128 queries, finer tail) below that (+3.7 % at B=2).  dev knob: OMNI_ATTN_WAVES = 4 | 8.
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("OMNI_ATTN_WAVES");
-    v = e ? atoi(e) : 0;
+    v = omni_dev_env_int("OMNI_ATTN_WAVES", 0);
     if (v != 4 && v != 8) v = 0;
   }
   if (v) return v;
@@ -1358,8 +1351,7 @@ int attn_mfma_shape() {
   // dev knob: OMNI_ATTN_MFMA = 32 (default: flash_attn_fwd_pipe_kernel, 32x32x16) | 16 (flash_attn_fwd_pipe16_kernel, 16x16x32)
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("OMNI_ATTN_MFMA");
-    v = e ? atoi(e) : 32;
+    v = omni_dev_env_int("OMNI_ATTN_MFMA", 32);
     if (v != 16) v = 32;
   }
   return v;
@@ -1368,8 +1360,7 @@ int attn_pingpong() {
   // dev knob: OMNI_ATTN_PP = 0 (default) | 1 (wave groups half an iteration apart in the 8-wave kernel: measured 878 vs 912 TF/s)
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("OMNI_ATTN_PP");
-    v = e ? atoi(e) : 0;
+    v = omni_dev_env_int("OMNI_ATTN_PP", 0);
   }
   return v;
 }
@@ -1415,8 +1406,7 @@ int launch_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
 #endif  // OMNI_DEV
 }  // namespace
 
-// dev-only (NOT part of the C-ABI): switch the block order inside one process (A/B runs)
-extern "C" void omni_dev_attn_set_block_order(int v) { g_attn_block_order = v; }
+
 
 int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq,
                              int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H,

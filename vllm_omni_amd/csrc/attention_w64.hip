@@ -44,18 +44,6 @@ constexpr int K_SLOT0 = 0, V_SLOT0 = NSLOT * TILE_BYTES;
 constexpr int LDS_BYTES = 2 * NSLOT * TILE_BYTES; // 96 KiB
 constexpr int QBLK = 256;                         // queries per workgroup
 
-// every AGPR, as a clobber list: makes the kernel descriptor allocate the accumulator half of the register file and tells the
-// compiler that nothing of its own survives there
-#define OMNI_A1(x) "a" #x
-#define OMNI_A10(d) OMNI_A1(d##0), OMNI_A1(d##1), OMNI_A1(d##2), OMNI_A1(d##3), OMNI_A1(d##4), OMNI_A1(d##5), OMNI_A1(d##6), \
-                    OMNI_A1(d##7), OMNI_A1(d##8), OMNI_A1(d##9)
-#define OMNI_ALL_AGPRS                                                                                                        \
-  OMNI_A1(0), OMNI_A1(1), OMNI_A1(2), OMNI_A1(3), OMNI_A1(4), OMNI_A1(5), OMNI_A1(6), OMNI_A1(7), OMNI_A1(8), OMNI_A1(9),      \
-  OMNI_A10(1), OMNI_A10(2), OMNI_A10(3), OMNI_A10(4), OMNI_A10(5), OMNI_A10(6), OMNI_A10(7), OMNI_A10(8), OMNI_A10(9),          \
-  OMNI_A10(10), OMNI_A10(11), OMNI_A10(12), OMNI_A10(13), OMNI_A10(14), OMNI_A10(15), OMNI_A10(16), OMNI_A10(17),               \
-  OMNI_A10(18), OMNI_A10(19), OMNI_A10(20), OMNI_A10(21), OMNI_A10(22), OMNI_A10(23), OMNI_A10(24), OMNI_A1(250),               \
-  OMNI_A1(251), OMNI_A1(252), OMNI_A1(253), OMNI_A1(254), OMNI_A1(255)
-
 constexpr int A_O = 0, A_Q = 128, A_K = 192;
 
 #ifndef OMNI_W64_P2SPLIT

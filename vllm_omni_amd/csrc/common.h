@@ -119,3 +119,28 @@ int omni_internal_teacache_decide(const omni_teacache* tc, const omni_bf16* mod,
                                   int32_t n_img_rows, int32_t n_txt_rows, int32_t D, int32_t blocked, void* stream);
 int omni_internal_teacache_post(const omni_teacache* tc, omni_bf16* hidden, const omni_bf16* hidden_in, int32_t n_img_rows,
                                 int32_t rows_per_item, int32_t D, void* stream);
+// Tuning knobs: the product library reads NOTHING from the process environment and keeps no mutable global state; a build with
+// -DOMNI_DEV (tools/build_variants.sh: same-box A/B runs) reads its knobs through this one function.
+#ifdef OMNI_DEV
+#include <stdlib.h>
+static inline int omni_dev_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#else
+static inline int omni_dev_env_int(const char*, int dflt) { return dflt; }
+#endif
+
+// every AGPR, as a clobber list: makes the kernel descriptor allocate the accumulator half of the register file and tells the
+// compiler that nothing of its own survives there
+#define OMNI_A1(x) "a" #x
+#define OMNI_A10(d) OMNI_A1(d##0), OMNI_A1(d##1), OMNI_A1(d##2), OMNI_A1(d##3), OMNI_A1(d##4), OMNI_A1(d##5), OMNI_A1(d##6), \
+                    OMNI_A1(d##7), OMNI_A1(d##8), OMNI_A1(d##9)
+#define OMNI_ALL_AGPRS                                                                                                        \
+  OMNI_A1(0), OMNI_A1(1), OMNI_A1(2), OMNI_A1(3), OMNI_A1(4), OMNI_A1(5), OMNI_A1(6), OMNI_A1(7), OMNI_A1(8), OMNI_A1(9),      \
+  OMNI_A10(1), OMNI_A10(2), OMNI_A10(3), OMNI_A10(4), OMNI_A10(5), OMNI_A10(6), OMNI_A10(7), OMNI_A10(8), OMNI_A10(9),          \
+  OMNI_A10(10), OMNI_A10(11), OMNI_A10(12), OMNI_A10(13), OMNI_A10(14), OMNI_A10(15), OMNI_A10(16), OMNI_A10(17),               \
+  OMNI_A10(18), OMNI_A10(19), OMNI_A10(20), OMNI_A10(21), OMNI_A10(22), OMNI_A10(23), OMNI_A10(24), OMNI_A1(250),               \
+  OMNI_A1(251), OMNI_A1(252), OMNI_A1(253), OMNI_A1(254), OMNI_A1(255)
+
+

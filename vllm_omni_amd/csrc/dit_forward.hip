@@ -75,19 +75,13 @@ Workspace carve(void* base, const omni_dit_weights* w, int64_t Ri, int64_t Rt, i
 // lines (include/omni_cdna4.h: omni_gemm_group.a_k32_rows).  The residual stream, q/k/v and everything the caller sees stay
 // row-major.  dev knob: OMNI_DIT_ACT_BLOCKED=0.
 bool dit_act_blocked() {
-  static const bool v = [] {
-    const char* e = getenv("OMNI_DIT_ACT_BLOCKED");
-    return e ? atoi(e) != 0 : true;
-  }();
+  static const bool v = omni_dev_env_int("OMNI_DIT_ACT_BLOCKED", 1) != 0;
   return v;
 }
 // q/k RMSNorm + RoPE inside the QKV GEMM's coalesced epilogue (saves two passes over q and k per layer); dev knob
 // OMNI_DIT_FUSE_QKROPE=0 restores the separate omni_qk_norm_rope launches (bit-identical results).
 bool dit_fuse_qkrope() {
-  static const bool v = [] {
-    const char* e = getenv("OMNI_DIT_FUSE_QKROPE");
-    return e ? atoi(e) != 0 : true;
-  }();
+  static const bool v = omni_dev_env_int("OMNI_DIT_FUSE_QKROPE", 1) != 0;
   return v;
 }
 
@@ -245,7 +239,7 @@ int prepare_positions(const omni_dit_batch* b, const Workspace& ws, omni_stream 
 }
 }  // namespace
 
-extern "C" int omni_abi_version(void) { return 5; }
+extern "C" int omni_abi_version(void) { return 6; }
 extern "C" const char* omni_build_arch(void) { return "gfx950"; }
 extern "C" const char* omni_status_string(int status) {
   switch (status) {

@@ -6,8 +6,11 @@
 //      half a phase apart (one in an MFMA-only cluster while its SIMD partner issues reads and LDS-DMA), see its comment;
 //   1  gemm_bf16_ring_kernel — round 1's kernel, now the fallback for what the ping-pong kernel does not take (K % 64 != 0,
 //      operand offsets beyond 32 bits, outputs that cannot use the row-coalesced epilogue); bit-identical results.
-// The first design (0), the 4-wave kernel (2), the two-phase ping-pong variants (5, 6) and the ablation entry points are
-// compiled only with -DOMNI_DEV (tools/build_variants.sh).  OMNI_GEMM_VARIANT / omni_dev_gemm_set_variant pick a family:
+// The first design (0), the hipcc-scheduled 4-wave kernel (2), the hand-placed 4-wave kernel with the accumulators in the AGPR
+// half (4, "Q4": bit-identical, measured -8 % against the ping-pong kernel — see its comment), the two-phase ping-pong variants
+// (5, 6) and the ablation entry points are compiled only with -DOMNI_DEV (tools/build_variants.sh); there a family is picked by
+// omni_gemm_params.kernel_hint = 16 + family or by OMNI_GEMM_VARIANT.  The product library takes omni_gemm_params.kernel_hint =
+// OMNI_GEMM_KERNEL_RING (force the fallback family) and nothing else: no environment variable, no global setter.  Families:
 //   1  gemm_bf16_ring_kernel — the production kernel: BK = 32 stages in a 5-deep LDS ring (all 160 KiB), a continuous
 //      DMA / fragment-read / MFMA pipeline (see the comment above the kernel), K32-blocked operand layouts for full-line
 //      DMA requests, row-coalesced epilogue through LDS (gemm_epilogue_lds) incl. the fused q/k norm + RoPE.
@@ -26,6 +29,9 @@
 //
 // Roofline: MFMA-bound.  Algorithmic work = 2*M*N*K flop per launch.
 #include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -257,7 +263,7 @@ struct EpiFromPartials {
   int b_begin, b_end;       // row batches (64 rows each) of the tile this workgroup finishes
 };
 
-template <int EPI, typename WriteTile, typename CSrc = EpiFromLds>
+template <int EPI, typename WriteTile, typename CSrc = EpiFromLds, int NT = NTHREADS>
 OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_gemm_group& G, int m0, int n0, char* smem,
                                         int tid, WriteTile write_tile, CSrc csrc = CSrc{}) {
   constexpr bool FROM_PARTIALS = std::is_same<CSrc, EpiFromPartials>::value;
@@ -266,7 +272,8 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
   //   row-map loads (b+2)  |  residual/gate/LDS loads (b+1)  |  math + stores (b)
   // in a ROLLED loop: fully unrolled, hipcc hoists all 16 rows' 64-bit addresses and predicates above phase 1, where
   // they are live together with the 128 accumulator registers and spill.
-  constexpr int BATCH = 4, NBATCH = BM / 16 / BATCH;
+  constexpr int RS = NT / 32;              // rows in flight per pass: a row is written by 32 threads (16 B each)
+  constexpr int BATCH = 4, NBATCH = BM / RS / BATCH;
   constexpr bool SPLIT = EPI == OMNI_EPI_BIAS_SPLIT3 || EPI == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE;
   constexpr bool QKROPE = EPI == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE;
   struct RowIdx { int ro[BATCH], im[BATCH], ps[BATCH]; };
@@ -278,7 +285,7 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
     int mc[BATCH];
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
-      mc[j] = min(m0 + (b * BATCH + j) * 16 + rsub, M - 1);     // rows past M: clamped here, masked at the store
+      mc[j] = min(m0 + (b * BATCH + j) * RS + rsub, M - 1);     // rows past M: clamped here, masked at the store
       x.ro[j] = mc[j];
     }
     if (G.out_row_map) {                 // uniform branches around whole groups of loads, none between the loads
@@ -339,7 +346,7 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
         d.r[j] = *reinterpret_cast<const u32x4_t*>(G.res + (int64_t)x.ro[j] * G.ldres + n);
       }
       if constexpr (FROM_PARTIALS) {
-        const int64_t row = csrc.row_base + min(m0 + (b * BATCH + j) * 16 + rsub, M - 1);
+        const int64_t row = csrc.row_base + min(m0 + (b * BATCH + j) * RS + rsub, M - 1);
         const float* src = csrc.ws + row * N + n;
         f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
         for (int sp = 0; sp < csrc.nsplit; ++sp) {
@@ -359,7 +366,7 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
 #pragma unroll
         for (int e = 0; e < 4; ++e) d.c[j][e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
       } else {
-        d.c[j] = *reinterpret_cast<const u32x4_t*>(lds_row + (b * BATCH + j) * 16 * EPI_LDS_STRIDE);
+        d.c[j] = *reinterpret_cast<const u32x4_t*>(lds_row + (b * BATCH + j) * RS * EPI_LDS_STRIDE);
       }
       if (QKROPE && which < 2) {   // cos / sin of the 4 rotation pairs this lane holds (sub = lane's 16-B chunk within its head);
                                    // `which` is uniform over the workgroup (split_n is a multiple of the tile width): V tiles skip
@@ -410,7 +417,7 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
                           : obase + (int64_t)d0.ro[j] * G.ldo + ncol_out;
       // The store is issued from inline asm: `res` may alias `out` (in-place residual), and for a compiler-visible
       // store hipcc drains vmcnt(0) before the next loads although a thread never re-reads a row it has written.
-      if (m0 + (b * BATCH + j) * 16 + rsub < M)
+      if (m0 + (b * BATCH + j) * RS + rsub < M)
         asm volatile("global_store_dwordx4 %0, %1, off" OMNI_EPI_STORE_POLICY ::"v"(dst), "v"(o));
     }
     d0 = d1;
@@ -1582,37 +1589,267 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_bf16_w4_kernel(const omni_
 
 #endif  // OMNI_DEV
 
+#ifdef OMNI_DEV
+// ------------------------------------------------------------------------------------------------
+// Q4: 4 waves x (128 x 128), ONE wave per SIMD, the 256 accumulator registers in the AGPR half, named literally in the MFMA
+// statements (never touched by the compiler); both fragment register sets (2 x 64 VGPRs) compiler-allocated.
+//
+// Why: the part runs at its package power limit, what a GEMM achieves is set by energy per
+// flop, and the 8-wave ping-pong kernel reads 48 KiB of fragments per 16-k step where this geometry (the vendor kernel's)
+// reads 32 KiB: 16 ds_read_b128 per 64 MFMAs instead of 24.  Round 1's hipcc-scheduled attempt (gemm_bf16_w4_kernel, -20 %)
+// lost the accumulators to spills and the pipelining to the compiler's waitcnt pass; here every MFMA, read, DMA and wait is
+// placed by hand.
+//
+// K-tile = 64 k = four 16-KiB half-tile slots (A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255; the ping-pong
+// kernel's LDS image: 128-B rows, 16-B chunk index XOR (row >> 1) & 7); ring = 2 K-tiles = 128 KiB.  A wave reads its A
+// half-tile and its W half-tile once per K-tile (32 ds_read_b128 for 128 MFMAs).  Per K-tile t two phases of 64 MFMAs of
+// v_mfma_f32_16x16x32_bf16, each on 64 DIFFERENT accumulators (no dependent chain inside a phase):
+//   X(t): MFMAs on fragment set X = (t, k 0-31)   ||  16 reads: set Y <- (t, k 32-63)
+//         then: my DMA pieces of K-tile t+1 have landed (issued a whole phase ago: vmcnt(0)), Y arrived -> s_barrier
+//               (= every wave has finished reading K-tile t's slots and K-tile t+1 is visible to all)
+//   Y(t): MFMAs on set Y                         ||  16 reads: set X <- (t+1, k 0-31)  ||  16 LDS-DMA pieces: K-tile t+2 into
+//         the slots K-tile t just left (they land during X(t+1))
+// ONE barrier per K-tile (128 MFMAs, ~2100 matrix-pipe cycles).
+// ------------------------------------------------------------------------------------------------
+constexpr int Q4_THREADS = 256;
+#ifndef OMNI_Q4_STAGGER
+#define OMNI_Q4_STAGGER 1
+#endif
+#ifndef OMNI_Q4_ABL
+#define OMNI_Q4_ABL 0   // dev-only timing ablations (results wrong): 1 no DMA in the loop, 2 no fragment reads, 4 no barrier, 8 no MFMA
+#endif
+
+template <int N>
+using q4ic = std::integral_constant<int, N>;
+
+template <int ACC>   // C^T block ACC (4 AGPRs) += W fragment (A operand) x A fragment (B operand)
+OMNI_DEVINL void q4_mfma(const bf16x8_t& wfrag, const bf16x8_t& afrag) {
+  if (OMNI_Q4_ABL & 8) { asm volatile("" ::"v"(wfrag), "v"(afrag)); return; }
+  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wfrag), "v"(afrag), "i"(ACC), "i"(ACC + 3));
+}
+template <int A>
+OMNI_DEVINL void q4_acc_write(float v) { asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "i"(A)); }
+template <int A>
+OMNI_DEVINL float q4_acc_read() {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(A));
+  return v;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(Q4_THREADS, 1) void gemm_bf16_q4_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
+                                                                     int tiles_n, int GROUP_M) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = tiles_m * tiles_n;
+  const int bid = (int)blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int band_sz = GROUP_M * tiles_n;
+  const int band = lid / band_sz, in_band = lid - band * band_sz;
+  const int first_m = band * GROUP_M;
+  const int gm = min(GROUP_M, tiles_m - first_m);
+  const int mt = first_m + in_band % gm;
+  const int nt = in_band / gm;
+  const int gi = (mt >= mtiles0) ? 1 : 0;
+  const omni_gemm_group G = pick_group(P, gi);
+  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
+  const int n0 = nt * BN;
+  const int M = G.M, N = P.N, K = P.K;
+  if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;   // device-side predicate (omni_teacache)
+  asm volatile("" ::: OMNI_ALL_AGPRS);                               // allocate a[0:255]
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g4 = lane >> 4;
+
+  // ---- per-lane DMA source byte offsets (SADDR form).  Slot row lr = (wave * 4 + i) * 8 + (lane >> 3) of half-tile h.
+  uint32_t a_off[2][4], w_off[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int lr = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((lr >> 1) & 7);               // logical 16-B chunk landing in physical chunk lane & 7
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ar = min(m0 + h * 128 + lr, M - 1);
+      if (G.a_row_map) ar = G.a_row_map[ar];
+      const int64_t ae = G.a_k32_rows ? ((int64_t)(c >> 2) * G.a_k32_rows + ar) * 32 + (c & 3) * 8
+                                      : (int64_t)ar * G.lda + c * 8;
+      a_off[h][i] = (uint32_t)(ae * 2);
+      const int wr = min(n0 + h * 128 + lr, N - 1);
+      const int64_t we = P.w_k32_blocked ? ((int64_t)(c >> 2) * N + wr) * 32 + (c & 3) * 8 : (int64_t)wr * K + c * 8;
+      w_off[h][i] = (uint32_t)(we * 2);
+    }
+  }
+  const int64_t astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * 128 : 128;
+  const int64_t wstep = P.w_k32_blocked ? (int64_t)N * 128 : 128;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int nkt = K / PBK;
+  const char* const Ab = reinterpret_cast<const char*>(G.A);
+  const char* const Wb = reinterpret_cast<const char*>(G.W);
+  // piece p = 0..15 of K-tile `tile`: half-tile h = p >> 2 (A0, A1, W0, W1), piece i = p & 3 of this wave
+  auto issue_piece = [&](int tile, auto pp) {
+    constexpr int p = decltype(pp)::value, h = p >> 2, i = p & 3;
+    const uint32_t dst = lds0 + (uint32_t)(((tile & 1) * 4 + h) * PSLOT_BYTES) + (wave * 4 + i) * 1024;
+    if constexpr (h < 2) glds16_saddr(Ab + tile * astep, a_off[h][i], dst);
+    else glds16_saddr(Wb + tile * wstep, w_off[h - 2][i], dst);
+  };
+  auto issue_tile = [&](int tile) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(tile, q4ic<I>{}), ...); }(std::make_integer_sequence<int, 16>{});
+  };
+
+  // ---- fragment read addresses: row l15 of a 16-row block (block = offset immediate), logical chunk ks * 4 + g4
+  uint32_t a_rd[2], w_rd[2];                        // [ks], K-tile parity 0 (parity 1: + 4 slots)
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const uint32_t chunk = ((uint32_t)(ks * 4 + g4) ^ ((l15 >> 1) & 7)) << 4;
+    a_rd[ks] = lds0 + wm * PSLOT_BYTES + l15 * 128 + chunk;
+    w_rd[ks] = lds0 + (2 + wn) * PSLOT_BYTES + l15 * 128 + chunk;
+  }
+
+  // ---- prologue: K-tiles 0 and 1 in flight, accumulators <- bias under the flight
+  issue_tile(0);
+  if (nkt > 1) issue_tile(1);
+  {
+    // acc[nb][mb] (4 AGPRs at (nb * 8 + mb) * 4) = C[wm*128 + mb*16 + l15][wn*128 + nb*16 + 4*g4 .. +4]
+    float bini[8][4];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const int n = n0 + wn * 128 + nb * 16 + g4 * 4;
+      u32x2_t b = {0u, 0u};
+      if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
+      bini[nb][0] = bf16_lo(b[0]); bini[nb][1] = bf16_hi(b[0]); bini[nb][2] = bf16_lo(b[1]); bini[nb][3] = bf16_hi(b[1]);
+    }
+    [&]<int... I>(std::integer_sequence<int, I...>) { (q4_acc_write<I>(bini[I >> 5][I & 3]), ...); }(std::make_integer_sequence<int, 256>{});
+  }
+  bf16x8_t xa[8], xw[8], ya[8], yw[8];
+  // fragment reads of one set: index r = 0..15: r < 8 -> W block r, else A block r - 8
+  auto read_frag = [&](auto rr_, bf16x8_t (&fa)[8], bf16x8_t (&fw)[8], uint32_t aaddr, uint32_t waddr) {
+    constexpr int r = decltype(rr_)::value;
+    if constexpr (r < 8) fw[r] = lds_read16<r * 2048>(waddr);
+    else fa[r - 8] = lds_read16<(r - 8) * 2048>(aaddr);
+  };
+  if (nkt > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  [&]<int... I>(std::integer_sequence<int, I...>) { (read_frag(q4ic<I>{}, xa, xw, a_rd[0], w_rd[0]), ...); }(std::make_integer_sequence<int, 16>{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  // one phase: 64 MFMAs on set (fa, fw) in 16 groups of 4; group g carries read g of the OTHER set (if do_read) and DMA piece g
+  // of K-tile `dtile` (if do_dma).  The four waves leave every barrier together and run the same instruction stream on four
+  // SIMDs: whatever they issue to the CU's ONE texture addresser / LDS pipeline they issue in the same cycle, and three of
+  // them queue (an LDS-DMA piece occupies the addresser ~16 cycles: that queue is the "~60 cycles per piece" of
+  // MI355X_MICROARCH).  STAG (= the wave index when OMNI_Q4_STAGGER) moves the group's memory operations behind its MFMA
+  // number STAG instead of its last one: the waves' requests arrive one MFMA (~16 cycles) apart.
+  auto phase = [&](auto stag_c, bf16x8_t (&fa)[8], bf16x8_t (&fw)[8], bf16x8_t (&oa)[8], bf16x8_t (&ow)[8], bool do_read,
+                   uint32_t raddr_a, uint32_t raddr_w, bool do_dma, int dtile) {
+    constexpr int STAG = decltype(stag_c)::value;
+    auto group = [&](auto gg) {
+      constexpr int g = decltype(gg)::value;        // MFMAs 4g .. 4g+3: (nb, mb) = (i >> 3, i & 7)
+      auto mem = [&] {
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_read && !(OMNI_Q4_ABL & 2)) read_frag(gg, oa, ow, raddr_a, raddr_w);
+        if (do_dma && !(OMNI_Q4_ABL & 1)) issue_piece(dtile, gg);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      q4_mfma<(4 * g + 0) * 4>(fw[(4 * g + 0) >> 3], fa[(4 * g + 0) & 7]);
+      if constexpr (STAG == 0) mem();
+      q4_mfma<(4 * g + 1) * 4>(fw[(4 * g + 1) >> 3], fa[(4 * g + 1) & 7]);
+      if constexpr (STAG == 1) mem();
+      q4_mfma<(4 * g + 2) * 4>(fw[(4 * g + 2) >> 3], fa[(4 * g + 2) & 7]);
+      if constexpr (STAG == 2) mem();
+      q4_mfma<(4 * g + 3) * 4>(fw[(4 * g + 3) >> 3], fa[(4 * g + 3) & 7]);
+      if constexpr (STAG == 3) mem();
+    };
+    [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (group(q4ic<Gs>{}), ...); }(std::make_integer_sequence<int, 16>{});
+  };
+
+  auto k_loop = [&](auto stag_c) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+    for (int t = 0; t < nkt; ++t) {
+      const uint32_t po = (uint32_t)((t & 1) * 4 * PSLOT_BYTES), pn = (uint32_t)(4 * PSLOT_BYTES) - po;
+      // X(t): reads Y <- (t, ks 1)
+      phase(stag_c, xa, xw, ya, yw, true, a_rd[1] + po, w_rd[1] + po, false, 0);
+      if (!(OMNI_Q4_ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(OMNI_Q4_ABL & 4)) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // Y(t): reads X <- (t+1, ks 0); DMA K-tile t+2 into K-tile t's slots
+      phase(stag_c, ya, yw, xa, xw, t + 1 < nkt, a_rd[0] + pn, w_rd[0] + pn, t + 2 < nkt, t + 2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#if OMNI_Q4_STAGGER
+  switch (wave) {
+    case 0: k_loop(q4ic<0>{}); break;
+    case 1: k_loop(q4ic<1>{}); break;
+    case 2: k_loop(q4ic<2>{}); break;
+    default: k_loop(q4ic<3>{}); break;
+  }
+#else
+  k_loop(q4ic<3>{});
+#endif
+  __builtin_amdgcn_s_setprio(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results -> v_accvgpr_read: software wait states
+
+  auto write_tile = [&]() {
+    // (the bias is already in the accumulators)
+    auto one = [&](auto ii) {
+      constexpr int i = decltype(ii)::value, nb = i >> 3, mb = i & 7;
+      float v[4] = {q4_acc_read<i * 4 + 0>(), q4_acc_read<i * 4 + 1>(), q4_acc_read<i * 4 + 2>(), q4_acc_read<i * 4 + 3>()};
+      if (EPI == OMNI_EPI_BIAS_GELU_TANH) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
+      }
+      u32x2_t o;
+      o[0] = pack_bf16x2(v[0], v[1]);
+      o[1] = pack_bf16x2(v[2], v[3]);
+      char* rowp = smem + (wm * 128 + mb * 16 + l15) * EPI_LDS_STRIDE + (wn * 128 + nb * 16 + g4 * 4) * 2;
+      *reinterpret_cast<u32x2_t*>(rowp) = o;
+    };
+    [&]<int... I>(std::integer_sequence<int, I...>) { (one(q4ic<I>{}), ...); }(std::make_integer_sequence<int, 64>{});
+  };
+  gemm_epilogue_lds_impl<EPI, decltype(write_tile), EpiFromLds, Q4_THREADS>(P, G, m0, n0, smem, tid, write_tile);
+}
+#endif  // OMNI_DEV (Q4)
+
 int gemm_group_m() {
   // dev knob: OMNI_GEMM_GROUP_M = row-tiles per L2 band
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("OMNI_GEMM_GROUP_M");
-    v = e ? atoi(e) : GROUP_M_DEFAULT;
+    v = omni_dev_env_int("OMNI_GEMM_GROUP_M", GROUP_M_DEFAULT);
     if (v < 1) v = 1;
   }
   return v;
 }
 
-int g_gemm_variant = -1;
-int gemm_variant() {
-  // dev knob: OMNI_GEMM_VARIANT = 3 (default) ping-pong BK=64 kernel, 1 -> 5-stage BK=32 ring, 0 -> 2-stage BK=64 pipeline,
-  // 2 -> 4 waves x 128x128.  Shapes the ping-pong kernel does not take (K % 64, unaligned outputs) run on the ring kernel.
-  if (g_gemm_variant < 0) {
-    const char* e = getenv("OMNI_GEMM_VARIANT");
-    g_gemm_variant = e ? atoi(e) : 3;
-  }
-  return g_gemm_variant;
+// Kernel family of a call: 3 = ping-pong (default), 1 = ring (omni_gemm_params.kernel_hint == OMNI_GEMM_KERNEL_RING, and the
+// fallback for what the ping-pong kernel does not take).  -DOMNI_DEV builds: kernel_hint >= 16 selects family hint - 16
+// (0 first design, 2 hipcc-scheduled 4-wave, 4 Q4, 5 / 6 two-phase ping-pong), else OMNI_GEMM_VARIANT from the environment.
+int gemm_variant(const omni_gemm_params* p) {
+  if (p->kernel_hint == OMNI_GEMM_KERNEL_RING) return 1;
+#ifdef OMNI_DEV
+  if (p->kernel_hint >= 16) return p->kernel_hint - 16;
+  static const int env = omni_dev_env_int("OMNI_GEMM_VARIANT", 3);
+  return env;
+#else
+  return 3;
+#endif
 }
 
-bool gemm_variant_blocked_ok() { const int v = gemm_variant(); return v == 1 || v == 3 || v == 5 || v == 6; }
+bool gemm_variant_blocked_ok(const omni_gemm_params* p) { const int v = gemm_variant(p); return v == 1 || v >= 3; }
 
 // The row-coalesced epilogue moves 16 B per thread: every output / residual / gate pointer and stride must allow it.
 // (OMNI_GEMM_EPI_LDS=0 forces the direct epilogue: dev knob.)
 bool epilogue_rows_coalescable(const omni_gemm_params* p) {
   static int knob = -1;
   if (knob < 0) {
-    const char* e = getenv("OMNI_GEMM_EPI_LDS");
-    knob = e ? atoi(e) : 1;
+    knob = omni_dev_env_int("OMNI_GEMM_EPI_LDS", 1);
   }
   if (!knob) return false;
   static_assert(EPI_LDS_BYTES <= RLDS_BYTES, "C tile must fit the operand ring's LDS");
@@ -1645,8 +1882,7 @@ int gemm_num_cus() {
 bool ring_saddr_ok(const omni_gemm_params* p) {
   static int knob = -1;
   if (knob < 0) {
-    const char* e = getenv("OMNI_GEMM_SADDR");
-    knob = e ? atoi(e) : 1;
+    knob = omni_dev_env_int("OMNI_GEMM_SADDR", 1);
   }
   if (!knob) return false;
   const int64_t lim = 1ll << 32;
@@ -1667,8 +1903,7 @@ bool gemm_persistent() {
   // per tile (hardware-ordered dispatch).
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("OMNI_GEMM_PERSISTENT");
-    v = e ? atoi(e) : 0;
+    v = omni_dev_env_int("OMNI_GEMM_PERSISTENT", 0);
   }
   return v != 0;
 }
@@ -1681,8 +1916,7 @@ bool gemm_persistent() {
 int splitk_factor(const omni_gemm_params* p, int tiles_m, int tiles_n) {
   static int knob = -1;                       // dev knob: OMNI_GEMM_SPLITK=0 disables
   if (knob < 0) {
-    const char* e = getenv("OMNI_GEMM_SPLITK");
-    knob = e ? atoi(e) : 1;
+    knob = omni_dev_env_int("OMNI_GEMM_SPLITK", 1);
   }
   if (!knob || !p->splitk_ws || p->splitk_ws_floats <= 0 || !OMNI_PP_MFMA16) return 1;
   const int tiles = tiles_m * tiles_n;
@@ -1711,6 +1945,8 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp2_kernel<EPI, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_w4_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_q4_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
 #endif
@@ -1728,20 +1964,20 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
     attr_set = true;
   }
 #ifdef OMNI_DEV
-  if (gemm_variant() == 0 && p->K % BK == 0) {
+  if (gemm_variant(p) == 0 && p->K % BK == 0) {
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(NTHREADS), LDS_BYTES, s, *p, mt0, tiles_m,
                        tiles_n, gemm_group_m());
     OMNI_CHECK_LAUNCH();
     return OMNI_OK;
   }
-  if (gemm_variant() == 2) {
+  if (gemm_variant(p) == 2) {
     hipLaunchKernelGGL(gemm_bf16_w4_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(W4_THREADS), RLDS_BYTES, s, *p, mt0,
                        tiles_m, tiles_n, gemm_group_m());
     OMNI_CHECK_LAUNCH();
     return OMNI_OK;
   }
-  if ((gemm_variant() == 5 || gemm_variant() == 6) && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
-    if (gemm_variant() == 5)
+  if ((gemm_variant(p) == 5 || gemm_variant(p) == 6) && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
+    if (gemm_variant(p) == 5)
       hipLaunchKernelGGL((gemm_bf16_pp2_kernel<EPI, false>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
                          tiles_m, tiles_n, gemm_group_m());
     else
@@ -1751,9 +1987,18 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
     return OMNI_OK;
   }
 #endif
+#ifdef OMNI_DEV
+  if (gemm_variant(p) == 4 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p) &&
+      splitk_factor(p, tiles_m, tiles_n) == 1) {
+    hipLaunchKernelGGL((gemm_bf16_q4_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(Q4_THREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
+                       tiles_n, gemm_group_m());
+    OMNI_CHECK_LAUNCH();
+    return OMNI_OK;
+  }
+#endif
   if (false) {
   }
-  else if (gemm_variant() == 3 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
+  else if (gemm_variant(p) >= 3 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
     const int nsplit = splitk_factor(p, tiles_m, tiles_n);
     if (nsplit > 1) {
       hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, 1>), dim3(tiles_m * tiles_n * nsplit), dim3(NTHREADS), RLDS_BYTES, s, *p,
@@ -1785,8 +2030,7 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
 
 }  // namespace
 
-// dev-only (NOT part of the C-ABI in include/omni_cdna4.h): switch the kernel family inside one process (A/B tests).
-extern "C" void omni_dev_gemm_set_variant(int v) { g_gemm_variant = v; }
+
 
 #ifdef OMNI_DEV
 // dev-only (NOT part of the C-ABI in include/omni_cdna4.h): time the 2-stage kernel with parts removed.
@@ -1858,7 +2102,7 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
   const bool split3 = p->epilogue == OMNI_EPI_BIAS_SPLIT3 || p->epilogue == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE;
   if (split3 && (p->split_n <= 0 || p->split_n % 32 != 0 || p->N != 3 * p->split_n)) return OMNI_ERR_UNSUPPORTED;
   if (p->epilogue == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE) {     // the fused norm+RoPE exists in the ring kernel's coalesced epilogue only
-    if (p->split_n % 128 != 0 || !gemm_variant_blocked_ok()) return OMNI_ERR_UNSUPPORTED;
+    if (p->split_n % 128 != 0 || !gemm_variant_blocked_ok(p)) return OMNI_ERR_UNSUPPORTED;
     if (!epilogue_rows_coalescable(p)) return OMNI_ERR_ALIGN;
   }
   for (int g = 0; g < p->ngroups; ++g) {
@@ -1869,11 +2113,11 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
       if (p->epilogue != OMNI_EPI_BIAS && p->epilogue != OMNI_EPI_BIAS_GELU_TANH) return OMNI_ERR_UNSUPPORTED;
       if (p->N % 32 != 0 || (!G.out_row_map && G.out_k32_rows < G.M)) return OMNI_ERR_BAD_ARG;
     }
-    if ((G.a_k32_rows || G.out_k32_rows) && !gemm_variant_blocked_ok()) return OMNI_ERR_UNSUPPORTED;
+    if ((G.a_k32_rows || G.out_k32_rows) && !gemm_variant_blocked_ok(p)) return OMNI_ERR_UNSUPPORTED;
     if (G.out_k32_rows && !epilogue_rows_coalescable(p)) return OMNI_ERR_ALIGN;
   }
   if (p->w_k32_blocked != 0 && p->w_k32_blocked != 1) return OMNI_ERR_BAD_ARG;
-  if (p->w_k32_blocked && !gemm_variant_blocked_ok()) return OMNI_ERR_UNSUPPORTED;   // only the ring / ping-pong kernels read that layout
+  if (p->w_k32_blocked && !gemm_variant_blocked_ok(p)) return OMNI_ERR_UNSUPPORTED;   // only the ring / ping-pong kernels read that layout
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (p->epilogue) {
     case OMNI_EPI_BIAS: return launch<OMNI_EPI_BIAS>(p, s);

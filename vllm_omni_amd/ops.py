@@ -55,6 +55,9 @@ class GemmGroupArgs:
         self.row_item_map, self.rows_per_item = row_item_map, rows_per_item
 
 
+GEMM_KERNEL_AUTO, GEMM_KERNEL_RING = 0, 1      # omni_gemm_params.kernel_hint
+
+
 def w_to_k32_blocked(w: torch.Tensor) -> torch.Tensor:
     """[N, K] row-major -> the same values in K32-blocked order [K/32][N][32] (omni_gemm_params.w_k32_blocked = 1),
     returned as an [N, K]-shaped contiguous tensor so that shape checks and pointer plumbing stay unchanged."""
@@ -65,10 +68,12 @@ def w_to_k32_blocked(w: torch.Tensor) -> torch.Tensor:
 
 
 def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0, m_override: list[int] | None = None,
-         w_k32_blocked: bool = False, splitk_ws: torch.Tensor | None = None):
+         w_k32_blocked: bool = False, splitk_ws: torch.Tensor | None = None, kernel_hint: int = 0):
     """Y_g = epilogue(A_g @ W_g.T + bias_g) for up to two groups sharing N, K (omni_gemm_bf16).  `splitk_ws`: optional fp32
-    device workspace; with it, launches of at most 128 tiles in at most 10 row tiles split their K loop (ABI v4)."""
+    device workspace; with it, launches of at most 128 tiles in at most 10 row tiles split their K loop (ABI v4).
+    `kernel_hint`: 0 = automatic, GEMM_KERNEL_RING = force the fallback (ring) kernel (ABI v6; cross-checks)."""
     p = N.GemmParams()
+    p.kernel_hint = int(kernel_hint)
     if splitk_ws is not None:
         if splitk_ws.dtype != torch.float32 or not splitk_ws.is_cuda or not splitk_ws.is_contiguous():
             raise N.OmniNativeError("splitk_ws must be a contiguous float32 GPU tensor")
