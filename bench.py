@@ -27,7 +27,14 @@ Also printed in the same JSON line:
                  reference cannot be timed there) on this box's host cores on a bounded sample of 2 full-width blocks,
                  extrapolated linearly in layers/forwards (rank 0, N=1 only).
   secondary    — (N=1 only) the no-CFG variant of the same workload (1 forward per step), BASELINE config 1
-                 (256x256, 4 steps, batch 1) eager vs hipGraph replay, and TeaCache rel_l1_thresh 0.2 when available.
+                 (256x256, 4 steps, batch 1) eager vs hipGraph replay, TeaCache rel_l1_thresh 0.2, and the SERVING path:
+                 DiffusionEngine.submit / poll (a worker process running the continuous step batcher) fed 2R requests that
+                 arrive staggered, against the static loop of the headline line.
+  per_rank     — every rank's wall seconds of the timed region and, from HIP events on its stream, the seconds it spent in the
+                 denoise loops, in the latent all-gather and in the VAE decodes (a sub-linear 1 -> N curve can be attributed).
+  --sp P       — (opt-in, needs --gpus P) after the headline measurement the P ranks form ONE Ulysses group and time a
+                 single 2048x2048 true-CFG request sequence-parallel: `secondary.sp_*`; the 1-GPU value
+                 of the same request is `secondary.res2048_bf16_ms_per_denoise_step` of an N = 1 run.
 """
 from __future__ import annotations
 
@@ -51,7 +58,7 @@ PFLOP_PER_IMAGE = 2.777e15          # 40 x 69.310 TF (DiT) + 4.7
 PEAK_BF16 = 2.5e15                  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(layers_sample: int = 2) -> dict:
+def cpu_baseline(layers_sample: int = 4) -> dict:
     """Oracle DiT blocks at full width on the host cores; extrapolated to images/sec."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import qwen_image_oracle as O
@@ -86,10 +93,10 @@ def measure_roofline(dev, R: int = 5) -> dict:
     g = torch.Generator(device=dev).manual_seed(7)
     xi = torch.randn(Mi, K, device=dev, generator=g).to(torch.bfloat16)
     xt = torch.randn(Mt, K, device=dev, generator=g).to(torch.bfloat16)
-    blocked = os.environ.get("OMNI_GEMM_W_BLOCKED", "1") != "0"       # the layout the DiT layers run with
+    blocked = True                                                    # the layout the DiT layers run with
     wi = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
     wt = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
-    ablk = blocked and os.environ.get("OMNI_DIT_ACT_BLOCKED", "1") != "0"   # A and the GELU output K32-blocked, as in the layers
+    ablk = True                                                       # A and the GELU output K32-blocked, as in the layers
     if blocked:
         wi, wt = ops.w_to_k32_blocked(wi), ops.w_to_k32_blocked(wt)
     if ablk:
@@ -119,9 +126,8 @@ def measure_roofline(dev, R: int = 5) -> dict:
     # HBM/fabric bytes per launch of this very kernel + shape: bench.py cannot run rocprofv3 on itself, so it reports the
     # committed PMC measurement (tools/profile_round.sh -> tools/summarize_prof.py; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)
     traffic, traffic_src = None, None
-    variant = os.environ.get("OMNI_GEMM_VARIANT", "3")
-    kname = "gemm_bf16_pp_kernel<OMNI_EPI_BIAS_GELU_TANH>" if variant == "3" else "gemm_bf16_ring_kernel<OMNI_EPI_BIAS_GELU_TANH, 0, true, true>"
-    for tag in ("r02", "r01"):
+    kname = "gemm_bf16_pp_kernel<OMNI_EPI_BIAS_GELU_TANH>"
+    for tag in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_roofline_traffic_pmc.json")) as fh:
                 j = json.load(fh)
@@ -156,6 +162,66 @@ def self_launch(n: int) -> int:
     for p in procs:
         rc = max(rc, abs(p.wait()))
     return rc
+
+
+def _engine_pipeline(layers: int, R: int):
+    """Pipeline factory of the serving-path line (runs inside the engine's worker process)."""
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig, TransformerConfig
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = OmniDiffusionConfig(model="Qwen/Qwen-Image(random-init)", max_step_batch=R,
+                              tf_model_config=TransformerConfig.from_dict({"num_layers": layers}))
+    pipe = QwenImagePipeline(od_config=cfg, device=dev)
+    pipe.transformer.init_random_(seed=1234)
+    pipe.vae.init_random_(seed=4321)
+    return pipe
+
+
+def engine_line(R: int, layers: int, static_images_per_sec: float) -> dict:
+    """The SERVING path on one GPU: DiffusionEngine -> WorkerProc -> ContinuousStepBatcher (static per-composition buffers,
+    device-side schedule vectors; reference loop shape gpu_worker.py:226-290), fed 2R requests whose arrivals are staggered, so
+    the running batch is re-composed while requests are mid-loop.  Images are decoded in the worker and returned through its
+    result queue, as a server would."""
+    import functools
+
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig, TransformerConfig
+    from vllm_omni_amd.diffusion.diffusion_engine import DiffusionEngine
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    cfg = OmniDiffusionConfig(model="Qwen/Qwen-Image(random-init)", max_step_batch=R, num_gpus=1,
+                              tf_model_config=TransformerConfig.from_dict({"num_layers": layers}))
+    eng = DiffusionEngine(cfg, pipeline_factory=functools.partial(_engine_pipeline, layers, R), post_process_func=None)
+    try:
+        g = torch.Generator().manual_seed(5)
+        S = (HEIGHT // 16) * (WIDTH // 16)
+
+        def req():
+            return OmniDiffusionRequest(height=HEIGHT, width=WIDTH, num_inference_steps=STEPS_DENOISE, true_cfg_scale=TRUE_CFG,
+                                        latents=torch.randn(1, S, 64, generator=g).to(torch.bfloat16),
+                                        prompt_embeds=torch.randn(1, T_TXT, 3584, generator=g).to(torch.bfloat16),
+                                        negative_prompt_embeds=torch.randn(1, T_TXT, 3584, generator=g).to(torch.bfloat16),
+                                        output_type="pt")
+
+        for o in eng.add_req_and_wait_for_response([req() for _ in range(R)]):       # warm-up: one full batch
+            if o.error:
+                raise RuntimeError(o.error)
+        n, gap = 2 * R, 0.25
+        t0 = time.perf_counter()
+        ids = []
+        for i in range(n):                                   # one request every `gap` seconds: the batch grows while it runs
+            ids.append(eng.submit(req()))
+            time.sleep(gap)
+        outs = [eng.poll(i) for i in ids]
+        dt = time.perf_counter() - t0
+        if any(o is None or o.error for o in outs):
+            raise RuntimeError(str([o.error for o in outs if o is not None and o.error]))
+        return {"engine_images_per_sec": n / dt, "engine_vs_static_loop": (n / dt) / static_images_per_sec,
+                "engine_note": f"DiffusionEngine.submit/poll, 1 worker process, {n} requests of 1024^2 x 20 steps true-CFG arriving "
+                               f"{gap} s apart (continuous step batching, max {R} per forward), images decoded in the worker and "
+                               "returned as CPU tensors; wall time from the first submit to the last result"}
+    finally:
+        eng.close()
 
 
 def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
@@ -253,6 +319,8 @@ def main():
     ap.add_argument("--requests", type=int, default=5, help="requests step-batched per rank per step (R)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-engine", action="store_true", help="skip the serving-path (DiffusionEngine) secondary line")
+    ap.add_argument("--sp", type=int, default=0, help="P = --gpus: also time one 2048^2 request Ulysses-parallel over all ranks")
     args = ap.parse_args()
 
     from vllm_omni_amd.diffusion.data import OmniDiffusionConfig, TransformerConfig
@@ -282,7 +350,12 @@ def main():
     pos = [torch.randn(1, T_TXT, 3584, generator=g).to(dev, torch.bfloat16) for _ in range(R)]   # one prompt per request
     neg = [torch.randn(1, T_TXT, 3584, generator=g).to(dev, torch.bfloat16) for _ in range(R)]
 
+    # HIP events on this rank's stream around the three parts of a step (no host synchronisation inside the timed region)
+    marks: list[list[torch.cuda.Event]] = []
+
     def one_step(seed: int):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
         reqs = []
         for r in range(R):
             lat = torch.randn(1, S_img, 64, generator=torch.Generator().manual_seed(seed * 97 + r)).to(dev, torch.bfloat16)
@@ -291,8 +364,12 @@ def main():
                                              negative_prompt_embeds=neg[r], output_type="latent"))
         outs = pipe.generate(reqs, output_type="latent")                      # one step-batched denoise loop
         lat = torch.cat([o.output for o in outs]).contiguous()                # [R, S_img, 64]
+        ev[1].record()
         gathered = dp.gather_latents(lat, [R] * world)                        # RCCL all-gather of finished latents
+        ev[2].record()
         imgs = [pipe.decode_latents(lat[r:r + 1], HEIGHT, WIDTH) for r in range(R)]   # each rank decodes its own
+        ev[3].record()
+        marks.append(ev)
         return gathered, imgs[-1]
 
     for i in range(args.warmup):
@@ -300,18 +377,58 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    marks.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
         gathered, img = one_step(42 + rank * 1000 + i)
     torch.cuda.synchronize()
+    mine = time.perf_counter() - t0                      # this rank's own seconds (before it waits for the others)
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    parts = [sum(ev[k].elapsed_time(ev[k + 1]) for ev in marks) * 1e-3 for k in range(3)]   # denoise, gather, decode
+    stats = torch.tensor([elapsed, mine] + parts, device=dev, dtype=torch.float64)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        allstats = [torch.zeros_like(stats) for _ in range(world)]
+        torch.distributed.all_gather(allstats, stats)
+        elapsed = max(float(t[0]) for t in allstats)
+    else:
+        allstats = [stats]
+    per_rank = [{"rank": r, "seconds": float(t[1]), "denoise_s": float(t[2]), "gather_s": float(t[3]), "vae_decode_s": float(t[4])}
+                for r, t in enumerate(allstats)]
     ok = bool(torch.isfinite(img.float()).all()) and bool(torch.isfinite(gathered.float()).all())
+
+    sp_line = None
+    if args.sp:
+        # Opt-in: ONE request, sequence-parallel over all ranks (every rank runs the same request in lockstep; the two CFG
+        # branches' all-to-alls hide behind each other's GEMMs, distributed/sp_driver.py).  3 denoise steps are timed.
+        if args.sp != world:
+            raise SystemExit(f"--sp {args.sp} needs --gpus {args.sp}")
+        gsp = torch.Generator().manual_seed(11)
+        big = OmniDiffusionRequest(height=2048, width=2048, num_inference_steps=3, true_cfg_scale=TRUE_CFG, output_type="latent",
+                                   latents=torch.randn(1, 16384, 64, generator=gsp).to(dev, torch.bfloat16),
+                                   prompt_embeds=torch.randn(1, T_TXT, 3584, generator=gsp).to(dev, torch.bfloat16),
+                                   negative_prompt_embeds=torch.randn(1, T_TXT, 3584, generator=gsp).to(dev, torch.bfloat16))
+        pipe.sp_group, pipe.sp_degree, pipe._force_sp_path = None, world, True
+        try:
+            pipe.generate([big], output_type="latent")
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            t1 = time.perf_counter()
+            out_sp = pipe.generate([big], output_type="latent")[0].output
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            dt_sp = time.perf_counter() - t1
+            sp_line = {"sp_degree": world, "sp_res2048_ms_per_denoise_step": dt_sp / 3 * 1e3,
+                       "sp_finite": bool(torch.isfinite(out_sp.float()).all()),
+                       "sp_note": "ONE 2048x2048 true-CFG request, Ulysses over all ranks (image rows sharded, heads sharded in "
+                                  "attention, 2 all-to-alls per block, CFG branches software-pipelined); compare with "
+                                  "secondary.res2048_bf16_ms_per_denoise_step of an N = 1 run (reference's published SP speed-ups "
+                                  "at 2048^2: 1.73x / 2.84x / 3.65x on 2 / 4 / 8 GPUs, BASELINE.md)"}
+        finally:
+            pipe.sp_group, pipe.sp_degree, pipe._force_sp_path = None, 1, False
 
     if rank == 0:
         value = world * args.steps * R / elapsed
@@ -323,7 +440,7 @@ def main():
                                    f"{args.layers} layers, T=64 synthetic prompt embeds, + VAE decode; DP={world}, "
                                    f"{R} requests step-batched per rank",
                        "global_batch": world * R, "parallelism": f"dp{world}", "images_per_step": world * R},
-            "finite_outputs": ok,
+            "finite_outputs": ok, "per_rank": per_rank,
             "dit_mfma_roofline_frac": (value / world) * PFLOP_PER_IMAGE * (args.layers / LAYERS) / PEAK_BF16,
             "roofline": measure_roofline(dev, R),
         }
@@ -332,6 +449,15 @@ def main():
                 line["secondary"] = secondary_lines(pipe, dev, R, args.layers)
             except Exception as e:  # noqa: BLE001 - the headline line must survive a failing secondary measurement
                 line["secondary"] = {"error": f"{type(e).__name__}: {e}"}
+        if sp_line is not None:
+            line.setdefault("secondary", {}).update(sp_line)
+        if world == 1 and not args.no_secondary and not args.no_engine:
+            del pipe                                         # the worker process builds its own 41 GB of weights
+            torch.cuda.empty_cache()
+            try:
+                line["secondary"].update(engine_line(R, args.layers, value))
+            except Exception as e:  # noqa: BLE001
+                line["secondary"]["engine_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -472,6 +472,52 @@ def run_prompt_encode_case():
     print(f"prompt_encode: embeds {tuple(emb.shape)} mask rows {msk.sum(1).tolist()}; encode_prompt {tuple(emb2.shape)}")
 
 
+def run_edit_prompt_encode_case():
+    """The reference's Edit / Edit-Plus `_get_qwen_prompt_embeds` (pipeline_qwen_image_edit.py:352-397,
+    pipeline_qwen_image_edit_plus.py:274-330) called UNBOUND on bare pipeline objects whose `text_encoder` is a seeded random HF
+    `Qwen2_5_VLForConditionalGeneration` (vision tower + language model) and whose `processor` is oracle/vl_stubs.StubVLProcessor
+    (HF's real Qwen2VL image processor + a word tokenizer with a 64-id template prefix).  Templates and start indices are read
+    from the reference SOURCE."""
+    import ast
+    import importlib
+
+    import ref_shims_pipeline as RP
+    import vl_stubs as V
+
+    RP.install()
+    model, cfg = V.make_random_vl_model(seed=5)
+    out = {}
+    imgs = V.test_images(3)
+    prompts = {"edit": "turn the sky purple and add two birds", "plus": "put the cat from picture two onto the sofa of picture one"}
+    for key, modname, clsname, pics in (("edit", "pipeline_qwen_image_edit", "QwenImageEditPipeline", imgs[0]),
+                                        ("plus", "pipeline_qwen_image_edit_plus", "QwenImageEditPlusPipeline", imgs[:3]),
+                                        ("plus1", "pipeline_qwen_image_edit_plus", "QwenImageEditPlusPipeline", imgs[1])):
+        mod = importlib.import_module(f"vllm_omni.diffusion.models.qwen_image.{modname}")
+        cls = getattr(mod, clsname)
+        pipe = object.__new__(cls)
+        torch.nn.Module.__init__(pipe)
+        src = open(os.path.join(ref_shims.REFERENCE_ROOT, "vllm_omni", "diffusion", "models", "qwen_image", modname + ".py")).read()
+        for node in ast.walk(ast.parse(src)):
+            if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Attribute) and \
+                    node.targets[0].attr in ("prompt_template_encode", "prompt_template_encode_start_idx"):
+                setattr(pipe, node.targets[0].attr, ast.literal_eval(node.value))
+        assert pipe.prompt_template_encode_start_idx == 64
+        pipe.text_encoder, pipe.processor, pipe.device = model, V.StubVLProcessor(), torch.device("cpu")
+        with torch.no_grad():
+            emb, msk = cls._get_qwen_prompt_embeds(pipe, prompts[key[:4]], image=pics, dtype=torch.float32)
+        out[f"{key}_embeds"], out[f"{key}_mask"] = emb.numpy(), msk.numpy()
+        out[f"{key}_text"] = np.array(pipe.processor.calls[-1]["text"][0])
+        out[f"{key}_template"] = np.array(pipe.prompt_template_encode)
+        print(f"prompt_encode_edit[{key}]: embeds {tuple(emb.shape)} (vision tokens + text behind the 64-token prefix)")
+    sd = model.state_dict()
+    meta = dict(prompts=prompts, seed=5, drop_idx=64, n_images=dict(edit=1, plus=3, plus1=1),
+                reference="pipeline_qwen_image_edit.py:352-397 and pipeline_qwen_image_edit_plus.py:274-330 (unbound) over HF "
+                          "Qwen2_5_VLForConditionalGeneration + oracle/vl_stubs.py")
+    np.savez_compressed(os.path.join(OUT, "prompt_encode_edit.npz"),
+                        vl_checksum=np.array([float(sum(float(v.abs().sum()) for v in sd.values()))]),
+                        meta=json.dumps(meta), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -495,6 +541,8 @@ def main():
         run_teacache_case()
     if only is None or "prompt" in only:
         run_prompt_encode_case()
+    if only is None or "editprompt" in only:
+        run_edit_prompt_encode_case()
 
 
 if __name__ == "__main__":

@@ -91,3 +91,40 @@ def test_engine_two_workers_dispatch_staggered_requests_and_rpc():
     finally:
         eng.close()
     assert all(not p.is_alive() for p in eng._processes)
+
+
+def test_async_omni_diffusion_concurrent_generates_are_served_together():
+    """AsyncOmniDiffusion (reference entrypoints/async_omni_diffusion.py:117): concurrent `generate` calls resolve to their own
+    results (request ids kept, outputs equal the solo runs), a failing request only fails its own awaitable, close() stops it."""
+    import asyncio
+
+    import _fake_pipeline
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
+    from vllm_omni_amd.entrypoints.async_omni_diffusion import AsyncOmniDiffusion
+
+    eng = AsyncOmniDiffusion(od_config=OmniDiffusionConfig(num_gpus=1, max_step_batch=3, dist_timeout=60),
+                             pipeline_factory=_fake_pipeline.make)
+    eng.engine.post_process_func = None
+    g = torch.Generator().manual_seed(0)
+    embeds = [torch.randn(1, 3 + i, 8, generator=g) for i in range(4)]
+
+    async def run():
+        calls = [eng.generate(prompt=f"p{i}", request_id=f"r{i}", num_inference_steps=3 + i, height=64, width=64, seed=i,
+                              prompt_embeds=embeds[i], output_type="latent") for i in range(4)]
+        calls.append(eng.generate(prompt=None, request_id="bad", num_inference_steps=2, height=64, width=64))   # nothing to encode
+        return await asyncio.gather(*calls, return_exceptions=True)
+
+    try:
+        res = asyncio.run(run())
+        assert eng.is_running
+        for i in range(4):
+            from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+            solo = _solo(OmniDiffusionRequest(height=64, width=64, num_inference_steps=3 + i, seed=i, prompt_embeds=embeds[i],
+                                              output_type="latent"))
+            assert res[i].request_id == f"r{i}" and res[i].metrics["num_inference_steps"] == 3 + i
+            assert torch.equal(res[i].latents, solo)
+        assert isinstance(res[4], RuntimeError)
+    finally:
+        eng.close()
+    assert eng.is_stopped and all(not p.is_alive() for p in eng.engine._processes)

@@ -171,3 +171,48 @@ def test_vae_mid_attention_handles_token_counts_that_are_not_multiples_of_32():
     r_d = rel_l2(img, ref_d)
     print(f"60-token mid attention: encode rel_l2 {r_e:.3e}, decode rel_l2 {r_d:.3e}")
     assert mean.shape == (1, 16, 1, 6, 10) and r_e <= 3e-2 and r_d <= 3e-2
+
+
+@pytest.mark.parametrize("plus", [False, True])
+def test_edit_request_with_prompt_and_picture_runs_text_to_image(plus):
+    """Round-2 verdict N4: an Edit request with `prompt` + `image` and NO `prompt_embeds` runs end to end — the prompt and the
+    picture(s) go through the Qwen2.5-VL vision tower + language model (QwenEditPromptEncoder over a random-weight HF model and
+    the stub processor), the picture is VAE-encoded, the denoise loop and the decode run on the HIP kernels — and equals the
+    same request served from the embeddings that encoder returns."""
+    import vl_stubs as V
+
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import AutoencoderKLQwenImage
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image_edit import QwenImageEditPipeline
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image_edit_plus import QwenImageEditPlusPipeline
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+    from vllm_omni_amd.diffusion.models.qwen_image.text_encoder import QwenEditPromptEncoder
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    heads, joint, layers = 2, 128, 2
+    m = QwenImageTransformer2DModel(num_layers=layers, num_attention_heads=heads, joint_attention_dim=joint, device=DEV)
+    m.init_random_(seed=3)
+    vae = AutoencoderKLQwenImage(device=DEV, with_encoder=True).init_random_(seed=4)
+    model, _ = V.make_random_vl_model(seed=5, hidden=joint, dtype=torch.bfloat16)
+    enc = QwenEditPromptEncoder(model.to(DEV), V.StubVLProcessor(), dtype=BF16, multi_image=plus)
+    cls = QwenImageEditPlusPipeline if plus else QwenImageEditPipeline
+    pipe = cls(device=DEV, transformer=m, vae=vae, text_encoder=enc)
+    g = torch.Generator().manual_seed(8)
+    pics = [torch.rand(1, 3, 64, 96, generator=g) * 2 - 1, torch.rand(1, 3, 96, 64, generator=g) * 2 - 1]
+    image = pics if plus else pics[0]
+    lat = torch.randn(1, 64, 64, generator=g).to(BF16)
+    req = OmniDiffusionRequest(prompt="make the sky purple", negative_prompt="blurry", height=128, width=128, num_inference_steps=3,
+                               true_cfg_scale=4.0, latents=lat, extra={"image": image}, output_type="pt")
+    out = pipe.generate([req])[0]
+    assert out.error is None and out.output.shape == (1, 3, 128, 128) and torch.isfinite(out.output.float()).all()
+    pe, pm = enc.get_qwen_prompt_embeds("make the sky purple", image=image, device=DEV)
+    ne, nm = enc.get_qwen_prompt_embeds("blurry", image=image, device=DEV)
+    assert int(pm.sum()) > len("make the sky purple".split())            # vision tokens are part of the prompt rows
+    req2 = OmniDiffusionRequest(prompt_embeds=pe, prompt_embeds_mask=pm, negative_prompt_embeds=ne, negative_prompt_embeds_mask=nm,
+                                height=128, width=128, num_inference_steps=3, true_cfg_scale=4.0, latents=lat,
+                                extra={"image": image}, output_type="pt")
+    out2 = pipe.generate([req2])[0]
+    assert torch.equal(out.output, out2.output)
+    other = pipe.generate([OmniDiffusionRequest(prompt="make the sky purple", negative_prompt="blurry", height=128, width=128,
+                                                num_inference_steps=3, true_cfg_scale=4.0, latents=lat, output_type="pt",
+                                                extra={"image": image, "prompt_image": [p.flip(-1) for p in pics] if plus else pics[0].flip(-1)})])[0]
+    assert not torch.equal(other.output, out.output)                     # the picture the tower sees matters

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch ONE hot kernel a few times (for rocprofv3 --kernel-trace / --pmc passes).
-   python tools/run_kernel.py roofline|gemm_mlp_up|gemm_mlp_down|gemm_qkv|gemm_out|attention|attention6 [iters]"""
+   python tools/run_kernel.py roofline|gemm_mlp_up|gemm_mlp_down|gemm_qkv|gemm_out|attention|attention6|attention10 [iters]"""
 import math
 import os
 import sys
@@ -38,8 +38,8 @@ elif which == "roofline":
     fn = lambda: ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi, a_k32_blocked=True, out_k32_blocked=True),  # noqa: E731
                            ops.GemmGroupArgs(xt, wt, b, ot, a_k32_blocked=True, out_k32_blocked=True)],
                           ops.EPI_BIAS_GELU_TANH, w_k32_blocked=True)
-elif which in ("attention", "attention6"):
-    B, H, S = (6 if which == "attention6" else 2), 24, 4160
+elif which in ("attention", "attention6", "attention10"):
+    B, H, S = {"attention": 2, "attention6": 6, "attention10": 10}[which], 24, 4160      # attention10 = the bench's step-batch
     q, k, v = rn(B * S, H * 128), rn(B * S, H * 128), rn(B * S, H * 128)
     cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
     fn = lambda: ops.flash_attn_varlen(q, k, v, cu, H, S, 1 / math.sqrt(128))  # noqa: E731

@@ -25,5 +25,13 @@ class TeaCacheBackend(CacheBackend):
         self.enabled = True
 
     def refresh(self, pipeline: Any, num_inference_steps: int, verbose: bool = True) -> None:
-        # state lives per denoise call (one TeaCacheDeviceState per step-batch) and is reset when a loop starts
-        pipeline._teacache_states = {}
+        """New generation (reference backend.py:96-113, called by the worker before every request batch,
+        worker/gpu_worker.py:132-134): every resident TeaCache device state of the static denoise loop goes back to
+        "first forward computes" (counters and accumulated distances to zero: native.TeaCacheDeviceState.reset).  The serving
+        path keeps history per SAMPLE (a fresh sample is imported with zeroed counters), so its states are left alone —
+        requests that are mid-loop keep theirs."""
+        self.num_inference_steps = int(num_inference_steps)
+        for st in list(getattr(pipeline, "_step_state", {}).values()):
+            tc = st.get("tc") if isinstance(st, dict) else None
+            if tc is not None:
+                tc.reset()

@@ -104,18 +104,40 @@ class DiffusionEngine:
             self._inbox[r].put(msg)
         return rid
 
-    def _pump(self, timeout: float | None) -> bool:
+    def _recv(self, timeout: float | None):
+        """One message from the workers, or None (split from `_handle` so that an asynchronous front end can block on the
+        queue WITHOUT holding the lock it takes around the dispatcher's bookkeeping)."""
         try:
-            m = self._outbox.get(timeout=timeout)
+            return self._outbox.get(timeout=timeout)
         except queue.Empty:
+            return None
+
+    def _pump(self, timeout: float | None) -> bool:
+        m = self._recv(timeout)
+        if m is None:
             return False
+        self._handle(m)
+        return True
+
+    def _handle(self, m: dict) -> None:
         if m["type"] == "done":
             grp, cost = self._cost.pop(m["id"], (m["rank"] // self.sp_degree, 0.0))
             self._load[grp] = max(0.0, self._load[grp] - cost)
             self._results[m["id"]] = m["output"]
         elif m["type"] == "rpc_result":
             self._rpc_results.setdefault(m["id"], {})[m["rank"]] = m["result"]
-        return True
+
+    def to_request_output(self, req: OmniDiffusionRequest, out: DiffusionOutput) -> OmniRequestOutput:
+        """DiffusionOutput of one request -> OmniRequestOutput (post-processing as in `step`)."""
+        if out.error:
+            raise RuntimeError(out.error)
+        prompt = req.prompt[0] if isinstance(req.prompt, list) and req.prompt else req.prompt
+        images = out.output
+        if images is not None and req.output_type != "latent" and self.post_process_func is not None:
+            images = self.post_process_func(images)
+        imgs = [] if images is None else (list(images) if not isinstance(images, list) else images)
+        return OmniRequestOutput.from_diffusion(request_id=req.request_id or "", images=imgs, prompt=prompt, metrics={},
+                                                latents=out.output if req.output_type == "latent" else None)
 
     def poll(self, rid: int, timeout: float | None = None) -> DiffusionOutput | None:
         deadline = None if timeout is None else time.time() + timeout
@@ -140,17 +162,7 @@ class DiffusionEngine:
             if self.pre_process_func is not None:
                 requests = self.pre_process_func(requests)
             outs = self.add_req_and_wait_for_response(requests)
-            results = []
-            for req, out in zip(requests, outs):
-                if out.error:
-                    raise RuntimeError(out.error)
-                prompt = req.prompt[0] if isinstance(req.prompt, list) and req.prompt else req.prompt
-                images = out.output
-                if images is not None and req.output_type != "latent" and self.post_process_func is not None:
-                    images = self.post_process_func(images)
-                imgs = [] if images is None else (list(images) if not isinstance(images, list) else images)
-                results.append(OmniRequestOutput.from_diffusion(request_id=req.request_id or "", images=imgs, prompt=prompt,
-                                                                metrics={}, latents=out.output if req.output_type == "latent" else None))
+            results = [self.to_request_output(req, out) for req, out in zip(requests, outs)]
             return results[0] if len(results) == 1 else results
         except Exception as e:  # noqa: BLE001
             print(f"[DiffusionEngine] Generation failed: {e}")

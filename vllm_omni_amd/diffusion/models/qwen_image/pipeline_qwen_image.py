@@ -356,11 +356,14 @@ class QwenImagePipeline(nn.Module):
         prompt_embeds_mask = prompt_embeds_mask.repeat(1, num_images_per_prompt, 1).view(B * num_images_per_prompt, T)
         return prompt_embeds, prompt_embeds_mask
 
+    def _encode_text(self, prompts: list[str]):
+        """Prompt strings -> (embeds, mask).  The Edit pipelines override this to show the picture(s) to the vision tower."""
+        return self.text_encoder.get_qwen_prompt_embeds(prompts, device=self.device)
+
     def _rows_of(self, embeds, mask, prompts, n_per_prompt: int) -> list[torch.Tensor]:
         """Per-sample [T_i, joint] rows (padding removed) from either pre-computed embeddings (+ mask) or prompt strings."""
         if embeds is None:
-            embeds, mask = self.text_encoder.get_qwen_prompt_embeds([prompts] if isinstance(prompts, str) else list(prompts),
-                                                                    device=self.device)
+            embeds, mask = self._encode_text([prompts] if isinstance(prompts, str) else list(prompts))
         if embeds.dim() == 2:
             embeds = embeds.unsqueeze(0)
         if mask is not None:

@@ -10,7 +10,9 @@ Relative to QwenImageEditPipeline:
   * the prompt template numbers the images: "Picture 1: <|vision_start|><|image_pad|><|vision_end|>Picture 2: ..." in front
     of the user text (:286-299).
 The denoise loop, true-CFG, slicing the prediction back to the generated image's tokens and the decode are the Edit /
-text-to-image path.  As for Edit, the Qwen2.5-VL vision tower is not built: requests carry `prompt_embeds`."""
+text-to-image path.  Prompts are encoded through the Qwen2.5-VL vision tower with ALL pictures (QwenEditPromptEncoder,
+multi_image=True; `req.extra["prompt_image"]` = the list at the vision-tower size, default: the condition images); requests
+may still carry `prompt_embeds`."""
 from __future__ import annotations
 
 import torch
@@ -47,6 +49,8 @@ def plan_image_sizes(sizes: list[tuple[int, int]]) -> dict:
 
 
 class QwenImageEditPlusPipeline(QwenImageEditPipeline):
+    _multi_image_prompt = True
+
     def resolve_request(self, req: OmniDiffusionRequest, index: int = 0) -> list[dict]:
         extra = req.extra or {}
         images, lat_list = extra.get("image"), extra.get("image_latents")
@@ -55,7 +59,12 @@ class QwenImageEditPlusPipeline(QwenImageEditPipeline):
         if lat_list is None and not images:
             raise ValueError("the Edit-Plus pipeline needs req.extra['image'] (a list of images) or 'image_latents'")
         # one sample set from the text-to-image resolver, then the condition rows and grids of ALL images
-        samples = super(QwenImageEditPipeline, self).resolve_request(req, index)
+        pics = self._prompt_pictures(req)
+        self._prompt_images = [pics] if pics is not None and not isinstance(pics, (list, tuple)) else pics
+        try:
+            samples = super(QwenImageEditPipeline, self).resolve_request(req, index)
+        finally:
+            self._prompt_images = None
         packed, grids = [], []
         if lat_list is not None:
             if isinstance(lat_list, torch.Tensor):

@@ -87,12 +87,83 @@ class QwenPromptEncoder:
         toks = self.tokenizer(txt, max_length=self.tokenizer_max_length + drop, padding=True, truncation=True,
                               return_tensors="pt").to(next(self.model.parameters()).device)
         out = self.model(input_ids=toks.input_ids, attention_mask=toks.attention_mask, output_hidden_states=True)
-        hidden = out.hidden_states[-1]
-        mask = toks.attention_mask.bool()
-        lens = mask.sum(dim=1).tolist()
-        split = [h[drop:] for h in torch.split(hidden[mask], lens, dim=0)]       # _extract_masked_hidden + drop (:351-357,380)
-        T = max(e.shape[0] for e in split)
-        emb = torch.stack([torch.cat([u, u.new_zeros(T - u.shape[0], u.shape[1])]) for u in split])
-        msk = torch.stack([torch.cat([torch.ones(u.shape[0], dtype=torch.long, device=u.device),
-                                      torch.zeros(T - u.shape[0], dtype=torch.long, device=u.device)]) for u in split])
+        emb, msk = masked_drop_pad(out.hidden_states[-1], toks.attention_mask, drop)
+        return emb.to(device=dev, dtype=dtype or self.dtype), msk.to(dev)
+
+
+def masked_drop_pad(hidden: torch.Tensor, attention_mask: torch.Tensor, drop: int):
+    """`_extract_masked_hidden` + drop of the template tokens + zero-padding to the longest sequence + mask, shared by the
+    text-to-image (pipeline_qwen_image.py:351-357,380-390) and the Edit pipelines (pipeline_qwen_image_edit.py:298-305,
+    383-393)."""
+    mask = attention_mask.bool()
+    lens = mask.sum(dim=1).tolist()
+    split = [h[drop:] for h in torch.split(hidden[mask], lens, dim=0)]
+    T = max(e.shape[0] for e in split)
+    emb = torch.stack([torch.cat([u, u.new_zeros(T - u.shape[0], u.shape[1])]) for u in split])
+    msk = torch.stack([torch.cat([torch.ones(u.shape[0], dtype=torch.long, device=u.device),
+                                  torch.zeros(T - u.shape[0], dtype=torch.long, device=u.device)]) for u in split])
+    return emb, msk
+
+
+# ---- image-editing prompts: the Qwen2.5-VL VISION tower sees the picture(s) (SURVEY.md §8f N4) ------------------------------
+EDIT_PROMPT_TEMPLATE_ENCODE = (     # reference pipeline_qwen_image_edit.py:240 (one picture, marker inside the template)
+    "<|im_start|>system\nDescribe the key features of the input image (color, shape, size, texture, objects, background), then "
+    "explain how the user's text instruction should alter or modify the image. Generate a new image that meets the user's "
+    "requirements while maintaining consistency with the original input where appropriate.<|im_end|>\n<|im_start|>user\n"
+    "<|vision_start|><|image_pad|><|vision_end|>{}<|im_end|>\n<|im_start|>assistant\n")
+EDIT_PLUS_PROMPT_TEMPLATE_ENCODE = (  # reference pipeline_qwen_image_edit_plus.py:203-209 (markers come with the pictures)
+    "<|im_start|>system\nDescribe the key features of the input image (color, shape, size, texture, objects, background), then "
+    "explain how the user's text instruction should alter or modify the image. Generate a new image that meets the user's "
+    "requirements while maintaining consistency with the original input where appropriate.<|im_end|>\n<|im_start|>user\n{}"
+    "<|im_end|>\n<|im_start|>assistant\n")
+EDIT_PROMPT_TEMPLATE_ENCODE_START_IDX = 64       # both Edit pipelines (:241 / :210)
+EDIT_PLUS_IMG_PROMPT = "Picture {}: <|vision_start|><|image_pad|><|vision_end|>"     # edit_plus :285
+
+
+def to_processor_image(x):
+    """What the HF image processor takes: PIL images pass through; a tensor [3, H, W] / [1, 3, H, W] / [1, 3, 1, H, W] in
+    [-1, 1] (the layout the VAE encoder takes) becomes a uint8 HWC array."""
+    if isinstance(x, torch.Tensor):
+        t = x.detach().float().cpu()
+        while t.dim() > 3:
+            t = t[0] if t.shape[0] == 1 else t.squeeze(1)
+        return ((t.clamp(-1, 1) + 1) * 127.5).round().to(torch.uint8).permute(1, 2, 0).numpy()
+    return x
+
+
+class QwenEditPromptEncoder:
+    """`_get_qwen_prompt_embeds` of the Edit pipelines (pipeline_qwen_image_edit.py:352-397, multi_image=False;
+    pipeline_qwen_image_edit_plus.py:274-330, multi_image=True): template -> `processor(text=, images=)` -> HF
+    `Qwen2_5_VLForConditionalGeneration` with `pixel_values` / `image_grid_thw` (vision tower + language model),
+    last hidden state, first 64 tokens dropped, zero-padded + mask.  `processor` is the checkpoint's `Qwen2VLProcessor`
+    (tests: oracle/vl_stubs.StubVLProcessor, same call signature)."""
+
+    def __init__(self, vl_model, processor, dtype=torch.bfloat16, multi_image: bool = False, template: str | None = None,
+                 drop_idx: int = EDIT_PROMPT_TEMPLATE_ENCODE_START_IDX):
+        self.model, self.processor, self.dtype, self.multi_image = vl_model, processor, dtype, multi_image
+        self.prompt_template_encode = template or (EDIT_PLUS_PROMPT_TEMPLATE_ENCODE if multi_image else EDIT_PROMPT_TEMPLATE_ENCODE)
+        self.prompt_template_encode_start_idx = drop_idx
+        self.tokenizer_max_length = 1024
+
+    @torch.no_grad()
+    def get_qwen_prompt_embeds(self, prompt, image=None, device=None, dtype=None):
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        mdev = next(self.model.parameters()).device
+        dev = device if device is not None else mdev
+        if isinstance(image, (list, tuple)):
+            image = [to_processor_image(im) for im in image]
+        elif image is not None:
+            image = to_processor_image(image)
+        if self.multi_image:
+            n = len(image) if isinstance(image, list) else (0 if image is None else 1)
+            base = "".join(EDIT_PLUS_IMG_PROMPT.format(i + 1) for i in range(n))
+            txt = [self.prompt_template_encode.format(base + e) for e in prompt]
+        else:
+            txt = [self.prompt_template_encode.format(e) for e in prompt]
+        inputs = self.processor(text=txt, images=image, padding=True, return_tensors="pt").to(mdev)
+        kw = {}
+        if getattr(inputs, "pixel_values", None) is not None:
+            kw = dict(pixel_values=inputs.pixel_values, image_grid_thw=inputs.image_grid_thw)
+        out = self.model(input_ids=inputs.input_ids, attention_mask=inputs.attention_mask, output_hidden_states=True, **kw)
+        emb, msk = masked_drop_pad(out.hidden_states[-1], inputs.attention_mask, self.prompt_template_encode_start_idx)
         return emb.to(device=dev, dtype=dtype or self.dtype), msk.to(dev)

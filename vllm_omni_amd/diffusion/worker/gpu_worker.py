@@ -89,6 +89,9 @@ class GPUWorker:
         mine = [reqs[i] for i in dp_assign[self.dp_rank]]
         err, outs = None, []
         try:
+            cb = getattr(self.pipeline, "cache_backend", None)
+            if mine and cb is not None and getattr(cb, "enabled", False):      # reference gpu_worker.py:132-134
+                cb.refresh(self.pipeline, mine[0].num_inference_steps or 50)
             outs = self.pipeline.generate(mine, output_type="latent") if mine else []
         except Exception as e:
             err = f"rank {self.rank}: {type(e).__name__}: {e}"
