@@ -23,6 +23,16 @@ PREFIX_IDS = 64
 _SPECIAL = {"<|vision_start|>": VISION_START, "<|vision_end|>": VISION_END, "<|im_start|>": IM_START, "<|im_end|>": IM_END}
 
 
+class _Features:
+    """What the processor returns: attribute access + `.to(device)` (BatchFeature's surface as the pipelines use it)."""
+
+    def __init__(self, feats: dict):
+        self.__dict__.update(feats)
+
+    def to(self, device):
+        return _Features({k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in self.__dict__.items()})
+
+
 class StubVLProcessor:
     def __init__(self, min_pixels: int = 56 * 56, max_pixels: int = 28 * 28 * 16):
         from transformers import Qwen2VLImageProcessorPil
@@ -67,9 +77,7 @@ class StubVLProcessor:
         L = max(len(x) for x in ids)
         feats["input_ids"] = torch.tensor([x + [0] * (L - len(x)) for x in ids], dtype=torch.long)
         feats["attention_mask"] = torch.tensor([[1] * len(x) + [0] * (L - len(x)) for x in ids], dtype=torch.long)
-        out = types.SimpleNamespace(**feats)
-        out.to = lambda device: out
-        return out
+        return _Features(feats)
 
 
 def make_random_vl_model(seed: int = 5, hidden: int = 64, dtype=torch.float32):
