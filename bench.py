@@ -291,6 +291,27 @@ def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
     out["res2048_note"] = ("2048x2048, true-CFG, batch 1, bf16 (the fp8-weight variant of BASELINE config 5 is not built): 3 steps "
                            "timed, images/s extrapolated to 50 steps + one measured VAE decode")
     del lat
+    # BASELINE config 5 proper: the same request with the block GEMMs in fp8 (e4m3 weights per output channel, activations
+    # quantised per token in front of each GEMM, scaled MFMA at twice the bf16 rate; attention, norms, residuals stay bf16)
+    pipe.transformer.enable_fp8()
+    try:
+        t3f = timed(lambda: pipe.generate(big, output_type="latent"))
+        out["res2048_fp8_ms_per_denoise_step"] = t3f / 3 * 1e3
+        out["res2048_fp8_50step_images_per_sec_extrapolated"] = 1.0 / (50 * t3f / 3 + tv)
+        # roofline of the mixed-precision step: GEMM flops against the fp8 peak (5 PF), attention flops against the bf16 peak
+        gemm_flop = 2 * (423.01e12 - 4.0 * 24 * (16384 + T_TXT) ** 2 * 128 * layers)
+        attn_flop = 2 * 4.0 * 24 * (16384 + T_TXT) ** 2 * 128 * layers
+        out["res2048_fp8_roofline_frac"] = (gemm_flop / 5.0e15 + attn_flop / 2.5e15) / (t3f / 3)
+        head = reqs(R, HEIGHT, STEPS_DENOISE, cfg=True)
+        t = timed(lambda: [pipe.decode_latents(o.output, HEIGHT, WIDTH) for o in pipe.generate(head, output_type="latent")])
+        out["fp8_1024px_images_per_sec"] = R / t
+        out["res2048_fp8_note"] = ("as res2048_bf16_* with transformer.enable_fp8(): OCP e4m3 operands for the eight block GEMMs per "
+                                   "layer (v_mfma_scale_f32_16x16x128_f8f6f4), bf16 attention / norms / residual streams; the "
+                                   "reference has no fp8 path — accuracy vs the bf16 path is in tests/test_gpu_fp8.py; "
+                                   "roofline_frac = (GEMM flop / 5 PF + attention flop / 2.5 PF) / measured step time; "
+                                   "fp8_1024px_images_per_sec = the headline workload (R requests, 20 steps, + VAE) in this mode")
+    finally:
+        pipe.transformer.enable_fp8(False)
     # TeaCache (device-side decisions, no host sync) on the headline workload
     try:
         from vllm_omni_amd.diffusion.cache.teacache.config import TeaCacheConfig

@@ -106,6 +106,11 @@ typedef struct {
   const int32_t* tile_skip; /* nullable DEVICE array, one int32 per 256-row tile of this group: non-zero = the workgroups of
                              * that row tile return at once (its rows belong to items whose block stack is skipped this
                              * forward, omni_teacache).  A device-side predicate: no host round trip.  ABI v3. */
+  /* ABI v7 — omni_gemm_params.fp8 only: fp32 dequantisation scales, a_scale[r] of A's STORED row r (the row a_row_map picks,
+   * or the logical row) and w_scale[n] of output channel n:  Y = epilogue((A8 . W8^T) * a_scale[r] * w_scale[n] + bias[n]).
+   * Both come from omni_quantize_fp8_rows. */
+  const float* a_scale;
+  const float* w_scale;
 } omni_gemm_group;
 
 typedef struct {
@@ -132,12 +137,29 @@ typedef struct {
    * >= 16 select development families and are honoured only by libraries built with -DOMNI_DEV; the product library ignores
    * them.  The library itself has no switches: no environment variable and no process-global setter changes what a call does. */
   int32_t kernel_hint;
-  int32_t reserved0;
+  /* ABI v7 — fp8 = 1: A and W hold OCP fp8 e4m3 values (one byte each) instead of bf16, in the K64-blocked order
+   * [K/64][rows][64] (what omni_quantize_fp8_rows writes; a_k32_rows / w_k32_blocked then carry the row counts R / 1 as for
+   * bf16 — byte for byte it is the K32-blocked layout of a bf16 matrix with K/2 columns), with per-row / per-output-channel
+   * fp32 scales in omni_gemm_group.a_scale / w_scale.  K counts fp8 elements and must be a multiple of 128.  The products run
+   * on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 MFMA rate; block scales fixed at 1, the fp32 scales are applied
+   * to the fp32 accumulators in the epilogue).  No split-K.  Outputs, bias and every epilogue stay bf16 as without it. */
+  int32_t fp8;
 } omni_gemm_params;
 #define OMNI_GEMM_KERNEL_AUTO 0
 #define OMNI_GEMM_KERNEL_RING 1
 
 int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream);
+
+/* ABI v7 — dynamic per-row fp8 (OCP e4m3) quantisation of a bf16 matrix for omni_gemm_params.fp8:
+ *   scale[r] = max(amax_k |x[r, k]|, tiny) / 448;   y8[r, k] = e4m3_rn(x[r, k] / scale[r])
+ * x: [rows, K] bf16, row-major with stride ldx, or K32-blocked [K/32][x_k32_rows][32] when x_k32_rows > 0 (ldx ignored).
+ * y8: K64-blocked bytes [K/64][y_rows][64] (y_rows >= rows: the row count of the buffer, = omni_gemm_group.a_k32_rows of
+ * the consuming GEMM); scale: fp32 [rows].  K % 64 == 0, K <= 16384.  One wave per row, the row held in registers: x is
+ * read once (2 B/element) and y8 written once (1 B/element): HBM-bound.  Used for activations (per token) and, once at
+ * load time, for weights (per output channel).  (vLLM's dynamic per-token fp8 recipe; the reference has no fp8 path —
+ * BASELINE.json config 5 asks for one.) */
+int omni_quantize_fp8_rows(const omni_bf16* x, int64_t ldx, int32_t x_k32_rows, int32_t rows, int32_t K, uint8_t* y8,
+                           int32_t y_rows, float* scale, omni_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * AdaLN-modulate:  y = LayerNorm(x; eps, no affine) * (1 + scale[item]) + shift[item]
@@ -276,6 +298,16 @@ typedef struct {
   const omni_bf16 *txt_mlp_w1, *txt_mlp_b1, *txt_mlp_w2, *txt_mlp_b2;
 } omni_dit_layer_weights;
 
+/* ABI v7 — optional fp8 copies of a layer's eight GEMM weights (BASELINE.json config 5): OCP e4m3 bytes in the K64-blocked
+ * order + one fp32 scale per output channel, both written by omni_quantize_fp8_rows(weight [out, in]).  With
+ * omni_dit_weights.fp8_layers set, every block GEMM runs as omni_gemm_params.fp8: its bf16 input (AdaLN output, attention
+ * output, GELU output) is quantised per token by omni_quantize_fp8_rows right in front of it; biases, epilogues, the residual
+ * streams, q/k/v, the attention and everything outside the block GEMMs stay bf16. */
+typedef struct {
+  const uint8_t *to_qkv_w8, *add_qkv_w8, *to_out_w8, *to_add_out_w8, *img_mlp_w1_8, *img_mlp_w2_8, *txt_mlp_w1_8, *txt_mlp_w2_8;
+  const float *to_qkv_s, *add_qkv_s, *to_out_s, *to_add_out_s, *img_mlp_w1_s, *img_mlp_w2_s, *txt_mlp_w1_s, *txt_mlp_w2_s;
+} omni_dit_fp8_layer;
+
 typedef struct {
   int32_t num_layers, num_heads, head_dim, joint_dim, in_channels, out_channels_packed; /* 60,24,128,3584,64,64 */
   int32_t gemm_w_k32_blocked; /* 1: the eight [out,in] matrices of every layer (to_qkv, add_qkv, to_out, to_add_out,
@@ -285,6 +317,7 @@ typedef struct {
   const omni_bf16 *txt_norm_w, *img_in_w, *img_in_b, *txt_in_w, *txt_in_b;
   const omni_bf16 *norm_out_w, *norm_out_b, *proj_out_w, *proj_out_b;
   const omni_dit_layer_weights* layers; /* HOST array [num_layers] of device pointers */
+  const omni_dit_fp8_layer* fp8_layers; /* ABI v7: nullable HOST array [num_layers]; NULL = bf16 GEMMs */
 } omni_dit_weights;
 
 /* ------------------------------------------------------------------------------------------------

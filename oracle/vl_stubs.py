@@ -83,10 +83,13 @@ class StubVLProcessor:
 def make_random_vl_model(seed: int = 5, hidden: int = 64, dtype=torch.float32):
     from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
 
+    half = hidden // 4 // 2                                     # rotary pairs per head (4 heads): the three M-RoPE sections sum to it
+    sec = [half // 4, (half - half // 4) // 2]
+    sec.append(half - sum(sec))
     cfg = Qwen2_5_VLConfig(
         text_config=dict(vocab_size=VOCAB, hidden_size=hidden, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
                          intermediate_size=128, max_position_embeddings=4096, bos_token_id=1, eos_token_id=2, pad_token_id=0,
-                         rope_scaling={"type": "default", "mrope_section": [2, 3, 3], "rope_type": "default"}),
+                         rope_scaling={"type": "default", "mrope_section": sec, "rope_type": "default"}),
         vision_config=dict(depth=2, hidden_size=32, out_hidden_size=hidden, num_heads=2, intermediate_size=64, patch_size=14,
                            spatial_merge_size=2, temporal_patch_size=2, window_size=56, fullatt_block_indexes=[1], in_channels=3),
         image_token_id=IMAGE_TOKEN, video_token_id=499, vision_start_token_id=VISION_START, vision_end_token_id=VISION_END)

@@ -525,3 +525,103 @@ def test_gemm_split_k_matches_the_unsplit_kernel(K, N):
     ref = a[map_i.long().cpu()] @ wi.t() + b
     assert rel_l2(run(ops.EPI_BIAS, True)[0], ref) <= 4e-3
     assert not bool(torch.isnan(ws[: 2 * (Mi + Mt) * N]).any())   # at least two splits were written: the split path did run
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp8 (BASELINE.json config 5): dynamic per-row e4m3 quantisation + the scaled-MFMA GEMM (ABI v7)
+def _e4m3_ref(x: torch.Tensor):
+    """Reference of omni_quantize_fp8_rows in torch: per-row scale = amax / 448, round-to-nearest-even e4m3fn."""
+    amax = x.float().abs().amax(dim=1).clamp_min(1e-12)
+    sc = amax * (1.0 / 448.0)
+    q = (x.float() * (1.0 / sc)[:, None]).to(torch.float8_e4m3fn)
+    return q, sc
+
+
+@pytest.mark.parametrize("blocked_in", [False, True])
+@pytest.mark.parametrize("rows,K", [(700, 3072), (130, 12288), (5, 64)])
+def test_quantize_fp8_rows_matches_torch_e4m3(rows, K, blocked_in):
+    from vllm_omni_amd import ops
+
+    x = rnd((rows, K), 41, 3.0)
+    x[3 % rows, 17 % K] = 250.0                                           # an outlier sets its row's scale
+    xin = ops.w_to_k32_blocked(g_(x)) if blocked_in else g_(x)
+    y8, sc = ops.quantize_fp8_rows(xin, x_k32_blocked=blocked_in)
+    torch.cuda.synchronize()
+    q_ref, sc_ref = _e4m3_ref(bf16_round(x))
+    assert torch.allclose(sc.cpu(), sc_ref, rtol=1e-6, atol=0)
+    got = ops.k64_blocked_fp8_to_rows(y8).cpu()
+    same = (got.view(torch.uint8) == q_ref.view(torch.uint8)).float().mean()
+    assert same >= 0.999, same                                            # (1/scale as a multiply: rare 1-ulp ties)
+    assert rel_l2(got.float() * sc.cpu()[:, None], bf16_round(x)) <= 4e-2  # e4m3: 3 mantissa bits
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res", "split3_qknorm_rope"])
+def test_gemm_fp8_scaled_mfma_equals_the_dequantised_product(epi):
+    """omni_gemm_params.fp8: e4m3 operands through v_mfma_scale_f32_16x16x128_f8f6f4.  The checker multiplies the DEQUANTISED
+    operands in fp32 (products of fp8 values are exact in fp32, so the kernel must agree to fp32 summation order + the one bf16
+    rounding of the output), which pins the operand layout, the scales and every epilogue; the distance to the UNQUANTISED
+    product (what fp8 costs) is printed and bounded separately."""
+    from vllm_omni_amd import ops
+
+    Mi, Mt, N, K = 700, 130, 768, 1024
+    a_i, a_t = rnd((Mi, K), 51), rnd((Mt, K), 52)
+    wi, wt, b = rnd((N, K), 53, 0.05), rnd((N, K), 54, 0.05), rnd((N,), 55, 0.5)
+    Ai8, sai = ops.quantize_fp8_rows(g_(a_i))
+    At8, sat = ops.quantize_fp8_rows(g_(a_t))
+    Wi8, swi = ops.quantize_fp8_rows(g_(wi))
+    Wt8, swt = ops.quantize_fp8_rows(g_(wt))
+    deq = lambda y8, sc: ops.k64_blocked_fp8_to_rows(y8).float().cpu() * sc.cpu()[:, None]       # noqa: E731
+    ref_i = deq(Ai8, sai) @ deq(Wi8, swi).t() + b
+    ref_t = deq(At8, sat) @ deq(Wt8, swt).t() + b
+    full_i = a_i @ wi.t() + b
+    kw_i, kw_t, e = {}, {}, ops.EPI_BIAS
+    oi = torch.zeros(Mi, N, dtype=BF16, device=dev())
+    ot = torch.zeros(Mt, N, dtype=BF16, device=dev())
+    if epi == "gelu":
+        e = ops.EPI_BIAS_GELU_TANH
+        gelu = lambda t: torch.nn.functional.gelu(t, approximate="tanh")                          # noqa: E731
+        ref_i, ref_t, full_i = gelu(ref_i), gelu(ref_t), gelu(full_i)
+    elif epi == "gate_res":
+        e = ops.EPI_BIAS_GATE_RES
+        res_i, res_t, gate = rnd((Mi, N), 56), rnd((Mt, N), 57), rnd((3, N), 58)
+        oi, ot = g_(res_i), g_(res_t)
+        item_i, item_t = torch.arange(Mi) % 3, torch.arange(Mt) % 3
+        kw_i = dict(res=oi, gate=g_(gate), gate_item_stride=N, row_item_map=item_i.to(torch.int32).to(dev()))
+        kw_t = dict(res=ot, gate=g_(gate), gate_item_stride=N, row_item_map=item_t.to(torch.int32).to(dev()))
+        ref_i = res_i + gate[item_i] * bf16_round(ref_i)
+        ref_t = res_t + gate[item_t] * bf16_round(ref_t)
+        full_i = res_i + gate[item_i] * full_i
+    if epi == "split3_qknorm_rope":
+        # the fused QKV epilogue needs its tables: compare the fp8 launch with the bf16 launch of the SAME epilogue on the
+        # dequantised operands instead (bit-for-bit the same epilogue code behind different main loops)
+        from vllm_omni_amd.diffusion.models.qwen_image.rope import rope_table
+
+        D = 256
+        N = 3 * D
+        wq, bq = rnd((N, K), 59, 0.05), rnd((N,), 60, 0.5)
+        Wq8, swq = ops.quantize_fp8_rows(g_(wq))
+        cos, sin = rope_table((1, 26, 32), 0)
+        nw = [(1 + rnd((128,), 61 + i, 0.1)).to(BF16).to(dev()) for i in range(2)]
+        pos = (torch.arange(Mi) % cos.shape[0]).to(torch.int32).to(dev())
+        outs = []
+        for fp8 in (True, False):
+            q, k, v = (torch.zeros(Mi, D, dtype=BF16, device=dev()) for _ in range(3))
+            A = Ai8 if fp8 else ops.w_to_k32_blocked(deq(Ai8, sai).to(BF16).to(dev()))
+            W = Wq8 if fp8 else ops.w_to_k32_blocked(deq(Wq8, swq).to(BF16).to(dev()))
+            ops.gemm([ops.GemmGroupArgs(A, W, g_(bq), q, out1=k, out2=v, a_k32_blocked=True, qk_norm_q_w=nw[0], qk_norm_k_w=nw[1],
+                                        qk_rope_cos=cos.to(dev(), BF16), qk_rope_sin=sin.to(dev(), BF16), qk_row_pos=pos,
+                                        a_scale=sai if fp8 else None, w_scale=swq if fp8 else None)],
+                     ops.EPI_BIAS_SPLIT3_QKNORM_ROPE, split_n=D, w_k32_blocked=True, fp8=fp8)
+            torch.cuda.synchronize()
+            outs.append((q, k, v))
+        for x8, x16 in zip(*outs):
+            assert rel_l2(x8, x16.float().cpu()) <= 6e-3          # bf16-rounded dequantised operands on the other side
+        return
+    ops.gemm([ops.GemmGroupArgs(Ai8, Wi8, g_(b), oi, a_k32_blocked=True, a_scale=sai, w_scale=swi, **kw_i),
+              ops.GemmGroupArgs(At8, Wt8, g_(b), ot, a_k32_blocked=True, a_scale=sat, w_scale=swt, **kw_t)], e,
+             w_k32_blocked=True, fp8=True)
+    torch.cuda.synchronize()
+    r_i, r_t, r_full = rel_l2(oi, ref_i), rel_l2(ot, ref_t), rel_l2(oi, full_i)
+    print(f"fp8 gemm [{epi}]: vs dequantised fp32 product {r_i:.2e} / {r_t:.2e}; vs the unquantised product {r_full:.2e}")
+    assert r_i <= 4e-3 and r_t <= 4e-3
+    assert r_full <= 6e-2                                         # two e4m3 operands: ~2^-4 relative per element, averaged over K

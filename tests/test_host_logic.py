@@ -49,8 +49,8 @@ def test_ctypes_struct_layout_matches_c():
     # sizes the C compiler produces for the ABI structs (computed with the same alignment rules)
     from vllm_omni_amd import _native as N
 
-    assert ctypes.sizeof(N.GemmGroup) == 200 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 200 + 16 + 8  # ABI v3: + tile_skip; v4: + split-K workspace; v6: + kernel_hint
-    assert N.GemmParams.splitk_ws.offset == 24 + 2 * 200 and N.GemmParams.kernel_hint.offset == 24 + 2 * 200 + 16
+    assert ctypes.sizeof(N.GemmGroup) == 216 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 216 + 16 + 8  # ABI v3: + tile_skip; v4: + split-K workspace; v6: + kernel_hint
+    assert N.GemmParams.splitk_ws.offset == 24 + 2 * 216 and N.GemmParams.kernel_hint.offset == 24 + 2 * 216 + 16
     assert ctypes.sizeof(N.TeaCache) == 24 + 10 * 8 and N.DitBatch.teacache.offset == ctypes.sizeof(N.DitBatch) - 8
     assert ctypes.sizeof(N.DitLayerWeights) == 24 * 8
     assert N.GemmParams.g.offset == 24 and N.DitWeights.t_lin1_w.offset == 32   # w_k32_blocked flags live in padding / ABI v2

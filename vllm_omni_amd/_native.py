@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OMNI_CDNA4_LIB", os.path.join(_HERE, "libomni_cdna4.so"))   # env override: dev sweeps
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_bf16_p = C.c_void_p  # device pointer to uint16_t bf16 bits
 c_i32_p = C.c_void_p
@@ -36,6 +36,7 @@ class GemmGroup(C.Structure):
         ("qk_row_pos", c_i32_p), ("qk_eps", C.c_float),
         ("a_k32_rows", C.c_int32), ("out_k32_rows", C.c_int32), ("qk_q_scale", C.c_float),      # qk_q_scale: ABI v5
         ("tile_skip", c_i32_p),
+        ("a_scale", C.c_void_p), ("w_scale", C.c_void_p),                                        # ABI v7 (fp8)
     ]
 
 
@@ -44,7 +45,7 @@ class GemmParams(C.Structure):
         ("ngroups", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("epilogue", C.c_int32),
         ("split_n", C.c_int32), ("w_k32_blocked", C.c_int32), ("g", GemmGroup * 2),
         ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_int64),          # ABI v4
-        ("kernel_hint", C.c_int32), ("reserved0", C.c_int32),                # ABI v6: 0 auto, 1 = ring (fallback) kernel
+        ("kernel_hint", C.c_int32), ("fp8", C.c_int32),                      # ABI v6: kernel_hint; v7: fp8 operands
     ]
 
 
@@ -71,6 +72,14 @@ class DitLayerWeights(C.Structure):
     _fields_ = [(n, c_bf16_p) for n in _LAYER_FIELDS]
 
 
+_FP8_FIELDS = ["to_qkv", "add_qkv", "to_out", "to_add_out", "img_mlp_w1", "img_mlp_w2", "txt_mlp_w1", "txt_mlp_w2"]
+
+
+class DitFp8Layer(C.Structure):
+    """omni_dit_fp8_layer: e4m3 copies (K64-blocked) of a layer's eight GEMM weights, then their per-channel fp32 scales."""
+    _fields_ = [(f + ("_w8" if "mlp" not in f else "_8"), C.c_void_p) for f in _FP8_FIELDS] + [(f + "_s", C.c_void_p) for f in _FP8_FIELDS]
+
+
 class DitWeights(C.Structure):
     _fields_ = [
         ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("head_dim", C.c_int32), ("joint_dim", C.c_int32),
@@ -80,6 +89,7 @@ class DitWeights(C.Structure):
         ("txt_in_b", c_bf16_p),
         ("norm_out_w", c_bf16_p), ("norm_out_b", c_bf16_p), ("proj_out_w", c_bf16_p), ("proj_out_b", c_bf16_p),
         ("layers", C.POINTER(DitLayerWeights)),
+        ("fp8_layers", C.POINTER(DitFp8Layer)),                                                    # ABI v7, nullable
     ]
 
 
@@ -114,6 +124,8 @@ PROTOTYPES = {
     "omni_build_arch": (C.c_char_p, []),
     "omni_status_string": (C.c_char_p, [C.c_int]),
     "omni_gemm_bf16": (C.c_int, [C.POINTER(GemmParams), C.c_void_p]),
+    "omni_quantize_fp8_rows": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_void_p]),
     "omni_adaln_modulate": (C.c_int, [c_bf16_p, C.c_int64, c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p,
                                       c_bf16_p, C.c_int64, c_i32_p, C.c_int32, C.c_float, C.c_void_p]),
     "omni_adaln_modulate_ex": (C.c_int, [c_bf16_p, C.c_int64, c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p,

@@ -20,6 +20,8 @@ struct Workspace {
   int32_t *img_pos, *txt_pos;   // RoPE table row of every image / text stream row (joint_pos gathered through the joint-row maps)
   float* splitk;                // fp32 partial tiles of the split-K GEMMs (small batches only; include/omni_cdna4.h splitk_ws)
   int64_t splitk_floats;
+  uint8_t* x8;                  // fp8 mode: the e4m3 copy of the NEXT block GEMM's input ([K/64][rows][64]; image rows, then text rows)
+  float* x8_scale;              // fp8 mode: its per-row scales [n_joint_rows]
   size_t total;
 };
 
@@ -59,6 +61,11 @@ Workspace carve(void* base, const omni_dit_weights* w, int64_t Ri, int64_t Rt, i
   // row tiles (a CFG pair at 512x512: 53 MB); larger batches fill the chip without it
   ws.splitk_floats = Rj <= 4 * 256 ? 8 * Rj * D : (Rj <= 10 * 256 ? 2 * Rj * D : 0);
   ws.splitk = reinterpret_cast<float*>(take(ws.splitk_floats * 2));
+  ws.x8 = nullptr; ws.x8_scale = nullptr;
+  if (w->fp8_layers) {
+    ws.x8 = reinterpret_cast<uint8_t*>(take(Rj * 2 * D));             // Rj x 4D bytes (the MLP-down input is the widest)
+    ws.x8_scale = reinterpret_cast<float*>(take(Rj * 2));
+  }
   ws.total = off;
   return ws;
 }
@@ -126,6 +133,23 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   const bool q_prescale = fuse_qkrope && phase == BLOCK_ALL;
   const bool blk = dit_act_blocked() && (D % 32 == 0);
   const int32_t bRi = blk ? Ri : 0, bRt = blk ? Rt : 0, bRj = blk ? Ri + Rt : 0;
+  // fp8 mode (omni_dit_weights.fp8_layers): every block GEMM reads e4m3 operands; its bf16 input is quantised per token first
+  const omni_dit_fp8_layer* F = w->fp8_layers ? &w->fp8_layers[l] : nullptr;
+  if (F && (D % 128 != 0 || !ws.x8)) return OMNI_ERR_UNSUPPORTED;
+  // image rows -> x8[0 .. Ri), text rows -> x8[Ri ..): two [rows, K] operands in the K64-blocked order, scales alongside
+  auto quant_streams = [&](const omni_bf16* xi, int32_t xi_k32, const omni_bf16* xt, int32_t xt_k32, int32_t K) -> int {
+    OMNI_TRY(omni_quantize_fp8_rows(xi, K, xi_k32, Ri, K, ws.x8, Ri, ws.x8_scale, stream));
+    OMNI_TRY(omni_quantize_fp8_rows(xt, K, xt_k32, Rt, K, ws.x8 + (int64_t)Ri * K, Rt, ws.x8_scale + Ri, stream));
+    return OMNI_OK;
+  };
+  auto fp8_streams = [&](omni_gemm_params& p, int32_t K, const uint8_t* wi8, const float* wis, const uint8_t* wt8,
+                         const float* wts) {
+    p.fp8 = 1; p.w_k32_blocked = 1; p.splitk_ws = nullptr; p.splitk_ws_floats = 0;
+    p.g[0].A = reinterpret_cast<const omni_bf16*>(ws.x8); p.g[0].a_k32_rows = Ri; p.g[0].a_scale = ws.x8_scale;
+    p.g[1].A = reinterpret_cast<const omni_bf16*>(ws.x8 + (int64_t)Ri * K); p.g[1].a_k32_rows = Rt; p.g[1].a_scale = ws.x8_scale + Ri;
+    p.g[0].W = reinterpret_cast<const omni_bf16*>(wi8); p.g[0].w_scale = wis;
+    p.g[1].W = reinterpret_cast<const omni_bf16*>(wt8); p.g[1].w_scale = wts;
+  };
   // modulation vectors [shift1|scale1|gate1|shift2|scale2|gate2]  (reference :552-561)
   OMNI_TRY(linear_rows(temb, D, nT, L.img_mod_w, L.img_mod_b, 6 * (int64_t)D, D, ws.mod_img, 6 * D, 1,
                                   0, stream));
@@ -160,6 +184,10 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].out = ws.q; p.g[1].out1 = ws.k; p.g[1].out2 = ws.v; p.g[1].ldo = D; p.g[1].out_row_map = b->txt_joint_row;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
     p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
+    if (F) {
+      OMNI_TRY(quant_streams(xn_img, bRi, xn_txt, bRt, D));
+      fp8_streams(p, D, F->to_qkv_w8, F->to_qkv_s, F->add_qkv_w8, F->add_qkv_s);
+    }
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
   // per-head RMSNorm + RoPE on q and k (reference :397-410)
@@ -191,6 +219,16 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].row_item_map = b->txt_item;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
     p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
+    if (F) {                                  // the attention output in its joint order: ONE operand, both groups gather from it
+      const int32_t Rj = Ri + Rt;
+      OMNI_TRY(omni_quantize_fp8_rows(attn_src, D, attn_k32, Rj, D, ws.x8, Rj, ws.x8_scale, stream));
+      p.fp8 = 1; p.w_k32_blocked = 1; p.splitk_ws = nullptr; p.splitk_ws_floats = 0;
+      for (int g = 0; g < 2; ++g) {
+        p.g[g].A = reinterpret_cast<const omni_bf16*>(ws.x8); p.g[g].a_k32_rows = Rj; p.g[g].a_scale = ws.x8_scale;
+      }
+      p.g[0].W = reinterpret_cast<const omni_bf16*>(F->to_out_w8); p.g[0].w_scale = F->to_out_s;
+      p.g[1].W = reinterpret_cast<const omni_bf16*>(F->to_add_out_w8); p.g[1].w_scale = F->to_add_out_s;
+    }
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
   // norm2 + modulate (reference :590, :595)
@@ -208,6 +246,10 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w1; p.g[1].bias = L.txt_mlp_b1;
     p.g[1].out = h_txt; p.g[1].ldo = 4 * D;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
+    if (F) {
+      OMNI_TRY(quant_streams(xn_img, bRi, xn_txt, bRt, D));
+      fp8_streams(p, D, F->img_mlp_w1_8, F->img_mlp_w1_s, F->txt_mlp_w1_8, F->txt_mlp_w1_s);
+    }
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
   // MLP down + gated residual (reference :592, :597)
@@ -223,6 +265,10 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].gate = ws.mod_txt + 5 * D; p.g[1].gate_item_stride = 6 * D; p.g[1].row_item_map = b->txt_item;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
     p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
+    if (F) {
+      OMNI_TRY(quant_streams(h_img, bRi, h_txt, bRt, 4 * D));
+      fp8_streams(p, 4 * D, F->img_mlp_w2_8, F->img_mlp_w2_s, F->txt_mlp_w2_8, F->txt_mlp_w2_s);
+    }
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
   return OMNI_OK;
@@ -239,7 +285,7 @@ int prepare_positions(const omni_dit_batch* b, const Workspace& ws, omni_stream 
 }
 }  // namespace
 
-extern "C" int omni_abi_version(void) { return 6; }
+extern "C" int omni_abi_version(void) { return 7; }
 extern "C" const char* omni_build_arch(void) { return "gfx950"; }
 extern "C" const char* omni_status_string(int status) {
   switch (status) {

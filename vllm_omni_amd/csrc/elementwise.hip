@@ -432,6 +432,54 @@ __global__ __launch_bounds__(256) void teacache_post_kernel(uint16_t* __restrict
     }
   }
 }
+
+// ---- dynamic per-row fp8 (OCP e4m3) quantisation (omni_quantize_fp8_rows) ------------------------------------------------
+// One wave per row.  A lane owns the 16-byte chunks c = lane, lane + 64, ... of the row (8 bf16 each), so a K32-blocked source
+// (64-B slabs) and a row-major one are both read as whole 16-B pieces; the row stays in registers between the amax pass and
+// the conversion.  Output chunk c (8 bytes) goes to slab c >> 3 of the K64-blocked destination.
+OMNI_DEVINL uint32_t cvt_pk_fp8x4(float a, float b, float c, float d) {
+  uint32_t r = 0;
+  asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2\n\tv_cvt_pk_fp8_f32 %0, %3, %4 op_sel:[0,0,1]" : "+v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+  return r;
+}
+
+template <int NCH>   // NCH = chunks per lane (K = NCH * 64 * 8 at most)
+__global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const uint16_t* __restrict__ x, int64_t ldx, int x_k32_rows,
+                                                                int rows, int K, uint8_t* __restrict__ y8, int y_rows,
+                                                                float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunks = K >> 3;
+  u32x4_t v[NCH];
+  float amax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    v[i] = u32x4_t{0u, 0u, 0u, 0u};
+    if (c < nchunks) {
+      const uint16_t* src = x_k32_rows ? x + ((int64_t)(c >> 2) * x_k32_rows + row) * 32 + (c & 3) * 8
+                                       : x + (int64_t)row * ldx + c * 8;
+      v[i] = *reinterpret_cast<const u32x4_t*>(src);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(bf16_lo(v[i][e])), fabsf(bf16_hi(v[i][e]))));
+    }
+  }
+  amax = wave_max<64>(amax);
+  const float sc = fmaxf(amax, 1e-12f) * (1.0f / 448.0f);       // e4m3fn: largest finite 448
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunks) {
+      u32x2_t o;
+      o[0] = cvt_pk_fp8x4(bf16_lo(v[i][0]) * inv, bf16_hi(v[i][0]) * inv, bf16_lo(v[i][1]) * inv, bf16_hi(v[i][1]) * inv);
+      o[1] = cvt_pk_fp8x4(bf16_lo(v[i][2]) * inv, bf16_hi(v[i][2]) * inv, bf16_lo(v[i][3]) * inv, bf16_hi(v[i][3]) * inv);
+      *reinterpret_cast<u32x2_t*>(y8 + ((int64_t)(c >> 3) * y_rows + row) * 64 + (c & 7) * 8) = o;
+    }
+  }
+}
 }  // namespace
 
 int omni_internal_teacache_decide(const omni_teacache* tc, const omni_bf16* mod, int32_t n_items, int32_t rows_per_item,
@@ -461,6 +509,28 @@ int omni_internal_teacache_post(const omni_teacache* tc, omni_bf16* hidden, cons
   const int64_t nchunk = (int64_t)n_img_rows * D / 8;
   hipLaunchKernelGGL(teacache_post_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, hidden_in,
                      tc->prev_res, tc->skip, nchunk, rows_per_item * (D / 8));
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+extern "C" int omni_quantize_fp8_rows(const omni_bf16* x, int64_t ldx, int32_t x_k32_rows, int32_t rows, int32_t K,
+                                      uint8_t* y8, int32_t y_rows, float* scale, omni_stream stream) {
+  if (!x || !y8 || !scale || rows <= 0 || K <= 0 || y_rows < rows || x_k32_rows < 0 || (x_k32_rows && x_k32_rows < rows))
+    return OMNI_ERR_BAD_ARG;
+  if (K % 64 || K > 16384) return OMNI_ERR_UNSUPPORTED;
+  if (!omni_aligned16(x) || (reinterpret_cast<uintptr_t>(y8) & 7) || (!x_k32_rows && (ldx % 8))) return OMNI_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((rows + 3) / 4), block(256);
+  const int nch = (K / 8 + 63) / 64;
+#define OMNI_Q8(N)                                                                                                    \
+  hipLaunchKernelGGL(quantize_fp8_rows_kernel<N>, grid, block, 0, s, x, ldx, x_k32_rows, rows, K, y8, y_rows, scale)
+  if (nch <= 1) OMNI_Q8(1);
+  else if (nch <= 2) OMNI_Q8(2);
+  else if (nch <= 6) OMNI_Q8(6);
+  else if (nch <= 8) OMNI_Q8(8);
+  else if (nch <= 24) OMNI_Q8(24);
+  else OMNI_Q8(32);
+#undef OMNI_Q8
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }

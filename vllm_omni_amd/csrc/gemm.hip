@@ -160,7 +160,7 @@ OMNI_DEVINL omni_gemm_group pick_group(const omni_gemm_params& P, int gi) {
   OMNI_PICK(gate); OMNI_PICK(gate_item_stride); OMNI_PICK(row_item_map); OMNI_PICK(rows_per_item);
   OMNI_PICK(a_k32_rows); OMNI_PICK(out_k32_rows);
   OMNI_PICK(qk_norm_q_w); OMNI_PICK(qk_norm_k_w); OMNI_PICK(qk_rope_cos); OMNI_PICK(qk_rope_sin); OMNI_PICK(qk_row_pos);
-  OMNI_PICK(qk_eps); OMNI_PICK(qk_q_scale); OMNI_PICK(tile_skip);
+  OMNI_PICK(qk_eps); OMNI_PICK(qk_q_scale); OMNI_PICK(tile_skip); OMNI_PICK(a_scale); OMNI_PICK(w_scale);
 #undef OMNI_PICK
   return G;
 }
@@ -469,6 +469,49 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           v[j] = acc[nb][mb][j];
+          if (EPI == OMNI_EPI_BIAS_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
+        }
+        u32x2_t o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2_t*>(rowp + nb * 32) = o;
+      }
+    }
+  });
+}
+
+// fp8: C = acc * a_scale[stored row] * w_scale[col] + bias[col]  (fp32), then as the bf16 kernel (GELU, bf16 rounding, LDS tile)
+template <int EPI>
+OMNI_DEVINL void gemm_epilogue_lds_fp8(const omni_gemm_params& P, const omni_gemm_group& G, f32x4_t (&acc)[4][8], int m0,
+                                       int n0, int wm, int wn, int l15, int g, char* smem, int tid) {
+  gemm_epilogue_lds_impl<EPI>(P, G, m0, n0, smem, tid, [&]() {
+    const int ncol = wn * 64 + g * 4;
+    float sw[4][4], bi[4][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int n = n0 + ncol + nb * 16;
+      f32x4_t w4 = {0.f, 0.f, 0.f, 0.f};
+      u32x2_t b = {0u, 0u};
+      if (n < P.N) {
+        w4 = *reinterpret_cast<const f32x4_t*>(G.w_scale + n);
+        if (G.bias) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
+      }
+      sw[nb][0] = w4[0]; sw[nb][1] = w4[1]; sw[nb][2] = w4[2]; sw[nb][3] = w4[3];
+      bi[nb][0] = bf16_lo(b[0]); bi[nb][1] = bf16_hi(b[0]); bi[nb][2] = bf16_lo(b[1]); bi[nb][3] = bf16_hi(b[1]);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const int rl = wm * 128 + mb * 16 + l15;
+      int ar = min(m0 + rl, G.M - 1);
+      if (G.a_row_map) ar = G.a_row_map[ar];
+      const float sa = G.a_scale[ar];
+      char* rowp = smem + rl * EPI_LDS_STRIDE + ncol * 2;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[nb][mb][j] * sa * sw[nb][j] + bi[nb][j];
           if (EPI == OMNI_EPI_BIAS_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
         }
         u32x2_t o;
@@ -894,6 +937,30 @@ OMNI_DEVINL void pp_mfma16(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 #endif
 }
+// fp8 (omni_gemm_params.fp8): ONE v_mfma_scale_f32_16x16x128_f8f6f4 replaces the two 16x16x32 bf16 MFMAs of a (block, block) pair.
+// Its A / B operand is 8 VGPRs = 32 fp8 of one row: bytes 0-15 = k 16g .. 16g+15, bytes 16-31 = k 64+16g .. 64+16g+15 (g = lane >> 4;
+// measured with .gpu_scratch-style probes, profiles/r03_mx_mfma_operand_probe.log) — exactly the two 16-B chunks (g, 4 + g) of a
+// 128-B LDS row that the bf16 kernel's ks = 0 / 1 fragment reads already fetch.  So the fp8 kernel IS the bf16 kernel on a matrix
+// with half the columns (byte-identical DMA, LDS image, swizzle and fragment reads), with this instruction in the cluster.
+// Block scales (E8M0, one byte per lane and 32-k block) are the constant 1.0 (0x7f): the per-row / per-channel fp32 scales are
+// applied to the accumulators in the epilogue.
+typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
+OMNI_DEVINL void pp_mfma_fp8(f32x4_t& acc, const bf16x8_t& a_lo, const bf16x8_t& a_hi, const bf16x8_t& b_lo, const bf16x8_t& b_hi,
+                             uint32_t one) {
+  const u32x4_t al = __builtin_bit_cast(u32x4_t, a_lo), ah = __builtin_bit_cast(u32x4_t, a_hi);
+  const u32x4_t bl = __builtin_bit_cast(u32x4_t, b_lo), bh = __builtin_bit_cast(u32x4_t, b_hi);
+  const u32x8_t a = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+  const u32x8_t b = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+#if defined(OMNI_FP8_PROBE) && OMNI_FP8_PROBE == 1     // bisect: the bf16 instruction on the same registers (wrong results)
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(al), "v"(bl));
+#elif defined(OMNI_FP8_PROBE) && OMNI_FP8_PROBE == 2   // bisect: the builtin instead of the asm statement
+  typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+  acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_bit_cast(i32x8_t, a), __builtin_bit_cast(i32x8_t, b), acc, 0, 0, 0,
+                                                         (int)one, 0, (int)one);
+#else
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(one));
+#endif
+}
 constexpr int PBK = 64;
 constexpr int PSLOT_BYTES = 128 * PBK * 2;    // 16 KiB per half-tile
 constexpr int PLDS_BYTES = 8 * PSLOT_BYTES;   // 128 KiB ring
@@ -902,7 +969,7 @@ constexpr int PLDS_BYTES = 8 * PSLOT_BYTES;   // 128 KiB ring
 // tile b / nsplit with split = b % nsplit and stores its fp32 accumulators to P.splitk_ws[split][row][col]; the epilogue runs
 // in gemm_splitk_finish_kernel.  A DiT forward over one or two 256x256 images has 36 workgroups in its N = 3072 GEMMs, each
 // streaming its 256 x K weight panel at the pace of one CU's k-loop (~1.2 us per K-tile): the weights arrive at ~1 TB/s.
-template <int EPI, int SPLITK = 0>
+template <int EPI, int SPLITK = 0, int FP8 = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
                                                                      int tiles_n, int GROUP_M, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1003,7 +1070,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   for (int nb = 0; nb < 4; ++nb) {
     const int n = n0 + wn * 64 + nb * 16 + g4 * 4;
     u32x2_t b = {0u, 0u};
-    if (!SPLITK && G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);   // split-K: the finish adds the bias
+    if (!SPLITK && !FP8 && G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);   // split-K: the finish adds the bias; fp8: the epilogue does (after the scales)
     const f32x4_t bini = {bf16_lo(b[0]), bf16_hi(b[0]), bf16_lo(b[1]), bf16_hi(b[1])};
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = bini;
@@ -1045,6 +1112,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   // wf[nq][16-row block of the 32 W rows][ks]; afx[16-row block of the 64 A rows][ks] (mq 0 and mq 1 share the registers)
   bf16x8_t wf[2][2][2], afx[4][2];
   bf16x8_t (&afy)[4][2] = afx;
+  uint32_t mx_one = 0x7f7f7f7fu;                   // E8M0 1.0 in every byte: the MFMA's block scales (fp8 build only)
+  asm volatile("" : "+v"(mx_one));
 #define OMNI_PP_READ_A(AF, sb)                                                             \
   do {                                                                                     \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                  \
@@ -1063,6 +1132,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   } while (0)
 // the quadrant's 16 MFMAs: 8 accumulators round-robin, each touched again 8 instructions (128 pipe cycles) later
 #define OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1)                                                            \
+  if (FP8) {                                                                                               \
+    _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_) {                                                  \
+      pp_mfma_fp8(acc[2 * (nq)][4 * (mq) + mb_], wf[nq][0][0], wf[nq][0][1], AF[mb_][0], AF[mb_][1], mx_one);     \
+      pp_mfma_fp8(acc[2 * (nq) + 1][4 * (mq) + mb_], wf[nq][1][0], wf[nq][1][1], AF[mb_][0], AF[mb_][1], mx_one); \
+    }                                                                                                      \
+  } else                                                                                                   \
   _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                      \
     _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_) {                                                  \
       pp_mfma16(acc[2 * (nq)][4 * (mq) + mb_], wf[nq][0][ks_], AF[mb_][ks_]);                              \
@@ -1178,7 +1253,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
     }
     return;
   }
-  gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l15, g4, smem, tid);
+  if (FP8) gemm_epilogue_lds_fp8<EPI>(P, G, acc, m0, n0, wm, wn, l15, g4, smem, tid);
+  else gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l15, g4, smem, tid);
 #else
   static_assert(!SPLITK, "split-K is built for the 16x16x32 accumulator layout");
   gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi, smem, tid);
@@ -1959,9 +2035,21 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI, 1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI, 0, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
     attr_set = true;
+  }
+  if (p->fp8) {
+    // the fp8 operands are, byte for byte, K32-blocked bf16 matrices with K / 2 columns: the kernel runs on that view
+    omni_gemm_params q = *p;
+    q.K = p->K / 2;
+    if (!epilogue_rows_coalescable(&q) || !ring_saddr_ok(&q)) return OMNI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, 0, 1>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, q, mt0, tiles_m,
+                       tiles_n, gemm_group_m(), 1);
+    OMNI_CHECK_LAUNCH();
+    return OMNI_OK;
   }
 #ifdef OMNI_DEV
   if (gemm_variant(p) == 0 && p->K % BK == 0) {
@@ -2080,6 +2168,15 @@ extern "C" int omni_dev_gemm_ring_ablate(const omni_gemm_params* p, int mode, om
 extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
   if (!p || p->ngroups < 1 || p->ngroups > 2 || p->N <= 0 || p->K <= 0) return OMNI_ERR_BAD_ARG;
   if (p->K % RBK != 0 || p->N % 8 != 0) return OMNI_ERR_UNSUPPORTED;
+  if (p->fp8 != 0 && p->fp8 != 1) return OMNI_ERR_BAD_ARG;
+  if (p->fp8) {                                      // e4m3 operands: K64-blocked layouts only, whole 128-k tiles, fp32 scales
+    if (p->K % 128 != 0 || p->N % 4 != 0 || !p->w_k32_blocked || !OMNI_PP_MFMA16) return OMNI_ERR_UNSUPPORTED;
+    for (int g = 0; g < p->ngroups; ++g) {
+      if (!p->g[g].a_scale || !p->g[g].w_scale) return OMNI_ERR_BAD_ARG;
+      if (!p->g[g].a_k32_rows) return OMNI_ERR_UNSUPPORTED;
+      if (reinterpret_cast<uintptr_t>(p->g[g].w_scale) & 15) return OMNI_ERR_ALIGN;
+    }
+  }
   for (int g = 0; g < p->ngroups; ++g) {
     const omni_gemm_group& G = p->g[g];
     if (!G.A || !G.W || !G.out || G.M <= 0) return OMNI_ERR_BAD_ARG;

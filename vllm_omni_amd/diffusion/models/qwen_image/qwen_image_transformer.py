@@ -281,6 +281,7 @@ class QwenImageTransformer2DModel(nn.Module):
         self._native = None        # (DitWeights struct, keep-alive list)
         self._native_gen = 0       # bumped whenever the pointer table is invalidated (captured hipGraphs must be re-captured)
         self._w_blocked = False    # the 8 big matrices per layer currently hold the K32-blocked re-layout
+        self.fp8 = False           # enable_fp8(): the block GEMMs run on e4m3 copies of their weights (BASELINE config 5)
         self._workspace = None
         self._batch_cache: dict = {}
 
@@ -303,6 +304,17 @@ class QwenImageTransformer2DModel(nn.Module):
         before it can be replayed."""
         self._native = None
         self._native_gen += 1
+
+    def enable_fp8(self, on: bool = True) -> None:
+        """Run the eight block GEMMs of every layer in fp8 (OCP e4m3 operands on the scaled MFMA at twice the bf16 rate,
+        omni_gemm_params.fp8): weights are quantised ONCE per output channel when the native pointer table is (re)built,
+        activations per token in front of each GEMM; everything else stays bf16.  The bf16 parameters are kept (they remain
+        the source of truth for state_dict / load_weights).  BASELINE.json config 5; the reference has no fp8 path to match:
+        accuracy is stated against the bf16 path / the fp32 oracle in tests/test_gpu_fp8.py."""
+        if bool(on) != self.fp8:
+            self.fp8 = bool(on)
+            self._workspace = None          # the workspace grows by the e4m3 activation buffer
+            self._invalidate_native()
 
     def _set_weight_layout(self, blocked: bool) -> None:
         """In-place (one matrix of scratch) switch between the reference's row-major [out, in] and the K32-blocked order
@@ -430,7 +442,23 @@ class QwenImageTransformer2DModel(nn.Module):
         w.norm_out_w, w.norm_out_b = self.norm_out.linear.weight.data_ptr(), self.norm_out.linear.bias.data_ptr()
         w.proj_out_w, w.proj_out_b = self.proj_out.weight.data_ptr(), self.proj_out.bias.data_ptr()
         w.layers = C.cast(layers, C.POINTER(N.DitLayerWeights))
-        self._native = (w, layers)
+        keep = [layers]
+        if self.fp8:
+            f8 = (N.DitFp8Layer * L)()
+            names = N._FP8_FIELDS
+            for i, blk in enumerate(self.transformer_blocks):
+                a = blk.attn
+                mats = (a.to_qkv.weight, a.add_kv_proj.weight, a.to_out[0].weight, a.to_add_out.weight,
+                        blk.img_mlp.net[0].proj.weight, blk.img_mlp.net[2].weight,
+                        blk.txt_mlp.net[0].proj.weight, blk.txt_mlp.net[2].weight)
+                for f, m in zip(names, mats):
+                    w8, sc = ops.quantize_fp8_rows(m.data, x_k32_blocked=self._w_blocked)     # per output channel
+                    keep += [w8, sc]
+                    setattr(f8[i], f + ("_w8" if "mlp" not in f else "_8"), w8.data_ptr())
+                    setattr(f8[i], f + "_s", sc.data_ptr())
+            w.fp8_layers = C.cast(f8, C.POINTER(N.DitFp8Layer))
+            keep.append(f8)
+        self._native = (w, keep)
         return w
 
     # ------------------------------------------------------------------ batches

@@ -46,8 +46,9 @@ class GemmGroupArgs:
     def __init__(self, a, w, bias=None, out=None, *, a_row_map=None, out_row_map=None, out1=None, out2=None,
                  res=None, gate=None, gate_item_stride=0, row_item_map=None, rows_per_item=0,
                  a_k32_blocked=False, out_k32_blocked=False, qk_norm_q_w=None, qk_norm_k_w=None, qk_rope_cos=None,
-                 qk_rope_sin=None, qk_row_pos=None, qk_eps=1e-6):
+                 qk_rope_sin=None, qk_row_pos=None, qk_eps=1e-6, a_scale=None, w_scale=None):
         self.a_k32_blocked, self.out_k32_blocked = a_k32_blocked, out_k32_blocked
+        self.a_scale, self.w_scale = a_scale, w_scale            # fp8 operands (gemm(..., fp8=True)): fp32 row / channel scales
         self.qk = (qk_norm_q_w, qk_norm_k_w, qk_rope_cos, qk_rope_sin, qk_row_pos, qk_eps)
         self.a, self.w, self.bias, self.out = a, w, bias, out
         self.a_row_map, self.out_row_map, self.out1, self.out2 = a_row_map, out_row_map, out1, out2
@@ -68,12 +69,16 @@ def w_to_k32_blocked(w: torch.Tensor) -> torch.Tensor:
 
 
 def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0, m_override: list[int] | None = None,
-         w_k32_blocked: bool = False, splitk_ws: torch.Tensor | None = None, kernel_hint: int = 0):
+         w_k32_blocked: bool = False, splitk_ws: torch.Tensor | None = None, kernel_hint: int = 0, fp8: bool = False):
     """Y_g = epilogue(A_g @ W_g.T + bias_g) for up to two groups sharing N, K (omni_gemm_bf16).  `splitk_ws`: optional fp32
     device workspace; with it, launches of at most 128 tiles in at most 10 row tiles split their K loop (ABI v4).
-    `kernel_hint`: 0 = automatic, GEMM_KERNEL_RING = force the fallback (ring) kernel (ABI v6; cross-checks)."""
+    `kernel_hint`: 0 = automatic, GEMM_KERNEL_RING = force the fallback (ring) kernel (ABI v6; cross-checks).
+    `fp8`: A and W are uint8 tensors of OCP e4m3 values in the K64-blocked order (`quantize_fp8_rows`), with fp32
+    `a_scale` / `w_scale` per group (ABI v7): Y = epilogue((A8 @ W8.T) * a_scale[:, None] * w_scale[None, :] + bias)."""
     p = N.GemmParams()
     p.kernel_hint = int(kernel_hint)
+    p.fp8 = 1 if fp8 else 0
+    op_dtype = torch.uint8 if fp8 else BF16
     if splitk_ws is not None:
         if splitk_ws.dtype != torch.float32 or not splitk_ws.is_cuda or not splitk_ws.is_contiguous():
             raise N.OmniNativeError("splitk_ws must be a contiguous float32 GPU tensor")
@@ -89,12 +94,14 @@ def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0
         m, k, lda = _rows2d(g.a, "A")
         if g.w.shape != (N_, K_) or not g.w.is_contiguous():
             raise N.OmniNativeError("all groups must share a contiguous [N, K] weight shape")
-        G.A, G.lda = _p(g.a, name="A"), lda
+        G.A, G.lda = _p(g.a, op_dtype, name="A"), lda
         G.M = m_override[i] if m_override else (g.a_row_map.numel() if g.a_row_map is not None else m)
         if g.a_row_map is None and k != K_:
             raise N.OmniNativeError(f"A has K={k}, W has K={K_}")
         G.a_row_map = _p(g.a_row_map, torch.int32, "a_row_map")
-        G.W, G.bias = _p(g.w, name="W"), _p(g.bias, name="bias")
+        G.W, G.bias = _p(g.w, op_dtype, name="W"), _p(g.bias, name="bias")
+        if fp8:
+            G.a_scale, G.w_scale = _p(g.a_scale, torch.float32, "a_scale"), _p(g.w_scale, torch.float32, "w_scale")
         G.out, G.ldo = _p(g.out, name="out"), g.out.stride(0)
         G.out1, G.out2 = _p(g.out1, name="out1"), _p(g.out2, name="out2")
         G.out_row_map = _p(g.out_row_map, torch.int32, "out_row_map")
@@ -110,6 +117,26 @@ def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0
         G.a_k32_rows = g.a.shape[0] if g.a_k32_blocked else 0       # blocked tensors keep their [rows, K] shape
         G.out_k32_rows = g.out.shape[0] if g.out_k32_blocked else 0
     N.check(N.lib().omni_gemm_bf16(C.byref(p), _stream()), "omni_gemm_bf16")
+
+
+def quantize_fp8_rows(x: torch.Tensor, *, x_k32_blocked: bool = False, out: torch.Tensor | None = None,
+                      scale: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """Dynamic per-row fp8 quantisation (omni_quantize_fp8_rows): x [rows, K] bf16 (row-major, or K32-blocked with
+    x_k32_blocked) -> (y8 uint8 [rows, K] holding e4m3 bytes in the K64-blocked order [K/64][rows][64], scale fp32 [rows]) with
+    x[r, k] ~= e4m3(y8)[r, k] * scale[r].  Rows of activations = tokens; rows of a weight = output channels."""
+    rows, K, ldx = _rows2d(x, "x")
+    y8 = torch.empty(rows, K, dtype=torch.uint8, device=x.device) if out is None else out
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device) if scale is None else scale
+    N.check(N.lib().omni_quantize_fp8_rows(_p(x, name="x"), ldx, rows if x_k32_blocked else 0, rows, K,
+                                           _p(y8, torch.uint8, "y8"), y8.shape[0], _p(sc, torch.float32, "scale"), _stream()),
+            "omni_quantize_fp8_rows")
+    return y8, sc
+
+
+def k64_blocked_fp8_to_rows(y8: torch.Tensor) -> torch.Tensor:
+    """[rows, K]-shaped uint8 tensor holding [K/64][rows][64] -> row-major float8_e4m3fn view [rows, K] (tests / debugging)."""
+    r, k = y8.shape
+    return y8.view(k // 64, r, 64).transpose(0, 1).contiguous().view(r, k).view(torch.float8_e4m3fn)
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, *, gelu: bool = False,
