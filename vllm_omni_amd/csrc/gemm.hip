@@ -418,7 +418,9 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
       // The store is issued from inline asm: `res` may alias `out` (in-place residual), and for a compiler-visible
       // store hipcc drains vmcnt(0) before the next loads although a thread never re-reads a row it has written.
       if (m0 + (b * BATCH + j) * RS + rsub < M)
-        asm volatile("global_store_dwordx4 %0, %1, off" OMNI_EPI_STORE_POLICY ::"v"(dst), "v"(o));
+        // (+ wait states: a 128-bit store reads its data VGPRs after issue, and hipcc does not know this statement is a store —
+        // the hazard was observed in gemm_epilogue_direct_k32, whose next instruction re-used the data registers)
+        asm volatile("global_store_dwordx4 %0, %1, off" OMNI_EPI_STORE_POLICY "\n\ts_nop 1" ::"v"(dst), "v"(o));
     }
     d0 = d1;
   }
@@ -478,6 +480,75 @@ OMNI_DEVINL void gemm_epilogue_lds(const omni_gemm_params& P, const omni_gemm_gr
       }
     }
   });
+}
+
+// Direct epilogue for K32-BLOCKED outputs without a row map (the MLP-up / GELU launch: 27 % of the DiT flops, the roofline
+// kernel).  In the blocked layout [N/32][R][32] the 16 rows of an accumulator block are 16 x 64 B = 1 KiB CONTIGUOUS, and a
+// lane's four values are 8 contiguous bytes of its row: the wave's store instruction for (mb, nb) covers half of that KiB
+// (32 B of each of 16 consecutive rows) and the one for nb ^ 1, issued right behind it, the other half — whole lines without
+// the bf16 C tile in LDS, its two barriers and the second pass (13.3 us -> a few us of the ~90 us a tile takes).
+template <int EPI, int FP8>
+OMNI_DEVINL void gemm_epilogue_direct_k32(const omni_gemm_params& P, const omni_gemm_group& G, f32x4_t (&acc)[4][8], int m0,
+                                          int n0, int wm, int wn, int l15, int g) {
+  const int M = G.M, N = P.N;
+  float sw[4][4], bi[4][4];
+  if (FP8) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int n = n0 + wn * 64 + nb * 16 + g * 4;
+      f32x4_t w4 = {0.f, 0.f, 0.f, 0.f};
+      u32x2_t b = {0u, 0u};
+      if (n < N) {
+        w4 = *reinterpret_cast<const f32x4_t*>(G.w_scale + n);
+        if (G.bias) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
+      }
+      sw[nb][0] = w4[0]; sw[nb][1] = w4[1]; sw[nb][2] = w4[2]; sw[nb][3] = w4[3];
+      bi[nb][0] = bf16_lo(b[0]); bi[nb][1] = bf16_hi(b[0]); bi[nb][2] = bf16_lo(b[1]); bi[nb][3] = bf16_hi(b[1]);
+    }
+  }
+  uint16_t* const obase = G.out;
+  const int64_t R = G.out_k32_rows;
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const int row = m0 + wm * 128 + mb * 16 + l15;
+    float sa = 1.0f;
+    if (FP8) {
+      int ar = min(row, M - 1);
+      if (G.a_row_map) ar = G.a_row_map[ar];
+      sa = G.a_scale[ar];
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {                 // one 32-column slab = the accumulator blocks nb = 2 sl, 2 sl + 1
+      uint32_t a[2], b[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int nb = 2 * sl + h;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = FP8 ? acc[nb][mb][j] * sa * sw[nb][j] + bi[nb][j] : acc[nb][mb][j];   // bf16: the bias is in the accumulator
+          if (EPI == OMNI_EPI_BIAS_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
+        }
+        (h ? b : a)[0] = pack_bf16x2(v[0], v[1]);
+        (h ? b : a)[1] = pack_bf16x2(v[2], v[3]);
+      }
+      // lane (l15, g) holds columns 4g..4g+3 of block 2sl (a) and of block 2sl+1 (b).  v_permlane16_swap exchanges a's odd
+      // 16-lane rows with b's even ones: afterwards an even-g lane owns 8 consecutive columns of block 2sl (its own four and
+      // its right neighbour's), an odd-g lane 8 consecutive columns of block 2sl+1 — 16 contiguous bytes each, and the wave's
+      // single store covers the 16 rows' 64-B slab pieces completely: one contiguous KiB.
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+      // even g: (a = own block-2sl cols 4g.., b = neighbour g+1's block-2sl cols);  odd g: (a = neighbour g-1's block-2sl+1 cols, b = own)
+      const u32x4_t o = {a[0], a[1], b[0], b[1]};
+      const int n = n0 + wn * 64 + sl * 32 + (g & 1) * 16 + (g >> 1) * 8;
+      uint16_t* dst = obase + ((int64_t)(n >> 5) * R + row) * 32 + (n & 31);
+      // the wait states behind the store are part of the statement: a 128-bit store reads its data registers a few cycles after
+      // issue, hipcc cannot see that this asm is a store and re-uses them at once as GELU temporaries (observed: dword 0 of
+      // the piece = the next block's exponent argument)
+      if (row < M && n < N)
+        asm volatile("global_store_dwordx4 %0, %1, off" OMNI_EPI_STORE_POLICY "\n\ts_nop 2" ::"v"(dst), "v"(o) : "memory");
+    }
+  }
 }
 
 // fp8: C = acc * a_scale[stored row] * w_scale[col] + bias[col]  (fp32), then as the bf16 kernel (GELU, bf16 rounding, LDS tile)
@@ -930,6 +1001,9 @@ OMNI_DEVINL void pp_mfma(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
 #ifndef OMNI_PP_MFMA16
 #define OMNI_PP_MFMA16 1
 #endif
+#ifndef OMNI_PP_DIRECT_K32
+#define OMNI_PP_DIRECT_K32 1   // K32-blocked outputs are stored straight from the accumulators (gemm_epilogue_direct_k32)
+#endif
 OMNI_DEVINL void pp_mfma16(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
 #if OMNI_PP_ABL == 1
   asm volatile("" : "+v"(acc) : "v"(a), "v"(b));
@@ -1252,6 +1326,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
       }
     }
     return;
+  }
+  if constexpr ((EPI == OMNI_EPI_BIAS || EPI == OMNI_EPI_BIAS_GELU_TANH) && OMNI_PP_DIRECT_K32) {
+    if (G.out_k32_rows && !G.out_row_map) {          // uniform over the workgroup
+      gemm_epilogue_direct_k32<EPI, FP8>(P, G, acc, m0, n0, wm, wn, l15, g4);
+      return;
+    }
   }
   if (FP8) gemm_epilogue_lds_fp8<EPI>(P, G, acc, m0, n0, wm, wn, l15, g4, smem, tid);
   else gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l15, g4, smem, tid);
