@@ -180,6 +180,15 @@ int omni_adaln_modulate_ex(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_
                            const int32_t* row_item_map, int32_t rows_per_item, float eps, int32_t y_k32_rows,
                            omni_stream stream);
 
+/* ABI v7 — AdaLN-modulate with the result quantised to fp8 in the same pass (the row is in registers anyway):
+ * y8 / y8_scale as omni_quantize_fp8_rows would produce them from the bf16-ROUNDED result (bit-identical to running the two
+ * kernels one after the other), K64-blocked with y8_rows rows.  y (nullable): additionally the bf16 result, K32-blocked with
+ * y_k32_rows rows (TeaCache reads the modulated input of the first block).  D % 64 == 0. */
+int omni_adaln_modulate_fp8(const omni_bf16* x, int64_t ldx, int32_t rows, int32_t D, const omni_bf16* scale,
+                            const omni_bf16* shift, int64_t mod_item_stride, const int32_t* row_item_map,
+                            int32_t rows_per_item, float eps, omni_bf16* y, int32_t y_k32_rows, uint8_t* y8,
+                            int32_t y8_rows, float* y8_scale, omni_stream stream);
+
 /* RMSNorm over the last dim with learned weight: y = x * rsqrt(mean(x^2) + eps) * w.
  * Replaces vllm RMSNorm at qwen_image_transformer.py:758 (txt_norm, D = 3584).  D % 8 == 0, D <= 8192. */
 int omni_rmsnorm(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows, int32_t D,

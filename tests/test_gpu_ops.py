@@ -625,3 +625,21 @@ def test_gemm_fp8_scaled_mfma_equals_the_dequantised_product(epi):
     print(f"fp8 gemm [{epi}]: vs dequantised fp32 product {r_i:.2e} / {r_t:.2e}; vs the unquantised product {r_full:.2e}")
     assert r_i <= 4e-3 and r_t <= 4e-3
     assert r_full <= 6e-2                                         # two e4m3 operands: ~2^-4 relative per element, averaged over K
+
+
+def test_adaln_modulate_fp8_fused_equals_adaln_then_quantize():
+    """omni_adaln_modulate_fp8 (the fp8 mode's AdaLN: quantisation fused into the pass that has the row in registers) returns
+    the same bytes and scales as omni_adaln_modulate_ex followed by omni_quantize_fp8_rows, and the same bf16 copy."""
+    from vllm_omni_amd import ops
+
+    rows, D, items = 300, 3072, 3
+    x = g_(rnd((rows, D), 71, 2.0))
+    mod = g_(rnd((items, 2 * D), 72, 0.3))
+    item = (torch.arange(rows) % items).to(torch.int32).to(dev())
+    y = ops.adaln_modulate(x, mod[:, D:], mod[:, :D], mod_item_stride=2 * D, row_item_map=item, out_k32_blocked=True)
+    y8_ref, sc_ref = ops.quantize_fp8_rows(y, x_k32_blocked=True)
+    y8, sc, yb = ops.adaln_modulate_fp8(x, mod[:, D:], mod[:, :D], mod_item_stride=2 * D, row_item_map=item, want_bf16=True)
+    y8b, scb, none = ops.adaln_modulate_fp8(x, mod[:, D:], mod[:, :D], mod_item_stride=2 * D, row_item_map=item)
+    torch.cuda.synchronize()
+    assert none is None and torch.equal(yb, y)
+    assert torch.equal(sc, sc_ref) and torch.equal(y8, y8_ref) and torch.equal(y8b, y8_ref) and torch.equal(scb, sc_ref)

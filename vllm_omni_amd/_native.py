@@ -130,6 +130,9 @@ PROTOTYPES = {
                                       c_bf16_p, C.c_int64, c_i32_p, C.c_int32, C.c_float, C.c_void_p]),
     "omni_adaln_modulate_ex": (C.c_int, [c_bf16_p, C.c_int64, c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p,
                                          c_bf16_p, C.c_int64, c_i32_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "omni_adaln_modulate_fp8": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, c_bf16_p, C.c_int64, c_i32_p,
+                                          C.c_int32, C.c_float, c_bf16_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                          C.c_void_p]),
     "omni_rmsnorm": (C.c_int, [c_bf16_p, C.c_int64, c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, C.c_float,
                                C.c_void_p]),
     "omni_qk_norm_rope": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p,

@@ -156,12 +156,22 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   OMNI_TRY(linear_rows(temb, D, nT, L.txt_mod_w, L.txt_mod_b, 6 * (int64_t)D, D, ws.mod_txt, 6 * D, 1,
                                   0, stream));
   if (phase != BLOCK_POST) {
-  // norm1 + modulate (reference :564-567)
+  // norm1 + modulate (reference :564-567).  fp8 mode: the e4m3 copy + per-token scale come out of the same pass (the bf16
+  // result is still written for the image stream when TeaCache reads it)
+  const bool fused_q = F && blk;
+  if (fused_q) {
+    OMNI_TRY(omni_adaln_modulate_fp8(hidden_img, D, Ri, D, ws.mod_img + D, ws.mod_img, 6 * D, b->img_item, 0, eps,
+                                     b->teacache ? xn_img : nullptr, bRi, ws.x8, Ri, ws.x8_scale, stream));
+    OMNI_TRY(after_img_norm1(xn_img));
+    OMNI_TRY(omni_adaln_modulate_fp8(hidden_txt, D, Rt, D, ws.mod_txt + D, ws.mod_txt, 6 * D, b->txt_item, 0, eps, nullptr, 0,
+                                     ws.x8 + (int64_t)Ri * D, Rt, ws.x8_scale + Ri, stream));
+  } else {
   OMNI_TRY(omni_adaln_modulate_ex(hidden_img, D, xn_img, D, Ri, D, ws.mod_img + D, ws.mod_img, 6 * D, b->img_item,
                                   0, eps, bRi, stream));
   OMNI_TRY(after_img_norm1(xn_img));
   OMNI_TRY(omni_adaln_modulate_ex(hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + D, ws.mod_txt, 6 * D, b->txt_item,
                                   0, eps, bRt, stream));
+  }
   // fused QKV projections of both streams, scattered into the joint q/k/v (reference :380-394, :414-416)
   {
     omni_gemm_params p = {};
@@ -185,7 +195,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
     p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
     if (F) {
-      OMNI_TRY(quant_streams(xn_img, bRi, xn_txt, bRt, D));
+      if (!fused_q) OMNI_TRY(quant_streams(xn_img, bRi, xn_txt, bRt, D));
       fp8_streams(p, D, F->to_qkv_w8, F->to_qkv_s, F->add_qkv_w8, F->add_qkv_s);
     }
     OMNI_TRY(omni_gemm_bf16(&p, stream));
@@ -232,10 +242,18 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
   // norm2 + modulate (reference :590, :595)
+  const bool fused_q2 = F && blk;
+  if (fused_q2) {
+    OMNI_TRY(omni_adaln_modulate_fp8(hidden_img, D, Ri, D, ws.mod_img + 4 * D, ws.mod_img + 3 * D, 6 * D, b->img_item, 0, eps,
+                                     nullptr, 0, ws.x8, Ri, ws.x8_scale, stream));
+    OMNI_TRY(omni_adaln_modulate_fp8(hidden_txt, D, Rt, D, ws.mod_txt + 4 * D, ws.mod_txt + 3 * D, 6 * D, b->txt_item, 0, eps,
+                                     nullptr, 0, ws.x8 + (int64_t)Ri * D, Rt, ws.x8_scale + Ri, stream));
+  } else {
   OMNI_TRY(omni_adaln_modulate_ex(hidden_img, D, xn_img, D, Ri, D, ws.mod_img + 4 * D, ws.mod_img + 3 * D, 6 * D,
                                   b->img_item, 0, eps, bRi, stream));
   OMNI_TRY(omni_adaln_modulate_ex(hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + 4 * D, ws.mod_txt + 3 * D, 6 * D,
                                   b->txt_item, 0, eps, bRt, stream));
+  }
   // MLP up + GELU-tanh (reference :591, :596 -> diffusers FeedForward)
   {
     omni_gemm_params p = {};
@@ -247,7 +265,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].out = h_txt; p.g[1].ldo = 4 * D;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
     if (F) {
-      OMNI_TRY(quant_streams(xn_img, bRi, xn_txt, bRt, D));
+      if (!fused_q2) OMNI_TRY(quant_streams(xn_img, bRi, xn_txt, bRt, D));
       fp8_streams(p, D, F->img_mlp_w1_8, F->img_mlp_w1_s, F->txt_mlp_w1_8, F->txt_mlp_w1_s);
     }
     OMNI_TRY(omni_gemm_bf16(&p, stream));

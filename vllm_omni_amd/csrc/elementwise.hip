@@ -20,6 +20,12 @@ OMNI_DEVINL u32x4_t pack8(const float* f) {
   return w;
 }
 
+OMNI_DEVINL uint32_t cvt_pk_fp8x4(float a, float b, float c, float d) {
+  uint32_t r = 0;
+  asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2\n\tv_cvt_pk_fp8_f32 %0, %3, %4 op_sel:[0,0,1]" : "+v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // AdaLN-modulate / RMSNorm: one wave per row, the row lives in registers (NCH chunks of 512 elements).
 // bytes/row = 2*D (read) + 2*D (write) + modulation vectors (L2-resident).
@@ -31,7 +37,8 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
                                                       const uint16_t* __restrict__ scale_or_w,
                                                       const uint16_t* __restrict__ shift, int64_t item_stride,
                                                       const int32_t* __restrict__ row_item_map, int rows_per_item,
-                                                      float eps, int y_k32_rows) {
+                                                      float eps, int y_k32_rows, uint8_t* __restrict__ y8 = nullptr,
+                                                      int y8_rows = 0, float* __restrict__ y8_scale = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -77,6 +84,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
     moff = (int64_t)item * item_stride;
   }
   uint16_t* yr = y + (int64_t)row * ldy;
+  float amax = 0.0f;                                   // fp8 output: per-row amax of the bf16-ROUNDED result
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int e = (c * 64 + lane) * 8;
@@ -91,9 +99,32 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = v[c][i] * rstd * sc[i];
       }
-      // K32-blocked output: the 8 elements stay one 16-B granule, at ((e/32) * R + row) * 32 + e%32
-      uint16_t* dst = y_k32_rows ? y + ((int64_t)(e >> 5) * y_k32_rows + row) * 32 + (e & 31) : yr + e;
-      *reinterpret_cast<u32x4_t*>(dst) = pack8(o);
+      const u32x4_t pk = pack8(o);
+      if (y) {
+        // K32-blocked output: the 8 elements stay one 16-B granule, at ((e/32) * R + row) * 32 + e%32
+        uint16_t* dst = y_k32_rows ? y + ((int64_t)(e >> 5) * y_k32_rows + row) * 32 + (e & 31) : yr + e;
+        *reinterpret_cast<u32x4_t*>(dst) = pk;
+      }
+      if (MODE == 0 && y8) {                           // keep the bf16-rounded values: the same numbers omni_quantize_fp8_rows
+        unpack8(pk, v[c]);                             // would read back from y, so fused == unfused bit for bit
+#pragma unroll
+        for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[c][i]));
+      }
+    }
+  }
+  if (MODE == 0 && y8) {
+    amax = wave_max<64>(amax);
+    const float q = fmaxf(amax, 1e-12f) * (1.0f / 448.0f), inv = 1.0f / q;
+    if (lane == 0) y8_scale[row] = q;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int e = (c * 64 + lane) * 8;
+      if (e < D) {
+        u32x2_t o8;
+        o8[0] = cvt_pk_fp8x4(v[c][0] * inv, v[c][1] * inv, v[c][2] * inv, v[c][3] * inv);
+        o8[1] = cvt_pk_fp8x4(v[c][4] * inv, v[c][5] * inv, v[c][6] * inv, v[c][7] * inv);
+        *reinterpret_cast<u32x2_t*>(y8 + ((int64_t)(e >> 6) * y8_rows + row) * 64 + (e & 63)) = o8;
+      }
     }
   }
 }
@@ -101,12 +132,12 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
 template <int MODE>
 int launch_rownorm(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int rows, int D, const omni_bf16* a,
                    const omni_bf16* b, int64_t stride, const int32_t* map, int rpi, float eps, hipStream_t s,
-                   int y_k32_rows = 0) {
+                   int y_k32_rows = 0, uint8_t* y8 = nullptr, int y8_rows = 0, float* y8_scale = nullptr) {
   const int nch = (D + 511) / 512;
   const dim3 grid((rows + 3) / 4), block(256);
 #define OMNI_RN(N)                                                                                            \
   hipLaunchKernelGGL((rownorm_kernel<N, MODE>), grid, block, 0, s, x, ldx, y, ldy, rows, D, a, b, stride, map, \
-                     rpi, eps, y_k32_rows)
+                     rpi, eps, y_k32_rows, y8, y8_rows, y8_scale)
   if (nch <= 1) OMNI_RN(1);
   else if (nch <= 2) OMNI_RN(2);
   else if (nch <= 4) OMNI_RN(4);
@@ -437,11 +468,6 @@ __global__ __launch_bounds__(256) void teacache_post_kernel(uint16_t* __restrict
 // One wave per row.  A lane owns the 16-byte chunks c = lane, lane + 64, ... of the row (8 bf16 each), so a K32-blocked source
 // (64-B slabs) and a row-major one are both read as whole 16-B pieces; the row stays in registers between the amax pass and
 // the conversion.  Output chunk c (8 bytes) goes to slab c >> 3 of the K64-blocked destination.
-OMNI_DEVINL uint32_t cvt_pk_fp8x4(float a, float b, float c, float d) {
-  uint32_t r = 0;
-  asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2\n\tv_cvt_pk_fp8_f32 %0, %3, %4 op_sel:[0,0,1]" : "+v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
-  return r;
-}
 
 template <int NCH>   // NCH = chunks per lane (K = NCH * 64 * 8 at most)
 __global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const uint16_t* __restrict__ x, int64_t ldx, int x_k32_rows,
@@ -548,6 +574,21 @@ extern "C" int omni_adaln_modulate_ex(const omni_bf16* x, int64_t ldx, omni_bf16
     return OMNI_ERR_ALIGN;
   return launch_rownorm<0>(x, ldx, y, ldy, rows, D, scale, shift, mod_item_stride, row_item_map, rows_per_item, eps,
                            static_cast<hipStream_t>(stream), y_k32_rows);
+}
+
+extern "C" int omni_adaln_modulate_fp8(const omni_bf16* x, int64_t ldx, int32_t rows, int32_t D, const omni_bf16* scale,
+                                       const omni_bf16* shift, int64_t mod_item_stride, const int32_t* row_item_map,
+                                       int32_t rows_per_item, float eps, omni_bf16* y, int32_t y_k32_rows, uint8_t* y8,
+                                       int32_t y8_rows, float* y8_scale, omni_stream stream) {
+  if (!x || !y8 || !y8_scale || !scale || !shift || rows <= 0 || D <= 0 || y8_rows < rows) return OMNI_ERR_BAD_ARG;
+  if (!row_item_map && rows_per_item <= 0) return OMNI_ERR_BAD_ARG;
+  if (y && (y_k32_rows <= 0 || y_k32_rows < rows)) return OMNI_ERR_BAD_ARG;       // the optional bf16 copy is K32-blocked
+  if (D % 64 || D > 8192) return OMNI_ERR_UNSUPPORTED;
+  if (!omni_aligned16(x) || (y && !omni_aligned16(y)) || (reinterpret_cast<uintptr_t>(y8) & 7) || !omni_aligned16(scale) ||
+      !omni_aligned16(shift) || (ldx % 8) || (mod_item_stride % 8))
+    return OMNI_ERR_ALIGN;
+  return launch_rownorm<0>(x, ldx, y, D, rows, D, scale, shift, mod_item_stride, row_item_map, rows_per_item, eps,
+                           static_cast<hipStream_t>(stream), y ? y_k32_rows : 0, y8, y8_rows, y8_scale);
 }
 
 extern "C" int omni_adaln_modulate(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows,

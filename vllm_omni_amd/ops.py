@@ -133,6 +133,21 @@ def quantize_fp8_rows(x: torch.Tensor, *, x_k32_blocked: bool = False, out: torc
     return y8, sc
 
 
+def adaln_modulate_fp8(x, scale, shift, *, mod_item_stride: int, row_item_map=None, rows_per_item: int = 0, eps: float = 1e-6,
+                       want_bf16: bool = False):
+    """AdaLN-modulate with the fp8 quantisation fused in (omni_adaln_modulate_fp8): -> (y8 uint8 [rows, D] K64-blocked,
+    scale fp32 [rows], y bf16 [rows, D] K32-blocked or None)."""
+    rows, D, ldx = _rows2d(x, "x")
+    y8 = torch.empty(rows, D, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    y = torch.empty(rows, D, dtype=BF16, device=x.device) if want_bf16 else None
+    N.check(N.lib().omni_adaln_modulate_fp8(_p(x, name="x"), ldx, rows, D, _p(scale, name="scale"), _p(shift, name="shift"),
+                                            mod_item_stride, _p(row_item_map, torch.int32, "row_item_map"), rows_per_item, eps,
+                                            _p(y, name="y"), rows if want_bf16 else 0, _p(y8, torch.uint8, "y8"), rows,
+                                            _p(sc, torch.float32, "scale_out"), _stream()), "omni_adaln_modulate_fp8")
+    return y8, sc, y
+
+
 def k64_blocked_fp8_to_rows(y8: torch.Tensor) -> torch.Tensor:
     """[rows, K]-shaped uint8 tensor holding [K/64][rows][64] -> row-major float8_e4m3fn view [rows, K] (tests / debugging)."""
     r, k = y8.shape
