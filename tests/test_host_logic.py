@@ -487,3 +487,30 @@ def test_teacache_backend_refresh_resets_resident_states_and_worker_calls_it():
     out = w.execute_model([OmniDiffusionRequest(height=64, width=64, num_inference_steps=7, prompt_embeds=torch.zeros(1, 1, 8))],
                           decode=False)
     assert out.error is None and State.resets == 4 and be.num_inference_steps == 7
+
+
+def test_build_rejects_compiler_allocated_agprs_in_kernels_that_own_them():
+    """csrc/build.py: a kernel whose asm statements own a[0:255] (marker OMNI_OWNS_AGPRS) must not contain compiler-generated
+    AGPR traffic (hipcc parks spills / constants there under pressure and silently corrupts the accumulators); kernels without
+    the marker may use AGPRs freely."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vllm_omni_amd", "csrc"))
+    import build as csrc_build
+
+    owned = ["kern_a:", "\t;;#ASMSTART", "\t; omni: AGPRs owned by asm", "\t;;#ASMEND", "\tv_mov_b32 v1, v2",
+             "\t;;#ASMSTART", "\tv_accvgpr_write_b32 a[5], v1", "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[4:7], a[0:15]",
+             "\t;;#ASMEND", "\ts_endpgm", ".Lfunc_end0:"]
+    free = ["kern_b:", "\tv_accvgpr_write_b32 a3, v7", "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[4:7], a[0:15]", "\ts_endpgm",
+            ".Lfunc_end1:"]
+    assert csrc_build.agpr_violations(owned + free) == {}
+    spill = list(owned)
+    spill.insert(5, "\tv_accvgpr_write_b32 a1, v200 ; 4-byte Folded Spill")
+    spill.insert(spill.index("\ts_endpgm"), "\tv_accvgpr_read_b32 v200, a1")
+    got = csrc_build.agpr_violations(spill + free)
+    assert list(got) == ["kern_a"] and [c for _, c in got["kern_a"]] == ["v_accvgpr_write_b32 a1, v200", "v_accvgpr_read_b32 v200, a1"]
+    tup = list(owned)
+    tup.insert(5, "\tv_accvgpr_mov_b32 a[2:3], a[0:1]")
+    assert list(csrc_build.agpr_violations(tup)) == ["kern_a"]
+    # the sources that carry the marker are the ones the build checks
+    csrc = os.path.dirname(csrc_build.__file__)
+    marked = sorted(f for f in os.listdir(csrc) if f.endswith(".hip") and "OMNI_OWNS_AGPRS" in open(os.path.join(csrc, f)).read())
+    assert "attention_w64.hip" in marked

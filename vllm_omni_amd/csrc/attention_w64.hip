@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
   const int seq_len = cu_seqlens[b + 1] - seq_start;
   if (qb * QBLK >= seq_len) return;
 
-  asm volatile("" ::: OMNI_ALL_AGPRS);   // allocate a[0:255]
+  asm volatile(OMNI_OWNS_AGPRS ::: OMNI_ALL_AGPRS);   // allocate a[0:255]
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const int ntiles = (seq_len + KVBLK - 1) / KVBLK;

@@ -11,8 +11,10 @@ from __future__ import annotations
 
 import concurrent.futures as cf
 import os
+import re
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemm.hip", "attention.hip", "attention_w64.hip", "elementwise.hip", "vae.hip", "dit_forward.hip"]
@@ -26,6 +28,57 @@ def _stale(target: str, deps: list[str]) -> bool:
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+_AGPR = re.compile(r"\ba(\d+|\[\d+(:\d+)?\])")
+
+
+def agpr_violations(asm_lines) -> dict[str, list[tuple[int, str]]]:
+    """{kernel: [(line, instruction), ...]} for every function of a device-assembly listing that carries the OMNI_OWNS_AGPRS
+    marker and yet has compiler-generated instructions (outside #ASMSTART/#ASMEND) naming an AGPR."""
+    out: dict[str, list[tuple[int, str]]] = {}
+    fn, owned, inasm, hits = None, False, False, []
+    for n, line in enumerate(asm_lines, 1):
+        m = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if m and not m.group(1).startswith(".L"):
+            fn, owned, inasm, hits = m.group(1), False, False, []
+            continue
+        if "#ASMSTART" in line:
+            inasm = True
+        elif "#ASMEND" in line:
+            inasm = False
+        elif inasm:
+            owned = owned or "omni: AGPRs owned by asm" in line
+        else:
+            code = line.split(";")[0].strip()
+            if code and not code.startswith(".") and _AGPR.search(code):
+                hits.append((n, code))
+        if line.startswith(".Lfunc_end") and fn is not None:
+            if owned and hits:
+                out[fn] = hits
+            fn, hits = None, []
+    return out
+
+
+def check_agpr_ownership(src: str, verbose: bool = True) -> None:
+    """A kernel that keeps its accumulators in literal `a[...]` registers inside asm statements (marker: OMNI_OWNS_AGPRS, the
+    all-AGPR clobber statement of common.h) is only correct while hipcc itself never allocates an AGPR in it: under register
+    pressure the allocator parks spilled VGPRs and constants there, silently overwriting the kernel's data (seen in round 3:
+    one O^T register of the attention kernel corrupted only when a late rescale branch was taken).  There is no way to
+    reserve them, so the build CHECKS: the device assembly of such a kernel must not name an AGPR outside the kernel's own
+    asm statements.  Raises RuntimeError otherwise."""
+    if "OMNI_OWNS_AGPRS" not in open(src).read():
+        return
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.run([HIPCC, *FLAGS, "--cuda-device-only", "-S", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
+        with open(out) as f:
+            bad = agpr_violations(f)
+    for fn, hits in bad.items():
+        raise RuntimeError(f"{os.path.basename(src)}: hipcc allocated AGPRs in {fn}, which owns a[0:255] through asm "
+                           f"({len(hits)} instructions, first: line {hits[0][0]}: {hits[0][1]}) - lower the VGPR pressure")
+    if verbose:
+        print(f"agpr ownership check: {os.path.basename(src)} ok", flush=True)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -42,6 +95,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        check_agpr_ownership(src, verbose)
 
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         list(ex.map(compile_one, srcs, objs))

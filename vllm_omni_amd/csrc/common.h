@@ -133,6 +133,9 @@ static inline int omni_dev_env_int(const char*, int dflt) { return dflt; }
 
 // every AGPR, as a clobber list: makes the kernel descriptor allocate the accumulator half of the register file and tells the
 // compiler that nothing of its own survives there
+// (nothing RESERVES them: hipcc may still allocate AGPRs under register pressure — build.py checks the device assembly of
+// every kernel carrying the OMNI_OWNS_AGPRS marker and fails the build if it did)
+#define OMNI_OWNS_AGPRS "; omni: AGPRs owned by asm"
 #define OMNI_A1(x) "a" #x
 #define OMNI_A10(d) OMNI_A1(d##0), OMNI_A1(d##1), OMNI_A1(d##2), OMNI_A1(d##3), OMNI_A1(d##4), OMNI_A1(d##5), OMNI_A1(d##6), \
                     OMNI_A1(d##7), OMNI_A1(d##8), OMNI_A1(d##9)

@@ -1815,7 +1815,7 @@ __global__ __launch_bounds__(Q4_THREADS, 1) void gemm_bf16_q4_kernel(const omni_
   const int n0 = nt * BN;
   const int M = G.M, N = P.N, K = P.K;
   if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;   // device-side predicate (omni_teacache)
-  asm volatile("" ::: OMNI_ALL_AGPRS);                               // allocate a[0:255]
+  asm volatile(OMNI_OWNS_AGPRS ::: OMNI_ALL_AGPRS);                               // allocate a[0:255]
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, g4 = lane >> 4;
 
