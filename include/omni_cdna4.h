@@ -281,8 +281,18 @@ typedef struct {
   float clamp_lo, clamp_hi; /* applied if clamp_lo < clamp_hi */
   int32_t downsample2x;   /* 1 (3x3 only): ZeroPad2d((0,1,0,1)) + stride-2 conv of the VAE ENCODER's downsample2d/3d
                            * (autoencoder_kl_qwenimage.py:162-166): Hout = Hin / 2, source = 2*dst + tap.  ABI v3 */
+  int32_t x_padded;       /* ABI v8.  1: x (and res) are ZERO-BORDERED rasters [B, Hin + 2, Win + 2, C]: the conv's zero padding
+                           * (F.pad in QwenImageCausalConv3d.forward, :80-84) is resident in memory instead of re-created per tap */
+  int32_t y_padded;       /* ABI v8.  1: y is written as a zero-bordered raster too (needs x_padded, Cin % 32 == 0,
+                           * Cout % 8 == 0, no up/downsample): the decoder's 3x3 / 1x1 convs run as a GEMM over nine row-shifted
+                           * views of x, LDS-DMA fed (vae.hip conv_bordered_kernel) */
 } omni_conv_params;
 int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream);
+
+/* Nearest-exact x2 upsample (QwenImageUpsample, autoencoder_kl_qwenimage.py:112-124) between zero-bordered rasters:
+ * x [B, H + 2, W + 2, C] -> y [B, 2H + 2, 2W + 2, C].  C % 8 == 0.  ABI v8 */
+int omni_vae_upsample2x_bordered(const omni_bf16* x, omni_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                                 omni_stream stream);
 
 /* Channel RMS-norm (F.normalize(dim=C) * sqrt(C) * gamma) with optional SiLU: NHWC rows of C channels. */
 int omni_vae_rmsnorm_silu(const omni_bf16* x, omni_bf16* y, int64_t rows, int32_t C, const omni_bf16* gamma,

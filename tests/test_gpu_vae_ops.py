@@ -1,0 +1,85 @@
+"""VAE kernels over zero-bordered rasters (vae.hip conv_bordered_kernel / upsample2x_bordered_kernel) against torch fp32 —
+the conv the reference runs as F.pad + Conv3d on the last temporal slice (autoencoder_kl_qwenimage.py:69-84), the upsample of
+QwenImageUpsample (:112-124)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rnd(shape, seed, s=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * s).to(torch.bfloat16)
+
+
+def _border(x):
+    return torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))
+
+
+@pytest.mark.parametrize("cin,cout,ks,hw,B,use_res", [
+    (96, 96, 3, (20, 37), 2, True),        # 512-pixel x 96-channel tiles, ragged last tile, two images
+    (192, 384, 3, (33, 18), 1, False),     # 256 x 192 tiles, two channel tiles
+    (384, 192, 3, (16, 16), 2, True),
+    (192, 192, 3, (40, 24), 1, True),
+    (192, 384, 1, (21, 19), 2, False),     # the res-block shortcut: 1x1
+    (384, 384, 3, (9, 130), 1, False),     # rows longer than a tile
+    (192, 384, 3, (256, 256), 1, True),    # a full round of 512 px x 192 ch tiles: the 128-pixel-per-wave kernel, two runs per tile
+    (96, 384, 3, (300, 200), 1, False),    # the same with ragged runs (200 of 256 pixels)
+    (96, 96, 3, (256, 1024), 1, True),     # many 256 px x 96 ch tiles, runs shorter than the row
+    (192, 192, 1, (512, 512), 1, False),   # 1x1 through the big kernel
+])
+def test_bordered_conv_matches_torch(cin, cout, ks, hw, B, use_res):
+    from vllm_omni_amd import ops
+
+    H, W = hw
+    x, w, b = _rnd((B, H, W, cin), 1), _rnd((cout, ks, ks, cin), 2, 0.05), _rnd((cout,), 3)
+    res = _rnd((B, H, W, cout), 4) if use_res else None
+    ref = torch.nn.functional.conv2d(x.to(DEV).float().permute(0, 3, 1, 2), w.to(DEV).float().permute(0, 3, 1, 2), b.to(DEV).float(),
+                                     padding=ks // 2).cpu()                         # fp32 reference (computed on the GPU: size)
+    ref = ref.permute(0, 2, 3, 1) + (res.float() if use_res else 0.0)
+    y = ops.vae_conv2d(_border(x).to(DEV), w.to(DEV), b.to(DEV), res=_border(res).to(DEV) if use_res else None,
+                       x_bordered=True, y_bordered=True).float().cpu()
+    assert y.shape == (B, H + 2, W + 2, cout)
+    # the border stays exactly zero (the next layer's padding), the interior matches fp32 to bf16 rounding of the output
+    assert float(y[:, 0].abs().max()) == 0.0 and float(y[:, -1].abs().max()) == 0.0
+    assert float(y[:, :, 0].abs().max()) == 0.0 and float(y[:, :, -1].abs().max()) == 0.0
+    got = y[:, 1:-1, 1:-1]
+    err = float((got - ref).norm() / ref.norm())
+    assert err <= 4e-3, err
+    # and the gather kernel (plain rasters) agrees with it
+    y_plain = ops.vae_conv2d(x.to(DEV), w.to(DEV), b.to(DEV), res=res.to(DEV) if use_res else None).float().cpu()
+    assert float((got - y_plain).norm() / ref.norm()) <= 4e-3
+
+
+def test_gather_conv_reads_bordered_input():
+    """conv_out of the decoder: bordered raster in, plain raster out (3 output channels: the gather kernel)."""
+    from vllm_omni_amd import ops
+
+    x, w, b = _rnd((2, 19, 23, 96), 5), _rnd((3, 3, 3, 96), 6, 0.05), _rnd((3,), 7)
+    ref = ops.vae_conv2d(x.to(DEV), w.to(DEV), b.to(DEV), clamp=(-1.0, 1.0))
+    got = ops.vae_conv2d(_border(x).to(DEV), w.to(DEV), b.to(DEV), clamp=(-1.0, 1.0), x_bordered=True)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+
+
+def test_bordered_upsample_is_nearest_exact():
+    from vllm_omni_amd import ops
+
+    x = _rnd((2, 7, 11, 96), 8)
+    ref = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest-exact").permute(0, 2, 3, 1)
+    y = ops.vae_upsample2x_bordered(_border(x).to(DEV)).float().cpu()
+    assert y.shape == (2, 16, 24, 96)
+    assert torch.equal(y[:, 1:-1, 1:-1], ref)
+    assert float(y[:, 0].abs().max()) == 0.0 and float(y[:, -1].abs().max()) == 0.0 and float(y[:, :, 0].abs().max()) == 0.0 \
+        and float(y[:, :, -1].abs().max()) == 0.0
+
+
+def test_bordered_conv_rejects_what_it_is_not_built_for():
+    from vllm_omni_amd import ops
+    from vllm_omni_amd._native import OmniNativeError
+
+    x, w = _rnd((1, 10, 10, 16), 9).to(DEV), _rnd((96, 3, 3, 16), 10).to(DEV)
+    with pytest.raises(OmniNativeError):                                   # Cin % 32
+        ops.vae_conv2d(x, w, x_bordered=True, y_bordered=True)
+    x, w = _rnd((1, 10, 10, 96), 9).to(DEV), _rnd((96, 3, 3, 96), 10).to(DEV)
+    with pytest.raises(OmniNativeError):                                   # bordered output needs bordered input
+        ops.vae_conv2d(x, w, y_bordered=True)

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OMNI_CDNA4_LIB", os.path.join(_HERE, "libomni_cdna4.so"))   # env override: dev sweeps
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_bf16_p = C.c_void_p  # device pointer to uint16_t bf16 bits
 c_i32_p = C.c_void_p
@@ -55,6 +55,7 @@ class ConvParams(C.Structure):
         ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
         ("ksize", C.c_int32), ("upsample2x", C.c_int32), ("silu", C.c_int32),
         ("clamp_lo", C.c_float), ("clamp_hi", C.c_float), ("downsample2x", C.c_int32),
+        ("x_padded", C.c_int32), ("y_padded", C.c_int32),
     ]
 
 
@@ -151,6 +152,7 @@ PROTOTYPES = {
     "omni_cfg_euler_step": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, C.c_int32, C.c_int32, C.c_float, c_f32_p,
                                       C.c_int32, C.c_void_p]),
     "omni_vae_conv2d": (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
+    "omni_vae_upsample2x_bordered": (C.c_int, [c_bf16_p, c_bf16_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "omni_vae_rmsnorm_silu": (C.c_int, [c_bf16_p, c_bf16_p, C.c_int64, C.c_int32, c_bf16_p, C.c_int32, C.c_void_p]),
     "omni_softmax_rows": (C.c_int, [c_bf16_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "omni_dit_workspace_bytes": (C.c_size_t, [C.POINTER(DitWeights), C.c_int32, C.c_int32, C.c_int32]),

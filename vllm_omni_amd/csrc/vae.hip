@@ -68,10 +68,16 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const omni_conv_params P) {
           if (iy < P.Hin && ix < P.Win)
             v = *reinterpret_cast<const u32x4_t*>(x + (((int64_t)a_b[i] * P.Hin + iy) * P.Win + ix) * P.Cin + ci);
         } else {
+        if (P.x_padded) {
+          // the input carries a one-pixel zero border ([Hin + 2][Win + 2] raster): no bounds to check
+          v = *reinterpret_cast<const u32x4_t*>(x + (((int64_t)a_b[i] * (P.Hin + 2) + a_oy[i] + ky + 1 - pad) * (P.Win + 2) +
+                                                     a_ox[i] + kx + 1 - pad) * P.Cin + ci);
+        } else {
         const int uy = a_oy[i] + ky - pad, ux = a_ox[i] + kx - pad;
         if (uy >= 0 && uy < Hout && ux >= 0 && ux < Wout) {
           const int iy = P.upsample2x ? (uy >> 1) : uy, ix = P.upsample2x ? (ux >> 1) : ux;
           v = *reinterpret_cast<const u32x4_t*>(x + (((int64_t)a_b[i] * P.Hin + iy) * P.Win + ix) * P.Cin + ci);
+        }
         }
         }
       }
@@ -157,6 +163,236 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const omni_conv_params P) {
         for (int j = 0; j < nv; ++j) dst[j] = f32_to_bf16_bits(v[j]);
       }
     }
+}
+
+// ---- 3x3 / 1x1 convolution over ZERO-BORDERED rasters: a GEMM with nine shifted A matrices ------------------------------
+// Activations carry a one-pixel zero border: [B][Hp = H + 2][Wp = W + 2][C].  Over the bordered raster a 3x3 convolution is
+//   y[m] = sum over taps t of  x[m + (ky - 1) * Wp + (kx - 1)] . W_t^T            (m = py * Wp + px, all of the raster)
+// i.e. a GEMM whose A operand for k-tile (tap, channel chunk) is the SAME row-major [pixels][Cin] matrix at a constant row
+// offset: every A tile is a contiguous block of rows, fetched by LDS-DMA (no gather, no bounds logic: rows before / behind
+// the image are outside the buffer descriptor and land as zeros).  Only interior pixels are computed; the kernel also writes
+// the zero border of y (the next layer's padding; the norm kernel maps 0 to 0).
+// Workgroup = 8 waves (two per SIMD), wave tile 64 pixels x 96 channels (2 x 3 MFMA 32x32x16 tiles, operands swapped so a
+// lane owns a pixel and 4 consecutive channels per register quad); WM x WN waves: 4 x 2 (256 px x 192 ch, Cout >= 192) or
+// 8 x 1 (512 px x 96 ch).  K-tile = 32 channels of one tap ROW (ky): the A tile holds pixels m0 - 1 .. m0 + MT + 14 of the
+// ky-shifted raster and serves the three kx taps at row offsets 0 / 1 / 2 (3 instead of 9 A tiles through L2 per channel
+// chunk; 36 MFMAs per wave between barriers).  Two LDS stages, ONE barrier per K-tile (the next K-tile's DMA is issued right
+// behind it and lands during this one's 36 MFMAs; a third stage measured no gain).  LDS rows are 64 B with the 16-B chunk index XORed by
+// (row >> 2) & 3 (applied on the global-address side of the DMA): ds_read_b128 fragment reads are conflict-free at any
+// row offset (16 consecutive rows always hit 16 different (row & 3, chunk) slots).
+OMNI_DEVINL u32x4_t conv_srd(const void* base, uint64_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  u32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);     // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0xffffffffull ? 0xffffffffull : bytes));
+  r[3] = 0x00020000u;
+  return r;
+}
+// LDS-DMA of one 1-KiB piece: lane L -> LDS byte lds_addr + 16 L; the whole (possibly "negative" = wrapped) byte offset is in
+// the VGPR, so the descriptor's range check sees all of it
+OMNI_DEVINL void conv_dma16(const u32x4_t& srd, uint32_t voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(srd) : "memory");
+}
+
+constexpr int CONV_MAX_SEG = 4;                                  // runs per tile
+// PB = 32-pixel blocks per wave.  PB = 2: K-tile of 32 channels (64-B LDS rows); PB = 4: 16 channels (32-B rows) — the wave
+// tile 128 px x 96 ch reads 7 fragments per 12 MFMAs instead of 5 per 6 (the kernel is LDS-read bound: 8 waves x 5 KiB per
+// 192 MFMA cycles is 83 % of the LDS pipe) at the same 36 MFMAs per wave between barriers.
+template <int WM, int WN, int PB>
+constexpr int conv_lds_bytes() {
+  constexpr int RB = PB == 4 ? 32 : 64, RPP = 1024 / RB;
+  return 2 * ((32 * PB * WM) / RPP + CONV_MAX_SEG + 3 * ((96 * WN) / RPP)) * 1024;
+}
+
+// Tiles are made of RUNS of interior pixels: a run = L consecutive pixels of one image row (L a multiple of the wave's pixel
+// count, chosen by the launcher: the row width when it fits), a tile = MT / L runs.  Border pixels are never computed, so
+// power-of-two images give whole numbers of tiles per round of 256 CUs (over the full bordered raster 258^2 needs 2.02 rounds
+// = 3); the zero border of y is written by the workgroups whose runs touch it.
+template <int WM, int WN, int PB>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_bordered_kernel(const omni_conv_params P, int L) {
+  constexpr int NW = WM * WN, MT = 32 * PB * WM, NT = 96 * WN;
+  constexpr int KC = PB == 4 ? 16 : 32;                          // channels per K-tile
+  constexpr int RB = KC * 2, RPP = 1024 / RB;                    // LDS row bytes; rows per 1-KiB DMA piece
+  constexpr int A_MAX = MT / RPP + CONV_MAX_SEG;                 // every run carries L + RPP rows: pixels x0 - 1 .. x0 + L + RPP - 2
+  constexpr int W_PIECES = NT / RPP;                             // per kx tap
+  constexpr int STAGE = (A_MAX + 3 * W_PIECES) * 1024;
+  static_assert(2 * STAGE <= 160 * 1024, "two stages must fit the CU's LDS");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM;
+  const int Hp = P.Hin + 2, Wp = P.Win + 2;
+  const int npix = Hp * Wp;                                      // bordered raster of ONE image
+  const int nk = P.ksize, cpt = P.Cin / KC;                      // taps per axis; K-tiles per tap row
+  const int nkt = nk * cpt;                                      // K-tile = (ky, channel chunk): all kx taps of it
+  const int Ktot = nk * nk * P.Cin;
+  const int seg = MT / L, rp = L / RPP + 1;                      // runs per tile; DMA pieces per run
+  const int rpr = (P.Win + L - 1) / L, nruns = P.Hin * rpr;      // runs per image row; runs per image
+  const int a_pieces = seg * rp;
+  const int run0 = blockIdx.x * seg, n0 = blockIdx.y * NT, img = blockIdx.z;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+  const u32x4_t x_srd = conv_srd(P.x + (int64_t)img * npix * P.Cin, (uint64_t)npix * P.Cin * 2);
+  const u32x4_t w_srd = conv_srd(P.w, (uint64_t)P.Cout * Ktot * 2);
+  // LDS rows hold RB / 16 chunks of 16 B; chunk index XOR swizzle: 64-B rows (r >> 2) & 3, 32-B rows (r >> 3) & 1 — in both
+  // cases 16 consecutive rows (at ANY start: the kx taps read at row offsets 0 / 1 / 2) hit 16 different 16-B bank groups.
+  // DMA side: lane -> row-in-piece lane / (RB / 16), LDS chunk lane % (RB / 16) holds the logical chunk XORed the same way.
+  constexpr int CPR = RB / 16;                                   // chunks per row: 4 or 2
+  const int lrow = lane / CPR;
+  const uint32_t lc16 = (uint32_t)(((lane % CPR) ^ (PB == 4 ? (lrow >> 3) & 1 : (lrow >> 2) & 3)) * 16);
+  const uint32_t a_lane = (uint32_t)(lrow * P.Cin * 2) + lc16;
+  const uint32_t w_lane = (uint32_t)(lrow * Ktot * 2) + lc16;
+  // raster index of the pixel LEFT of run r's first pixel (runs past the image repeat the last one: computed, never stored)
+  auto run_origin = [&](int r) {
+    const int run = min(run0 + r, nruns - 1);
+    const int y = run / rpr;
+    return (y + 1) * Wp + (run - y * rpr) * L;
+  };
+
+  // K-tile (ky, cc): per run ONE A block — rows origin + (ky - 1) Wp .. of channel chunk cc; the kx = 0, 1, 2 taps read it at
+  // row offsets 0, 1, 2 (a third of the L2 -> LDS traffic of one tile per tap) — and the W rows of its nk taps.
+  auto issue = [&](int ky, int cc, int slot) {
+    const int shift = nk == 3 ? (ky - 1) * Wp : 0;
+    const uint32_t sbase = lds0 + slot * STAGE;
+    for (int g = wave; g < a_pieces + nk * W_PIECES; g += NW) {
+      if (g < a_pieces) {
+        const int r = g / rp, j = g - r * rp;
+        // modulo-2^32 arithmetic: a row before the image wraps to just below 2^32, past the descriptor's range (the launcher
+        // keeps the image 16 MiB short of 4 GiB) -> zeros
+        const uint32_t row_bytes = (uint32_t)(run_origin(r) + RPP * j + shift) * (uint32_t)(P.Cin * 2) + (uint32_t)(cc * RB);
+        conv_dma16(x_srd, a_lane + row_bytes, sbase + g * 1024);
+      } else {
+        const int q = g - a_pieces, kx = q / W_PIECES, rblk = q - kx * W_PIECES;
+        const uint32_t row_bytes = (uint32_t)(n0 + RPP * rblk) * (uint32_t)(Ktot * 2) + (uint32_t)(((ky * nk + kx) * P.Cin + cc * KC) * 2);
+        conv_dma16(w_srd, w_lane + row_bytes, sbase + (A_MAX + q) * 1024);
+      }
+    }
+  };
+
+  f32x16_t acc[PB][3];
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[pb][nb][i] = 0.f;
+
+  auto frag_addr = [&](int r, int c) {
+    return (uint32_t)(r * RB + ((c ^ (PB == 4 ? (r >> 3) & 1 : (r >> 2) & 3)) << 4));
+  };
+  uint32_t w_rd[3][KC / 16];
+#pragma unroll
+  for (int ks = 0; ks < KC / 16; ++ks)
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) w_rd[nb][ks] = (uint32_t)(A_MAX * 1024) + frag_addr(wn * 96 + nb * 32 + l31, ks * 2 + hi);
+  // this wave's 32 PB pixels lie in ONE run (L is a multiple of that): run wr, pixels wi .. of it
+  const int wr = (wm * 32 * PB) / L, wi = wm * 32 * PB - wr * L;
+  const int a_row0 = wr * (L + RPP) + wi + l31;                  // LDS row of pixel block 0's kx = 0 operand
+
+  int iky = 0, icc = 0;                                          // (ky, chunk) of the next K-tile to issue
+  auto issue_next = [&](int kt) {
+    issue(iky, icc, kt & 1);
+    if (++icc == cpt) { icc = 0; ++iky; }
+  };
+  issue_next(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of K-tile kt (the only ones in flight)
+    __syncthreads();                                             // K-tile kt is in LDS; everyone is done with K-tile kt-1's slot
+    if (kt + 1 < nkt) issue_next(kt + 1);
+    const char* st = smem + (kt & 1) * STAGE;
+    for (int kx = 0; kx < nk; ++kx) {
+      const int dx = nk == 3 ? kx : 1;                           // block row 0 is the pixel left of the run
+      const char* wst = st + kx * (W_PIECES * 1024);
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) {
+        bf16x8_t af[PB], wf[3];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) af[pb] = *reinterpret_cast<const bf16x8_t*>(st + frag_addr(a_row0 + pb * 32 + dx, ks * 2 + hi));
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) wf[nb] = *reinterpret_cast<const bf16x8_t*>(wst + w_rd[nb][ks]);
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb) acc[pb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], af[pb], acc[pb][nb], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: lane owns one pixel (column of the swapped product), channels nbase + 8 q + 4 hi + {0..3}
+  const bool do_clamp = P.clamp_lo < P.clamp_hi;
+  const int my_run = run0 + wr;
+  const int ry = my_run / rpr, rx0 = (my_run - ry * rpr) * L;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int x = rx0 + wi + pb * 32 + l31;
+    if (my_run >= nruns || x >= P.Win) continue;
+    const int64_t row = ((int64_t)img * npix + (ry + 1) * Wp + x + 1) * P.Cout;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 96 + nb * 32 + q * 8 + hi * 4;
+        if (n >= P.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[pb][nb][q * 4 + j];
+        if (P.bias) {
+          const u32x2_t b = *reinterpret_cast<const u32x2_t*>(P.bias + n);
+          v[0] += bf16_lo(b[0]); v[1] += bf16_hi(b[0]); v[2] += bf16_lo(b[1]); v[3] += bf16_hi(b[1]);
+        }
+        if (P.res) {
+          const u32x2_t r = *reinterpret_cast<const u32x2_t*>(P.res + row + n);
+          v[0] += bf16_lo(r[0]); v[1] += bf16_hi(r[0]); v[2] += bf16_lo(r[1]); v[3] += bf16_hi(r[1]);
+        }
+        if (do_clamp) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], P.clamp_lo), P.clamp_hi);
+        }
+        u32x2_t o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2_t*>(P.y + row + n) = o;
+      }
+  }
+
+  // the zero border of y, channels [n0, n0 + NT): every run writes the border pixels it touches — the pixel left of a row's
+  // first run and right of its last, the stretch above a run of the first image row / below one of the last (with the corners)
+  const int c8 = (min(NT, P.Cout - n0)) / 8;
+  auto zero_px = [&](int m_first, int count) {
+    for (int i = tid; i < count * c8; i += 64 * NW) {
+      const int px = i / c8, c = i - px * c8;
+      *reinterpret_cast<u32x4_t*>(P.y + ((int64_t)img * npix + m_first + px) * P.Cout + n0 + c * 8) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+  };
+  for (int r = 0; r < seg; ++r) {
+    const int run = run0 + r;
+    if (run >= nruns) break;
+    const int y = run / rpr, x0 = (run - y * rpr) * L, len = min(L, P.Win - x0);
+    const bool first = x0 == 0, last = x0 + len == P.Win;
+    if (first) zero_px((y + 1) * Wp, 1);
+    if (last) zero_px((y + 1) * Wp + P.Win + 1, 1);
+    if (y == 0) zero_px(x0 + 1 - (first ? 1 : 0), len + (first ? 1 : 0) + (last ? 1 : 0));
+    if (y == P.Hin - 1) zero_px((Hp - 1) * Wp + x0 + 1 - (first ? 1 : 0), len + (first ? 1 : 0) + (last ? 1 : 0));
+  }
+}
+
+// nearest-exact x2 upsample between zero-bordered rasters (QwenImageUpsample, autoencoder_kl_qwenimage.py:112-124):
+// y[oy + 1][ox + 1] = x[(oy >> 1) + 1][(ox >> 1) + 1], border zero.  16 B per lane, HBM-bound.
+__global__ __launch_bounds__(256) void upsample2x_bordered_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                                  int B, int H, int W, int C) {
+  const int c8 = C / 8, Ho = 2 * H + 2, Wo = 2 * W + 2;
+  const int64_t total = (int64_t)B * Ho * Wo * c8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % c8);
+    const int64_t p = i / c8;
+    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((int64_t)Wo * Ho));
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (oy >= 1 && oy <= 2 * H && ox >= 1 && ox <= 2 * W)
+      v = *reinterpret_cast<const u32x4_t*>(x + ((((int64_t)b * (H + 2) + ((oy - 1) >> 1) + 1) * (W + 2)) + ((ox - 1) >> 1) + 1) * C + c * 8);
+    *reinterpret_cast<u32x4_t*>(y + p * C + c * 8) = v;
+  }
 }
 
 // channel RMS-norm (+SiLU) over NHWC pixels: C/8 lanes per pixel (C % 8 == 0, C <= 512 -> <= 64 lanes)
@@ -254,6 +490,51 @@ extern "C" int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream) {
   const int Wout = p->upsample2x ? 2 * p->Win : (p->downsample2x ? p->Win / 2 : p->Win);
   const int64_t M = (int64_t)p->B * Hout * Wout;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (p->y_padded) {
+    // zero-bordered rasters in and out: the shifted-GEMM kernel
+    if (!p->x_padded || p->upsample2x || p->downsample2x || p->Cin % 32 || p->Cout % 8) return OMNI_ERR_UNSUPPORTED;
+    if (!omni_aligned16(p->y) || (p->bias && (reinterpret_cast<uintptr_t>(p->bias) & 7)) || (p->res && !omni_aligned16(p->res)))
+      return OMNI_ERR_ALIGN;
+    const int64_t npix = (int64_t)(p->Hin + 2) * (p->Win + 2);
+    if (npix * p->Cin * 2 >= (1ll << 32) - (1 << 24) || p->B > 65535) return OMNI_ERR_UNSUPPORTED;   // 32-bit DMA offsets per image
+    constexpr int lds_big2 = conv_lds_bytes<4, 2, 4>(), lds_small = conv_lds_bytes<4, 1, 2>();
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bordered_kernel<4, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              lds_big2) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bordered_kernel<4, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              lds_small) != hipSuccess)
+        return OMNI_ERR_LAUNCH;
+      attr_set = true;
+    }
+    // run length: a multiple of the wave's pixel count `gran`, the row width when it fits the tile, tile / L <= CONV_MAX_SEG
+    auto run_len = [&](int mt, int gran) {
+      int L = (p->Win + gran - 1) / gran * gran;
+      if (L > mt) L = mt;
+      while (mt % L || mt / L > CONV_MAX_SEG) L += gran;          // (mt / gran is a power of two: terminates at mt)
+      return L;
+    };
+    auto tiles_of = [&](int mt, int gran) {
+      const int L = run_len(mt, gran);
+      const int64_t runs = (int64_t)p->Hin * ((p->Win + L - 1) / L);
+      return (runs + mt / L - 1) / (mt / L);
+    };
+    // Cout >= 192: 128-pixel waves (8 waves = 512 px x 192 ch, one workgroup per CU) when they fill the chip at least once
+    // (+10 % over the small tiles at 258^2 / 514^2); else four-wave workgroups of 256 px x 96 ch, two per CU (for Cout = 96 the
+    // 8 x 1 arrangement of 128-pixel waves measured 443 vs 568 TF/s at 1026^2: the K loop is only nine K-tiles long there)
+    if (p->Cout >= 192 && p->Cin % 16 == 0 && tiles_of(512, 128) * ((p->Cout + 191) / 192) * p->B >= 256) {
+      const int L = run_len(512, 128);
+      hipLaunchKernelGGL((conv_bordered_kernel<4, 2, 4>), dim3((unsigned)tiles_of(512, 128), (p->Cout + 191) / 192, p->B), dim3(512),
+                         lds_big2, s, *p, L);
+    } else {
+      const int L = run_len(256, 64);
+      hipLaunchKernelGGL((conv_bordered_kernel<4, 1, 2>), dim3((unsigned)tiles_of(256, 64), (p->Cout + 95) / 96, p->B), dim3(256),
+                         lds_small, s, *p, L);
+    }
+    OMNI_CHECK_LAUNCH();
+    return OMNI_OK;
+  }
+  if (p->x_padded && (p->upsample2x || p->downsample2x)) return OMNI_ERR_UNSUPPORTED;
   if (p->Cout % 96 == 0) {
     hipLaunchKernelGGL(conv2d_kernel<3>, dim3((unsigned)((M + CBM - 1) / CBM), p->Cout / 96), dim3(256), 0, s, *p);
   } else {
@@ -290,6 +571,19 @@ extern "C" int omni_softmax_rows(omni_bf16* s, int64_t ld, int64_t rows, int32_t
   if (!omni_aligned16(s) || (ld % 8)) return OMNI_ERR_ALIGN;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, static_cast<hipStream_t>(stream), s, ld,
                      cols, scale);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+extern "C" int omni_vae_upsample2x_bordered(const omni_bf16* x, omni_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                                            omni_stream stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return OMNI_ERR_BAD_ARG;
+  if (C % 8) return OMNI_ERR_UNSUPPORTED;
+  if (!omni_aligned16(x) || !omni_aligned16(y)) return OMNI_ERR_ALIGN;
+  const int64_t total = (int64_t)B * (2 * H + 2) * (2 * W + 2) * (C / 8);
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(upsample2x_bordered_kernel, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, y, B, H, W, C);
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }

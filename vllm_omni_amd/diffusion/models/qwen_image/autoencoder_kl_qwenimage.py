@@ -276,11 +276,60 @@ class AutoencoderKLQwenImage(nn.Module):
         x = ops.vae_conv2d(x, W["quant_conv.weight"], W["quant_conv.bias"])
         return x[..., : c.z_dim].permute(0, 3, 1, 2).unsqueeze(2).contiguous()   # mean half, [B, 16, 1, h, w]
 
+    # ---- decode over ZERO-BORDERED rasters -------------------------------------------------------------------------
+    # Between conv_in and conv_out every activation is [B, H + 2, W + 2, C] with a resident one-pixel zero border (the
+    # reference re-creates it with F.pad in front of every conv, autoencoder_kl_qwenimage.py:80-84): a 3x3 conv is then a
+    # GEMM over nine row-shifted views of the same matrix, fed by plain LDS-DMA (vae.hip conv_bordered_kernel).  The conv
+    # kernel writes zeros at border positions, the norm maps 0 to 0, the upsample kernel writes its own border.
+    def _res_block_b(self, W, pre, x):
+        kw = dict(x_bordered=True, y_bordered=True)
+        h = ops.vae_conv2d(x, W[pre + ".conv_shortcut.weight"], W[pre + ".conv_shortcut.bias"], **kw) \
+            if (pre + ".conv_shortcut.weight") in W else x
+        y = ops.vae_rmsnorm_silu(x, W[pre + ".norm1.gamma"])
+        y = ops.vae_conv2d(y, W[pre + ".conv1.weight"], W[pre + ".conv1.bias"], **kw)
+        y = ops.vae_rmsnorm_silu(y, W[pre + ".norm2.gamma"])
+        return ops.vae_conv2d(y, W[pre + ".conv2.weight"], W[pre + ".conv2.bias"], res=h, **kw)
+
+    @staticmethod
+    def _add_border(x):
+        return torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))
+
+    def _bordered_ok(self) -> bool:
+        c = self.config
+        return all((c.base_dim * m) % 32 == 0 for m in c.dim_mult)
+
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = False):
         """z [B, z_dim, 1, h, w] -> [B, 3, 1, 8h, 8w] in [-1, 1] (reference _decode :839-863, one frame)."""
         if z.dim() != 5 or z.shape[2] != 1:
             raise NotImplementedError("single-frame (image) decode only")
+        if not self._bordered_ok():
+            return self._decode_plain(z)
+        W = self._pack()
+        c = self.config
+        x = z[:, :, 0].permute(0, 2, 3, 1).contiguous().to(BF16)      # NHWC
+        x = ops.vae_conv2d(x, W["post_quant_conv.weight"], W["post_quant_conv.bias"])
+        x = ops.vae_conv2d(x, W["decoder.conv_in.weight"], W["decoder.conv_in.bias"])      # Cin = z_dim: the gather kernel
+        x = self._add_border(x)
+        x = self._res_block_b(W, "decoder.mid_block.resnets.0", x)
+        x = self._add_border(self._attn_block(W, "decoder.mid_block.attentions.0", x[:, 1:-1, 1:-1].contiguous()))
+        x = self._res_block_b(W, "decoder.mid_block.resnets.1", x)
+        n_up = len(c.dim_mult)
+        for i in range(n_up):
+            for j in range(c.num_res_blocks + 1):
+                x = self._res_block_b(W, f"decoder.up_blocks.{i}.resnets.{j}", x)
+            if i != n_up - 1:
+                u = f"decoder.up_blocks.{i}.upsamplers.0.resample.1"
+                x = ops.vae_conv2d(ops.vae_upsample2x_bordered(x), W[u + ".weight"], W[u + ".bias"], x_bordered=True, y_bordered=True)
+        x = ops.vae_rmsnorm_silu(x, W["decoder.norm_out.gamma"])
+        x = ops.vae_conv2d(x, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], clamp=(-1.0, 1.0), x_bordered=True)
+        img = x.permute(0, 3, 1, 2).unsqueeze(2)                       # [B, 3, 1, H, W]
+        return (img,)
+
+    @torch.no_grad()
+    def _decode_plain(self, z: torch.Tensor):
+        """The same network over plain NHWC rasters (the gather kernel does the zero padding per tap): channel counts the
+        bordered kernel is not built for."""
         W = self._pack()
         c = self.config
         x = z[:, :, 0].permute(0, 2, 3, 1).contiguous().to(BF16)      # NHWC

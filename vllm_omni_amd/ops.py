@@ -254,20 +254,36 @@ def cfg_euler_step_(latents, pos, neg, true_cfg_scale: float, dt: torch.Tensor, 
 
 
 def vae_conv2d(x, w, bias=None, *, gamma=None, silu=True, res=None, upsample2x=False, downsample2x=False, clamp=None,
-               out=None):
+               out=None, x_bordered=False, y_bordered=False):
     """NHWC bf16 conv (3x3 pad 1 or 1x1): x [B,H,W,Cin], w [Cout,ks,ks,Cin].  downsample2x: the encoder's zero-pad
-    (right/bottom) + stride-2 3x3 conv."""
+    (right/bottom) + stride-2 3x3 conv.  x_bordered: x (and res) are zero-bordered rasters [B,H+2,W+2,C]; y_bordered: so is
+    the output (the decoder's LDS-DMA-fed shifted-GEMM kernel; needs x_bordered, Cin % 32 == 0, Cout % 8 == 0)."""
     B, Hin, Win, Cin = x.shape
+    if x_bordered:
+        Hin, Win = Hin - 2, Win - 2
     Cout, ks = w.shape[0], w.shape[1]
     Hout, Wout = (2 * Hin, 2 * Win) if upsample2x else ((Hin // 2, Win // 2) if downsample2x else (Hin, Win))
-    y = torch.empty(B, Hout, Wout, Cout, dtype=BF16, device=x.device) if out is None else out
+    if out is None:
+        y = torch.empty(B, Hout + 2 * int(y_bordered), Wout + 2 * int(y_bordered), Cout, dtype=BF16, device=x.device)
+    else:
+        y = out
     p = N.ConvParams()
     p.x, p.w, p.bias, p.gamma = _p(x.contiguous(), name="x"), _p(w, name="w"), _p(bias, name="bias"), _p(gamma)
     p.res, p.y = _p(res, name="res"), _p(y, name="y")
     p.B, p.Hin, p.Win, p.Cin, p.Cout, p.ksize = B, Hin, Win, Cin, Cout, ks
     p.upsample2x, p.silu, p.downsample2x = int(upsample2x), int(silu), int(downsample2x)
+    p.x_padded, p.y_padded = int(x_bordered), int(y_bordered)
     p.clamp_lo, p.clamp_hi = clamp if clamp else (0.0, 0.0)
     N.check(N.lib().omni_vae_conv2d(C.byref(p), _stream()), "omni_vae_conv2d")
+    return y
+
+
+def vae_upsample2x_bordered(x):
+    """Nearest-exact x2 upsample between zero-bordered rasters: [B,H+2,W+2,C] -> [B,2H+2,2W+2,C]."""
+    B, Hp, Wp, Cc = x.shape
+    y = torch.empty(B, 2 * (Hp - 2) + 2, 2 * (Wp - 2) + 2, Cc, dtype=BF16, device=x.device)
+    N.check(N.lib().omni_vae_upsample2x_bordered(_p(x.contiguous(), name="x"), _p(y), B, Hp - 2, Wp - 2, Cc, _stream()),
+            "omni_vae_upsample2x_bordered")
     return y
 
 
