@@ -73,6 +73,9 @@ constexpr int A_O = 0, A_Q = 128, A_K = 192;
 #ifndef OMNI_W64_XHALF_IN_P2
 #define OMNI_W64_XHALF_IN_P2 1
 #endif
+#ifndef OMNI_W64_IDLE_WAVES
+#define OMNI_W64_IDLE_WAVES 1   // waves without query rows skip the arithmetic (0: they compute on clamped rows, as before)
+#endif
 #ifndef OMNI_W64_ABL
 #define OMNI_W64_ABL 0          // dev-only timing ablations (WRONG results): 1 no DMA, 2 no end-of-tile wait + barrier, 4 no exp,
 #endif                          // 8 no LDS fragment reads, 16 no row max, 32 no MFMA
@@ -277,6 +280,28 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
   issue_K(2, 2);
   issue_V(0, 0);
   issue_V(1, 1);
+
+  // ---- a wave WITHOUT query rows (the item's last q-block: 4160 = 16 x 256 + 64 leaves three of four waves empty in one
+  // block of seventeen) only feeds the rings: the same DMA pieces, counted waits and barriers as the loop below, no MFMA, no
+  // exp — the matrix pipe's energy for rows nobody stores is what the power-capped part gives back as clock
+  if (OMNI_W64_IDLE_WAVES && qb * QBLK + wave * 64 >= seq_len) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // (tiles 0 .. 2 published)
+    __syncthreads();                                  // (every wave has K(0) in registers)
+    issue_K(3, 0);
+    __syncthreads();                                  // (end of the prologue)
+    int st = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      const int s1 = st == 2 ? 0 : st + 1, s2 = st == 0 ? 2 : st - 1;
+      issue_V(t + 2, s2);
+      issue_K(t + 4, s1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __syncthreads();
+      st = s1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
 
   // ---- Q~ fragments (B operand: lane holds query l31, d = ks*16 + hi*8 .. +8) -> a[128:191]; O <- 0
   {
