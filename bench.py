@@ -180,7 +180,7 @@ def _engine_pipeline(layers: int, R: int):
 
 def engine_line(R: int, layers: int, static_images_per_sec: float) -> dict:
     """The SERVING path on one GPU: DiffusionEngine -> WorkerProc -> ContinuousStepBatcher (static per-composition buffers,
-    device-side schedule vectors; reference loop shape gpu_worker.py:226-290), fed 2R requests whose arrivals are staggered, so
+    device-side schedule vectors; reference loop shape gpu_worker.py:226-290), fed 4R requests whose arrivals are staggered, so
     the running batch is re-composed while requests are mid-loop.  Images are decoded in the worker and returned through its
     result queue, as a server would."""
     import functools
@@ -206,7 +206,7 @@ def engine_line(R: int, layers: int, static_images_per_sec: float) -> dict:
         for o in eng.add_req_and_wait_for_response([req() for _ in range(R)]):       # warm-up: one full batch
             if o.error:
                 raise RuntimeError(o.error)
-        n, gap = 2 * R, 0.25
+        n, gap = 4 * R, 0.1                                  # four batches' worth: the ramps (partial batches at both ends) are ~1/4 of the run
         t0 = time.perf_counter()
         ids = []
         for i in range(n):                                   # one request every `gap` seconds: the batch grows while it runs
