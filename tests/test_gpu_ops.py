@@ -392,10 +392,11 @@ def test_flash_attention_forced_rescale_spike():
     assert rel_l2(got, ref) <= 4e-3
 
 
-@pytest.mark.parametrize("lens,H", [([1100, 300, 257, 65, 1, 647], 24), ([2100], 64), ([256, 512, 1000, 64, 63], 32)])
+@pytest.mark.parametrize("lens,H", [([1100, 300, 257, 65, 1, 647], 24), ([2100], 64), ([256, 512, 1000, 64, 63], 32),
+                                    ([1056, 1057, 1088, 1089, 1055, 1072], 24)])   # last q-blocks of 32 / 33 / 64 / 65 / 31 / 48 rows
 def test_flash_attention_w64_kernel_varlen(lens, H):
     """Grids of >= 512 workgroups run the 64-queries-per-wave kernel (csrc/attention_w64.hip): ragged items, tails that are
-    not a multiple of 64 keys / 256 queries, items shorter than one tile."""
+    not a multiple of 64 keys / 256 queries, items shorter than one tile; waves without query rows only feed the rings."""
     from vllm_omni_amd import ops
 
     assert len(lens) * H * ((max(lens) + 255) // 256) >= 512
