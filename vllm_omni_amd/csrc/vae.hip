@@ -1,9 +1,15 @@
 // VAE-decode kernels for gfx950 (AutoencoderKLQwenImage.decode for one frame).
 //
-//  * omni_vae_conv2d: 3x3 (pad 1) / 1x1 convolution as an implicit GEMM on v_mfma_f32_32x32x16_bf16.
+//  * omni_vae_conv2d: 3x3 (pad 1) / 1x1 convolution on v_mfma_f32_32x32x16_bf16.
 //    Activations are NHWC bf16, weights [Cout][ky][kx][Cin] (the temporal slice [-1] of the reference's causal
 //    Conv3d weights: for a single frame the two zero front-pad frames make the other two slices dead,
 //    autoencoder_kl_qwenimage.py:69-84 — executing them, as the reference does, is 3x the MACs).
+//    Two kernels behind the one entry point:
+//    - conv_bordered_kernel (x_padded && y_padded: the decoder's layers between conv_in and conv_out): activations are
+//      zero-bordered rasters and the convolution is a GEMM over row-shifted views of one matrix, LDS-DMA fed — see the
+//      comment above that kernel;
+//    - conv2d_kernel (everything else: conv_in, conv_out, the encoder, fused x2 upsample / stride-2): an implicit GEMM with
+//      the im2col gather in the global->register stage:
 //    M = output pixels, N = Cout, K = ks*ks*Cin.  Workgroup tile 128 pixels x (32*NB) channels, 4 waves,
 //    each wave 32 pixels x 32*NB channels; swapped MFMA operands so a lane owns one pixel and 4 consecutive
 //    channels per register quad (8-byte NHWC stores).  The im2col gather (with optional fused nearest-exact
@@ -11,6 +17,7 @@
 //    bias, residual add and clamp are fused in the epilogue.
 //  * omni_vae_rmsnorm_silu: y = silu(x / max(||x||_2, 1e-12) * sqrt(C) * gamma) per pixel (QwenImageRMS_norm
 //    :108-109 + SiLU), 16 B per lane.
+//  * omni_vae_upsample2x_bordered: nearest-exact x2 between zero-bordered rasters.
 //  * omni_softmax_rows: in-place row softmax (scale folded) for the single-head mid-block attention.
 // Roofline: conv = MFMA-bound for Cin,Cout >= 96; norm/softmax = HBM-bound.
 #include "common.h"
