@@ -448,17 +448,23 @@ class QwenImagePipeline(nn.Module):
 
     # ------------------------------------------------------------------ continuous step batching (step_batcher.py)
     def begin_sample(self, a) -> None:
-        """Schedule of one sample: per-step model timestep (bf16-rounded t/1000) and dt, kept on the HOST (a step uploads one
-        small pinned vector for the whole group instead of gathering R device scalars)."""
+        """Schedule of one sample: per-step model timestep (bf16-rounded t/1000) and dt as DEVICE vectors.  A step reads its
+        values from per-slot device tables with a device-side step counter: nothing a step needs lives in host memory, so the
+        host may enqueue many steps ahead of the GPU (it does: ~10 ms to enqueue a 540-ms step) without racing a pending
+        host-to-device copy."""
         sm = a.sample
         sch = FlowMatchEulerSchedule(self.scheduler.config)
         ts = sch.set_timesteps(sm["steps"], sm["lat"].shape[0])
         a.n_steps = len(ts)
-        a.state = dict(sig_h=sch.model_timestep(ts).float().tolist(), dt_h=sch.dt().float().tolist(),
+        if a.n_steps >= self.SERVE_MAX_STEPS:
+            raise NotImplementedError(f"{a.n_steps} denoising steps: the step batcher's schedule tables hold {self.SERVE_MAX_STEPS - 1}")
+        a.state = dict(sig_d=sch.model_timestep(ts).float().to(self.device), dt_d=sch.dt().float().to(self.device),
                        lat=sm["lat"].to(self.device, BF16).clone(), pos=sm["pos"].to(self.device, BF16),
                        neg=None if sm["neg"] is None else sm["neg"].to(self.device, BF16),
                        cond=None if sm.get("cond") is None else sm["cond"].to(self.device, BF16),
                        home=None, tc=None)
+
+    SERVE_MAX_STEPS = 1024
 
     @staticmethod
     def batch_key(a):
@@ -497,8 +503,10 @@ class QwenImagePipeline(nn.Module):
                   pred_c=torch.empty(n_items * S, Cl, dtype=BF16, device=dev) if S_c else None,
                   prompt=torch.zeros(sum(lens), tr.joint_attention_dim, dtype=BF16, device=dev),
                   sig=torch.zeros(R, dtype=torch.float32, device=dev), dt=torch.zeros(R, dtype=torch.float32, device=dev),
-                  sig_h=torch.zeros(R, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(R),
-                  dt_h=torch.zeros(R, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(R), tc=None)
+                  # per-slot schedules and step counters, all on the device (see begin_sample)
+                  sig_tab=torch.zeros(R, self.SERVE_MAX_STEPS, dtype=torch.float32, device=dev),
+                  dt_tab=torch.zeros(R, self.SERVE_MAX_STEPS, dtype=torch.float32, device=dev),
+                  step_idx=torch.zeros(R, dtype=torch.int64, device=dev), tc=None)
         if tcfg is not None:
             from ...cache.teacache.native import TeaCacheDeviceState
 
@@ -535,6 +543,10 @@ class QwenImagePipeline(nn.Module):
             self._export_sample(occ)
         S, S_c, R, do_cfg = st["S"], st["S_c"], st["R"], st["do_cfg"]
         st["lat"][r * S:(r + 1) * S].copy_(a.state["lat"])
+        n = a.state["sig_d"].shape[0]
+        st["sig_tab"][r, :n].copy_(a.state["sig_d"])
+        st["dt_tab"][r, :n].copy_(a.state["dt_d"])
+        st["step_idx"][r:r + 1].fill_(a.step)               # (a kernel argument, not a host buffer read later)
         off = st["txt_off"]
         st["prompt"][off[r]:off[r + 1]].copy_(a.state["pos"])
         if do_cfg:
@@ -557,6 +569,9 @@ class QwenImagePipeline(nn.Module):
         R, S, S_c, do_cfg, n_items = st["R"], st["S"], st["S_c"], st["do_cfg"], st["n_items"]
         lat, lat_in, pred = st["lat"], st["lat_in"], st["pred"]
         Cl = lat.shape[1]
+        idx = st["step_idx"].clamp(max=self.SERVE_MAX_STEPS - 1).view(R, 1)
+        st["sig"].copy_(st["sig_tab"].gather(1, idx).view(R))
+        st["dt"].copy_(st["dt_tab"].gather(1, idx).view(R))
         if S_c:
             li = lat_in.view(n_items, S + S_c, Cl)
             li[:R, :S].copy_(lat.view(R, S, Cl))
@@ -572,6 +587,7 @@ class QwenImagePipeline(nn.Module):
             st["pred_c"].view(n_items, S, Cl).copy_(pred.view(n_items, S + S_c, Cl)[:, :S])
             pr = st["pred_c"]
         ops.cfg_euler_step_(lat, pr[: R * S], pr[R * S:] if do_cfg else None, st["cfg"], st["dt"], dt_rows_per_item=S)
+        st["step_idx"].add_(1)
 
     @torch.no_grad()
     def denoise_one_step(self, group: list) -> None:
@@ -585,11 +601,6 @@ class QwenImagePipeline(nn.Module):
         st = self._serve_state(group)
         for r, a in enumerate(group):
             self._import_sample(a, st, r)
-        for r, a in enumerate(group):
-            st["sig_h"][r] = a.state["sig_h"][a.step]
-            st["dt_h"][r] = a.state["dt_h"][a.step]
-        st["sig"].copy_(st["sig_h"], non_blocking=True)
-        st["dt"].copy_(st["dt_h"], non_blocking=True)
         tr.do_true_cfg = st["do_cfg"]
         self.last_teacache_state = st["tc"]
         if not self._use_graph(st["n_items"] * st["S"]):
@@ -599,11 +610,10 @@ class QwenImagePipeline(nn.Module):
         if st["graph"] is None or st["gen"] != tr._native_gen:
             # warm-up on a side stream, then capture (see _denoise); both advance `lat` and the TeaCache state of the resident
             # samples, so those are saved and restored around them
-            saved_lat = st["lat"].clone()
+            saved_lat, saved_idx = st["lat"].clone(), st["step_idx"].clone()
             saved_tc = None
             if st["tc"] is not None:
                 saved_tc = [st["tc"].export_item(i) for i in range(st["n_items"])]
-            st["dt"].zero_()
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -615,10 +625,10 @@ class QwenImagePipeline(nn.Module):
             st["graph"], st["gen"] = g, tr._native_gen
             st["keepalive"] = (st["prepared"], tr._workspace, tr._native)
             st["lat"].copy_(saved_lat)
+            st["step_idx"].copy_(saved_idx)
             if saved_tc is not None:
                 for i, sv in enumerate(saved_tc):
                     st["tc"].import_item(i, sv)
-            st["dt"].copy_(st["dt_h"], non_blocking=True)
         st["graph"].replay()
 
     def sample_result(self, a) -> torch.Tensor:
