@@ -190,9 +190,9 @@ def test_step_batcher_is_correct_when_the_host_runs_ahead_of_the_gpu():
 
     ref, _, _ = serve(sync=True)
     got, t_host, t_all = serve(sync=False)
-    if t_all < 1.2 * t_host:                            # the premise: the host really was ahead of the GPU
-        pytest.skip(f"the host did not run ahead of the GPU on this box ({t_host:.3f} s of {t_all:.3f} s)")
     for k in reqs:
         assert torch.equal(got[k], ref[k]), k               # same kernels, same order: any difference is a host / device race
         assert rel_l2(got[k], solo[k]) <= 5e-2, k           # vs the solo loop: other GEMM row grouping, amplified by true-CFG 4.0
                                                             # over 5-9 steps of a random-weight DiT (1-2e-2 measured)
+    if t_all < 1.2 * t_host:                            # the premise: the host really was ahead of the GPU
+        pytest.skip(f"results equal, but the host did not run ahead of the GPU on this box ({t_host:.3f} s of {t_all:.3f} s)")
