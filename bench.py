@@ -20,11 +20,11 @@ in HBM before the timed region.  value = N*K*R images / max-over-ranks seconds. 
 (weak scaling): no collective inside the denoise loop.
 
 Also printed in the same JSON line:
-  roofline     — dominant kernel = gemm_bf16_ring_kernel<GELU> (MLP up-projection, 27 % of the DiT FLOPs, one shape
+  roofline     — dominant kernel = gemm_bf16_pp_kernel<GELU> (the ping-pong MFMA GEMM; MLP up-projection, 27 % of the DiT FLOPs, one shape
                  per launch so rocprofv3's per-kernel average is shape-pure): algorithmic 2*M*N*K flop per launch
                  / average launch duration measured here with HIP events on the launch stream.
   cpu_baseline — the fp32 CPU oracle (kind "port": /root/reference does not exist on the GPU box, so the shim-imported
-                 reference cannot be timed there) on this box's host cores on a bounded sample of 2 full-width blocks,
+                 reference cannot be timed there) on this box's host cores on a bounded sample of 4 full-width blocks,
                  extrapolated linearly in layers/forwards (rank 0, N=1 only).
   secondary    — (N=1 only) the no-CFG variant of the same workload (1 forward per step), BASELINE config 1
                  (256x256, 4 steps, batch 1) eager vs hipGraph replay, TeaCache rel_l1_thresh 0.2, and the SERVING path:

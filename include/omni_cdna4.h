@@ -27,6 +27,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef uint16_t omni_bf16;
 typedef void* omni_stream; /* hipStream_t */
@@ -411,6 +415,9 @@ int omni_dit_block_qkv(const omni_dit_weights* w, int32_t layer, const omni_dit_
 int omni_dit_block_post(const omni_dit_weights* w, int32_t layer, const omni_dit_batch* b, omni_bf16* hidden_img,
                         omni_bf16* hidden_txt, const omni_bf16* temb, const omni_bf16* attn, omni_stream stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,21 @@ def test_library_exports_every_declared_symbol():
     assert dll.omni_abi_version() == _native.ABI_VERSION
 
 
+def test_integration_doc_asserts_the_current_abi_version():
+    """INTEGRATION.md shows the reference-side binding; a maintainer copying its `assert omni_abi_version() == N` must get
+    the shipped library's number (round-3 verdict item 12: the doc said 4 while the library was at 8)."""
+    from vllm_omni_amd import _native
+
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    asserted = [int(v) for v in re.findall(r"omni_abi_version\(\)\s*==\s*(\d+)", doc)]
+    assert asserted, "INTEGRATION.md no longer shows the ABI assertion"
+    assert set(asserted) == {_native.ABI_VERSION}
+    src = open(os.path.join(ROOT, "vllm_omni_amd", "csrc", "dit_forward.hip")).read() + open(
+        os.path.join(ROOT, "vllm_omni_amd", "csrc", "elementwise.hip")).read()
+    m = re.search(r"omni_abi_version\(void\)\s*\{\s*return\s+(\d+)", src) or re.search(r"omni_abi_version\(\)\s*\{\s*return\s+(\d+)", src)
+    assert m and int(m.group(1)) == _native.ABI_VERSION
+
+
 def test_product_library_has_no_switches():
     """Round-2 verdict: dev state in the product .so.  The library exports exactly the header's symbols (no omni_dev_* setters)
     and does not import getenv: tuning knobs and development kernel families exist only in -DOMNI_DEV builds."""
@@ -40,9 +55,14 @@ def test_product_library_has_no_switches():
     dyn = subprocess.run(["nm", "-D", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in dyn.splitlines() if " T " in ln}
     assert not [s for s in exported if s.startswith("omni_dev_")], exported
-    assert {s for s in exported if s.startswith("omni_") and not s.startswith("omni_internal_")} == set(N.PROTOTYPES)
+    # built with -fvisibility=hidden: the dynamic symbol table's defined functions are EXACTLY the header's (no C++-mangled
+    # omni_internal_* helpers, round-3 verdict item 15)
+    assert exported == set(N.PROTOTYPES), sorted(exported ^ set(N.PROTOTYPES))
     undefined = {ln.split()[-1].split("@")[0] for ln in dyn.splitlines() if " U " in ln}
     assert "getenv" not in undefined and "secure_getenv" not in undefined
+    # ... and neither does the product loader: the library path is not taken from the environment (dev A/B runs go through
+    # tools/devlib.py, which assigns _native.LIB_PATH)
+    assert "os.environ" not in open(N.__file__).read() and "getenv" not in open(N.__file__).read()
 
 
 def test_ctypes_struct_layout_matches_c():
@@ -514,3 +534,21 @@ def test_build_rejects_compiler_allocated_agprs_in_kernels_that_own_them():
     csrc = os.path.dirname(csrc_build.__file__)
     marked = sorted(f for f in os.listdir(csrc) if f.endswith(".hip") and "OMNI_OWNS_AGPRS" in open(os.path.join(csrc, f)).read())
     assert "attention_w64.hip" in marked
+
+
+def test_hot_gemm_kernels_do_not_spill_sgprs_inside_the_k_loop():
+    """Round-3 verdict item 16: several GEMM kernels report SGPR spills (to VGPR lanes, no scratch).  They all belong to the ring
+    FALLBACK kernel; every instance of the ping-pong kernel (the one the DiT runs) has zero lane-spill operations inside its
+    MFMA loops.  Checked on the device assembly hipcc produces for gemm.hip."""
+    from vllm_omni_amd.csrc import build as B
+
+    fake = ["k1:", ".LBB0_1:", "\tv_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]", "\tv_writelane_b32 v9, s4, 3",
+            "\ts_cbranch_scc1 .LBB0_1", "\tv_readlane_b32 s4, v9, 3", ".Lfunc_end0:",
+            "k2:", ".LBB1_1:", "\tv_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]", "\ts_cbranch_scc1 .LBB1_1",
+            "\tv_writelane_b32 v9, s4, 3", ".Lfunc_end1:"]
+    assert B.mfma_loop_lane_spills(fake) == {"k1": 1, "k2": 0}
+    asm = B.device_asm(os.path.join(ROOT, "vllm_omni_amd", "csrc", "gemm.hip"))
+    spills = B.mfma_loop_lane_spills(asm)
+    pp = {k: v for k, v in spills.items() if "gemm_bf16_pp_kernel" in k}
+    assert len(pp) >= 10, sorted(spills)
+    assert all(v == 0 for v in pp.values()), {k: v for k, v in pp.items() if v}

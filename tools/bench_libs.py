@@ -77,8 +77,8 @@ res = {l: [] for l in libs}
 for _ in range(rounds):
     for l in libs:
         path, *knobs = l.split("@")
-        env = dict(os.environ, OMNI_CDNA4_LIB=os.path.abspath(path), **dict(kv.split("=", 1) for kv in knobs))
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        env = dict(os.environ, OMNI_DEV_LIB=os.path.abspath(path), **dict(kv.split("=", 1) for kv in knobs))
+        out = subprocess.run([sys.executable, "-c", "import tools.devlib\n" + code], env=env, capture_output=True, text=True)
         line = [x for x in out.stdout.splitlines() if x.startswith("RESULT")]
         if not line:
             print(l, "FAILED", out.stderr[-400:])

@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemm.hip", "attention.hip", "attention_w64.hip", "elementwise.hip", "vae.hip", "dit_forward.hip"]
 LIB = os.path.join(os.path.dirname(HERE), "libomni_cdna4.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden", "-Wno-unused-result"]
 
 
 def _stale(target: str, deps: list[str]) -> bool:
@@ -58,6 +58,51 @@ def agpr_violations(asm_lines) -> dict[str, list[tuple[int, str]]]:
                 out[fn] = hits
             fn, hits = None, []
     return out
+
+
+def mfma_loop_lane_spills(asm_lines) -> dict[str, int]:
+    """{function: max number of SGPR-spill lane operations (v_writelane / v_readlane) inside any loop that issues MFMAs}.
+
+    hipcc spills SGPRs to VGPR lanes (no scratch) when a kernel runs out of scalar registers; in an epilogue that is free, inside
+    the K-loop it is per-iteration VALU work on the MFMA issue port.  Round-3 verdict item 16 asked which it is for the GEMM
+    kernels: `tests/test_host_logic.py` compiles gemm.hip to assembly and asserts 0 for every gemm_bf16_pp_kernel instance (the
+    ring FALLBACK kernel does spill inside its loop; it runs only for shapes the ping-pong kernel does not take)."""
+    out: dict[str, int] = {}
+    fn, body = None, []
+    for line in asm_lines:
+        m = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if m and not m.group(1).startswith(".L"):
+            fn, body = m.group(1), []
+            continue
+        if fn is None:
+            continue
+        if line.startswith(".Lfunc_end"):
+            labels = {}
+            for j, ln in enumerate(body):
+                lm = re.match(r"^(\.LBB\d+_\d+):", ln)
+                if lm:
+                    labels[lm.group(1)] = j
+            worst = 0
+            for j, ln in enumerate(body):
+                bm = re.search(r"\bs_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
+                if bm and labels.get(bm.group(1), j) < j:          # backward branch = a loop
+                    loop = body[labels[bm.group(1)]:j]
+                    if any("v_mfma" in x for x in loop):
+                        worst = max(worst, sum(1 for x in loop if re.search(r"\bv_(write|read)lane_b32", x)))
+            out[fn] = worst
+            fn = None
+        else:
+            body.append(line)
+    return out
+
+
+def device_asm(src: str) -> list[str]:
+    """Device assembly listing of one translation unit (for the build checks and their tests)."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.run([HIPCC, *FLAGS, "--cuda-device-only", "-S", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
+        with open(out) as f:
+            return f.read().splitlines()
 
 
 def check_agpr_ownership(src: str, verbose: bool = True) -> None:
