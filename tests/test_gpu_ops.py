@@ -392,6 +392,26 @@ def test_flash_attention_forced_rescale_spike():
     assert rel_l2(got, ref) <= 4e-3
 
 
+def test_flash_attention_first_tile_far_below_zero_stays_finite():
+    """Round-3 advisor finding (small-grid pipelined kernel, max baked into the accumulator): tile 0 'rescales' o = l = 0 by
+    exp2(-rowmax); a row whose every first-tile score sits below about -128 in the exp2 domain made that factor +inf and the whole
+    output row NaN.  All keys share a large component that one query opposes: its scores are ~ -150 in the exp2 domain."""
+    from vllm_omni_amd import ops
+
+    for L in (256, 272, 1024):                    # 1 - 4 q-blocks, one item, one head: the small-grid kernel
+        q, k, v = rnd((L, 128), 1, 0.3), rnd((L, 128), 2, 0.3), rnd((L, 128), 3)
+        k[:, 0] = 4.0
+        q[5, 0] = -300.0
+        q[L - 1, 0] = -400.0
+        ref = attn_ref(q, k, v, [L], 1)
+        cu = torch.tensor([0, L], dtype=torch.int32, device=dev())
+        got = ops.flash_attn_varlen(g_(q), g_(k), g_(v), cu, 1, L, 1 / math.sqrt(128))
+        torch.cuda.synchronize()
+        assert torch.isfinite(got.float()).all(), L
+        assert rel_l2(got, ref) <= 4e-3, L
+        assert rel_l2(got[5], ref[5]) <= 8e-3 and rel_l2(got[L - 1], ref[L - 1]) <= 8e-3, L
+
+
 @pytest.mark.parametrize("lens,H", [([1100, 300, 257, 65, 1, 647], 24), ([2100], 64), ([256, 512, 1000, 64, 63], 32),
                                     ([1056, 1057, 1088, 1089, 1055, 1072], 24)])   # last q-blocks of 32 / 33 / 64 / 65 / 31 / 48 rows
 def test_flash_attention_w64_kernel_varlen(lens, H):

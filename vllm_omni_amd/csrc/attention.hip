@@ -648,7 +648,9 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
         // (o = l = 0), which sets the first max — also when every score of the tile is far below zero.
         if (t == 0 || !__all(mxc[bq] <= DEFER)) {
           const float d = t == 0 ? mxc[bq] : fmaxf(mxc[bq], 0.0f);
-          const float alpha = __builtin_amdgcn_exp2f(-d);
+          // t == 0: o = l = 0, nothing to rescale — and exp2(-d) would be +inf when every score of the first tile sits below
+          // about -128 in the exp2 domain (0 * inf = NaN for the whole output row): only the shift by d applies there
+          const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);
           l_run[bq] *= alpha;
 #pragma unroll
           for (int dd = 0; dd < 4; ++dd)

@@ -92,6 +92,10 @@ class OmniDiffusionConfig:
                                      # items x 4160 rows fills the 256 CUs' tile rounds best at 1024^2: DESIGN.md 7)
     dist_timeout: int | None = None
     use_hip_graph: bool | None = None   # NEW: capture one denoise step as a hipGraph (None = automatic by size)
+    load_text_encoder: bool = True   # NEW: False = never build the ~16 GB Qwen2.5-VL prompt encoder on the workers (requests
+                                     # then carry prompt_embeds)
+    max_steps_in_flight: int = 2     # NEW: how many denoising steps a worker's host may enqueue ahead of the device
+                                     # (step_batcher.py: bounded run-ahead, so that a newcomer joins within this many steps)
 
     def __post_init__(self):
         if isinstance(self.parallel_config, dict):

@@ -11,6 +11,7 @@ requests continuously (step_batcher.py), decodes its own images and returns them
 from __future__ import annotations
 
 import itertools
+import os
 import queue
 import time
 from typing import Any, Callable
@@ -95,6 +96,11 @@ class DiffusionEngine:
     def submit(self, req: OmniDiffusionRequest) -> int:
         """Hand one request to the least-loaded rank; returns its ticket."""
         rid = next(self._ids)
+        if self.sp_degree > 1 and req.seed is None and req.generator is None and req.latents is None:
+            # the request is fanned out to every rank of a sequence-parallel group and each rank draws the initial noise
+            # itself: without a shared seed they would denoise DIFFERENT latents and mix their predictions.  seed=None is the
+            # default of the entry points, so it is made concrete here, once, before the fan-out.
+            req.seed = int.from_bytes(os.urandom(4), "little")
         grp = min(range(self.num_groups), key=lambda r: (self._load[r], r))
         cost = self._request_cost(req)
         self._load[grp] += cost

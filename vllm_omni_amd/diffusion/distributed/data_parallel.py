@@ -109,3 +109,14 @@ def unshard(gathered: torch.Tensor, assignment: list[list[int]]) -> list[torch.T
             out[i] = gathered[k]
             k += 1
     return out  # type: ignore[return-value]
+
+
+def unshard_indexed(gathered: torch.Tensor, assignment: list[list[int]]) -> dict[int, torch.Tensor]:
+    """As `unshard` for an assignment over a SUBSET of the request indices (one resolution of a mixed batch): {index: row}."""
+    out: dict[int, torch.Tensor] = {}
+    k = 0
+    for lst in assignment:
+        for i in lst:
+            out[i] = gathered[k]
+            k += 1
+    return out

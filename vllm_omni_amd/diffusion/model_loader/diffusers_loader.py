@@ -118,7 +118,15 @@ class DiffusersPipelineLoader:
         if hasattr(model, "load_text_encoder") and getattr(model, "text_encoder", None) is None and \
                 os.path.isdir(os.path.join(od_config.model, "text_encoder")) and \
                 os.path.isdir(os.path.join(od_config.model, "tokenizer")):
-            model.load_text_encoder(od_config.model, device=load_device)
+            # a checkpoint directory that lacks a piece the encoder needs (an Edit checkpoint without processor/, a trimmed
+            # local copy, a transformers build without the VL classes) still serves requests that bring prompt_embeds — as it
+            # did before the auto-load existed; `od_config.cache_config`-style switch: extra key load_text_encoder=False skips it
+            if getattr(od_config, "load_text_encoder", True):
+                try:
+                    model.load_text_encoder(od_config.model, device=load_device)
+                except (FileNotFoundError, ImportError, OSError) as e:
+                    print(f"[DiffusersPipelineLoader] prompt encoder not loaded ({type(e).__name__}: {e}); "
+                          "requests must carry prompt_embeds", flush=True)
         return model.eval() if hasattr(model, "eval") else model
 
 

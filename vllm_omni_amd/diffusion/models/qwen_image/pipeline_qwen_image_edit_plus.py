@@ -11,7 +11,8 @@ Relative to QwenImageEditPipeline:
     of the user text (:286-299).
 The denoise loop, true-CFG, slicing the prediction back to the generated image's tokens and the decode are the Edit /
 text-to-image path.  Prompts are encoded through the Qwen2.5-VL vision tower with ALL pictures (QwenEditPromptEncoder,
-multi_image=True; `req.extra["prompt_image"]` = the list at the vision-tower size, default: the condition images); requests
+multi_image=True; `req.extra["prompt_image"]` = the list at the vision-tower size, default: the condition images resized to
+~384^2 as in the reference's pre-process); requests
 may still carry `prompt_embeds`."""
 from __future__ import annotations
 
@@ -48,8 +49,36 @@ def plan_image_sizes(sizes: list[tuple[int, int]]) -> dict:
     return {"width": width, "height": height, "condition_image_sizes": cond, "vae_image_sizes": vae}
 
 
+def _picture_size(x) -> tuple[int, int]:
+    """(width, height) of a PIL image or a [..., H, W] tensor."""
+    if isinstance(x, torch.Tensor):
+        return int(x.shape[-1]), int(x.shape[-2])
+    return x.size
+
+
 class QwenImageEditPlusPipeline(QwenImageEditPipeline):
     _multi_image_prompt = True
+
+    def _prompt_pictures(self, req: OmniDiffusionRequest):
+        """The pictures the vision tower sees.  `extra['prompt_image']` is used as given; by default the condition images are
+        resized to ~384^2 at their own aspect ratio (`CONDITION_IMAGE_SIZE`), as the reference's pre-process does before prompt
+        encoding (:96-123,637-650,699) — round 3 fed the VAE-sized images, so the embeddings differed from the reference's."""
+        from .text_encoder import resize_picture
+
+        extra = req.extra or {}
+        if extra.get("prompt_image") is not None:
+            return extra["prompt_image"]
+        pics = extra.get("image")
+        if pics is None:
+            return None
+        if not isinstance(pics, (list, tuple)):
+            pics = [pics]
+        out = []
+        for im in pics:
+            w, h = _picture_size(im)
+            cw, ch, _ = calculate_dimensions(CONDITION_IMAGE_SIZE, w / h)
+            out.append(resize_picture(im, ch, cw))
+        return out
 
     def resolve_request(self, req: OmniDiffusionRequest, index: int = 0) -> list[dict]:
         extra = req.extra or {}

@@ -121,14 +121,42 @@ EDIT_PLUS_IMG_PROMPT = "Picture {}: <|vision_start|><|image_pad|><|vision_end|>"
 
 
 def to_processor_image(x):
-    """What the HF image processor takes: PIL images pass through; a tensor [3, H, W] / [1, 3, H, W] / [1, 3, 1, H, W] in
-    [-1, 1] (the layout the VAE encoder takes) becomes a uint8 HWC array."""
+    """What the HF image processor takes: PIL images pass through; a tensor [3, H, W] / [1, 3, H, W] / [3, 1, H, W] /
+    [1, 3, 1, H, W] in [-1, 1] (the layouts the VAE encoder takes: one picture, optional batch and frame axes of size 1) becomes
+    a uint8 HWC array.  Anything else (a batch of several pictures, a wrong channel count) raises — one bad
+    `req.extra['image']` must not hang or crash the worker."""
     if isinstance(x, torch.Tensor):
         t = x.detach().float().cpu()
-        while t.dim() > 3:
-            t = t[0] if t.shape[0] == 1 else t.squeeze(1)
+        shape = tuple(t.shape)
+        if t.dim() == 5 and t.shape[0] == 1 and t.shape[2] == 1:        # [1, 3, 1, H, W]
+            t = t[0, :, 0]
+        elif t.dim() == 4 and t.shape[0] == 1:                          # [1, 3, H, W]
+            t = t[0]
+        elif t.dim() == 4 and t.shape[1] == 1:                          # [3, 1, H, W]
+            t = t[:, 0]
+        if t.dim() != 3 or t.shape[0] != 3:
+            raise ValueError(f"cannot interpret a tensor of shape {shape} as ONE RGB picture "
+                             "([3,H,W], [1,3,H,W], [3,1,H,W] or [1,3,1,H,W])")
         return ((t.clamp(-1, 1) + 1) * 127.5).round().to(torch.uint8).permute(1, 2, 0).numpy()
     return x
+
+
+def resize_picture(x, height: int, width: int):
+    """diffusers `VaeImageProcessor.resize(image, height, width)` as the reference calls it for the vision-tower copies of the
+    condition images (pipeline_qwen_image_edit_plus.py:116,650; third-party, restated: PIL -> `Image.resize((w, h), LANCZOS)`,
+    tensor -> `F.interpolate(size=(h, w))`, i.e. nearest)."""
+    if isinstance(x, torch.Tensor):
+        t = x
+        lead = t.dim()
+        if lead == 3:
+            t = t.unsqueeze(0)
+        elif lead == 5:
+            t = t[:, :, 0]
+        t = torch.nn.functional.interpolate(t.float(), size=(height, width)).to(x.dtype)
+        return t[0] if lead == 3 else (t.unsqueeze(2) if lead == 5 else t)
+    from PIL import Image
+
+    return x.resize((width, height), resample=Image.LANCZOS)
 
 
 class QwenEditPromptEncoder:

@@ -13,6 +13,7 @@ The batcher is model-agnostic: the pipeline supplies `resolve_request` (request 
 update for a list of active samples) and `finish_request`."""
 from __future__ import annotations
 
+import collections
 import itertools
 from dataclasses import dataclass, field
 from typing import Any
@@ -29,13 +30,23 @@ class ActiveSample:
 
 
 class ContinuousStepBatcher:
-    def __init__(self, pipeline, max_items: int | None = None):
+    def __init__(self, pipeline, max_items: int | None = None, max_steps_in_flight: int | None = None):
         self.pipeline = pipeline
-        cap = max_items or int(getattr(getattr(pipeline, "od_config", None), "max_step_batch", 4) or 4)
+        cfg = getattr(pipeline, "od_config", None)
+        cap = max_items or int(getattr(cfg, "max_step_batch", 4) or 4)
         self.max_samples = max(1, cap)
         self.active: list[ActiveSample] = []
         self._pending: dict[Any, dict] = {}        # tag -> {"req": request, "left": samples still running, "done": {k: lat}}
         self._seq = itertools.count()
+        # fairness across batch keys (resolutions / CFG settings): the key served longest ago goes next
+        self._tick = 0
+        self._last_served: dict[Any, int] = {}
+        # bounded run-ahead: the host enqueues a step in ~10 ms, the GPU needs ~500 ms for it.  Unthrottled, the host composes
+        # batches many steps ahead of GPU time — with whatever requests had arrived at HOST time: staggered arrivals then run
+        # their first steps almost alone (round 3's serving line lost ~5 % to this).  One event per enqueued step; `ready()`
+        # is false while `max_steps_in_flight` of them are still pending, so a newcomer joins within that many steps.
+        self.max_steps_in_flight = int(max_steps_in_flight or getattr(cfg, "max_steps_in_flight", 2) or 2)
+        self._inflight: collections.deque = collections.deque()
 
     # ------------------------------------------------------------------ admission
     def add(self, req, tag) -> None:
@@ -53,15 +64,55 @@ class ContinuousStepBatcher:
     def outstanding_steps(self) -> int:
         return sum(a.n_steps - a.step for a in self.active)
 
+    # ------------------------------------------------------------------ run-ahead throttle
+    def _device_is_gpu(self) -> bool:
+        dev = getattr(self.pipeline, "device", None)
+        return getattr(dev, "type", "cpu") == "cuda"
+
+    def ready(self) -> bool:
+        """May the host enqueue another step now?  (False: `max_steps_in_flight` steps are still queued on the device.)"""
+        while self._inflight and self._inflight[0].query():
+            self._inflight.popleft()
+        return len(self._inflight) < self.max_steps_in_flight
+
+    def wait_ready(self, idle=None) -> None:
+        """Block until `ready()`; `idle()` (e.g. the worker's inbox poll) runs while waiting, else the oldest event is awaited."""
+        while not self.ready():
+            if idle is None:
+                self._inflight[0].synchronize()
+            else:
+                idle()
+
+    def _mark_step(self) -> None:
+        if self._device_is_gpu():
+            import torch
+
+            ev = torch.cuda.Event()
+            ev.record()
+            self._inflight.append(ev)
+
     # ------------------------------------------------------------------ one scheduling quantum
+    def next_group(self) -> list[ActiveSample]:
+        """The samples of the next forward.  Batch keys (what one ragged forward can mix: token grid, CFG on / scale) are served
+        ROUND-ROBIN — the key whose last forward lies furthest back goes next, so traffic at one resolution never waits behind
+        another resolution's whole loop; within a key admission is FIFO: the `max_samples` oldest samples run, a waiting sample
+        takes the first slot that frees up (continuous batching with a bounded batch, not time slicing — time slicing would
+        re-compose the batch every step for no gain in throughput)."""
+        by_key: dict[Any, list[ActiveSample]] = {}
+        for a in sorted(self.active, key=lambda a: a.seq):
+            by_key.setdefault(self.pipeline.batch_key(a), []).append(a)
+        for k in [k for k in self._last_served if k not in by_key]:
+            del self._last_served[k]
+        key = min(by_key, key=lambda k: (self._last_served.get(k, -1), by_key[k][0].seq))
+        self._tick += 1
+        self._last_served[key] = self._tick
+        return by_key[key][: self.max_samples]
+
     def step(self) -> list[tuple[Any, Any]]:
-        """Advance the OLDEST compatible group of active samples by one denoising step; return finished (tag, output)s."""
+        """Advance one group of active samples by one denoising step; return finished (tag, output)s."""
         if not self.active:
             return []
-        self.active.sort(key=lambda a: a.seq)
-        head = self.active[0]
-        key = self.pipeline.batch_key(head)
-        group = [a for a in self.active if self.pipeline.batch_key(a) == key][: self.max_samples]
+        group = self.next_group()
         try:
             self.pipeline.denoise_one_step(group)
         except Exception as e:  # noqa: BLE001 — a failing step aborts the REQUESTS that were in it, nothing else
@@ -72,12 +123,24 @@ class ContinuousStepBatcher:
             if a.step >= a.n_steps:
                 self.active.remove(a)
                 p = self._pending[a.tag]
-                p["done"][a.sample["k"]] = self.pipeline.sample_result(a)
+                try:
+                    p["done"][a.sample["k"]] = self.pipeline.sample_result(a)
+                except Exception as e:  # noqa: BLE001
+                    finished += self.abort({a.tag}, f"{type(e).__name__}: {e}")
+                    continue
                 p["left"] -= 1
                 if p["left"] == 0:
                     del self._pending[a.tag]
-                    finished.append((a.tag, self.pipeline.finish_request(p["req"], [p["done"][k] for k in range(p["n"])],
-                                                                         a.sample)))
+                    # the decode runs here, after the request left `active` and `_pending`: a failure (e.g. out of memory while
+                    # decoding a large image) must still produce this request's answer, and only this request's
+                    try:
+                        out = self.pipeline.finish_request(p["req"], [p["done"][k] for k in range(p["n"])], a.sample)
+                    except Exception as e:  # noqa: BLE001
+                        from .data import DiffusionOutput
+
+                        out = DiffusionOutput(error=f"{type(e).__name__}: {e}")
+                    finished.append((a.tag, out))
+        self._mark_step()
         return finished
 
     def abort(self, tags, error: str) -> list[tuple[Any, Any]]:
@@ -101,5 +164,6 @@ class ContinuousStepBatcher:
     def drain(self) -> list[tuple[Any, Any]]:
         out = []
         while self.active:
+            self.wait_ready()
             out += self.step()
         return out

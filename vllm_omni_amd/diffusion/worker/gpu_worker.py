@@ -74,11 +74,10 @@ class GPUWorker:
                 return DiffusionOutput(error="empty request list")
             for r in reqs:                                   # identical on all ranks: raises everywhere or nowhere
                 self.pipeline._req_params(r)
-            shapes = {((r.height or 1024), (r.width or 1024)) for r in reqs}
-            if self.world > 1 and len(shapes) != 1:
-                raise NotImplementedError("a DP batch must share one resolution (one gather shape)")
-            costs = [float((r.num_inference_steps or 50) * ((r.height or 1024) // 16) * ((r.width or 1024) // 16))
-                     for r in reqs]
+                if self.world > 1 and ((r.num_outputs_per_prompt or 1) != 1 or (isinstance(r.prompt, list) and len(r.prompt) != 1)):
+                    raise NotImplementedError("a data-parallel batch carries one sample per request (one gather row each)")
+            shape_of = [((r.height or 1024), (r.width or 1024)) for r in reqs]
+            costs = [float((r.num_inference_steps or 50) * (h // 16) * (w // 16)) for r, (h, w) in zip(reqs, shape_of)]
             # requests are sharded over the data-parallel GROUPS; the ranks of a sequence-parallel group run the same share in
             # lockstep and only the group's first rank contributes rows to the gather
             dp_assign = dp.shard_requests(costs, self.dp_world)
@@ -86,7 +85,8 @@ class GPUWorker:
             assign = [dp_assign[r // P] if r % P == 0 else [] for r in range(self.world)]
         except Exception as e:  # same policy as the reference busy loop: report, do not kill the worker
             return DiffusionOutput(error=f"{type(e).__name__}: {e}")
-        mine = [reqs[i] for i in dp_assign[self.dp_rank]]
+        mine_idx = dp_assign[self.dp_rank]
+        mine = [reqs[i] for i in mine_idx]
         err, outs = None, []
         try:
             cb = getattr(self.pipeline, "cache_backend", None)
@@ -99,20 +99,40 @@ class GPUWorker:
         if failed:
             return DiffusionOutput(error=err or "another data-parallel rank failed; batch aborted on all ranks")
         try:
-            h, w = next(iter(shapes))
-            S = (h // 16) * (w // 16)
             dev = self.pipeline.device
-            if self.rank % self.sp_degree:
-                outs = []                                    # not the group's first rank: nothing to contribute
-            local = torch.cat([o.output for o in outs]) if outs else torch.empty((0, S, 64), dtype=torch.bfloat16, device=dev)
-            gathered = dp.gather_latents(local.contiguous(), [len(a) for a in assign])
-            lat = torch.stack(dp.unshard(gathered, assign))
+            contributes = self.rank % self.sp_degree == 0    # not the group's first rank: nothing to contribute
+            mine_out = dict(zip(mine_idx, outs)) if contributes else {}
+            lat: list[torch.Tensor | None] = [None] * len(reqs)
+            imgs: list[torch.Tensor | None] = [None] * len(reqs)
+            # one gather per resolution (a gather needs one row shape), in sorted order: the same sequence of collectives on
+            # every rank.  Mixed-resolution batches are legal (the reference has no collective here, so no such constraint).
+            for (h, w) in sorted(set(shape_of)):
+                S = (h // 16) * (w // 16)
+                sub = [[i for i in a if shape_of[i] == (h, w)] for a in assign]
+                my = sub[self.rank]
+                local = (torch.cat([mine_out[i].output.reshape(-1, S, 64) for i in my]) if my
+                         else torch.empty((0, S, 64), dtype=torch.bfloat16, device=dev))
+                gathered = dp.gather_latents(local.contiguous(), [len(a) for a in sub])
+                rows = dp.unshard_indexed(gathered, sub)
+                for i, t in rows.items():
+                    lat[i] = t
+                if not decode:
+                    continue
+                # every rank now holds every latent of this resolution: the VAE decodes are dealt round-robin over the ranks
+                # (round 3: `output_rank` decoded all of them serially) and the pixels return in one more gather
+                order = sorted(rows)
+                deal = [[i for n, i in enumerate(order) if n % self.world == r] for r in range(self.world)]
+                px = [self.pipeline.decode_latents(lat[i].unsqueeze(0), h, w) for i in deal[self.rank]]
+                loc = (torch.cat(px).reshape(len(px), 1, -1) if px else torch.empty((0, 1, 3 * h * w), dtype=torch.bfloat16, device=dev))
+                allpx = dp.gather_latents(loc.to(torch.bfloat16).contiguous(), [len(d) for d in deal])
+                for i, t in dp.unshard_indexed(allpx, deal).items():
+                    imgs[i] = t.reshape(3, h, w)
             if self.rank != output_rank:
                 return DiffusionOutput(output=None)
-            if not decode:
-                return DiffusionOutput(output=lat)
-            imgs = [self.pipeline.decode_latents(lat[i:i + 1], h, w) for i in range(lat.shape[0])]
-            return DiffusionOutput(output=torch.cat(imgs))
+            res = lat if not decode else imgs
+            if len(set(shape_of)) == 1:
+                return DiffusionOutput(output=torch.stack(res))
+            return DiffusionOutput(output=res)              # mixed resolutions: a list, request order
         except Exception as e:
             return DiffusionOutput(error=f"{type(e).__name__}: {e}")
 
@@ -143,7 +163,49 @@ class WorkerProc:
         self.rank, self.inbox, self.outbox = rank, inbox, outbox
         self.worker = GPUWorker(local_rank=rank, rank=rank, od_config=od_config, pipeline=pipeline)
         self.worker.init_device_and_model(pipeline_factory)
-        self.batcher = ContinuousStepBatcher(self.worker.pipeline, max_items=od_config.max_step_batch)
+        self.batcher = ContinuousStepBatcher(self.worker.pipeline, max_items=od_config.max_step_batch,
+                                             max_steps_in_flight=getattr(od_config, "max_steps_in_flight", 2))
+        # results on their way to the host: (message, event).  A finished request's image is copied to PINNED memory with a
+        # non-blocking copy and handed to the result queue when the copy's event has completed — the loop never blocks on a
+        # device-to-host copy (round 3: one blocking `.to("cpu")` per finished request, behind everything already queued).
+        self._outgoing: list[tuple[dict, object]] = []
+
+    # -- results ----------------------------------------------------------------------------------------------------
+    def _stage(self, x):
+        """Device tensors -> pinned host tensors, asynchronously (the caller records ONE event after staging a message)."""
+        if isinstance(x, torch.Tensor):
+            if not x.is_cuda:
+                return x.detach()
+            host = torch.empty(x.shape, dtype=x.dtype, device="cpu", pin_memory=True)
+            host.copy_(x.detach(), non_blocking=True)
+            return host
+        if isinstance(x, (list, tuple)):
+            return type(x)(self._stage(v) for v in x)
+        if isinstance(x, DiffusionOutput):
+            return DiffusionOutput(output=self._stage(x.output), error=x.error, trajectory_timesteps=x.trajectory_timesteps,
+                                   trajectory_latents=self._stage(x.trajectory_latents))
+        return x
+
+    def _send(self, msg: dict, key: str = "output") -> None:
+        if torch.cuda.is_available() and getattr(self.worker.pipeline, "device", torch.device("cpu")).type == "cuda":
+            msg[key] = self._stage(msg[key])
+            ev = torch.cuda.Event()
+            ev.record()
+            self._outgoing.append((msg, ev))
+        else:
+            msg[key] = _to_cpu(msg[key])
+            self.outbox.put(msg)
+
+    def _flush(self, block: bool = False) -> None:
+        """Hand every message whose copy has completed to the result queue, in order."""
+        while self._outgoing:
+            msg, ev = self._outgoing[0]
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            self._outgoing.pop(0)
+            self.outbox.put(msg)
 
     # -- message handling -------------------------------------------------------------------------------------------
     def _handle(self, msg) -> bool:
@@ -156,12 +218,17 @@ class WorkerProc:
             # completion in lockstep (a continuous batcher would have to agree on every step's composition across ranks);
             # the group's first rank answers
             try:
-                out = self.worker.pipeline.generate([msg["request"]])[0]
+                req = msg["request"]
+                if req.seed is None and req.generator is None and req.latents is None:
+                    # every rank of the group would draw its OWN initial noise (the engine seeds such requests before the
+                    # fan-out; a request that reaches a worker unseeded some other way must not silently produce garbage)
+                    raise ValueError("a sequence-parallel request needs seed, generator or latents: the group's ranks must "
+                                     "start from the same noise")
+                out = self.worker.pipeline.generate([req])[0]
             except Exception as e:  # noqa: BLE001
                 out = DiffusionOutput(error=f"{type(e).__name__}: {e}")
             if self.rank % self.worker.sp_degree == 0:
-                self.outbox.put({"type": "done", "id": msg["id"], "rank": self.rank, "output": _to_cpu(out),
-                                 "outstanding_steps": 0})
+                self._send({"type": "done", "id": msg["id"], "rank": self.rank, "output": out, "outstanding_steps": 0})
         elif kind == "add":
             try:
                 self.batcher.add(msg["request"], tag=msg["id"])
@@ -181,24 +248,39 @@ class WorkerProc:
             self.outbox.put({"type": "error", "rank": self.rank, "error": f"unknown message type {kind!r}"})
         return True
 
+    POLL_S = 0.001        # inbox wait while the device is busy (throttled) or results are in flight
+
     def worker_busy_loop(self) -> None:
+        """idle: block for work.  busy: look at the inbox between two denoising steps (requests that arrive now join the batch
+        at the next step), enqueue the next step only while fewer than `max_steps_in_flight` are queued on the device, and hand
+        finished results over as their host copies complete."""
         while True:
+            self._flush()
+            busy = self.batcher.has_work() or bool(self._outgoing)
+            throttled = self.batcher.has_work() and not self.batcher.ready()
             try:
-                # idle: block for work; busy: only look (requests that arrive now join the batch at the next step)
-                msg = self.inbox.get(timeout=None) if not self.batcher.has_work() else self.inbox.get_nowait()
+                if not busy:
+                    msg = self.inbox.get(timeout=None)
+                elif throttled or not self.batcher.has_work():
+                    msg = self.inbox.get(timeout=self.POLL_S)   # nothing to enqueue right now: wait here, not in a spin
+                else:
+                    msg = self.inbox.get_nowait()
                 if not self._handle(msg):
+                    self._flush(block=True)
                     return
                 continue                                        # keep draining before the next step
             except queue.Empty:
                 pass
+            if throttled or not self.batcher.has_work():
+                continue
             try:
                 finished = self.batcher.step()              # a failing step aborts only the requests that were in it
             except Exception as e:  # noqa: BLE001 — scheduler bug: abort everything once per request, keep the worker alive
                 finished = self.batcher.abort({a.tag for a in self.batcher.active} | set(self.batcher._pending),
                                               f"{type(e).__name__}: {e}")
             for tag, out in finished:
-                self.outbox.put({"type": "done", "id": tag, "rank": self.rank, "output": _to_cpu(out),
-                                 "outstanding_steps": self.batcher.outstanding_steps()})
+                self._send({"type": "done", "id": tag, "rank": self.rank, "output": out,
+                            "outstanding_steps": self.batcher.outstanding_steps()})
 
     @staticmethod
     def worker_main(rank: int, world: int, od_config: OmniDiffusionConfig, inbox, outbox, ready, pipeline_factory=None,
