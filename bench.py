@@ -472,13 +472,13 @@ def main():
                 line["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         if sp_line is not None:
             line.setdefault("secondary", {}).update(sp_line)
-        if world == 1 and not args.no_secondary and not args.no_engine:
+        if world == 1 and not args.no_engine:
             del pipe                                         # the worker process builds its own 41 GB of weights
             torch.cuda.empty_cache()
             try:
-                line["secondary"].update(engine_line(R, args.layers, value))
+                line.setdefault("secondary", {}).update(engine_line(R, args.layers, value))
             except Exception as e:  # noqa: BLE001
-                line["secondary"]["engine_error"] = f"{type(e).__name__}: {e}"
+                line.setdefault("secondary", {})["engine_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -325,7 +325,9 @@ typedef struct {
  * order + one fp32 scale per output channel, both written by omni_quantize_fp8_rows(weight [out, in]).  With
  * omni_dit_weights.fp8_layers set, every block GEMM runs as omni_gemm_params.fp8: its bf16 input (AdaLN output, attention
  * output, GELU output) is quantised per token by omni_quantize_fp8_rows right in front of it; biases, epilogues, the residual
- * streams, q/k/v, the attention and everything outside the block GEMMs stay bf16. */
+ * streams, q/k/v, the attention and everything outside the block GEMMs stay bf16.
+ * ABI v9 — per GEMM class: the four classes are (to_qkv, add_qkv), (to_out, to_add_out), (img/txt mlp w1), (img/txt mlp w2);
+ * a class whose two weight pointers are NULL runs in bf16 from omni_dit_layer_weights as without fp8 (mixed recipes). */
 typedef struct {
   const uint8_t *to_qkv_w8, *add_qkv_w8, *to_out_w8, *to_add_out_w8, *img_mlp_w1_8, *img_mlp_w2_8, *txt_mlp_w1_8, *txt_mlp_w2_8;
   const float *to_qkv_s, *add_qkv_s, *to_out_s, *to_add_out_s, *img_mlp_w1_s, *img_mlp_w2_s, *txt_mlp_w1_s, *txt_mlp_w2_s;

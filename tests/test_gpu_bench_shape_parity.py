@@ -111,18 +111,20 @@ def _product_trajectory(pipe, req):
     return out, traj
 
 
-def test_headline_1024px_at_real_depth_60_layers():
+@pytest.mark.parametrize("steps", [4, 20])
+def test_headline_1024px_at_real_depth_60_layers(steps):
     """BASELINE config 2's model and shape — 60 full-width layers, ONE 1024x1024 item (4096 image + 64 / 48 text rows),
-    true-CFG — for one forward and a 4-step loop (the 20-step schedule's step size would need 40 fp32-oracle forwards; 4
-    steps cover the same per-step arithmetic at 5x the step size).  Checker: the fp32 oracle on the GPU; calibration: the
-    same oracle in bf16 (the dtype the reference runs in).  The drift after every step is printed for both."""
+    true-CFG — for one forward and the denoise loop of reference pipeline_qwen_image.py:530-586: a 4-step schedule and THE
+    BENCHMARKED 20-STEP schedule (40 fp32-oracle forwards + 40 bf16-eager ones on the GPU).  Checker: the fp32 oracle on the
+    GPU; calibration: the same oracle in bf16 (the dtype the reference runs in).  The drift after every step is printed for
+    both."""
     from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
     from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
     from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
 
     torch.backends.cuda.matmul.allow_tf32 = False
     m = _perturbed_random_model(60, seed=1234)
-    grid, S, steps = (1, 64, 64), 4096, 4
+    grid, S = (1, 64, 64), 4096
     g = torch.Generator(device=DEV).manual_seed(42)
     lat = torch.randn(1, S, 64, device=DEV, generator=g).to(BF16)
     pos = torch.randn(1, 64, 3584, device=DEV, generator=g).to(BF16)
@@ -155,7 +157,39 @@ def test_headline_1024px_at_real_depth_60_layers():
     print(f"   final: product {r:.3e} cos {c:.6f}; bf16-eager {r_eager:.3e}; product vs bf16-eager {rel_l2(out, eager):.3e}")
     assert torch.isfinite(out.float()).all()
     assert r_f <= max(1e-2, 1.1 * r_f_eager)
-    assert r <= max(2e-2, 1.1 * r_eager) and c >= 0.997
+    assert r <= max(2e-2, 1.1 * r_eager) and c >= (0.997 if steps == 4 else 0.995)
+
+
+def test_60_layers_at_the_bench_step_batch_of_10_items():
+    """What one bench forward is: 60 full-width layers over the 10-item step-batch (R = 5 requests x 2 CFG branches, 10 x (4096
+    + 64) rows = 163 row tiles) as ONE ragged forward — every item against its OWN B = 1 fp32-oracle forward (per-request
+    semantics), with the bf16-eager reference algorithm of the same item as the calibration."""
+    torch.backends.cuda.matmul.allow_tf32 = False
+    m = _perturbed_random_model(60, seed=1234)
+    P32 = _oracle_params(m)
+    Pb = _oracle_params(m, BF16)
+    B, S, T = 10, 4096, 64
+    g = torch.Generator(device=DEV).manual_seed(6)
+    lat = torch.randn(B, S, 64, device=DEV, generator=g).to(BF16)
+    txt = torch.randn(B, T, 3584, device=DEV, generator=g).to(BF16)
+    sig = torch.full((B,), 0.6015625, device=DEV)
+    out = m(hidden_states=lat, encoder_hidden_states=txt, timestep=sig, img_shapes=[[(1, 64, 64)]] * B,
+            txt_seq_lens=[T] * B, return_dict=False)[0]
+    torch.cuda.synchronize()
+    rows = []
+    with torch.no_grad():
+        for i in range(B):
+            ref = O.dit_forward(P32, lat[i:i + 1].float(), txt[i:i + 1].float(), sig[i:i + 1], (1, 64, 64), num_heads=24)
+            eag = O.dit_forward(Pb, lat[i:i + 1], txt[i:i + 1], sig[i:i + 1].to(BF16), (1, 64, 64), num_heads=24)
+            rows.append((rel_l2(out[i:i + 1], ref), cosine(out[i:i + 1], ref), rel_l2(eag, ref)))
+            del ref, eag
+    for i, (r, c, e) in enumerate(rows):
+        print(f"   item {i}: product vs fp32 oracle {r:.3e} cos {c:.6f}; bf16-eager reference algorithm {e:.3e}")
+    worst, eager = max(r for r, _, _ in rows), max(e for _, _, e in rows)
+    print(f"60 layers @ 10 x (4096+64) rows: worst product {worst:.3e}, worst bf16-eager {eager:.3e}")
+    assert torch.isfinite(out.float()).all()
+    for r, c, e in rows:
+        assert r <= max(1e-2, 1.1 * e) and c >= 0.999
 
 
 def test_config1_256px_4steps_at_real_depth_60_layers():

@@ -168,6 +168,13 @@ def test_step_batcher_is_correct_when_the_host_runs_ahead_of_the_gpu():
     reqs = {"a": req(9), "b": req(6), "c": req(7), "d": req(5)}
     solo = {k: pipe.generate([copy.deepcopy(r)], output_type="latent")[0].output.float().cpu() for k, r in reqs.items()}
 
+    # calibrate torch.cuda._sleep: its unit is the device's clock64() tick, which differs between GPU families
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1000)
+    e0.record(); torch.cuda._sleep(2_000_000); e1.record()
+    torch.cuda.synchronize()
+    sleep_hz = 2_000_000 / (e0.elapsed_time(e1) * 1e-3)
+
     def serve(sync: bool):
         torch.cuda.synchronize()
         b = ContinuousStepBatcher(pipe, max_items=3)
@@ -182,6 +189,13 @@ def test_step_batcher_is_correct_when_the_host_runs_ahead_of_the_gpu():
         b.add(rq["a"], "a"); step()
         b.add(rq["b"], "b"); step()                          # b starts while a is at step 1
         b.add(rq["c"], "c"); b.add(rq["d"], "d")            # c joins; d waits for a slot
+        if not sync:
+            # the premise is FORCED, not hoped for: a device-side delay (~0.4 s of spinning) behind the last admission (whose
+            # host-to-device copies wait for the stream) keeps the GPU behind the host however fast the box's GPU or slow its
+            # host is; step() is called directly, i.e. WITHOUT the worker's run-ahead throttle — the host gets as far ahead as
+            # it can
+            torch.cuda._sleep(int(0.4 * sleep_hz))
+        t0 = time.perf_counter()
         while b.has_work():
             step()
         t_host = time.perf_counter() - t0
@@ -194,5 +208,5 @@ def test_step_batcher_is_correct_when_the_host_runs_ahead_of_the_gpu():
         assert torch.equal(got[k], ref[k]), k               # same kernels, same order: any difference is a host / device race
         assert rel_l2(got[k], solo[k]) <= 5e-2, k           # vs the solo loop: other GEMM row grouping, amplified by true-CFG 4.0
                                                             # over 5-9 steps of a random-weight DiT (1-2e-2 measured)
-    if t_all < 1.2 * t_host:                            # the premise: the host really was ahead of the GPU
-        pytest.skip(f"results equal, but the host did not run ahead of the GPU on this box ({t_host:.3f} s of {t_all:.3f} s)")
+    # the premise held: every step was enqueued while the GPU was still inside the delay / the first steps
+    assert t_all >= 2.0 * t_host, f"host {t_host:.3f} s, until GPU done {t_all:.3f} s: the host was not ahead of the GPU"

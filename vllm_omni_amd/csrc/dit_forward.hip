@@ -136,6 +136,10 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   // fp8 mode (omni_dit_weights.fp8_layers): every block GEMM reads e4m3 operands; its bf16 input is quantised per token first
   const omni_dit_fp8_layer* F = w->fp8_layers ? &w->fp8_layers[l] : nullptr;
   if (F && (D % 128 != 0 || !ws.x8)) return OMNI_ERR_UNSUPPORTED;
+  // ABI v9: per GEMM CLASS — a class whose two weight pointers are NULL stays bf16 (mixed recipes: the classes that feed the
+  // residual stream directly are the accuracy-critical ones)
+  const bool f_qkv = F && F->to_qkv_w8 && F->add_qkv_w8, f_out = F && F->to_out_w8 && F->to_add_out_w8;
+  const bool f_up = F && F->img_mlp_w1_8 && F->txt_mlp_w1_8, f_down = F && F->img_mlp_w2_8 && F->txt_mlp_w2_8;
   // image rows -> x8[0 .. Ri), text rows -> x8[Ri ..): two [rows, K] operands in the K64-blocked order, scales alongside
   auto quant_streams = [&](const omni_bf16* xi, int32_t xi_k32, const omni_bf16* xt, int32_t xt_k32, int32_t K) -> int {
     OMNI_TRY(omni_quantize_fp8_rows(xi, K, xi_k32, Ri, K, ws.x8, Ri, ws.x8_scale, stream));
@@ -158,7 +162,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   if (phase != BLOCK_POST) {
   // norm1 + modulate (reference :564-567).  fp8 mode: the e4m3 copy + per-token scale come out of the same pass (the bf16
   // result is still written for the image stream when TeaCache reads it)
-  const bool fused_q = F && blk;
+  const bool fused_q = f_qkv && blk;
   if (fused_q) {
     OMNI_TRY(omni_adaln_modulate_fp8(hidden_img, D, Ri, D, ws.mod_img + D, ws.mod_img, 6 * D, b->img_item, 0, eps,
                                      b->teacache ? xn_img : nullptr, bRi, ws.x8, Ri, ws.x8_scale, stream));
@@ -194,7 +198,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].out = ws.q; p.g[1].out1 = ws.k; p.g[1].out2 = ws.v; p.g[1].ldo = D; p.g[1].out_row_map = b->txt_joint_row;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
     p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
-    if (F) {
+    if (f_qkv) {
       if (!fused_q) OMNI_TRY(quant_streams(xn_img, bRi, xn_txt, bRt, D));
       fp8_streams(p, D, F->to_qkv_w8, F->to_qkv_s, F->add_qkv_w8, F->add_qkv_s);
     }
@@ -229,7 +233,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].row_item_map = b->txt_item;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
     p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
-    if (F) {                                  // the attention output in its joint order: ONE operand, both groups gather from it
+    if (f_out) {                              // the attention output in its joint order: ONE operand, both groups gather from it
       const int32_t Rj = Ri + Rt;
       OMNI_TRY(omni_quantize_fp8_rows(attn_src, D, attn_k32, Rj, D, ws.x8, Rj, ws.x8_scale, stream));
       p.fp8 = 1; p.w_k32_blocked = 1; p.splitk_ws = nullptr; p.splitk_ws_floats = 0;
@@ -242,7 +246,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     OMNI_TRY(omni_gemm_bf16(&p, stream));
   }
   // norm2 + modulate (reference :590, :595)
-  const bool fused_q2 = F && blk;
+  const bool fused_q2 = f_up && blk;
   if (fused_q2) {
     OMNI_TRY(omni_adaln_modulate_fp8(hidden_img, D, Ri, D, ws.mod_img + 4 * D, ws.mod_img + 3 * D, 6 * D, b->img_item, 0, eps,
                                      nullptr, 0, ws.x8, Ri, ws.x8_scale, stream));
@@ -264,7 +268,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w1; p.g[1].bias = L.txt_mlp_b1;
     p.g[1].out = h_txt; p.g[1].ldo = 4 * D;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
-    if (F) {
+    if (f_up) {
       if (!fused_q2) OMNI_TRY(quant_streams(xn_img, bRi, xn_txt, bRt, D));
       fp8_streams(p, D, F->img_mlp_w1_8, F->img_mlp_w1_s, F->txt_mlp_w1_8, F->txt_mlp_w1_s);
     }
@@ -283,7 +287,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].gate = ws.mod_txt + 5 * D; p.g[1].gate_item_stride = 6 * D; p.g[1].row_item_map = b->txt_item;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
     p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
-    if (F) {
+    if (f_down) {
       OMNI_TRY(quant_streams(h_img, bRi, h_txt, bRt, 4 * D));
       fp8_streams(p, 4 * D, F->img_mlp_w2_8, F->img_mlp_w2_s, F->txt_mlp_w2_8, F->txt_mlp_w2_s);
     }
@@ -303,7 +307,7 @@ int prepare_positions(const omni_dit_batch* b, const Workspace& ws, omni_stream 
 }
 }  // namespace
 
-extern "C" int omni_abi_version(void) { return 8; }
+extern "C" int omni_abi_version(void) { return 9; }
 extern "C" const char* omni_build_arch(void) { return "gfx950"; }
 extern "C" const char* omni_status_string(int status) {
   switch (status) {

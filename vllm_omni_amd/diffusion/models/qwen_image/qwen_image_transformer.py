@@ -282,6 +282,7 @@ class QwenImageTransformer2DModel(nn.Module):
         self._native_gen = 0       # bumped whenever the pointer table is invalidated (captured hipGraphs must be re-captured)
         self._w_blocked = False    # the 8 big matrices per layer currently hold the K32-blocked re-layout
         self.fp8 = False           # enable_fp8(): the block GEMMs run on e4m3 copies of their weights (BASELINE config 5)
+        self._fp8_classes = frozenset()
         self._workspace = None
         self._batch_cache: dict = {}
 
@@ -305,16 +306,28 @@ class QwenImageTransformer2DModel(nn.Module):
         self._native = None
         self._native_gen += 1
 
-    def enable_fp8(self, on: bool = True) -> None:
-        """Run the eight block GEMMs of every layer in fp8 (OCP e4m3 operands on the scaled MFMA at twice the bf16 rate,
-        omni_gemm_params.fp8): weights are quantised ONCE per output channel when the native pointer table is (re)built,
-        activations per token in front of each GEMM; everything else stays bf16.  The bf16 parameters are kept (they remain
-        the source of truth for state_dict / load_weights).  BASELINE.json config 5; the reference has no fp8 path to match:
-        accuracy is stated against the bf16 path / the fp32 oracle in tests/test_gpu_fp8.py."""
-        if bool(on) != self.fp8:
-            self.fp8 = bool(on)
+    FP8_CLASSES = ("qkv", "out", "mlp_up", "mlp_down")      # the four GEMM classes of a block (both streams each)
+
+    def enable_fp8(self, on=True, classes=None) -> None:
+        """Run block GEMMs in fp8 (OCP e4m3 operands on the scaled MFMA at twice the bf16 rate, omni_gemm_params.fp8): weights
+        are quantised ONCE per output channel when the native pointer table is (re)built, activations per token in front of
+        each GEMM; everything else stays bf16.  The bf16 parameters are kept (they remain the source of truth for state_dict /
+        load_weights).  `classes` (ABI v9) picks which of the four GEMM classes run in fp8 — default: all; `on` may also be
+        that tuple.  The recipe `FP8_RECIPE_ACCURATE` keeps the two projections that write into the residual stream (out-proj,
+        MLP-down) in bf16.  BASELINE.json config 5; the reference has no fp8 path to match: accuracy is stated against the
+        bf16 path / the fp32 oracle in tests/test_gpu_fp8.py and printed next to every fp8 throughput figure by bench.py."""
+        if isinstance(on, (tuple, list, set, frozenset)):
+            on, classes = True, on
+        want = frozenset(self.FP8_CLASSES if classes is None else classes) if on else frozenset()
+        if not want <= set(self.FP8_CLASSES):
+            raise ValueError(f"fp8 classes {sorted(want)}: choose from {self.FP8_CLASSES}")
+        if want != getattr(self, "_fp8_classes", frozenset()):
+            self._fp8_classes = want
+            self.fp8 = bool(want)
             self._workspace = None          # the workspace grows by the e4m3 activation buffer
             self._invalidate_native()
+
+    FP8_RECIPE_ACCURATE = ("qkv", "mlp_up")
 
     def _set_weight_layout(self, blocked: bool) -> None:
         """In-place (one matrix of scratch) switch between the reference's row-major [out, in] and the K32-blocked order
@@ -451,7 +464,10 @@ class QwenImageTransformer2DModel(nn.Module):
                 mats = (a.to_qkv.weight, a.add_kv_proj.weight, a.to_out[0].weight, a.to_add_out.weight,
                         blk.img_mlp.net[0].proj.weight, blk.img_mlp.net[2].weight,
                         blk.txt_mlp.net[0].proj.weight, blk.txt_mlp.net[2].weight)
-                for f, m in zip(names, mats):
+                cls_of = ("qkv", "qkv", "out", "out", "mlp_up", "mlp_down", "mlp_up", "mlp_down")
+                for f, m, c in zip(names, mats, cls_of):
+                    if c not in self._fp8_classes:
+                        continue                                                              # NULL pointers: class stays bf16
                     w8, sc = ops.quantize_fp8_rows(m.data, x_k32_blocked=self._w_blocked)     # per output channel
                     keep += [w8, sc]
                     setattr(f8[i], f + ("_w8" if "mlp" not in f else "_8"), w8.data_ptr())
