@@ -178,19 +178,20 @@ def _engine_pipeline(layers: int, R: int):
     return pipe
 
 
-def engine_line(R: int, layers: int, static_images_per_sec: float) -> dict:
-    """The SERVING path on one GPU: DiffusionEngine -> WorkerProc -> ContinuousStepBatcher (static per-composition buffers,
-    device-side schedule vectors; reference loop shape gpu_worker.py:226-290), fed 4R requests whose arrivals are staggered, so
-    the running batch is re-composed while requests are mid-loop.  Images are decoded in the worker and returned through its
-    result queue, as a server would."""
+def engine_line(R: int, layers: int, static_images_per_sec: float, n_workers: int = 1, devices=None, dist_backend=None) -> dict:
+    """The SERVING path: DiffusionEngine -> one WorkerProc per GPU -> ContinuousStepBatcher (static per-composition buffers,
+    device-side schedule vectors, bounded host run-ahead; reference spawn shape diffusion_engine.py:211-270, loop shape
+    gpu_worker.py:226-290), fed 4R requests PER WORKER whose arrivals are staggered, so the running batches are re-composed
+    while requests are mid-loop; the dispatcher hands each request to the least-loaded worker.  Images are decoded in the
+    workers and returned through the result queue, as a server would.  Per worker: device-busy fraction from HIP events."""
     import functools
 
     from vllm_omni_amd.diffusion.data import OmniDiffusionConfig, TransformerConfig
     from vllm_omni_amd.diffusion.diffusion_engine import DiffusionEngine
     from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
 
-    cfg = OmniDiffusionConfig(model="Qwen/Qwen-Image(random-init)", max_step_batch=R, num_gpus=1,
-                              tf_model_config=TransformerConfig.from_dict({"num_layers": layers}))
+    cfg = OmniDiffusionConfig(model="Qwen/Qwen-Image(random-init)", max_step_batch=R, num_gpus=n_workers, devices=devices,
+                              dist_backend=dist_backend, tf_model_config=TransformerConfig.from_dict({"num_layers": layers}))
     eng = DiffusionEngine(cfg, pipeline_factory=functools.partial(_engine_pipeline, layers, R), post_process_func=None)
     try:
         g = torch.Generator().manual_seed(5)
@@ -203,23 +204,31 @@ def engine_line(R: int, layers: int, static_images_per_sec: float) -> dict:
                                         negative_prompt_embeds=torch.randn(1, T_TXT, 3584, generator=g).to(torch.bfloat16),
                                         output_type="pt")
 
-        for o in eng.add_req_and_wait_for_response([req() for _ in range(R)]):       # warm-up: one full batch
+        for o in eng.add_req_and_wait_for_response([req() for _ in range(R * n_workers)]):   # warm-up: one full batch per worker
             if o.error:
                 raise RuntimeError(o.error)
-        n, gap = 4 * R, 0.1                                  # four batches' worth: the ramps (partial batches at both ends) are ~1/4 of the run
+        eng.collective_rpc("serving_stats", kwargs={"reset": True})
+        n, gap = 4 * R * n_workers, 0.1 / n_workers         # four batches' worth per worker; the same arrival rate per worker
         t0 = time.perf_counter()
         ids = []
-        for i in range(n):                                   # one request every `gap` seconds: the batch grows while it runs
+        for i in range(n):                                   # one request every `gap` seconds: the batches grow while they run
             ids.append(eng.submit(req()))
             time.sleep(gap)
         outs = [eng.poll(i) for i in ids]
         dt = time.perf_counter() - t0
         if any(o is None or o.error for o in outs):
             raise RuntimeError(str([o.error for o in outs if o is not None and o.error]))
+        stats = eng.collective_rpc("serving_stats")
+        workers = [{"rank": r, "steps": st["steps"], "mean_batch": st["sample_steps"] / max(1, st["steps"]),
+                    "device_busy_s": st["busy_s"], "device_span_s": st["span_s"], "busy_frac": st["busy_frac"]}
+                   for r, st in enumerate(stats)]
         return {"engine_images_per_sec": n / dt, "engine_vs_static_loop": (n / dt) / static_images_per_sec,
-                "engine_note": f"DiffusionEngine.submit/poll, 1 worker process, {n} requests of 1024^2 x 20 steps true-CFG arriving "
-                               f"{gap} s apart (continuous step batching, max {R} per forward), images decoded in the worker and "
-                               "returned as CPU tensors; wall time from the first submit to the last result"}
+                "engine_workers": workers,
+                "engine_note": f"DiffusionEngine.submit/poll, {n_workers} worker process(es), {n} requests of 1024^2 x 20 steps true-CFG "
+                               f"arriving {gap:.3f} s apart (continuous step batching, max {R} per forward, host at most 2 steps "
+                               "ahead of the device), images decoded in the workers and returned as CPU tensors; wall time from the "
+                               "first submit to the last result; engine_workers[].busy_frac = device seconds inside denoise steps / "
+                               "span from the first to the last step (HIP events)"}
     finally:
         eng.close()
 
@@ -342,6 +351,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-engine", action="store_true", help="skip the serving-path (DiffusionEngine) secondary line")
     ap.add_argument("--sp", type=int, default=0, help="P = --gpus: also time one 2048^2 request Ulysses-parallel over all ranks")
+    # dev / test only: run the N-rank control flow (self-launch, rendezvous, per-rank stats, gather, JSON) on ONE device —
+    # every rank on device 0 over a gloo group (RCCL refuses duplicate GPUs).  tests/test_gpu_multirank_bench.py
+    ap.add_argument("--dist-backend", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     from vllm_omni_amd.diffusion.data import OmniDiffusionConfig, TransformerConfig
@@ -351,13 +364,21 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
-    rank, world, local = dp.init_distributed()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product kernels")
+    local_dev = None
+    if args.share_device:
+        local_dev = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    rank, world, local = dp.init_distributed(backend=args.dist_backend, local_device=local_dev)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from vllm_omni_amd.diffusion.distributed.numa import pin_to_gpu_numa
+
+    numa = pin_to_gpu_numa(local)                  # this rank's host threads next to its GPU (distributed/numa.py)
+    # idle ranks wait on the CPU (a gloo group): an RCCL barrier spins a kernel on the GPU the serving-path workers then use
+    cpu_group = torch.distributed.new_group(backend="gloo") if world > 1 else None
 
     R = args.requests
     cfg = OmniDiffusionConfig(model="Qwen/Qwen-Image(random-init)", max_step_batch=R,
@@ -408,14 +429,16 @@ def main():
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     parts = [sum(ev[k].elapsed_time(ev[k + 1]) for ev in marks) * 1e-3 for k in range(3)]   # denoise, gather, decode
-    stats = torch.tensor([elapsed, mine] + parts, device=dev, dtype=torch.float64)
+    stats = torch.tensor([elapsed, mine] + parts + [float(numa["node"]) if numa["node"] is not None else -1.0,
+                                                    1.0 if numa["pinned"] else 0.0, float(numa["cpus"])], dtype=torch.float64)
     if world > 1:
         allstats = [torch.zeros_like(stats) for _ in range(world)]
-        torch.distributed.all_gather(allstats, stats)
+        torch.distributed.all_gather(allstats, stats, group=cpu_group)
         elapsed = max(float(t[0]) for t in allstats)
     else:
         allstats = [stats]
-    per_rank = [{"rank": r, "seconds": float(t[1]), "denoise_s": float(t[2]), "gather_s": float(t[3]), "vae_decode_s": float(t[4])}
+    per_rank = [{"rank": r, "seconds": float(t[1]), "denoise_s": float(t[2]), "gather_s": float(t[3]), "vae_decode_s": float(t[4]),
+                 "numa_node": int(t[5]), "numa_pinned": bool(t[6]), "host_cpus": int(t[7])}
                 for r, t in enumerate(allstats)]
     ok = bool(torch.isfinite(img.float()).all()) and bool(torch.isfinite(gathered.float()).all())
 
@@ -472,18 +495,30 @@ def main():
                 line["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         if sp_line is not None:
             line.setdefault("secondary", {}).update(sp_line)
-        if world == 1 and not args.no_engine:
-            del pipe                                         # the worker process builds its own 41 GB of weights
-            torch.cuda.empty_cache()
+    # the serving topology (N = 1 and N > 1): rank 0 drives a DiffusionEngine with one worker process per GPU; the ranks of the
+    # static measurement release their weights first and (N > 1) wait on the CPU until rank 0 is through
+    run_engine = not args.no_engine and not args.sp
+    if run_engine:
+        del pipe                                             # every worker process builds its own 41 GB of weights
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        if world > 1:
+            torch.distributed.barrier(group=cpu_group)
+    if rank == 0:
+        if run_engine:
+            devices = [r % torch.cuda.device_count() for r in range(world)] if args.share_device else None
             try:
-                line.setdefault("secondary", {}).update(engine_line(R, args.layers, value))
+                line.setdefault("secondary", {}).update(engine_line(R, args.layers, value, n_workers=world, devices=devices,
+                                                                    dist_backend=args.dist_backend))
             except Exception as e:  # noqa: BLE001
                 line.setdefault("secondary", {})["engine_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
-        torch.distributed.barrier()
+        torch.distributed.barrier(group=cpu_group)
         torch.distributed.destroy_process_group()
 
 

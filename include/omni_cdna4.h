@@ -261,6 +261,11 @@ int omni_timestep_sinusoid(const float* t, int32_t B, int32_t dim, float scale, 
  * ---------------------------------------------------------------------------------------------- */
 int omni_cfg_euler_step(const omni_bf16* pos, const omni_bf16* neg, omni_bf16* latents, int32_t rows, int32_t C,
                         float true_cfg_scale, const float* dt, int32_t dt_rows_per_item, omni_stream stream);
+/* ABI v9 — same with the norm rescale optional: normalize = 0 -> pred = comb (the Layered pipeline's default,
+ * pipeline_qwen_image_layered.py:599-605 `cfg_normalize`); normalize = 1 == omni_cfg_euler_step. */
+int omni_cfg_euler_step_ex(const omni_bf16* pos, const omni_bf16* neg, omni_bf16* latents, int32_t rows, int32_t C,
+                           float true_cfg_scale, const float* dt, int32_t dt_rows_per_item, int32_t normalize,
+                           omni_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * VAE kernels (AutoencoderKLQwenImage.decode — and .encode for the Edit pipelines — for one frame,
@@ -391,6 +396,8 @@ typedef struct {
   void* workspace;
   size_t workspace_bytes;
   const omni_teacache* teacache;  /* nullable: TeaCache off.  All items must have the same number of image rows.  ABI v3 */
+  const omni_bf16* temb_add;      /* ABI v9, nullable: [n_temb, D] bf16 added to the timestep embedding — the Layered variant's
+                                   * addition_t_embedding(additional_t_cond) rows (qwen_image_transformer.py:47-62) */
 } omni_dit_batch;
 
 size_t omni_dit_workspace_bytes(const omni_dit_weights* w, int32_t n_img_rows, int32_t n_txt_rows, int32_t n_temb);

@@ -518,6 +518,95 @@ def run_edit_prompt_encode_case():
                         meta=json.dumps(meta), **out)
 
 
+def layered_params(case):
+    """make_dit_params + the Layered variant's `time_text_embed.addition_t_embedding.weight` [2, D] (seeded)."""
+    P = O.make_dit_params(case["layers"], seed=1234, bias_std=case["bias_std"], norm_jitter=case["jitter"],
+                          num_heads=case["heads"], joint_dim=case["joint"])
+    g = torch.Generator().manual_seed(4321)
+    P["time_text_embed.addition_t_embedding.weight"] = torch.randn(2, case["heads"] * 128, generator=g) * 0.5
+    return P
+
+
+def run_layered_case():
+    """The Layered variant, the buildable part (zero_cond_t = False): the reference DiT built with
+    use_additional_t_cond=True, use_layer3d_rope=True (qwen_image_transformer.py:47-62, 65-176) over the Layered pipeline's
+    sequence [layers + 1 generated frames ; condition image]; the pipeline's own helpers (_pack_latents / _unpack_latents /
+    calculate_dimensions / retrieve_timesteps with mu = sqrt(S_cond / 256)) and its diffuse() loop
+    (pipeline_qwen_image_layered.py:518-536, 538-615, 808-816) with cfg_normalize off (its default) and on."""
+    import ref_shims_pipeline as RP
+
+    case = dict(layers=2, heads=2, joint=128, img_layers=2, gen_grid=(8, 6), cond_grid=(6, 10), T=9, Tneg=5, steps=3, cfg=4.0,
+                bias_std=0.02, jitter=0.1)
+    P = layered_params(case)
+    model, cfg = ref_shims.build_reference_model(case["layers"], num_attention_heads=case["heads"],
+                                                 joint_attention_dim=case["joint"], dtype=torch.float32,
+                                                 use_additional_t_cond=True, use_layer3d_rope=True, zero_cond_t=False)
+    assert [n for n, _ in model.named_parameters()].count("time_text_embed.addition_t_embedding.weight") == 1
+    model.load_state_dict(P, strict=True)
+    gh, gw = case["gen_grid"]
+    ch, cw = case["cond_grid"]
+    nl = case["img_layers"]
+    shapes = [(1, gh, gw)] * (nl + 1) + [(1, ch, cw)]
+    S_gen, S_c = (nl + 1) * gh * gw, ch * cw
+    g = torch.Generator().manual_seed(42)
+    lat = torch.randn(1, S_gen, 64, generator=g)
+    img_lat = torch.randn(1, S_c, 64, generator=g)
+    pos = torch.randn(1, case["T"], case["joint"], generator=g)
+    neg = torch.randn(1, case["Tneg"], case["joint"], generator=g)
+    out = {}
+    # ---- one forward over a batch of two, additional_t_cond = [0, 1]
+    x2 = torch.cat([torch.cat([lat, img_lat], 1), torch.cat([lat.flip(1), img_lat], 1)])
+    fwd = ref_shims.reference_forward(
+        model, cfg, hidden_states=x2, encoder_hidden_states=torch.cat([pos, pos.flip(1)]),
+        encoder_hidden_states_mask=torch.ones(2, case["T"], dtype=torch.long), timestep=torch.tensor([0.62, 0.62]),
+        img_shapes=[shapes] * 2, txt_seq_lens=[case["T"]] * 2, additional_t_cond=torch.tensor([0, 1]))
+    out["fwd_in"], out["fwd_txt"], out["fwd_out"] = x2.numpy(), torch.cat([pos, pos.flip(1)]).numpy(), fwd.numpy()
+    # ---- helpers
+    pipe, mod = RP.reference_layered_shell(model, cfg)
+    L = mod.QwenImageLayeredPipeline
+    raw = torch.randn(2, nl + 1, 16, 2 * gh, 2 * gw, generator=g)
+    packed = L._pack_latents(raw, 2, 16, 2 * gh, 2 * gw, nl + 1)
+    out["pack_in"], out["pack_out"] = raw.numpy(), packed.numpy()
+    out["unpack_out"] = L._unpack_latents(packed, 16 * gh, 16 * gw, nl, 8).numpy()
+    ratios = [1.0, 0.75, 1.7777, 0.5]
+    out["dims_ratio"] = np.array(ratios)
+    out["dims_640"] = np.array([mod.calculate_dimensions(640 * 640, r) for r in ratios])
+    out["dims_1024"] = np.array([mod.calculate_dimensions(1024 * 1024, r) for r in ratios])
+    sig_in = np.linspace(1.0, 0, case["steps"] + 1)[:-1]
+    mu = (S_c / (256 * 256 / 16 / 16)) ** 0.5
+    timesteps, n = mod.retrieve_timesteps(pipe.scheduler, case["steps"], None, sigmas=sig_in, mu=mu)
+    assert n == case["steps"]
+    out["timesteps"], out["sigmas"], out["mu"] = timesteps.numpy(), pipe.scheduler.sigmas.numpy(), np.array(mu)
+    # ---- diffuse, cfg_normalize off / on
+    for norm in (False, True):
+        traj = []
+        sch = RP.FlowMatchEulerDiscreteSchedulerStub()
+        pipe.scheduler = sch
+        timesteps, _ = mod.retrieve_timesteps(sch, case["steps"], None, sigmas=sig_in, mu=mu)
+        orig_step = sch.step
+
+        def tap(*a, _o=orig_step, **k):
+            r = _o(*a, **k)
+            traj.append(r[0].clone())
+            return r
+
+        sch.step = tap
+        fc = __import__("importlib").import_module("vllm_omni.diffusion.forward_context")
+        with torch.no_grad(), fc.set_forward_context(omni_diffusion_config=cfg):
+            final = L.diffuse(pipe, pos, torch.ones(1, case["T"], dtype=torch.long), neg, torch.ones(1, case["Tneg"], dtype=torch.long),
+                              lat, img_lat, [shapes], [case["T"]], [case["Tneg"]], timesteps, True, None, case["cfg"], norm,
+                              torch.tensor([0], dtype=torch.long))
+        tag = "norm" if norm else "plain"
+        out[f"final_{tag}"], out[f"traj_{tag}"] = final.numpy(), torch.stack(traj).numpy()
+    meta = dict(case=case, params_sha256=params_checksum(P), param_seed=1234, t_embed_seed=4321,
+                reference="qwen_image_transformer.py:47-62,65-176,692-802 (use_additional_t_cond, use_layer3d_rope) and "
+                          "pipeline_qwen_image_layered.py:518-615,808-816 via oracle/ref_shims*.py; scheduler = restated stub")
+    np.savez_compressed(os.path.join(OUT, "layered_dit_and_pipeline.npz"), latents=lat.numpy(), image_latents=img_lat.numpy(),
+                        pos=pos.numpy(), neg=neg.numpy(), meta=json.dumps(meta), **out)
+    print(f"layered_dit_and_pipeline: fwd std {fwd.std():.4f}, final(plain) std {out['final_plain'].std():.4f}, "
+          f"final(norm) std {out['final_norm'].std():.4f}, timesteps {timesteps.tolist()}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -543,6 +632,8 @@ def main():
         run_prompt_encode_case()
     if only is None or "editprompt" in only:
         run_edit_prompt_encode_case()
+    if only is None or "layered" in only:
+        run_layered_case()
 
 
 if __name__ == "__main__":

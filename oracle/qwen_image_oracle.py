@@ -127,6 +127,25 @@ def rope_tables_multi(grids, txt_len: int, axes_dim=(16, 56, 56), theta: float =
     return (torch.cat(cos), torch.cat(sin)), (tc, ts)
 
 
+def rope_tables_layered(grids, txt_len: int, axes_dim=(16, 56, 56), theta: float = 10000.0):
+    """QwenEmbedLayer3DRope.forward (Layered variant) — qwen_image_transformer.py:101-142: entries idx < last sit at frame
+    position idx (`_compute_video_freqs(.., idx)`, :144-161), the LAST entry is the condition image at frame position -1
+    (`_compute_condition_freqs`, :163-176: `freqs_neg[0][-1:]`); text positions start at max(h//2, w//2 over all entries,
+    layer_num = len(grids) - 1) (:131-138)."""
+    cos, sin, start = [], [], 0
+    layer_num = len(grids) - 1
+    for idx, (f, h, w) in enumerate(grids):
+        (vc, vs), _ = rope_tables(f, h, w, 1, axes_dim, theta, frame_offset=(idx if idx != layer_num else -1))
+        cos.append(vc)
+        sin.append(vs)
+        start = max(start, h // 2, w // 2)
+    start = max(start, layer_num)
+    t_idx = torch.arange(start, start + txt_len)
+    tc = torch.cat([rope_axis_freqs(t_idx, d, theta)[0] for d in axes_dim], dim=1)
+    ts = torch.cat([rope_axis_freqs(t_idx, d, theta)[1] for d in axes_dim], dim=1)
+    return (torch.cat(cos), torch.cat(sin)), (tc, ts)
+
+
 def rope_tables(frame: int, height: int, width: int, txt_len: int, axes_dim=(16, 56, 56), theta: float = 10000.0,
                 frame_offset: int = 0):
     """QwenEmbedRope.forward + _compute_video_freqs, scale_rope=True — qwen_image_transformer.py:222-285.
@@ -223,7 +242,7 @@ def num_layers_of(P: Params) -> int:
 
 def dit_forward(P: Params, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor,
                 timestep: torch.Tensor, img_shape: tuple[int, int, int], num_heads: int = 24,
-                taps: dict | None = None) -> torch.Tensor:
+                taps: dict | None = None, layer3d_rope: bool = False, additional_t_cond: torch.Tensor | None = None) -> torch.Tensor:
     """QwenImageTransformer2DModel.forward — qwen_image_transformer.py:692-802 (no SP, no guidance).
 
     hidden_states [B,S_img,64] packed latents, encoder_hidden_states [B,T,joint_dim],
@@ -236,7 +255,13 @@ def dit_forward(P: Params, hidden_states: torch.Tensor, encoder_hidden_states: t
     enc = rms_norm(encoder_hidden_states, P["txt_norm.weight"])
     enc = F.linear(enc, P["txt_in.weight"], P["txt_in.bias"])
     temb = timestep_embedding(P, timestep, hidden.dtype)
-    if isinstance(img_shape[0], (tuple, list)):          # several images on the sequence axis (Edit pipelines)
+    if additional_t_cond is not None:                    # Layered: conditioning = timesteps_emb + addition_t_embedding(c)  (:55-60)
+        add = P["time_text_embed.addition_t_embedding.weight"][additional_t_cond.long().to(temb.device)]
+        temb = temb + add.to(temb.dtype)
+    if layer3d_rope:                                     # Layered: QwenEmbedLayer3DRope (:65-176)
+        shp = [tuple(g) for g in img_shape] if isinstance(img_shape[0], (tuple, list)) else [tuple(img_shape)]
+        vid_cs, txt_cs = rope_tables_layered(shp, T)
+    elif isinstance(img_shape[0], (tuple, list)):        # several images on the sequence axis (Edit pipelines)
         vid_cs, txt_cs = rope_tables_multi([tuple(g) for g in img_shape], T)
     else:
         vid_cs, txt_cs = rope_tables(*img_shape, T)
@@ -289,6 +314,78 @@ class SchedulerConfig:
     max_shift: float = 0.9
     shift_terminal: float | None = 0.02
     shift: float = 1.0
+
+
+def flow_match_sigmas_mu(sigmas_in, mu: float, cfg: SchedulerConfig = SchedulerConfig()):
+    """FlowMatchEulerDiscreteScheduler.set_timesteps(sigmas=, mu=) as the Layered pipeline drives it
+    (pipeline_qwen_image_layered.py:808-816: sigmas = linspace(1, 0, N + 1)[:-1], mu = sqrt(S_cond / 256)): exponential shift
+    with the GIVEN mu, terminal stretch, trailing 0.  Same float32 numpy arithmetic as `flow_match_sigmas`."""
+    import numpy as np
+
+    sigmas = np.array(sigmas_in).astype(np.float32)
+    sigmas = math.exp(mu) / (math.exp(mu) + (1 / sigmas - 1) ** 1.0)
+    if cfg.shift_terminal:
+        one_minus = 1 - sigmas
+        scale = one_minus[-1] / (1 - cfg.shift_terminal)
+        sigmas = 1 - (one_minus / scale)
+    sig = torch.from_numpy(np.asarray(sigmas)).to(torch.float32)
+    return sig * cfg.num_train_timesteps, torch.cat([sig, torch.zeros(1)])
+
+
+def layered_sigmas(num_inference_steps: int, cond_seq_len: int, cfg: SchedulerConfig = SchedulerConfig()):
+    """pipeline_qwen_image_layered.py:808-816."""
+    import numpy as np
+
+    base_seqlen = 256 * 256 / 16 / 16
+    return flow_match_sigmas_mu(np.linspace(1.0, 0, num_inference_steps + 1)[:-1], (cond_seq_len / base_seqlen) ** 0.5, cfg)
+
+
+def layered_calculate_dimensions(target_area: float, ratio: float) -> tuple[int, int]:
+    """pipeline_qwen_image_layered.py:108-116 -> (width, height), multiples of 32."""
+    width = math.sqrt(target_area * ratio)
+    height = width / ratio
+    return round(width / 32) * 32, round(height / 32) * 32
+
+
+def layered_pack_latents(latents: torch.Tensor) -> torch.Tensor:
+    """QwenImageLayeredPipeline._pack_latents — pipeline_qwen_image_layered.py:518-524.  [B, L, C, H, W] -> [B, L*(H/2)(W/2), 4C]."""
+    B, L, C, H, W = latents.shape
+    x = latents.view(B, L, C, H // 2, 2, W // 2, 2).permute(0, 1, 3, 5, 2, 4, 6)
+    return x.reshape(B, L * (H // 2) * (W // 2), C * 4)
+
+
+def layered_unpack_latents(latents: torch.Tensor, height: int, width: int, layers: int, vae_scale_factor: int = 8) -> torch.Tensor:
+    """QwenImageLayeredPipeline._unpack_latents — :526-541.  -> [B, C, layers + 1, H/8, W/8]."""
+    B, _, ch = latents.shape
+    h = 2 * (int(height) // (vae_scale_factor * 2))
+    w = 2 * (int(width) // (vae_scale_factor * 2))
+    x = latents.view(B, layers + 1, h // 2, w // 2, ch // 4, 2, 2).permute(0, 1, 4, 2, 5, 3, 6)
+    return x.reshape(B, layers + 1, ch // 4, h, w).permute(0, 2, 1, 3, 4)
+
+
+def layered_diffuse(P: Params, latents: torch.Tensor, image_latents: torch.Tensor, prompt_embeds: torch.Tensor,
+                    negative_prompt_embeds: torch.Tensor | None, img_shapes, num_inference_steps: int,
+                    true_cfg_scale: float = 4.0, cfg_normalize: bool = False, num_heads: int = 24,
+                    sched: SchedulerConfig = SchedulerConfig(), trajectory: list | None = None, is_rgb: int = 0) -> torch.Tensor:
+    """QwenImageLayeredPipeline.diffuse — pipeline_qwen_image_layered.py:543-615: the generated frames and the condition image
+    on one sequence axis, prediction sliced back to the generated rows, additional_t_cond = is_rgb, true-CFG combination with
+    the norm rescale only when `cfg_normalize` (default off, :662)."""
+    timesteps, sigmas = layered_sigmas(num_inference_steps, image_latents.shape[1], sched)
+    do_cfg = negative_prompt_embeds is not None and true_cfg_scale > 1
+    cond = torch.full((latents.shape[0],), int(is_rgb), dtype=torch.long)
+    S = latents.shape[1]
+    for i, t in enumerate(timesteps):
+        ts = t.expand(latents.shape[0]).to(latents.dtype)
+        x = torch.cat([latents, image_latents], dim=1)
+        pred = dit_forward(P, x, prompt_embeds, ts / 1000, img_shapes, num_heads, layer3d_rope=True, additional_t_cond=cond)[:, :S]
+        if do_cfg:
+            neg = dit_forward(P, x, negative_prompt_embeds, ts / 1000, img_shapes, num_heads, layer3d_rope=True,
+                              additional_t_cond=cond)[:, :S]
+            pred = cfg_combine(pred, neg, true_cfg_scale) if cfg_normalize else neg + true_cfg_scale * (pred - neg)
+        latents = euler_step(latents, pred, float(sigmas[i]), float(sigmas[i + 1]))
+        if trajectory is not None:
+            trajectory.append(latents.clone())
+    return latents
 
 
 def flow_match_sigmas(num_inference_steps: int, image_seq_len: int, cfg: SchedulerConfig = SchedulerConfig()):

@@ -265,7 +265,7 @@ def load_reference_dit():
 
 
 def build_reference_model(num_layers: int, *, num_attention_heads: int = 24, attention_head_dim: int = 128,
-                          joint_attention_dim: int = 3584, dtype=torch.float32):
+                          joint_attention_dim: int = 3584, dtype=torch.float32, **model_kw):
     """Instantiate the reference QwenImageTransformer2DModel on CPU (reference file :609-690)."""
     mod = load_reference_dit()
     data = importlib.import_module("vllm_omni.diffusion.data")
@@ -275,7 +275,7 @@ def build_reference_model(num_layers: int, *, num_attention_heads: int = 24, att
     with data.set_current_omni_diffusion_config(cfg):
         model = mod.QwenImageTransformer2DModel(od_config=cfg, num_attention_heads=num_attention_heads,
                                                 attention_head_dim=attention_head_dim,
-                                                joint_attention_dim=joint_attention_dim)
+                                                joint_attention_dim=joint_attention_dim, **model_kw)
     return model.to(dtype).eval(), cfg
 
 

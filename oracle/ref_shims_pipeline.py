@@ -233,3 +233,24 @@ def reference_diffuse(pipe, cfg, **kw):
     fc = importlib.import_module("vllm_omni.diffusion.forward_context")
     with torch.no_grad(), fc.set_forward_context(omni_diffusion_config=cfg):
         return type(pipe).diffuse(pipe, **kw)
+
+
+def load_reference_layered_module():
+    """vllm_omni/diffusion/models/qwen_image/pipeline_qwen_image_layered.py, unmodified (its transformers imports are real, its
+    diffusers / vllm imports are the stubs installed above)."""
+    install()
+    return importlib.import_module("vllm_omni.diffusion.models.qwen_image.pipeline_qwen_image_layered")
+
+
+def reference_layered_shell(transformer, cfg, scheduler=None):
+    """A bare QwenImageLayeredPipeline (no __init__: it loads a checkpoint) carrying what `diffuse` reads."""
+    mod = load_reference_layered_module()
+    pipe = object.__new__(mod.QwenImageLayeredPipeline)
+    nn.Module.__init__(pipe)
+    pipe.transformer = transformer
+    pipe.scheduler = scheduler or FlowMatchEulerDiscreteSchedulerStub()
+    pipe._interrupt = False
+    pipe._attention_kwargs = None
+    pipe._current_timestep = None
+    pipe.vae_scale_factor = 8
+    return pipe, mod

@@ -71,7 +71,8 @@ def test_ctypes_struct_layout_matches_c():
 
     assert ctypes.sizeof(N.GemmGroup) == 216 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 216 + 16 + 8  # ABI v3: + tile_skip; v4: + split-K workspace; v6: + kernel_hint
     assert N.GemmParams.splitk_ws.offset == 24 + 2 * 216 and N.GemmParams.kernel_hint.offset == 24 + 2 * 216 + 16
-    assert ctypes.sizeof(N.TeaCache) == 24 + 10 * 8 and N.DitBatch.teacache.offset == ctypes.sizeof(N.DitBatch) - 8
+    assert ctypes.sizeof(N.TeaCache) == 24 + 10 * 8 and N.DitBatch.teacache.offset == ctypes.sizeof(N.DitBatch) - 16
+    assert N.DitBatch.temb_add.offset == ctypes.sizeof(N.DitBatch) - 8                   # ABI v9: appended behind teacache
     assert ctypes.sizeof(N.DitLayerWeights) == 24 * 8
     assert N.GemmParams.g.offset == 24 and N.DitWeights.t_lin1_w.offset == 32   # w_k32_blocked flags live in padding / ABI v2
 
@@ -617,3 +618,63 @@ def test_processor_image_layouts_and_edit_plus_condition_size():
         assert (gw, gh) == (cw, ch) and abs(cw * ch - 384 * 384) / (384 * 384) < 0.1
     given = [torch.zeros(3, 8, 8)]
     assert shell._prompt_pictures(OmniDiffusionRequest(prompt="x", extra={"image": pics, "prompt_image": given})) is given
+
+
+def test_numa_pinning_reads_sysfs_and_degrades_quietly(tmp_path):
+    """distributed/numa.py: cpulist parsing, the sysfs walk (a fake tree), and the no-information cases leave the affinity alone."""
+    from vllm_omni_amd.diffusion.distributed import numa
+
+    assert numa.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and numa.parse_cpulist("") == []
+    dev = tmp_path / "bus/pci/devices/0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices/system/node/node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("64-127\n")
+    assert numa.numa_cpus_of("0000:c1:00.0", str(tmp_path)) == (1, list(range(64, 128)))
+    (dev / "numa_node").write_text("-1\n")
+    assert numa.numa_cpus_of("0000:c1:00.0", str(tmp_path)) is None
+    assert numa.numa_cpus_of("0000:ff:00.0", str(tmp_path)) is None
+    before = os.sched_getaffinity(0)
+    info = numa.pin_to_gpu_numa(0, str(tmp_path))              # no GPU here: nothing to pin to
+    assert info["pinned"] is False and os.sched_getaffinity(0) == before
+
+
+def test_layered_host_pieces_match_the_reference_run():
+    """Host side of the Layered variant against tests/golden/layered_dit_and_pipeline.npz (the reference's own helpers, run):
+    layer-3D RoPE tables, frame-wise pack / unpack, pre-process dimensions, the mu = sqrt(S_cond / 256) schedule."""
+    import json
+
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image_layered import QwenImageLayeredPipeline as L
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image_layered import preprocess
+    from vllm_omni_amd.diffusion.models.qwen_image.rope import grid_tokens, layered_grids, rope_table
+    from vllm_omni_amd.diffusion.models.qwen_image.scheduling_flow_match import FlowMatchEulerSchedule
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "layered_dit_and_pipeline.npz"))
+    c = json.loads(str(z["meta"]))["case"]
+    gh, gw = c["gen_grid"]
+    ch, cw = c["cond_grid"]
+    nl = c["img_layers"]
+    shapes = [(1, gh, gw)] * (nl + 1) + [(1, ch, cw)]
+    grid = layered_grids(shapes)
+    assert [e[3] for e in grid] == [0, 1, 2, -1] and grid_tokens(grid) == (nl + 1) * gh * gw + ch * cw
+    (vc, vs), (tc, ts) = O.rope_tables_layered(shapes, 11)
+    cos, sin = rope_table(grid, 11)
+    assert torch.equal(cos[:11], tc) and torch.equal(cos[11:], vc) and torch.equal(sin[:11], ts) and torch.equal(sin[11:], vs)
+    tiny = [(1, 2, 2)] * 6 + [(1, 2, 2)]                      # more layers than half-extent: the text start is the layer count
+    (_, _), (tc2, _) = O.rope_tables_layered(tiny, 3)
+    assert torch.equal(rope_table(layered_grids(tiny), 3)[0][:3], tc2)
+    t = torch.from_numpy
+    assert torch.equal(L._pack_latents(t(z["pack_in"]), 2, 16, 2 * gh, 2 * gw, nl + 1), t(z["pack_out"]))
+    assert torch.equal(L._unpack_latents(t(z["pack_out"]), 16 * gh, 16 * gw, nl), t(z["unpack_out"]))
+    for i, r in enumerate(z["dims_ratio"]):
+        for res in (640, 1024):
+            p = preprocess((int(1000 * r), 1000), res)
+            want = O.layered_calculate_dimensions(res * res, int(1000 * r) / 1000)
+            assert (p["calculated_width"], p["calculated_height"]) == want and p["width"] % 16 == 0 and p["height"] % 16 == 0
+        assert list(O.layered_calculate_dimensions(640 * 640, float(r))) == z["dims_640"][i].tolist()
+    sch = FlowMatchEulerSchedule()
+    ts_ = sch.set_timesteps(c["steps"], 123, np.linspace(1.0, 0, c["steps"] + 1)[:-1], mu=float(z["mu"]))
+    assert torch.equal(ts_, t(z["timesteps"])) and torch.equal(sch.sigmas, t(z["sigmas"]))
+    with pytest.raises(ValueError):
+        preprocess((100, 100), 512)

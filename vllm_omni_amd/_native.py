@@ -116,6 +116,7 @@ class DitBatch(C.Structure):
         ("noise_pred", c_bf16_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("teacache", C.POINTER(TeaCache)),
+        ("temb_add", c_bf16_p),                                                                    # ABI v9, nullable
     ]
 
 
@@ -151,6 +152,8 @@ PROTOTYPES = {
     "omni_timestep_sinusoid": (C.c_int, [c_f32_p, C.c_int32, C.c_int32, C.c_float, c_bf16_p, C.c_void_p]),
     "omni_cfg_euler_step": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, C.c_int32, C.c_int32, C.c_float, c_f32_p,
                                       C.c_int32, C.c_void_p]),
+    "omni_cfg_euler_step_ex": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, C.c_int32, C.c_int32, C.c_float, c_f32_p,
+                                         C.c_int32, C.c_int32, C.c_void_p]),                      # ABI v9
     "omni_vae_conv2d": (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
     "omni_vae_upsample2x_bordered": (C.c_int, [c_bf16_p, c_bf16_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "omni_vae_rmsnorm_silu": (C.c_int, [c_bf16_p, c_bf16_p, C.c_int64, C.c_int32, c_bf16_p, C.c_int32, C.c_void_p]),

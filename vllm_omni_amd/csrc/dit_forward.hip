@@ -340,6 +340,8 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
   OMNI_TRY(omni_timestep_sinusoid(b->timestep, nT, 256, 1000.0f, ws.tproj, stream));
   OMNI_TRY(linear_rows(ws.tproj, 256, nT, w->t_lin1_w, w->t_lin1_b, D, 256, ws.th, D, 0, 1, stream));
   OMNI_TRY(linear_rows(ws.th, D, nT, w->t_lin2_w, w->t_lin2_b, D, D, ws.temb, D, 0, 0, stream));
+  // Layered variant: conditioning = timestep_emb + addition_t_embedding[additional_t_cond]   (reference :55-60)
+  if (b->temb_add) OMNI_TRY(omni_internal_add_bf16(ws.temb, b->temb_add, (int64_t)nT * D, stream));
 
   // --- input projections (reference :743, :758-759) -------------------------------------------------------
   {

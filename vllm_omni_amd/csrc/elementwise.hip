@@ -305,7 +305,7 @@ __global__ void timestep_sinusoid_kernel(const float* __restrict__ t, int B, int
 __global__ __launch_bounds__(256) void cfg_euler_kernel(const uint16_t* __restrict__ pos,
                                                         const uint16_t* __restrict__ neg,
                                                         uint16_t* __restrict__ lat, int rows, float cfg_scale,
-                                                        const float* __restrict__ dt, int dt_rows_per_item) {
+                                                        const float* __restrict__ dt, int dt_rows_per_item, int normalize) {
   const int sub = threadIdx.x & 7;
   const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
   if (row >= rows) return;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void cfg_euler_kernel(const uint16_t* __restri
     }
     pp = wave_sum<8>(pp);
     cc = wave_sum<8>(cc);
-    const float r = sqrtf(pp) / sqrtf(cc);
+    const float r = normalize ? sqrtf(pp) / sqrtf(cc) : 1.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) pred[i] *= r;
   } else {
@@ -342,6 +342,11 @@ __global__ __launch_bounds__(256) void cfg_euler_kernel(const uint16_t* __restri
 }  // namespace
 
 namespace {
+// dst[i] += src[i] on bf16 (one rounding of the sum): conditioning = timestep_emb + addition_t_emb of the Layered variant
+__global__ __launch_bounds__(256) void add_bf16_kernel(uint16_t* __restrict__ dst, const uint16_t* __restrict__ src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = f32_to_bf16_bits(bf16_bits_to_f32(dst[i]) + bf16_bits_to_f32(src[i]));
+}
 __global__ __launch_bounds__(256) void gather_i32_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src,
                                                          const int32_t* __restrict__ idx, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -685,14 +690,27 @@ extern "C" int omni_timestep_sinusoid(const float* t, int32_t B, int32_t dim, fl
   return OMNI_OK;
 }
 
-extern "C" int omni_cfg_euler_step(const omni_bf16* pos, const omni_bf16* neg, omni_bf16* latents, int32_t rows,
-                                   int32_t C, float true_cfg_scale, const float* dt, int32_t dt_rows_per_item,
-                                   omni_stream stream) {
+extern "C" int omni_cfg_euler_step_ex(const omni_bf16* pos, const omni_bf16* neg, omni_bf16* latents, int32_t rows,
+                                      int32_t C, float true_cfg_scale, const float* dt, int32_t dt_rows_per_item,
+                                      int32_t normalize, omni_stream stream) {
   if (!pos || !latents || !dt || rows <= 0) return OMNI_ERR_BAD_ARG;
   if (C != 64) return OMNI_ERR_UNSUPPORTED;
   if (!omni_aligned16(pos) || !omni_aligned16(latents) || (neg && !omni_aligned16(neg))) return OMNI_ERR_ALIGN;
   hipLaunchKernelGGL(cfg_euler_kernel, dim3((rows + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream), pos,
-                     neg, latents, rows, true_cfg_scale, dt, dt_rows_per_item);
+                     neg, latents, rows, true_cfg_scale, dt, dt_rows_per_item, normalize ? 1 : 0);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+extern "C" int omni_cfg_euler_step(const omni_bf16* pos, const omni_bf16* neg, omni_bf16* latents, int32_t rows,
+                                   int32_t C, float true_cfg_scale, const float* dt, int32_t dt_rows_per_item,
+                                   omni_stream stream) {
+  return omni_cfg_euler_step_ex(pos, neg, latents, rows, C, true_cfg_scale, dt, dt_rows_per_item, 1, stream);
+}
+
+int omni_internal_add_bf16(omni_bf16* dst, const omni_bf16* src, int64_t n, void* stream) {
+  if (!dst || !src || n <= 0) return OMNI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dst, src, n);
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }

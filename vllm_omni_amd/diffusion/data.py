@@ -92,6 +92,10 @@ class OmniDiffusionConfig:
                                      # items x 4160 rows fills the 256 CUs' tile rounds best at 1024^2: DESIGN.md 7)
     dist_timeout: int | None = None
     use_hip_graph: bool | None = None   # NEW: capture one denoise step as a hipGraph (None = automatic by size)
+    devices: list[int] | None = None # device index of every rank (None: rank r -> cuda:r).  The reference maps a stage's
+                                     # `runtime.devices` list the same way (entrypoints/stage_utils.py:14-176); several ranks
+                                     # MAY share a device (then use dist_backend="gloo": RCCL refuses duplicate GPUs)
+    dist_backend: str | None = None  # None: "nccl" (= RCCL) with GPUs, "gloo" without
     load_text_encoder: bool = True   # NEW: False = never build the ~16 GB Qwen2.5-VL prompt encoder on the workers (requests
                                      # then carry prompt_embeds)
     max_steps_in_flight: int = 2     # NEW: how many denoising steps a worker's host may enqueue ahead of the device

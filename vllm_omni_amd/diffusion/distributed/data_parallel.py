@@ -16,11 +16,12 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: str | None = None, timeout_s: int | None = None) -> tuple[int, int, int]:
-    """env:// rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).  Returns (rank, world, local)."""
+def init_distributed(backend: str | None = None, timeout_s: int | None = None, local_device: int | None = None) -> tuple[int, int, int]:
+    """env:// rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).  Returns (rank, world, local).
+    `local_device` overrides LOCAL_RANK as the device index (explicit rank -> device maps)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    local = int(os.environ.get("LOCAL_RANK", str(rank))) if local_device is None else int(local_device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -89,6 +90,10 @@ def gather_latents(local: torch.Tensor, counts: list[int], group=None) -> torch.
         return local
     rank = dist.get_rank(group)
     assert local.shape[0] == counts[rank], (local.shape, counts, rank)
+    if local.is_cuda and dist.get_backend(group) != "nccl":
+        # a gloo group (the CPU tests; `bench.py --dist-backend gloo`, which exercises the N-rank control flow on ONE device)
+        # has no all_gather for device tensors: stage through the host
+        return gather_latents(local.cpu(), counts, group).to(local.device)
     mx = max(counts)
     S, Cc = local.shape[1], local.shape[2]
     send = local.new_zeros((mx, S, Cc))

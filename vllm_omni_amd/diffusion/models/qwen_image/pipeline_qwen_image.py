@@ -132,7 +132,7 @@ class QwenImagePipeline(nn.Module):
     @torch.no_grad()
     def _denoise(self, latents: list[torch.Tensor], pos: list[torch.Tensor], neg: list[torch.Tensor] | None,
                  grid, timesteps: torch.Tensor, dts: torch.Tensor, cfg_scales: list[float],
-                 cond: list[torch.Tensor] | None = None) -> list[torch.Tensor]:
+                 cond: list[torch.Tensor] | None = None, cfg_normalize: bool = True, t_cond: int | None = None) -> list[torch.Tensor]:
         """Step-batched denoising of R requests sharing (grid, schedule).  latents[r] [S_img, 64];
         pos[r]/neg[r] [T, joint_dim] (ragged T).  Item order: pos_0..pos_{R-1}, then neg_0..neg_{R-1}.
 
@@ -143,9 +143,12 @@ class QwenImagePipeline(nn.Module):
 
         `cond[r]` [S_c, 64] (Edit pipelines): packed condition-image latents appended to request r's rows on the sequence
         axis in every forward and sliced off the prediction (pipeline_qwen_image_edit.py:600-632); `grid` is then the
-        sequence of token grids ((1, h, w), (1, h_c, w_c), ...)."""
+        sequence of token grids ((1, h, w), (1, h_c, w_c), ...).  `cfg_normalize` = False: true-CFG combination without the norm
+        rescale; `t_cond`: the Layered variant's `additional_t_cond` (is_rgb) for every item."""
         tr, dev = self.transformer, self.device
         if self.sp_degree > 1 or getattr(self, "_force_sp_path", False):
+            if not cfg_normalize or t_cond is not None:
+                raise NotImplementedError("the Layered variant is not built sequence-parallel")
             return self._denoise_sp(latents, pos, neg, grid, timesteps, dts, cfg_scales, cond)
         R = len(latents)
         S = latents[0].shape[0]
@@ -164,7 +167,7 @@ class QwenImagePipeline(nn.Module):
         dt_dev = dts.to(dev, torch.float32).contiguous()
         graph_on = self._use_graph(n_items * S)
         tcfg = getattr(tr, "teacache", None)
-        key = (tuple(lens), tuple(grid), do_cfg, float(cfg_scales[0]), R,
+        key = (tuple(lens), tuple(grid), do_cfg, float(cfg_scales[0]), R, bool(cfg_normalize), t_cond,
                None if tcfg is None else (tcfg.rel_l1_thresh, tuple(tcfg.coefficients)))
         st = self._step_state.get(key) if graph_on else None
         if st is None:
@@ -208,12 +211,13 @@ class QwenImagePipeline(nn.Module):
                 lat_in[: R * S].copy_(lat)
                 if do_cfg:
                     lat_in[R * S:].copy_(lat)
-            tr.forward_ragged(prepared, lat_in, st["prompt"], sig1, out=pred, teacache=tc)
+            tr.forward_ragged(prepared, lat_in, st["prompt"], sig1, out=pred, teacache=tc,
+                              additional_t_cond=None if t_cond is None else [t_cond] * rb.n_temb)
             pr = pred
             if S_c:                                          # noise_pred[:, :latents.size(1)] (edit pipeline :632)
                 st["pred_c"].view(n_items, S, Cl).copy_(pred.view(n_items, S_tot, Cl)[:, :S])
                 pr = st["pred_c"]
-            ops.cfg_euler_step_(lat, pr[: R * S], pr[R * S:] if do_cfg else None, cfg_scales[0], dt1)
+            ops.cfg_euler_step_(lat, pr[: R * S], pr[R * S:] if do_cfg else None, cfg_scales[0], dt1, normalize=cfg_normalize)
 
         self.last_teacache_state = tc                         # statistics: tc.skipped_forwards() per item after the loop
         if not graph_on:
@@ -421,17 +425,19 @@ class QwenImagePipeline(nn.Module):
         samples = [s for i, r in enumerate(requests) for s in self.resolve_request(r, i)]
         groups: dict[tuple, list[int]] = {}
         for j, sm in enumerate(samples):
-            groups.setdefault((sm["height"], sm["width"], sm["steps"], sm["cfg"], sm["do_cfg"], sm["grid"]), []).append(j)
+            groups.setdefault((sm["height"], sm["width"], sm["steps"], sm["cfg"], sm["do_cfg"], sm["grid"], sm.get("mu"),
+                               sm.get("cfg_normalize", True), sm.get("t_cond")), []).append(j)
         cap = max(1, int(getattr(self.od_config, "max_step_batch", 4)))
         final: list[torch.Tensor | None] = [None] * len(samples)
-        for (height, width, steps, cfg, do_cfg, _grid), idxs in groups.items():
+        for (height, width, steps, cfg, do_cfg, _grid, mu, cfg_norm, t_cond), idxs in groups.items():
             for s0 in range(0, len(idxs), cap):
                 chunk = [samples[j] for j in idxs[s0:s0 + cap]]
-                timesteps, _ = self.prepare_timesteps(steps, None, chunk[0]["lat"].shape[0])
+                timesteps = self.scheduler.set_timesteps(steps, chunk[0]["lat"].shape[0], chunk[0].get("sigmas"), mu=mu)
                 outs = self._denoise([c["lat"] for c in chunk], [c["pos"] for c in chunk],
                                      [c["neg"] for c in chunk] if do_cfg else None, chunk[0]["grid"], timesteps,
                                      self.scheduler.dt(), [cfg] * len(chunk),
-                                     cond=[c["cond"] for c in chunk] if chunk[0].get("cond") is not None else None)
+                                     cond=[c["cond"] for c in chunk] if chunk[0].get("cond") is not None else None,
+                                     cfg_normalize=cfg_norm, t_cond=t_cond)
                 for j, o in zip(idxs[s0:s0 + cap], outs):
                     final[j] = o
         results = []
@@ -441,10 +447,12 @@ class QwenImagePipeline(nn.Module):
             if output_type == "latent" or r.output_type == "latent":
                 results.append(DiffusionOutput(output=lat))
             else:
-                sm = samples[mine[0]]
-                results.append(DiffusionOutput(output=torch.cat([self.decode_latents(lat[k:k + 1], sm["height"], sm["width"])
-                                                                 for k in range(lat.shape[0])])))
+                results.append(DiffusionOutput(output=self._decode_samples(lat, samples[mine[0]])))
         return results
+
+    def _decode_samples(self, lat: torch.Tensor, sample: dict) -> torch.Tensor:
+        """Finished packed latents [n, S, 64] of one request -> images (the Layered pipeline decodes one image per layer)."""
+        return torch.cat([self.decode_latents(lat[k:k + 1], sample["height"], sample["width"]) for k in range(lat.shape[0])])
 
     # ------------------------------------------------------------------ continuous step batching (step_batcher.py)
     def begin_sample(self, a) -> None:
@@ -454,7 +462,7 @@ class QwenImagePipeline(nn.Module):
         host-to-device copy."""
         sm = a.sample
         sch = FlowMatchEulerSchedule(self.scheduler.config)
-        ts = sch.set_timesteps(sm["steps"], sm["lat"].shape[0])
+        ts = sch.set_timesteps(sm["steps"], sm["lat"].shape[0], sm.get("sigmas"), mu=sm.get("mu"))
         a.n_steps = len(ts)
         if a.n_steps >= self.SERVE_MAX_STEPS:
             raise NotImplementedError(f"{a.n_steps} denoising steps: the step batcher's schedule tables hold {self.SERVE_MAX_STEPS - 1}")
@@ -469,7 +477,7 @@ class QwenImagePipeline(nn.Module):
     @staticmethod
     def batch_key(a):
         sm = a.sample
-        return (sm["grid"], sm["do_cfg"], sm["cfg"])
+        return (sm["grid"], sm["do_cfg"], sm["cfg"], sm.get("cfg_normalize", True), sm.get("t_cond"))
 
     # A "serve state" = everything one composition of a running batch needs, allocated ONCE: the static input / output
     # buffers of the forward, the ragged-batch descriptor, the per-request timestep / dt vectors, the TeaCache device state
@@ -485,7 +493,7 @@ class QwenImagePipeline(nn.Module):
         S_c = 0 if cond0 is None else int(cond0.shape[0])
         lens = [int(a.state["pos"].shape[0]) for a in group] + ([int(a.state["neg"].shape[0]) for a in group] if do_cfg else [])
         tcfg = getattr(tr, "teacache", None)
-        key = (tuple(lens), tuple(sm0["grid"]), do_cfg, float(sm0["cfg"]), R, S_c,
+        key = (tuple(lens), tuple(sm0["grid"]), do_cfg, float(sm0["cfg"]), R, S_c, sm0.get("cfg_normalize", True), sm0.get("t_cond"),
                None if tcfg is None else (tcfg.rel_l1_thresh, tuple(tcfg.coefficients)))
         st = self._serve_states.get(key)
         if st is not None:
@@ -496,6 +504,7 @@ class QwenImagePipeline(nn.Module):
         for t in lens:
             offs.append(offs[-1] + t)
         st = dict(key=key, R=R, S=S, S_c=S_c, do_cfg=do_cfg, cfg=float(sm0["cfg"]), n_items=n_items, rb=rb, txt_off=offs,
+                  cfg_normalize=bool(sm0.get("cfg_normalize", True)), t_cond=sm0.get("t_cond"),
                   prepared=tr.prepare_batch(rb), members=[None] * R, graph=None, gen=None,
                   lat=torch.zeros(R * S, Cl, dtype=BF16, device=dev),
                   lat_in=torch.zeros(n_items * S_tot, Cl, dtype=BF16, device=dev),
@@ -581,12 +590,14 @@ class QwenImagePipeline(nn.Module):
             lat_in[: R * S].copy_(lat)
             if do_cfg:
                 lat_in[R * S:].copy_(lat)
-        tr.forward_ragged(st["prepared"], lat_in, st["prompt"], st["sig"], out=pred, teacache=st["tc"])
+        tr.forward_ragged(st["prepared"], lat_in, st["prompt"], st["sig"], out=pred, teacache=st["tc"],
+                          additional_t_cond=None if st["t_cond"] is None else [st["t_cond"]] * st["rb"].n_temb)
         pr = pred
         if S_c:                                              # noise_pred[:, :latents.size(1)] (edit pipeline :632)
             st["pred_c"].view(n_items, S, Cl).copy_(pred.view(n_items, S + S_c, Cl)[:, :S])
             pr = st["pred_c"]
-        ops.cfg_euler_step_(lat, pr[: R * S], pr[R * S:] if do_cfg else None, st["cfg"], st["dt"], dt_rows_per_item=S)
+        ops.cfg_euler_step_(lat, pr[: R * S], pr[R * S:] if do_cfg else None, st["cfg"], st["dt"], dt_rows_per_item=S,
+                            normalize=st["cfg_normalize"])
         st["step_idx"].add_(1)
 
     @torch.no_grad()
@@ -640,8 +651,7 @@ class QwenImagePipeline(nn.Module):
         lat = torch.stack(latents)
         if req.output_type == "latent":
             return DiffusionOutput(output=lat)
-        return DiffusionOutput(output=torch.cat([self.decode_latents(lat[k:k + 1], sample["height"], sample["width"])
-                                                 for k in range(lat.shape[0])]))
+        return DiffusionOutput(output=self._decode_samples(lat, sample))
 
     def forward(self, req: OmniDiffusionRequest, **_kw) -> DiffusionOutput:
         """Reference entry point (:588-750): one request in, DiffusionOutput out."""

@@ -97,17 +97,37 @@ class _TimestepEmbedder(nn.Module):
 
 
 class QwenTimestepProjEmbeddings(nn.Module):
-    """reference :40-62 (no additional_t_cond)."""
+    """reference :40-62.  `use_additional_t_cond` (Layered variant): `addition_t_embedding = nn.Embedding(2, D)`, and the
+    conditioning is timestep_emb + addition_t_embedding(additional_t_cond)."""
 
-    def __init__(self, embedding_dim, device, dtype):
+    def __init__(self, embedding_dim, device, dtype, use_additional_t_cond: bool = False):
         super().__init__()
         self.timestep_embedder = _TimestepEmbedder(embedding_dim, device, dtype)
+        self.use_additional_t_cond = use_additional_t_cond
+        if use_additional_t_cond:
+            self.addition_t_embedding = nn.Embedding(2, embedding_dim, device=device, dtype=dtype)
+
+    def additional_rows(self, additional_t_cond, n: int):
+        """[n, D] rows of addition_t_embedding for the native forward's `temb_add`, or None.  Mirrors the reference's checks."""
+        if not self.use_additional_t_cond:
+            if additional_t_cond is not None:
+                raise ValueError("additional_t_cond was passed to a model built with use_additional_t_cond=False")
+            return None
+        if additional_t_cond is None:
+            raise ValueError("When additional_t_cond is True, addition_t_cond must be provided.")     # reference :56-57
+        idx = torch.as_tensor(additional_t_cond, dtype=torch.long, device=self.addition_t_embedding.weight.device).reshape(-1)
+        if idx.numel() == 1 and n > 1:
+            idx = idx.expand(n)
+        if idx.numel() != n:
+            raise ValueError(f"additional_t_cond carries {idx.numel()} entries for {n} conditioning rows")
+        return self.addition_t_embedding.weight.detach()[idx].contiguous()
 
     def forward(self, timestep: torch.Tensor, hidden_states: torch.Tensor, additional_t_cond=None) -> torch.Tensor:
-        if additional_t_cond is not None:
-            raise NotImplementedError("additional_t_cond belongs to the Layered variant (SURVEY.md §8f N4)")
         proj = ops.timestep_sinusoid(timestep.to(torch.float32).contiguous(), 256, 1000.0)     # Timesteps(256, scale=1000)
-        return self.timestep_embedder(proj)
+        emb = self.timestep_embedder(proj)
+        add = self.additional_rows(additional_t_cond, emb.shape[0])
+        # module-level surface only (hooks that re-walk the model); inside omni_dit_forward this add is `temb_add`
+        return emb if add is None else (emb + add)
 
 
 class _GeluProj(nn.Module):
@@ -183,6 +203,22 @@ class QwenEmbedRope(nn.Module):
         return RotaryTables(cplx[T:], cplx[:T], grid, T)
 
 
+class QwenEmbedLayer3DRope(QwenEmbedRope):
+    """`pos_embed` of the Layered variant (reference :65-176): img_shapes = [(1, h, w)] * (layers + 1) + [(1, h_c, w_c)]; entry
+    idx sits at frame idx, the LAST entry (the condition image) at frame -1, and the text positions start behind
+    max(h/2, w/2, number of layers).  Same table layout and kernels: only the host-side index arithmetic differs
+    (`rope.layered_grids`)."""
+
+    def forward(self, video_fhw, txt_seq_lens, device=None) -> RotaryTables:
+        from .rope import layered_grids
+
+        grid = layered_grids(_grid_of(video_fhw))
+        T = int(max(txt_seq_lens)) if not isinstance(txt_seq_lens, int) else int(txt_seq_lens)
+        cos, sin = rope_table(grid, T)
+        cplx = torch.complex(cos, sin).to(device) if device is not None else torch.complex(cos, sin)
+        return RotaryTables(cplx[T:], cplx[:T], grid, T)
+
+
 class QwenImageTransformerBlock(nn.Module):
     """One dual-stream MMDiT block (reference :461-605).  Inside `QwenImageTransformer2DModel.forward` the 60 blocks run in
     ONE native call; this module's own `forward` runs a single block through `omni_dit_block` with the reference's
@@ -208,7 +244,7 @@ class QwenImageTransformerBlock(nn.Module):
                 encoder_hidden_states_mask: torch.Tensor = None, temb: torch.Tensor = None,
                 image_rotary_emb=None, joint_attention_kwargs=None, modulate_index=None):
         if modulate_index is not None:
-            raise NotImplementedError("modulate_index belongs to the Layered variant (SURVEY.md §8f N4)")
+            raise NotImplementedError(ZERO_COND_T_MESSAGE)
         model = self._model_ref() if self._model_ref is not None else None
         if model is None:
             raise RuntimeError("block is not attached to a QwenImageTransformer2DModel")
@@ -241,16 +277,33 @@ class Transformer2DModelOutput(tuple):
         return self[0]
 
 
+ZERO_COND_T_MESSAGE = (
+    "zero_cond_t (the per-token `modulate_index` select between two modulation sets) is not built: in the reference snapshot "
+    "the block accepts `modulate_index` but calls `self.img_norm1(hidden_states, img_mod1)` without it and multiplies a 2B-row "
+    "`img_mod1` into B-row activations (qwen_image_transformer.py:552-564,590; its `_modulate` helper :505-539 is dead code), "
+    "so there is no defined behaviour to match.  use_additional_t_cond and use_layer3d_rope (the other two Layered flags) ARE built.")
+
+
 class QwenImageTransformer2DModel(nn.Module):
     def __init__(self, od_config=None, patch_size: int = 2, in_channels: int = 64, out_channels: int | None = 16,
                  num_layers: int = 60, attention_head_dim: int = 128, num_attention_heads: int = 24,
                  joint_attention_dim: int = 3584, guidance_embeds: bool = False,
-                 axes_dims_rope: tuple[int, int, int] = (16, 56, 56), device=None, dtype=BF16):
+                 axes_dims_rope: tuple[int, int, int] = (16, 56, 56), zero_cond_t: bool | None = None,
+                 use_additional_t_cond: bool | None = None, use_layer3d_rope: bool | None = None, device=None, dtype=BF16):
         super().__init__()
-        if od_config is not None and getattr(od_config, "tf_model_config", None) is not None:
-            nl = od_config.tf_model_config.get("num_layers", None)
+        tfc = getattr(od_config, "tf_model_config", None) if od_config is not None else None
+        if tfc is not None:
+            nl = tfc.get("num_layers", None)
             num_layers = nl if nl is not None else num_layers
             dtype = getattr(od_config, "dtype", dtype)
+        # the three Layered flags: explicit argument, else transformer/config.json (reference pipeline_qwen_image_layered.py:
+        # 210-219 reads them from od_config.tf_model_config), else off
+        flag = lambda v, k: bool(v if v is not None else (tfc.get(k, False) if tfc is not None else False))  # noqa: E731
+        zero_cond_t, use_additional_t_cond = flag(zero_cond_t, "zero_cond_t"), flag(use_additional_t_cond, "use_additional_t_cond")
+        use_layer3d_rope = flag(use_layer3d_rope, "use_layer3d_rope")
+        if zero_cond_t:
+            raise NotImplementedError(ZERO_COND_T_MESSAGE)
+        self.zero_cond_t, self.use_additional_t_cond, self.use_layer3d_rope = False, use_additional_t_cond, use_layer3d_rope
         if attention_head_dim != 128 or tuple(axes_dims_rope) != (16, 56, 56):
             raise ValueError("the CDNA4 attention / RoPE kernels are built for head_dim 128, axes (16, 56, 56)")
         if dtype != BF16:
@@ -266,7 +319,7 @@ class QwenImageTransformer2DModel(nn.Module):
         self.guidance_embeds = guidance_embeds
         self.do_true_cfg = False
         D = self.inner_dim
-        self.time_text_embed = QwenTimestepProjEmbeddings(D, device, dtype)
+        self.time_text_embed = QwenTimestepProjEmbeddings(D, device, dtype, use_additional_t_cond)
         self.txt_norm = _norm_w(joint_attention_dim, device, dtype)
         self.img_in = _linear(in_channels, D, device, dtype)
         self.txt_in = _linear(joint_attention_dim, D, device, dtype)
@@ -274,7 +327,7 @@ class QwenImageTransformer2DModel(nn.Module):
             [QwenImageTransformerBlock(D, attention_head_dim, device, dtype) for _ in range(num_layers)])
         self.norm_out = _NormOut(D, device, dtype)
         self.proj_out = _linear(D, patch_size * patch_size * self.out_channels, device, dtype)
-        self.pos_embed = QwenEmbedRope()
+        self.pos_embed = QwenEmbedLayer3DRope() if use_layer3d_rope else QwenEmbedRope()
         for i, blk in enumerate(self.transformer_blocks):
             blk.layer_idx, blk._model_ref = i, weakref.ref(self)
         self.teacache = None         # TeaCacheConfig when the native TeaCache path is enabled (cache/teacache/backend.py)
@@ -515,7 +568,8 @@ class QwenImageTransformer2DModel(nn.Module):
         return lib, w, b
 
     def forward_ragged(self, prepared: dict, latents: torch.Tensor, prompt_embeds: torch.Tensor,
-                       timestep: torch.Tensor, out: torch.Tensor | None = None, teacache=None) -> torch.Tensor:
+                       timestep: torch.Tensor, out: torch.Tensor | None = None, teacache=None,
+                       additional_t_cond=None) -> torch.Tensor:
         """latents [n_img_rows, 64] bf16, prompt_embeds [n_txt_rows, joint_dim] bf16, timestep [n_temb] fp32
         (sigma = t/1000 exactly as the pipeline passes it) -> noise_pred [n_img_rows, 64] bf16.
         `teacache`: a cache.teacache.native.TeaCacheDeviceState for this batch (device-side decisions, no host sync)."""
@@ -535,6 +589,10 @@ class QwenImageTransformer2DModel(nn.Module):
         b.noise_pred = out.data_ptr()
         if teacache is not None:
             b.teacache = C.pointer(teacache.struct_for(rb))
+        # Layered variant: addition_t_embedding rows, one per conditioning row (`additional_t_cond`: ints, e.g. is_rgb = 0)
+        temb_add = self.time_text_embed.additional_rows(additional_t_cond, rb.n_temb)
+        if temb_add is not None:
+            b.temb_add = temb_add.data_ptr()
         N.check(lib.omni_dit_forward(C.byref(w), C.byref(b), torch.cuda.current_stream().cuda_stream), "omni_dit_forward")
         return out
 
@@ -639,17 +697,22 @@ class QwenImageTransformer2DModel(nn.Module):
                 img_shapes=None, txt_seq_lens=None, guidance=None, attention_kwargs=None,
                 additional_t_cond=None, return_dict: bool = True):
         """Reference signature (:692-802).  B items of equal text length T (as the reference batches them)."""
-        if guidance is not None or additional_t_cond is not None:
-            raise NotImplementedError("guidance / additional_t_cond variants are outside the Qwen-Image T2I path")
+        if guidance is not None:
+            raise NotImplementedError("guidance-distilled variants are outside the Qwen-Image path")
         B, S_img, _ = hidden_states.shape
         T = encoder_hidden_states.shape[1]
         grid = _grid_of(img_shapes)
+        if self.use_layer3d_rope:
+            from .rope import layered_grids
+
+            grid = layered_grids(grid)
         if grid_tokens(grid) != S_img:
             raise ValueError(f"img_shapes {grid} does not match {S_img} image tokens")
         prepared = self.prepare_batch(build_ragged_batch([T] * B, grid))
         # the reference casts timestep to the activation dtype before the sinusoid (:746)
         ts = timestep.to(device=self.device, dtype=hidden_states.dtype).to(torch.float32).contiguous()
         out = self.forward_ragged(prepared, hidden_states.reshape(B * S_img, -1).contiguous(),
-                                  encoder_hidden_states.reshape(B * T, -1).contiguous(), ts)
+                                  encoder_hidden_states.reshape(B * T, -1).contiguous(), ts,
+                                  additional_t_cond=additional_t_cond)
         out = out.view(B, S_img, -1)
         return Transformer2DModelOutput(out) if return_dict else (out,)

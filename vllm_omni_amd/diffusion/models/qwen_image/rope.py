@@ -24,26 +24,44 @@ def _axis_angles(index: torch.Tensor, dim: int) -> torch.Tensor:
     return index.to(torch.float32)[:, None] * inv_freq[None, :]
 
 
-def normalize_grids(grid) -> tuple[tuple[int, int, int], ...]:
+def normalize_grids(grid) -> tuple[tuple[int, ...], ...]:
     """A token grid is one (frames, h, w) triple or a SEQUENCE of them: the Edit pipelines put the target latents and the
-    condition images on one sequence axis, each entry with its own frame index (reference :231-250, idx -> frame offset)."""
-    if len(grid) == 3 and all(isinstance(v, int) for v in grid):
+    condition images on one sequence axis, each entry with its own frame index (reference :231-250, idx -> frame offset).
+    Entries of FOUR numbers (frames, h, w, frame_index) are the Layered variant's (`QwenEmbedLayer3DRope`, :65-176): the
+    frame index is explicit (layer l -> l, the condition image -> -1) and the text positions start behind max(h/2, w/2,
+    number of layers) — see `layered_grids`."""
+    if len(grid) in (3, 4) and all(isinstance(v, int) for v in grid):
         return (tuple(grid),)
     out = tuple(tuple(int(v) for v in g) for g in grid)
-    if not out or any(len(g) != 3 for g in out):
+    if not out or any(len(g) not in (3, 4) for g in out) or len({len(g) for g in out}) != 1:
         raise ValueError(f"bad token grid {grid!r}")
     return out
 
 
+def layered_grids(grids) -> tuple[tuple[int, int, int, int], ...]:
+    """img_shapes of the Layered pipeline — [(1, h, w)] * (layers + 1) + [(1, h_c, w_c)] — as explicit-frame-index entries:
+    entry idx < last sits at frame idx, the LAST entry (the condition image) at frame -1 (reference :117-129)."""
+    g = normalize_grids(grids)
+    if any(len(e) == 4 for e in g):
+        return g
+    n = len(g) - 1
+    return tuple((f, h, w, (idx if idx != n else -1)) for idx, (f, h, w) in enumerate(g))
+
+
 def grid_tokens(grid) -> int:
-    return sum(f * h * w for f, h, w in normalize_grids(grid))
+    return sum(e[0] * e[1] * e[2] for e in normalize_grids(grid))
 
 
 @functools.lru_cache(maxsize=64)
-def _rope_table(grids: tuple[tuple[int, int, int], ...], n_txt_pos: int) -> tuple[torch.Tensor, torch.Tensor]:
+def _rope_table(grids: tuple[tuple[int, ...], ...], n_txt_pos: int) -> tuple[torch.Tensor, torch.Tensor]:
     parts, start = [], 0
-    for idx, (f, h, w) in enumerate(grids):
-        fi = torch.arange(idx, idx + f)                       # entry idx starts at frame position idx (:268)
+    layered = len(grids[0]) == 4
+    for idx, e in enumerate(grids):
+        f, h, w = e[:3]
+        f0 = e[3] if layered else idx                         # entry idx starts at frame position idx (:268); Layered: explicit
+        if layered and f != 1:
+            raise ValueError("Layered RoPE entries hold one frame each (reference :155,177: one row of the frame table)")
+        fi = torch.arange(f0, f0 + f)
         hi = torch.arange(h) - (h - h // 2)
         wi = torch.arange(w) - (w - w // 2)
         af, ah, aw = (_axis_angles(i, d) for i, d in zip((fi, hi, wi), AXES_DIM))
@@ -52,6 +70,8 @@ def _rope_table(grids: tuple[tuple[int, int, int], ...], n_txt_pos: int) -> tupl
             ah[None, :, None, :].expand(f, h, w, -1),
             aw[None, None, :, :].expand(f, h, w, -1)], dim=-1).reshape(f * h * w, -1))
         start = max(start, h // 2, w // 2)                    # text positions start behind the largest half-extent (:251-257)
+    if layered:
+        start = max(start, len(grids) - 1)                    # ... and behind the layer count (:136: max(max_vid_index, layer_num))
     ti = torch.arange(start, start + n_txt_pos)
     ang_txt = torch.cat([_axis_angles(ti, d) for d in AXES_DIM], dim=-1)
     ang = torch.cat([ang_txt] + parts, dim=0)

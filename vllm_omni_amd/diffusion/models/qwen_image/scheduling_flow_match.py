@@ -36,12 +36,15 @@ class FlowMatchEulerSchedule:
         self.timesteps: torch.Tensor | None = None
         self.sigmas: torch.Tensor | None = None
 
-    def set_timesteps(self, num_inference_steps: int, image_seq_len: int, sigmas=None):
+    def set_timesteps(self, num_inference_steps: int, image_seq_len: int, sigmas=None, mu: float | None = None):
+        """`mu` given: used as is (the Layered pipeline passes sqrt(S_cond / 256), pipeline_qwen_image_layered.py:808-816);
+        else linear in `image_seq_len` (calculate_shift)."""
         c = self.config
         if num_inference_steps is None or num_inference_steps < 1:
             raise ValueError("num_inference_steps must be >= 1")
         s = np.linspace(1.0, 1.0 / num_inference_steps, num_inference_steps) if sigmas is None else np.asarray(sigmas)
-        mu = calculate_shift(image_seq_len, c.base_image_seq_len, c.max_image_seq_len, c.base_shift, c.max_shift)
+        if mu is None:
+            mu = calculate_shift(image_seq_len, c.base_image_seq_len, c.max_image_seq_len, c.base_shift, c.max_shift)
         s = np.array(s).astype(np.float32)                    # diffusers computes the schedule in float32 numpy
         s = math.exp(mu) / (math.exp(mu) + (1 / s - 1) ** 1.0)
         if c.shift_terminal:

@@ -13,10 +13,12 @@ _DIFFUSION_MODELS = {
     "QwenImagePipeline": ("qwen_image", "pipeline_qwen_image", "QwenImagePipeline"),
     "QwenImageEditPipeline": ("qwen_image", "pipeline_qwen_image_edit", "QwenImageEditPipeline"),
     "QwenImageEditPlusPipeline": ("qwen_image", "pipeline_qwen_image_edit_plus", "QwenImageEditPlusPipeline"),
+    "QwenImageLayeredPipeline": ("qwen_image", "pipeline_qwen_image_layered", "QwenImageLayeredPipeline"),
 }
 _POST_PROCESS = {"QwenImagePipeline": "get_qwen_image_post_process_func",
                  "QwenImageEditPipeline": "get_qwen_image_post_process_func",
-                 "QwenImageEditPlusPipeline": "get_qwen_image_post_process_func"}
+                 "QwenImageEditPlusPipeline": "get_qwen_image_post_process_func",
+                 "QwenImageLayeredPipeline": "get_qwen_image_post_process_func"}
 _PRE_PROCESS: dict[str, str] = {}
 
 

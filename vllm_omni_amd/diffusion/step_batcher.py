@@ -46,7 +46,9 @@ class ContinuousStepBatcher:
         # their first steps almost alone (round 3's serving line lost ~5 % to this).  One event per enqueued step; `ready()`
         # is false while `max_steps_in_flight` of them are still pending, so a newcomer joins within that many steps.
         self.max_steps_in_flight = int(max_steps_in_flight or getattr(cfg, "max_steps_in_flight", 2) or 2)
-        self._inflight: collections.deque = collections.deque()
+        self._inflight: collections.deque = collections.deque()        # (start event, end event, samples in the step)
+        # serving statistics (bench.py's per-worker busy fraction): device seconds inside steps vs the span they cover
+        self._stats = {"steps": 0, "sample_steps": 0, "busy_s": 0.0, "first": None, "last": None}
 
     # ------------------------------------------------------------------ admission
     def add(self, req, tag) -> None:
@@ -71,25 +73,42 @@ class ContinuousStepBatcher:
 
     def ready(self) -> bool:
         """May the host enqueue another step now?  (False: `max_steps_in_flight` steps are still queued on the device.)"""
-        while self._inflight and self._inflight[0].query():
-            self._inflight.popleft()
+        while self._inflight and self._inflight[0][1].query():
+            self._retire(self._inflight.popleft())
         return len(self._inflight) < self.max_steps_in_flight
 
     def wait_ready(self, idle=None) -> None:
         """Block until `ready()`; `idle()` (e.g. the worker's inbox poll) runs while waiting, else the oldest event is awaited."""
         while not self.ready():
             if idle is None:
-                self._inflight[0].synchronize()
+                self._inflight[0][1].synchronize()
             else:
                 idle()
 
-    def _mark_step(self) -> None:
-        if self._device_is_gpu():
-            import torch
+    def _retire(self, rec) -> None:
+        e0, e1, n = rec
+        st = self._stats
+        st["steps"] += 1
+        st["sample_steps"] += n
+        st["busy_s"] += e0.elapsed_time(e1) * 1e-3
+        st["first"] = st["first"] or e0
+        st["last"] = e1
 
-            ev = torch.cuda.Event()
-            ev.record()
-            self._inflight.append(ev)
+    def stats(self, reset: bool = False) -> dict:
+        """{"steps", "sample_steps", "busy_s", "span_s", "busy_frac"} over the retired steps (device time from HIP events: the
+        start event of a step executes when the stream reaches it, so end - start is the step's own execution time and
+        span = first start .. last end includes whatever the device idled in between)."""
+        if self._device_is_gpu():
+            while self._inflight:
+                self._inflight[0][1].synchronize()
+                self._retire(self._inflight.popleft())
+        st = self._stats
+        span = st["first"].elapsed_time(st["last"]) * 1e-3 if st["first"] is not None else 0.0
+        out = {"steps": st["steps"], "sample_steps": st["sample_steps"], "busy_s": st["busy_s"], "span_s": span,
+               "busy_frac": (st["busy_s"] / span) if span > 0 else None}
+        if reset:
+            self._stats = {"steps": 0, "sample_steps": 0, "busy_s": 0.0, "first": None, "last": None}
+        return out
 
     # ------------------------------------------------------------------ one scheduling quantum
     def next_group(self) -> list[ActiveSample]:
@@ -113,6 +132,12 @@ class ContinuousStepBatcher:
         if not self.active:
             return []
         group = self.next_group()
+        e0 = None
+        if self._device_is_gpu():
+            import torch
+
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         try:
             self.pipeline.denoise_one_step(group)
         except Exception as e:  # noqa: BLE001 — a failing step aborts the REQUESTS that were in it, nothing else
@@ -140,7 +165,10 @@ class ContinuousStepBatcher:
 
                         out = DiffusionOutput(error=f"{type(e).__name__}: {e}")
                     finished.append((a.tag, out))
-        self._mark_step()
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._inflight.append((e0, e1, len(group)))
         return finished
 
     def abort(self, tags, error: str) -> list[tuple[Any, Any]]:

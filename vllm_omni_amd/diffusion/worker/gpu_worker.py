@@ -29,9 +29,13 @@ class GPUWorker:
         self.sp_degree, self.sp_group, self.dp_rank, self.dp_world = 1, None, rank, 1
 
     def init_device_and_model(self, pipeline_factory=None) -> None:
+        devs = getattr(self.od_config, "devices", None)
+        if devs:                                             # explicit rank -> device map (reference: runtime.devices)
+            self.local_rank = int(devs[self.rank % len(devs)])
         if torch.cuda.is_available():
             torch.cuda.set_device(self.local_rank)
-        self.rank, self.world, _ = dp.init_distributed(timeout_s=self.od_config.dist_timeout)
+        self.rank, self.world, _ = dp.init_distributed(backend=getattr(self.od_config, "dist_backend", None),
+                                                       timeout_s=self.od_config.dist_timeout, local_device=self.local_rank)
         # world = data-parallel groups x ulysses_degree (reference DiffusionParallelConfig); consecutive ranks form an SP group
         self.sp_degree = int(getattr(self.od_config.parallel_config, "ulysses_degree", 1) or 1)
         if self.sp_degree > 1 and self.world % self.sp_degree:
@@ -237,7 +241,10 @@ class WorkerProc:
                                  "output": DiffusionOutput(error=f"{type(e).__name__}: {e}")})
         elif kind == "rpc":
             try:
-                fn = getattr(self.worker, msg["method"], None) or getattr(self.worker.pipeline, msg["method"])
+                if msg["method"] == "serving_stats":        # this process's step batcher (bench.py: per-worker busy fraction)
+                    fn = self.batcher.stats
+                else:
+                    fn = getattr(self.worker, msg["method"], None) or getattr(self.worker.pipeline, msg["method"])
                 res = fn(*msg.get("args", ()), **msg.get("kwargs", {}))
                 if msg.get("output_rank") is None or msg["output_rank"] == self.rank:
                     self.outbox.put({"type": "rpc_result", "id": msg["id"], "rank": self.rank, "result": _to_cpu(res)})
@@ -289,6 +296,11 @@ class WorkerProc:
                           MASTER_PORT=str(master_port))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         try:
+            if torch.cuda.is_available():
+                from ..distributed.numa import pin_to_gpu_numa
+
+                devs = getattr(od_config, "devices", None)
+                pin_to_gpu_numa(int(devs[rank % len(devs)]) if devs else rank)                       # host threads next to this rank's GPU (distributed/numa.py)
             proc = WorkerProc(rank, od_config, inbox, outbox, pipeline_factory=pipeline_factory)
         except Exception as e:
             ready.put({"rank": rank, "status": "failed", "error": f"{type(e).__name__}: {e}\n{traceback.format_exc()}"})

@@ -242,14 +242,17 @@ def timestep_sinusoid(t: torch.Tensor, dim: int = 256, scale: float = 1000.0):
     return out
 
 
-def cfg_euler_step_(latents, pos, neg, true_cfg_scale: float, dt: torch.Tensor, dt_rows_per_item: int = 0):
-    """latents [rows,64] bf16 updated in place; dt fp32 device tensor."""
+def cfg_euler_step_(latents, pos, neg, true_cfg_scale: float, dt: torch.Tensor, dt_rows_per_item: int = 0,
+                    normalize: bool = True):
+    """latents [rows,64] bf16 updated in place; dt fp32 device tensor.  normalize=False: the true-CFG combination without the
+    norm rescale (the Layered pipeline's default)."""
     rows, Cc, _ = _rows2d(latents, "latents")
     if not (latents.is_contiguous() and pos.is_contiguous() and (neg is None or neg.is_contiguous())):
         raise N.OmniNativeError("cfg_euler_step_ needs contiguous [rows, 64] tensors")
-    N.check(N.lib().omni_cfg_euler_step(_p(pos, name="pos"), _p(neg, name="neg"), _p(latents, name="latents"), rows,
-                                        Cc, true_cfg_scale, _p(dt, torch.float32, "dt"), dt_rows_per_item, _stream()),
-            "omni_cfg_euler_step")
+    N.check(N.lib().omni_cfg_euler_step_ex(_p(pos, name="pos"), _p(neg, name="neg"), _p(latents, name="latents"), rows,
+                                           Cc, true_cfg_scale, _p(dt, torch.float32, "dt"), dt_rows_per_item,
+                                           1 if normalize else 0, _stream()),
+            "omni_cfg_euler_step_ex")
     return latents
 
 
