@@ -90,9 +90,17 @@ def rope_interleaved(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> t
     return x * c + rot * s
 
 
+FUSED_SDPA = False   # True: call F.scaled_dot_product_attention — the very op the reference's SDPAImpl calls (sdpa.py:55-63).  The
+                     # CHECKER keeps the spelled-out softmax(QK^T)V below (no dependence on a fused kernel's internals); bench.py's
+                     # cpu_baseline sets this so that the timed port does the reference's work the reference's way
+                     # (tools/time_reference_cpu.py: port / reference seconds per block on the authoring host).
+
+
 def sdpa_nhd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
     """SDPAImpl.forward — diffusion/attention/backends/sdpa.py:46-66: non-causal, no mask. [B,S,H,dh]."""
     q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+    if FUSED_SDPA:
+        return F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=scale).permute(0, 2, 1, 3)
     p = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
     return (p @ v).permute(0, 2, 1, 3)
 

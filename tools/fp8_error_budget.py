@@ -61,7 +61,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=60)
     ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--loop-recipes", default="", help="';'-separated class lists (e.g. 'qkv;qkv,out;all'): only the loop part, for these")
     args = ap.parse_args()
+    only_loop = [tuple(r.split(",")) for r in args.loop_recipes.split(";") if r]
     torch.backends.cuda.matmul.allow_tf32 = False
     from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
     from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
@@ -84,9 +86,13 @@ def main():
     recipes = {"bf16": (), "fp8 all": m.FP8_CLASSES, "fp8 qkv": ("qkv",), "fp8 out": ("out",), "fp8 mlp_up": ("mlp_up",),
                "fp8 mlp_down": ("mlp_down",), "fp8 qkv+mlp_up": ("qkv", "mlp_up"), "fp8 qkv+mlp_up+mlp_down": ("qkv", "mlp_up", "mlp_down"),
                "fp8 qkv+out+mlp_up": ("qkv", "out", "mlp_up"), "fp8 mlp_up+mlp_down": ("mlp_up", "mlp_down")}
+    if only_loop:
+        recipes = {"bf16": ()}
+        for r in only_loop:
+            recipes["fp8 " + "+".join(r)] = m.FP8_CLASSES if r == ("all",) else r
     print(f"== {L} layers, one 1024^2 item (4096+{T} rows): one forward vs the fp32 oracle", flush=True)
     out16 = None
-    for name, cls in recipes.items():
+    for name, cls in ({} if only_loop else recipes).items():
         m.enable_fp8(cls) if cls else m.enable_fp8(False)
         out, hs = walk(m, lat, pos, sig, grid)
         torch.cuda.synchronize()
@@ -96,7 +102,7 @@ def main():
         print(f"   {name:26s} pred vs fp32 {rel_l2(out, ref):.3e} (cos {cosine(out, ref):.5f})  vs bf16 path {rel_l2(out, out16):.3e}   "
               f"hidden_img err after layer 1/2/4/8/16/30/45/{L}: " + " ".join(f"{v:.2e}" for v in growth), flush=True)
         del hs
-    del ref_h
+    del ref_h, ref
     # ---- the CFG loop
     print(f"== {args.steps}-step true-CFG loop, final latent vs the fp32 oracle loop", flush=True)
     ts, sg = O.flow_match_sigmas(args.steps, S)
@@ -114,7 +120,9 @@ def main():
     req = OmniDiffusionRequest(height=1024, width=1024, num_inference_steps=args.steps, true_cfg_scale=4.0, latents=lat,
                                prompt_embeds=pos, negative_prompt_embeds=neg, output_type="latent")
     fin16 = None
-    for name in ("bf16", "fp8 all", "fp8 qkv+mlp_up", "fp8 qkv+mlp_up+mlp_down", "fp8 qkv+out+mlp_up", "fp8 mlp_up+mlp_down", "fp8 mlp_up"):
+    loop_names = list(recipes) if only_loop else ["bf16", "fp8 all", "fp8 qkv+mlp_up", "fp8 qkv+mlp_up+mlp_down", "fp8 qkv+out+mlp_up",
+                                                  "fp8 mlp_up+mlp_down", "fp8 mlp_up"]
+    for name in loop_names:
         cls = recipes[name]
         m.enable_fp8(cls) if cls else m.enable_fp8(False)
         fin = pipe.generate([req], output_type="latent")[0].output
@@ -129,7 +137,7 @@ def main():
     txtb = torch.randn(B, T, 3584, device=DEV, generator=g).to(BF16)
     sigb = torch.full((B,), 0.6015625, device=DEV)
     kw = dict(hidden_states=latb, encoder_hidden_states=txtb, timestep=sigb, img_shapes=[[grid]] * B, txt_seq_lens=[T] * B, return_dict=False)
-    for name in ("bf16", "fp8 all", "fp8 qkv+mlp_up", "fp8 qkv+mlp_up+mlp_down", "fp8 qkv+out+mlp_up", "fp8 mlp_up+mlp_down", "fp8 mlp_up"):
+    for name in loop_names:
         cls = recipes[name]
         m.enable_fp8(cls) if cls else m.enable_fp8(False)
         m(**kw)

@@ -200,6 +200,15 @@ class QwenImagePipeline(nn.Module):
         tc = st["tc"]
         if tc is not None:
             tc.reset()                                       # a new generation: first forward always computes
+        # Layered variant: the addition_t_embedding rows of this batch, gathered once, outside any graph capture
+        temb_add = None
+        if t_cond is not None:
+            rows = tr.time_text_embed.additional_rows([t_cond] * rb.n_temb, rb.n_temb)
+            if st.get("temb_add") is None:
+                st["temb_add"] = rows                        # kept with the step state: a captured graph holds its address ...
+            else:
+                st["temb_add"].copy_(rows)                   # ... so later generations refresh the VALUES in place
+            temb_add = st["temb_add"]
 
         def step(sig1, dt1):
             if S_c:
@@ -211,8 +220,7 @@ class QwenImagePipeline(nn.Module):
                 lat_in[: R * S].copy_(lat)
                 if do_cfg:
                     lat_in[R * S:].copy_(lat)
-            tr.forward_ragged(prepared, lat_in, st["prompt"], sig1, out=pred, teacache=tc,
-                              additional_t_cond=None if t_cond is None else [t_cond] * rb.n_temb)
+            tr.forward_ragged(prepared, lat_in, st["prompt"], sig1, out=pred, teacache=tc, temb_add=temb_add)
             pr = pred
             if S_c:                                          # noise_pred[:, :latents.size(1)] (edit pipeline :632)
                 st["pred_c"].view(n_items, S, Cl).copy_(pred.view(n_items, S_tot, Cl)[:, :S])
@@ -505,6 +513,7 @@ class QwenImagePipeline(nn.Module):
             offs.append(offs[-1] + t)
         st = dict(key=key, R=R, S=S, S_c=S_c, do_cfg=do_cfg, cfg=float(sm0["cfg"]), n_items=n_items, rb=rb, txt_off=offs,
                   cfg_normalize=bool(sm0.get("cfg_normalize", True)), t_cond=sm0.get("t_cond"),
+                  temb_add=None if sm0.get("t_cond") is None else tr.time_text_embed.additional_rows([sm0["t_cond"]] * R, R),
                   prepared=tr.prepare_batch(rb), members=[None] * R, graph=None, gen=None,
                   lat=torch.zeros(R * S, Cl, dtype=BF16, device=dev),
                   lat_in=torch.zeros(n_items * S_tot, Cl, dtype=BF16, device=dev),
@@ -590,8 +599,7 @@ class QwenImagePipeline(nn.Module):
             lat_in[: R * S].copy_(lat)
             if do_cfg:
                 lat_in[R * S:].copy_(lat)
-        tr.forward_ragged(st["prepared"], lat_in, st["prompt"], st["sig"], out=pred, teacache=st["tc"],
-                          additional_t_cond=None if st["t_cond"] is None else [st["t_cond"]] * st["rb"].n_temb)
+        tr.forward_ragged(st["prepared"], lat_in, st["prompt"], st["sig"], out=pred, teacache=st["tc"], temb_add=st["temb_add"])
         pr = pred
         if S_c:                                              # noise_pred[:, :latents.size(1)] (edit pipeline :632)
             st["pred_c"].view(n_items, S, Cl).copy_(pred.view(n_items, S + S_c, Cl)[:, :S])
