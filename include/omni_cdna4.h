@@ -398,9 +398,23 @@ typedef struct {
   const omni_teacache* teacache;  /* nullable: TeaCache off.  All items must have the same number of image rows.  ABI v3 */
   const omni_bf16* temb_add;      /* ABI v9, nullable: [n_temb, D] bf16 added to the timestep embedding — the Layered variant's
                                    * addition_t_embedding(additional_t_cond) rows (qwen_image_transformer.py:47-62) */
+  const omni_bf16* mod_table;     /* ABI v9, nullable: [num_layers][2 (image, text stream)][n_temb][6 D] bf16 — the blocks'
+                                   * modulation vectors for THIS forward's conditioning rows, taken from
+                                   * omni_dit_modulation_table; the 2 x num_layers weight-streaming GEMVs are then skipped */
 } omni_dit_batch;
 
 size_t omni_dit_workspace_bytes(const omni_dit_weights* w, int32_t n_img_rows, int32_t n_txt_rows, int32_t n_temb);
+
+/* ABI v9 — the modulation vectors of every block for M conditioning rows in ONE pass over the modulation weights:
+ *   table[l][s][m] = Linear_{l,s}(SiLU(temb[m]))   s = 0: img_mod, 1: txt_mod   (qwen_image_transformer.py:478-481,494-497,552-561)
+ * temb [M, D] bf16 = the timestep embeddings (time_text_embed) of all the denoising steps of a request — they are known
+ * before the loop starts — table [num_layers][2][M][6 D] bf16.  The reference re-streams these 13.6 GB of weights in EVERY
+ * forward (226 MB per block for 0.23 GFLOP); a request of N steps x 2 CFG branches reads them 2N times, here
+ * once.  At 256^2 (a forward is ~10 ms of which 2.7 ms is this stream) that is a quarter of the latency.  SiLU output is
+ * rounded to bf16 before the product, as in the reference's eager nn.Sequential(SiLU, Linear).  Caller-owned workspace. */
+size_t omni_dit_modulation_table_workspace_bytes(const omni_dit_weights* w, int32_t M);
+int omni_dit_modulation_table(const omni_dit_weights* w, const omni_bf16* temb, int32_t M, omni_bf16* table, void* workspace,
+                              size_t workspace_bytes, omni_stream stream);
 int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch* b, omni_stream stream);
 
 /* One dual-stream block (QwenImageTransformerBlock.forward, qwen_image_transformer.py:541-605) on caller-owned residual

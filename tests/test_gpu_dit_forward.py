@@ -12,6 +12,7 @@ from _util import bf16_round, cosine, golden_params, load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
+DEV = "cuda:0"
 
 
 def build_model(case, P):
@@ -75,3 +76,57 @@ def test_ragged_batch_equals_per_request():
                           sig[:1].repeat(2).contiguous())
     torch.cuda.synchronize()
     assert torch.equal(sh, sp)
+
+
+def test_modulation_table_equals_the_per_forward_gemvs():
+    """omni_dit_modulation_table: every block's modulation vectors for all the steps of a schedule in one pass over the
+    modulation weights.  Rows vs the per-forward GEMV (fp32 SiLU inside; the table rounds SiLU's output to bf16 like the
+    reference's eager nn.Sequential(SiLU, Linear)), a forward fed from the table vs one that streams the weights, and the whole
+    denoise loop with the switch on / off."""
+    from vllm_omni_amd import ops
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.batch import build_ragged_batch
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    heads, joint, layers = 2, 128, 3
+    P = O.make_dit_params(layers, seed=1234, bias_std=0.02, norm_jitter=0.1, num_heads=heads, joint_dim=joint)
+    m = QwenImageTransformer2DModel(num_layers=layers, num_attention_heads=heads, joint_attention_dim=joint, device=DEV)
+    m.load_weights(P.items())
+    D = heads * 128
+    sig = torch.tensor([0.91, 0.6015625, 0.33, 0.12, 0.02], device=DEV)
+    tab = m.modulation_table(sig)
+    assert tab.shape == (layers, 2, 5, 6 * D)
+    temb = m.time_text_embed(sig, None)
+    for l in (0, layers - 1):
+        blk = m.transformer_blocks[l]
+        for s, mod in ((0, blk.img_mod), (1, blk.txt_mod)):
+            ref = ops.linear_smallbatch(temb, mod[1].weight, mod[1].bias, act_in=1)
+            assert rel_l2(tab[l, s], ref) <= 3e-3, (l, s)
+    g = torch.Generator().manual_seed(3)
+    T = [7, 12]
+    lat = torch.randn(2 * 64, 64, generator=g).to(DEV, BF16)
+    txt = torch.randn(sum(T), joint, generator=g).to(DEV, BF16)
+    prepared = m.prepare_batch(build_ragged_batch(T, (1, 8, 8), temb_rows=[0, 1]))
+    two = sig[1:3].contiguous()
+    plain = m.forward_ragged(prepared, lat, txt, two).clone()
+    fed = m.forward_ragged(prepared, lat, txt, two, mod_table=tab[:, :, 1:3].contiguous())
+    torch.cuda.synchronize()
+    assert rel_l2(fed, plain) <= 4e-3
+    with pytest.raises(ValueError):
+        m.forward_ragged(prepared, lat, txt, two, mod_table=tab)                  # rows of ANOTHER number of conditioning rows
+    # whole loop, both switches, eager and as a replayed hipGraph
+    req = OmniDiffusionRequest(height=128, width=128, num_inference_steps=4, true_cfg_scale=4.0, output_type="latent",
+                               latents=torch.randn(1, 64, 64, generator=g).to(BF16),
+                               prompt_embeds=torch.randn(1, 9, joint, generator=g).to(BF16),
+                               negative_prompt_embeds=torch.randn(1, 5, joint, generator=g).to(BF16))
+    outs = {}
+    for pre in (False, True):
+        for graph in (False, True):
+            pipe = QwenImagePipeline(od_config=OmniDiffusionConfig(precompute_modulation=pre, use_hip_graph=graph), device=DEV, transformer=m)
+            outs[pre, graph] = pipe.generate([req], output_type="latent")[0].output.float().cpu()
+            again = pipe.generate([req], output_type="latent")[0].output.float().cpu()      # second generation: refreshed table
+            assert torch.equal(again, outs[pre, graph])
+    assert torch.equal(outs[True, False], outs[True, True]) and torch.equal(outs[False, False], outs[False, True])
+    assert rel_l2(outs[True, False], outs[False, False]) <= 1e-2

@@ -71,8 +71,9 @@ def test_ctypes_struct_layout_matches_c():
 
     assert ctypes.sizeof(N.GemmGroup) == 216 and ctypes.sizeof(N.GemmParams) == 24 + 2 * 216 + 16 + 8  # ABI v3: + tile_skip; v4: + split-K workspace; v6: + kernel_hint
     assert N.GemmParams.splitk_ws.offset == 24 + 2 * 216 and N.GemmParams.kernel_hint.offset == 24 + 2 * 216 + 16
-    assert ctypes.sizeof(N.TeaCache) == 24 + 10 * 8 and N.DitBatch.teacache.offset == ctypes.sizeof(N.DitBatch) - 16
-    assert N.DitBatch.temb_add.offset == ctypes.sizeof(N.DitBatch) - 8                   # ABI v9: appended behind teacache
+    assert ctypes.sizeof(N.TeaCache) == 24 + 10 * 8 and N.DitBatch.teacache.offset == ctypes.sizeof(N.DitBatch) - 24
+    assert N.DitBatch.temb_add.offset == ctypes.sizeof(N.DitBatch) - 16                  # ABI v9: appended behind teacache ...
+    assert N.DitBatch.mod_table.offset == ctypes.sizeof(N.DitBatch) - 8                  # ... then mod_table
     assert ctypes.sizeof(N.DitLayerWeights) == 24 * 8
     assert N.GemmParams.g.offset == 24 and N.DitWeights.t_lin1_w.offset == 32   # w_k32_blocked flags live in padding / ABI v2
 

@@ -117,6 +117,7 @@ class DitBatch(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("teacache", C.POINTER(TeaCache)),
         ("temb_add", c_bf16_p),                                                                    # ABI v9, nullable
+        ("mod_table", c_bf16_p),                                                                   # ABI v9, nullable
     ]
 
 
@@ -159,6 +160,9 @@ PROTOTYPES = {
     "omni_vae_rmsnorm_silu": (C.c_int, [c_bf16_p, c_bf16_p, C.c_int64, C.c_int32, c_bf16_p, C.c_int32, C.c_void_p]),
     "omni_softmax_rows": (C.c_int, [c_bf16_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "omni_dit_workspace_bytes": (C.c_size_t, [C.POINTER(DitWeights), C.c_int32, C.c_int32, C.c_int32]),
+    "omni_dit_modulation_table_workspace_bytes": (C.c_size_t, [C.POINTER(DitWeights), C.c_int32]),
+    "omni_dit_modulation_table": (C.c_int, [C.POINTER(DitWeights), c_bf16_p, C.c_int32, c_bf16_p, C.c_void_p, C.c_size_t,
+                                            C.c_void_p]),
     "omni_dit_forward": (C.c_int, [C.POINTER(DitWeights), C.POINTER(DitBatch), C.c_void_p]),
     "omni_dit_block": (C.c_int, [C.POINTER(DitWeights), C.c_int32, C.POINTER(DitBatch), c_bf16_p, c_bf16_p, c_bf16_p,
                                  C.c_void_p]),

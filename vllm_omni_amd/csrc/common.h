@@ -108,6 +108,7 @@ int omni_internal_flash_attn_w64(const omni_bf16* q, const omni_bf16* k, const o
 // internal (not part of the C-ABI): dst[i] = src[idx[i]] for int32 maps; used by omni_dit_forward
 int omni_internal_gather_i32(int32_t* dst, const int32_t* src, const int32_t* idx, int32_t n, void* stream);
 int omni_internal_add_bf16(omni_bf16* dst, const omni_bf16* src, int64_t n, void* stream);
+int omni_internal_silu_bf16(omni_bf16* dst, const omni_bf16* src, int64_t n, void* stream);
 
 // internal: flash attention with a per-item device predicate (item_skip[b] != 0 -> the item's blocks return at once);
 // q_prescaled = 1: q already carries softmax_scale * log2(e) (omni_gemm_group.qk_q_scale of the fused QKV epilogue)

@@ -154,26 +154,32 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[0].W = reinterpret_cast<const omni_bf16*>(wi8); p.g[0].w_scale = wis;
     p.g[1].W = reinterpret_cast<const omni_bf16*>(wt8); p.g[1].w_scale = wts;
   };
-  // modulation vectors [shift1|scale1|gate1|shift2|scale2|gate2]  (reference :552-561)
-  OMNI_TRY(linear_rows(temb, D, nT, L.img_mod_w, L.img_mod_b, 6 * (int64_t)D, D, ws.mod_img, 6 * D, 1,
-                                  0, stream));
-  OMNI_TRY(linear_rows(temb, D, nT, L.txt_mod_w, L.txt_mod_b, 6 * (int64_t)D, D, ws.mod_txt, 6 * D, 1,
-                                  0, stream));
+  // modulation vectors [shift1|scale1|gate1|shift2|scale2|gate2]  (reference :552-561): two weight-streaming GEMVs (226 MB
+  // of weights per layer) — or, ABI v9, rows of a table computed ONCE for all the denoising steps of a request
+  // (omni_dit_modulation_table: the conditioning of every step is known before the loop starts)
+  const omni_bf16 *mod_img = ws.mod_img, *mod_txt = ws.mod_txt;
+  if (b->mod_table) {
+    mod_img = b->mod_table + (int64_t)(2 * l + 0) * nT * 6 * D;
+    mod_txt = b->mod_table + (int64_t)(2 * l + 1) * nT * 6 * D;
+  } else {
+    OMNI_TRY(linear_rows(temb, D, nT, L.img_mod_w, L.img_mod_b, 6 * (int64_t)D, D, ws.mod_img, 6 * D, 1, 0, stream));
+    OMNI_TRY(linear_rows(temb, D, nT, L.txt_mod_w, L.txt_mod_b, 6 * (int64_t)D, D, ws.mod_txt, 6 * D, 1, 0, stream));
+  }
   if (phase != BLOCK_POST) {
   // norm1 + modulate (reference :564-567).  fp8 mode: the e4m3 copy + per-token scale come out of the same pass (the bf16
   // result is still written for the image stream when TeaCache reads it)
   const bool fused_q = f_qkv && blk;
   if (fused_q) {
-    OMNI_TRY(omni_adaln_modulate_fp8(hidden_img, D, Ri, D, ws.mod_img + D, ws.mod_img, 6 * D, b->img_item, 0, eps,
+    OMNI_TRY(omni_adaln_modulate_fp8(hidden_img, D, Ri, D, mod_img + D, mod_img, 6 * D, b->img_item, 0, eps,
                                      b->teacache ? xn_img : nullptr, bRi, ws.x8, Ri, ws.x8_scale, stream));
     OMNI_TRY(after_img_norm1(xn_img));
-    OMNI_TRY(omni_adaln_modulate_fp8(hidden_txt, D, Rt, D, ws.mod_txt + D, ws.mod_txt, 6 * D, b->txt_item, 0, eps, nullptr, 0,
+    OMNI_TRY(omni_adaln_modulate_fp8(hidden_txt, D, Rt, D, mod_txt + D, mod_txt, 6 * D, b->txt_item, 0, eps, nullptr, 0,
                                      ws.x8 + (int64_t)Ri * D, Rt, ws.x8_scale + Ri, stream));
   } else {
-  OMNI_TRY(omni_adaln_modulate_ex(hidden_img, D, xn_img, D, Ri, D, ws.mod_img + D, ws.mod_img, 6 * D, b->img_item,
+  OMNI_TRY(omni_adaln_modulate_ex(hidden_img, D, xn_img, D, Ri, D, mod_img + D, mod_img, 6 * D, b->img_item,
                                   0, eps, bRi, stream));
   OMNI_TRY(after_img_norm1(xn_img));
-  OMNI_TRY(omni_adaln_modulate_ex(hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + D, ws.mod_txt, 6 * D, b->txt_item,
+  OMNI_TRY(omni_adaln_modulate_ex(hidden_txt, D, xn_txt, D, Rt, D, mod_txt + D, mod_txt, 6 * D, b->txt_item,
                                   0, eps, bRt, stream));
   }
   // fused QKV projections of both streams, scattered into the joint q/k/v (reference :380-394, :414-416)
@@ -225,11 +231,11 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[0].a_k32_rows = attn_k32; p.g[1].a_k32_rows = attn_k32;
     p.g[0].A = attn_src; p.g[0].lda = D; p.g[0].a_row_map = b->img_joint_row; p.g[0].M = Ri;
     p.g[0].W = L.to_out_w; p.g[0].bias = L.to_out_b; p.g[0].out = hidden_img; p.g[0].ldo = D;
-    p.g[0].res = hidden_img; p.g[0].ldres = D; p.g[0].gate = ws.mod_img + 2 * D; p.g[0].gate_item_stride = 6 * D;
+    p.g[0].res = hidden_img; p.g[0].ldres = D; p.g[0].gate = mod_img + 2 * D; p.g[0].gate_item_stride = 6 * D;
     p.g[0].row_item_map = b->img_item;
     p.g[1].A = attn_src; p.g[1].lda = D; p.g[1].a_row_map = b->txt_joint_row; p.g[1].M = Rt;
     p.g[1].W = L.to_add_out_w; p.g[1].bias = L.to_add_out_b; p.g[1].out = hidden_txt; p.g[1].ldo = D;
-    p.g[1].res = hidden_txt; p.g[1].ldres = D; p.g[1].gate = ws.mod_txt + 2 * D; p.g[1].gate_item_stride = 6 * D;
+    p.g[1].res = hidden_txt; p.g[1].ldres = D; p.g[1].gate = mod_txt + 2 * D; p.g[1].gate_item_stride = 6 * D;
     p.g[1].row_item_map = b->txt_item;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
     p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
@@ -248,14 +254,14 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   // norm2 + modulate (reference :590, :595)
   const bool fused_q2 = f_up && blk;
   if (fused_q2) {
-    OMNI_TRY(omni_adaln_modulate_fp8(hidden_img, D, Ri, D, ws.mod_img + 4 * D, ws.mod_img + 3 * D, 6 * D, b->img_item, 0, eps,
+    OMNI_TRY(omni_adaln_modulate_fp8(hidden_img, D, Ri, D, mod_img + 4 * D, mod_img + 3 * D, 6 * D, b->img_item, 0, eps,
                                      nullptr, 0, ws.x8, Ri, ws.x8_scale, stream));
-    OMNI_TRY(omni_adaln_modulate_fp8(hidden_txt, D, Rt, D, ws.mod_txt + 4 * D, ws.mod_txt + 3 * D, 6 * D, b->txt_item, 0, eps,
+    OMNI_TRY(omni_adaln_modulate_fp8(hidden_txt, D, Rt, D, mod_txt + 4 * D, mod_txt + 3 * D, 6 * D, b->txt_item, 0, eps,
                                      nullptr, 0, ws.x8 + (int64_t)Ri * D, Rt, ws.x8_scale + Ri, stream));
   } else {
-  OMNI_TRY(omni_adaln_modulate_ex(hidden_img, D, xn_img, D, Ri, D, ws.mod_img + 4 * D, ws.mod_img + 3 * D, 6 * D,
+  OMNI_TRY(omni_adaln_modulate_ex(hidden_img, D, xn_img, D, Ri, D, mod_img + 4 * D, mod_img + 3 * D, 6 * D,
                                   b->img_item, 0, eps, bRi, stream));
-  OMNI_TRY(omni_adaln_modulate_ex(hidden_txt, D, xn_txt, D, Rt, D, ws.mod_txt + 4 * D, ws.mod_txt + 3 * D, 6 * D,
+  OMNI_TRY(omni_adaln_modulate_ex(hidden_txt, D, xn_txt, D, Rt, D, mod_txt + 4 * D, mod_txt + 3 * D, 6 * D,
                                   b->txt_item, 0, eps, bRt, stream));
   }
   // MLP up + GELU-tanh (reference :591, :596 -> diffusers FeedForward)
@@ -281,10 +287,10 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[0].a_k32_rows = bRi; p.g[1].a_k32_rows = bRt;
     p.g[0].A = h_img; p.g[0].lda = 4 * D; p.g[0].M = Ri; p.g[0].W = L.img_mlp_w2; p.g[0].bias = L.img_mlp_b2;
     p.g[0].out = hidden_img; p.g[0].ldo = D; p.g[0].res = hidden_img; p.g[0].ldres = D;
-    p.g[0].gate = ws.mod_img + 5 * D; p.g[0].gate_item_stride = 6 * D; p.g[0].row_item_map = b->img_item;
+    p.g[0].gate = mod_img + 5 * D; p.g[0].gate_item_stride = 6 * D; p.g[0].row_item_map = b->img_item;
     p.g[1].A = h_txt; p.g[1].lda = 4 * D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w2; p.g[1].bias = L.txt_mlp_b2;
     p.g[1].out = hidden_txt; p.g[1].ldo = D; p.g[1].res = hidden_txt; p.g[1].ldres = D;
-    p.g[1].gate = ws.mod_txt + 5 * D; p.g[1].gate_item_stride = 6 * D; p.g[1].row_item_map = b->txt_item;
+    p.g[1].gate = mod_txt + 5 * D; p.g[1].gate_item_stride = 6 * D; p.g[1].row_item_map = b->txt_item;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
     p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
     if (f_down) {
@@ -401,6 +407,36 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
     p.g[0].out = b->noise_pred; p.g[0].ldo = w->out_channels_packed;
     p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_floats;
     OMNI_TRY(omni_gemm_bf16(&p, stream));
+  }
+  return OMNI_OK;
+}
+
+extern "C" size_t omni_dit_modulation_table_workspace_bytes(const omni_dit_weights* w, int32_t M) {
+  if (!w || M <= 0) return 0;
+  const int64_t D = (int64_t)w->num_heads * w->head_dim;
+  return align_up((size_t)M * D * sizeof(omni_bf16)) + align_up((size_t)8 * M * 6 * D * sizeof(float));
+}
+
+extern "C" int omni_dit_modulation_table(const omni_dit_weights* w, const omni_bf16* temb, int32_t M, omni_bf16* table,
+                                         void* workspace, size_t workspace_bytes, omni_stream stream) {
+  if (!w || !w->layers || !temb || !table || !workspace || M <= 0) return OMNI_ERR_BAD_ARG;
+  const int64_t D = (int64_t)w->num_heads * w->head_dim;
+  if (D % 64 != 0) return OMNI_ERR_UNSUPPORTED;
+  if (workspace_bytes < omni_dit_modulation_table_workspace_bytes(w, M)) return OMNI_ERR_BAD_ARG;
+  omni_bf16* act = static_cast<omni_bf16*>(workspace);                        // silu(temb), rounded to bf16 as the reference's
+  float* splitk = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)M * D * sizeof(omni_bf16)));
+  OMNI_TRY(omni_internal_silu_bf16(act, temb, (int64_t)M * D, stream));      // nn.SiLU in front of the Linear (:478-481)
+  for (int l = 0; l < w->num_layers; ++l) {
+    const omni_dit_layer_weights& L = w->layers[l];
+    for (int s = 0; s < 2; ++s) {
+      omni_gemm_params p = {};
+      p.ngroups = 1; p.N = (int32_t)(6 * D); p.K = (int32_t)D; p.epilogue = OMNI_EPI_BIAS;
+      p.g[0].A = act; p.g[0].lda = D; p.g[0].M = M;
+      p.g[0].W = s ? L.txt_mod_w : L.img_mod_w; p.g[0].bias = s ? L.txt_mod_b : L.img_mod_b;
+      p.g[0].out = table + (int64_t)(2 * l + s) * M * 6 * D; p.g[0].ldo = 6 * D;
+      p.splitk_ws = splitk; p.splitk_ws_floats = (int64_t)8 * M * 6 * D;
+      OMNI_TRY(omni_gemm_bf16(&p, stream));
+    }
   }
   return OMNI_OK;
 }

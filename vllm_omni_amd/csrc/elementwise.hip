@@ -347,6 +347,10 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(uint16_t* __restrict__ ds
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = f32_to_bf16_bits(bf16_bits_to_f32(dst[i]) + bf16_bits_to_f32(src[i]));
 }
+__global__ __launch_bounds__(256) void silu_bf16_kernel(uint16_t* __restrict__ dst, const uint16_t* __restrict__ src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = f32_to_bf16_bits(silu_f(bf16_bits_to_f32(src[i])));
+}
 __global__ __launch_bounds__(256) void gather_i32_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src,
                                                          const int32_t* __restrict__ idx, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -706,6 +710,13 @@ extern "C" int omni_cfg_euler_step(const omni_bf16* pos, const omni_bf16* neg, o
                                    int32_t C, float true_cfg_scale, const float* dt, int32_t dt_rows_per_item,
                                    omni_stream stream) {
   return omni_cfg_euler_step_ex(pos, neg, latents, rows, C, true_cfg_scale, dt, dt_rows_per_item, 1, stream);
+}
+
+int omni_internal_silu_bf16(omni_bf16* dst, const omni_bf16* src, int64_t n, void* stream) {
+  if (!dst || !src || n <= 0) return OMNI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(silu_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dst, src, n);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
 }
 
 int omni_internal_add_bf16(omni_bf16* dst, const omni_bf16* src, int64_t n, void* stream) {

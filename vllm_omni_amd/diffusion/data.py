@@ -98,6 +98,9 @@ class OmniDiffusionConfig:
     dist_backend: str | None = None  # None: "nccl" (= RCCL) with GPUs, "gloo" without
     load_text_encoder: bool = True   # NEW: False = never build the ~16 GB Qwen2.5-VL prompt encoder on the workers (requests
                                      # then carry prompt_embeds)
+    precompute_modulation: bool = True  # NEW: compute every block's modulation vectors for ALL steps of a request in one pass
+                                     # over the modulation weights (omni_dit_modulation_table) instead of re-streaming 13.6 GB
+                                     # of weights in every forward
     max_steps_in_flight: int = 2     # NEW: how many denoising steps a worker's host may enqueue ahead of the device
                                      # (step_batcher.py: bounded run-ahead, so that a newcomer joins within this many steps)
 

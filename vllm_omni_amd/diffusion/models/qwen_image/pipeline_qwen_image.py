@@ -168,6 +168,7 @@ class QwenImagePipeline(nn.Module):
         graph_on = self._use_graph(n_items * S)
         tcfg = getattr(tr, "teacache", None)
         key = (tuple(lens), tuple(grid), do_cfg, float(cfg_scales[0]), R, bool(cfg_normalize), t_cond,
+               bool(getattr(self.od_config, "precompute_modulation", True)),
                None if tcfg is None else (tcfg.rel_l1_thresh, tuple(tcfg.coefficients)))
         st = self._step_state.get(key) if graph_on else None
         if st is None:
@@ -210,6 +211,16 @@ class QwenImagePipeline(nn.Module):
                 st["temb_add"].copy_(rows)                   # ... so later generations refresh the VALUES in place
             temb_add = st["temb_add"]
 
+        # modulation vectors of every step of this schedule, computed once (all requests of a static step-batch share it)
+        mod_tab = None
+        if getattr(self.od_config, "precompute_modulation", True):
+            mod_tab = tr.modulation_table(sig_in, None if t_cond is None else [t_cond] * len(timesteps))  # [L, 2, N, 6D]
+            if st.get("mod") is None:
+                st["mod"] = torch.empty(mod_tab.shape[0], 2, 1, mod_tab.shape[3], dtype=BF16, device=dev)  # static: graphs bake it
+        mod_now = st.get("mod") if mod_tab is not None else None
+        if mod_now is not None:
+            mod_now.copy_(mod_tab[:, :, 0:1])                 # defined contents for a graph's warm-up / capture forwards
+
         def step(sig1, dt1):
             if S_c:
                 li = lat_in.view(n_items, S_tot, Cl)
@@ -220,7 +231,7 @@ class QwenImagePipeline(nn.Module):
                 lat_in[: R * S].copy_(lat)
                 if do_cfg:
                     lat_in[R * S:].copy_(lat)
-            tr.forward_ragged(prepared, lat_in, st["prompt"], sig1, out=pred, teacache=tc, temb_add=temb_add)
+            tr.forward_ragged(prepared, lat_in, st["prompt"], sig1, out=pred, teacache=tc, temb_add=temb_add, mod_table=mod_now)
             pr = pred
             if S_c:                                          # noise_pred[:, :latents.size(1)] (edit pipeline :632)
                 st["pred_c"].view(n_items, S, Cl).copy_(pred.view(n_items, S_tot, Cl)[:, :S])
@@ -230,6 +241,8 @@ class QwenImagePipeline(nn.Module):
         self.last_teacache_state = tc                         # statistics: tc.skipped_forwards() per item after the loop
         if not graph_on:
             for i in range(len(timesteps)):
+                if mod_now is not None:
+                    mod_now.copy_(mod_tab[:, :, i:i + 1])
                 step(sig_in[i:i + 1], dt_dev[i:i + 1])
             return list(lat.clone().view(R, S, -1).unbind(0))
         tr._native_weights()      # (re)build the pointer table NOW: `_native_gen` then names the storages a replay would read
@@ -255,6 +268,8 @@ class QwenImagePipeline(nn.Module):
         for i in range(len(timesteps)):
             st["sig"].copy_(sig_in[i:i + 1], non_blocking=True)
             st["dt"].copy_(dt_dev[i:i + 1], non_blocking=True)
+            if mod_now is not None:
+                mod_now.copy_(mod_tab[:, :, i:i + 1])
             st["graph"].replay()
         return list(lat.clone().view(R, S, -1).unbind(0))
 
@@ -474,7 +489,10 @@ class QwenImagePipeline(nn.Module):
         a.n_steps = len(ts)
         if a.n_steps >= self.SERVE_MAX_STEPS:
             raise NotImplementedError(f"{a.n_steps} denoising steps: the step batcher's schedule tables hold {self.SERVE_MAX_STEPS - 1}")
-        a.state = dict(sig_d=sch.model_timestep(ts).float().to(self.device), dt_d=sch.dt().float().to(self.device),
+        sig_d = sch.model_timestep(ts).float().to(self.device)
+        # mod_tab: this sample's modulation table [L, 2, n_steps, 6D] (88 MB at 20 steps) — built when the sample first takes
+        # a slot of a running batch, not at admission: a long queue of waiting requests must not hold one each
+        a.state = dict(sig_d=sig_d, dt_d=sch.dt().float().to(self.device), mod_tab=None,
                        lat=sm["lat"].to(self.device, BF16).clone(), pos=sm["pos"].to(self.device, BF16),
                        neg=None if sm["neg"] is None else sm["neg"].to(self.device, BF16),
                        cond=None if sm.get("cond") is None else sm["cond"].to(self.device, BF16),
@@ -501,8 +519,9 @@ class QwenImagePipeline(nn.Module):
         S_c = 0 if cond0 is None else int(cond0.shape[0])
         lens = [int(a.state["pos"].shape[0]) for a in group] + ([int(a.state["neg"].shape[0]) for a in group] if do_cfg else [])
         tcfg = getattr(tr, "teacache", None)
+        use_tab = bool(getattr(self.od_config, "precompute_modulation", True))
         key = (tuple(lens), tuple(sm0["grid"]), do_cfg, float(sm0["cfg"]), R, S_c, sm0.get("cfg_normalize", True), sm0.get("t_cond"),
-               None if tcfg is None else (tcfg.rel_l1_thresh, tuple(tcfg.coefficients)))
+               use_tab, None if tcfg is None else (tcfg.rel_l1_thresh, tuple(tcfg.coefficients)))
         st = self._serve_states.get(key)
         if st is not None:
             return st
@@ -524,7 +543,9 @@ class QwenImagePipeline(nn.Module):
                   # per-slot schedules and step counters, all on the device (see begin_sample)
                   sig_tab=torch.zeros(R, self.SERVE_MAX_STEPS, dtype=torch.float32, device=dev),
                   dt_tab=torch.zeros(R, self.SERVE_MAX_STEPS, dtype=torch.float32, device=dev),
-                  step_idx=torch.zeros(R, dtype=torch.int64, device=dev), tc=None)
+                  step_idx=torch.zeros(R, dtype=torch.int64, device=dev), tc=None,
+                  # this step's modulation rows of every resident sample (gathered from the samples' tables before each step)
+                  mod=(torch.zeros(len(tr.transformer_blocks), 2, R, 6 * tr.inner_dim, dtype=BF16, device=dev) if use_tab else None))
         if tcfg is not None:
             from ...cache.teacache.native import TeaCacheDeviceState
 
@@ -599,7 +620,8 @@ class QwenImagePipeline(nn.Module):
             lat_in[: R * S].copy_(lat)
             if do_cfg:
                 lat_in[R * S:].copy_(lat)
-        tr.forward_ragged(st["prepared"], lat_in, st["prompt"], st["sig"], out=pred, teacache=st["tc"], temb_add=st["temb_add"])
+        tr.forward_ragged(st["prepared"], lat_in, st["prompt"], st["sig"], out=pred, teacache=st["tc"], temb_add=st["temb_add"],
+                          mod_table=st["mod"])
         pr = pred
         if S_c:                                              # noise_pred[:, :latents.size(1)] (edit pipeline :632)
             st["pred_c"].view(n_items, S, Cl).copy_(pred.view(n_items, S + S_c, Cl)[:, :S])
@@ -620,6 +642,13 @@ class QwenImagePipeline(nn.Module):
         st = self._serve_state(group)
         for r, a in enumerate(group):
             self._import_sample(a, st, r)
+            if st["mod"] is not None:
+                if a.state.get("mod_tab") is None:
+                    tc_ = a.sample.get("t_cond")
+                    a.state["mod_tab"] = tr.modulation_table(a.state["sig_d"], None if tc_ is None else [tc_] * a.n_steps)
+                # sample r's modulation rows for ITS step (`a.step`: the host's count of the steps enqueued for it — equal to
+                # the device-side counter when this copy executes, and the source table is never written again)
+                st["mod"][:, :, r].copy_(a.state["mod_tab"][:, :, min(a.step, a.n_steps - 1)])
         tr.do_true_cfg = st["do_cfg"]
         self.last_teacache_state = st["tc"]
         if not self._use_graph(st["n_items"] * st["S"]):

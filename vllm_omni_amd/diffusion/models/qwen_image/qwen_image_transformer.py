@@ -570,7 +570,8 @@ class QwenImageTransformer2DModel(nn.Module):
 
     def forward_ragged(self, prepared: dict, latents: torch.Tensor, prompt_embeds: torch.Tensor,
                        timestep: torch.Tensor, out: torch.Tensor | None = None, teacache=None,
-                       additional_t_cond=None, temb_add: torch.Tensor | None = None) -> torch.Tensor:
+                       additional_t_cond=None, temb_add: torch.Tensor | None = None,
+                       mod_table: torch.Tensor | None = None) -> torch.Tensor:
         """latents [n_img_rows, 64] bf16, prompt_embeds [n_txt_rows, joint_dim] bf16, timestep [n_temb] fp32
         (sigma = t/1000 exactly as the pipeline passes it) -> noise_pred [n_img_rows, 64] bf16.
         `teacache`: a cache.teacache.native.TeaCacheDeviceState for this batch (device-side decisions, no host sync)."""
@@ -599,8 +600,32 @@ class QwenImageTransformer2DModel(nn.Module):
             raise ValueError("temb_add must be a contiguous bf16 [n_temb, D] tensor")
         if temb_add is not None:
             b.temb_add = temb_add.data_ptr()
+        if mod_table is not None:                            # this forward's rows of modulation_table(): the GEMVs are skipped
+            L = len(self.transformer_blocks)
+            if tuple(mod_table.shape) != (L, 2, rb.n_temb, 6 * self.inner_dim) or mod_table.dtype != BF16 \
+                    or not mod_table.is_contiguous() or not mod_table.is_cuda:
+                raise ValueError(f"mod_table must be a contiguous bf16 GPU tensor [{L}, 2, {rb.n_temb}, {6 * self.inner_dim}]")
+            b.mod_table = mod_table.data_ptr()
         N.check(lib.omni_dit_forward(C.byref(w), C.byref(b), torch.cuda.current_stream().cuda_stream), "omni_dit_forward")
         return out
+
+    @torch.no_grad()
+    def modulation_table(self, sigma: torch.Tensor, additional_t_cond=None) -> torch.Tensor:
+        """The blocks' modulation vectors for M conditioning rows in ONE pass over the 13.6 GB of modulation weights
+        (omni_dit_modulation_table): sigma fp32 [M] (what forward_ragged takes as `timestep`, e.g. all the steps of a schedule)
+        -> bf16 [num_layers, 2, M, 6 D].  A denoise loop hands `table[:, :, rows]` of its current step to forward_ragged instead
+        of re-streaming those weights in every forward."""
+        sig = sigma.to(self.device, torch.float32).reshape(-1).contiguous()
+        M = int(sig.numel())
+        temb = self.time_text_embed(sig, None, additional_t_cond).contiguous()                    # [M, D] bf16, the forward's own kernels
+        lib, w = N.lib(), self._native_weights()
+        L, D = len(self.transformer_blocks), self.inner_dim
+        table = torch.empty(L, 2, M, 6 * D, dtype=BF16, device=self.device)
+        need = lib.omni_dit_modulation_table_workspace_bytes(C.byref(w), M)
+        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        N.check(lib.omni_dit_modulation_table(C.byref(w), temb.data_ptr(), M, table.data_ptr(), ws.data_ptr(), need,
+                                              torch.cuda.current_stream().cuda_stream), "omni_dit_modulation_table")
+        return table
 
     def _run_block(self, layer: int, hidden_states, encoder_hidden_states, temb, image_rotary_emb):
         """Module-surface entry of ONE block (QwenImageTransformerBlock.forward): [B,S,D], [B,T,D], temb [B,D] -> (enc, hid)."""
