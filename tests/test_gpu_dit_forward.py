@@ -98,12 +98,15 @@ def test_modulation_table_equals_the_per_forward_gemvs():
     sig = torch.tensor([0.91, 0.6015625, 0.33, 0.12, 0.02], device=DEV)
     tab = m.modulation_table(sig)
     assert tab.shape == (layers, 2, 5, 6 * D)
-    temb = m.time_text_embed(sig, None)
-    for l in (0, layers - 1):
-        blk = m.transformer_blocks[l]
-        for s, mod in ((0, blk.img_mod), (1, blk.txt_mod)):
-            ref = ops.linear_smallbatch(temb, mod[1].weight, mod[1].bias, act_in=1)
-            assert rel_l2(tab[l, s], ref) <= 3e-3, (l, s)
+    # up to 8 rows the table is filled by the GEMV kernel itself, beyond that by the GEMM kernel (one pass over the weights)
+    sig12 = torch.linspace(0.97, 0.03, 12, device=DEV)
+    for sg, tb in ((sig, tab), (sig12, m.modulation_table(sig12))):
+        temb = m.time_text_embed(sg, None)
+        for l in (0, layers - 1):
+            blk = m.transformer_blocks[l]
+            for s, mod in ((0, blk.img_mod), (1, blk.txt_mod)):
+                ref = torch.cat([ops.linear_smallbatch(temb[i:i + 8], mod[1].weight, mod[1].bias, act_in=1) for i in range(0, len(sg), 8)])
+                assert rel_l2(tb[l, s], ref) <= 3e-3, (l, s, len(sg))
     g = torch.Generator().manual_seed(3)
     T = [7, 12]
     lat = torch.randn(2 * 64, 64, generator=g).to(DEV, BF16)
@@ -117,7 +120,7 @@ def test_modulation_table_equals_the_per_forward_gemvs():
     with pytest.raises(ValueError):
         m.forward_ragged(prepared, lat, txt, two, mod_table=tab)                  # rows of ANOTHER number of conditioning rows
     # whole loop, both switches, eager and as a replayed hipGraph
-    req = OmniDiffusionRequest(height=128, width=128, num_inference_steps=4, true_cfg_scale=4.0, output_type="latent",
+    req = OmniDiffusionRequest(height=128, width=128, num_inference_steps=10, true_cfg_scale=4.0, output_type="latent",
                                latents=torch.randn(1, 64, 64, generator=g).to(BF16),
                                prompt_embeds=torch.randn(1, 9, joint, generator=g).to(BF16),
                                negative_prompt_embeds=torch.randn(1, 5, joint, generator=g).to(BF16))
@@ -129,4 +132,4 @@ def test_modulation_table_equals_the_per_forward_gemvs():
             again = pipe.generate([req], output_type="latent")[0].output.float().cpu()      # second generation: refreshed table
             assert torch.equal(again, outs[pre, graph])
     assert torch.equal(outs[True, False], outs[True, True]) and torch.equal(outs[False, False], outs[False, True])
-    assert rel_l2(outs[True, False], outs[False, False]) <= 1e-2
+    assert rel_l2(outs[True, False], outs[False, False]) <= 2e-2      # 10 steps of true-CFG 4.0: SiLU rounded to bf16 in the table's GEMM path

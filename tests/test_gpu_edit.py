@@ -204,8 +204,13 @@ def test_edit_request_with_prompt_and_picture_runs_text_to_image(plus):
                                true_cfg_scale=4.0, latents=lat, extra={"image": image}, output_type="pt")
     out = pipe.generate([req])[0]
     assert out.error is None and out.output.shape == (1, 3, 128, 128) and torch.isfinite(out.output.float()).all()
-    pe, pm = enc.get_qwen_prompt_embeds("make the sky purple", image=image, device=DEV)
-    ne, nm = enc.get_qwen_prompt_embeds("blurry", image=image, device=DEV)
+    # what the vision tower is shown: Edit -> the picture itself; Edit-Plus -> every picture resized to ~384^2 at its own aspect
+    # ratio (the reference's CONDITION_IMAGE_SIZE pre-process, pipeline_qwen_image_edit_plus.py:96-123)
+    shown = pipe._prompt_pictures(req)
+    if plus:
+        assert [tuple(s_.shape[-2:]) for s_ in shown] == [(320, 480), (480, 320)]
+    pe, pm = enc.get_qwen_prompt_embeds("make the sky purple", image=shown, device=DEV)
+    ne, nm = enc.get_qwen_prompt_embeds("blurry", image=shown, device=DEV)
     assert int(pm.sum()) > len("make the sky purple".split())            # vision tokens are part of the prompt rows
     req2 = OmniDiffusionRequest(prompt_embeds=pe, prompt_embeds_mask=pm, negative_prompt_embeds=ne, negative_prompt_embeds_mask=nm,
                                 height=128, width=128, num_inference_steps=3, true_cfg_scale=4.0, latents=lat,

@@ -423,6 +423,18 @@ extern "C" int omni_dit_modulation_table(const omni_dit_weights* w, const omni_b
   const int64_t D = (int64_t)w->num_heads * w->head_dim;
   if (D % 64 != 0) return OMNI_ERR_UNSUPPORTED;
   if (workspace_bytes < omni_dit_modulation_table_workspace_bytes(w, M)) return OMNI_ERR_BAD_ARG;
+  if (M <= 8) {
+    // a handful of rows (BASELINE config 1: 4 steps): the weight-streaming GEMV, one launch per matrix at HBM speed (the GEMM
+    // kernel below needs two launches per matrix and is paced by one CU's k-loop per 256-column panel: 2.5x slower at M = 4)
+    for (int l = 0; l < w->num_layers; ++l) {
+      const omni_dit_layer_weights& L = w->layers[l];
+      OMNI_TRY(omni_linear_smallbatch(temb, D, M, L.img_mod_w, L.img_mod_b, 6 * D, (int32_t)D,
+                                      table + (int64_t)(2 * l + 0) * M * 6 * D, 6 * D, 1, 0, stream));
+      OMNI_TRY(omni_linear_smallbatch(temb, D, M, L.txt_mod_w, L.txt_mod_b, 6 * D, (int32_t)D,
+                                      table + (int64_t)(2 * l + 1) * M * 6 * D, 6 * D, 1, 0, stream));
+    }
+    return OMNI_OK;
+  }
   omni_bf16* act = static_cast<omni_bf16*>(workspace);                        // silu(temb), rounded to bf16 as the reference's
   float* splitk = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)M * D * sizeof(omni_bf16)));
   OMNI_TRY(omni_internal_silu_bf16(act, temb, (int64_t)M * D, stream));      // nn.SiLU in front of the Linear (:478-481)

@@ -1974,6 +1974,194 @@ __global__ __launch_bounds__(Q4_THREADS, 1) void gemm_bf16_q4_kernel(const omni_
 }
 #endif  // OMNI_DEV (Q4)
 
+#ifdef OMNI_DEV
+// ------------------------------------------------------------------------------------------------
+// V4 (dev family 7): the Q4 geometry (4 waves x 128 x 128, accumulators in literal AGPRs) on the VENDOR kernel's schedule.
+//
+// Round 4 disassembled the hipBLASLt kernel torch.mm picks at the DiT shapes (Custom_Cijk_..._MT256x256x64_MI16x16x1_SK3,
+// DESIGN.md 7 item 24).  Its K-loop is what Q4 tried to be, but: (a) NO branch inside the loop (the tail K-tiles are peeled;
+// Q4's run-time `do_read / do_dma` flags cost 29 scalar branches per K-tile), (b) exactly ONE scalar / memory instruction
+// between two MFMAs, (c) the whole K-tile's fragments live in registers (128 VGPRs), so an LDS buffer is free for the
+// DMA of K-tile t + 2 as soon as its k 32-63 halves have been read: 3-deep pipeline out of 2 LDS buffers, (d) three
+// barriers per K-tile, each right behind the reads that free a region.  Per K-tile and wave: 128 MFMAs, 32 ds_read_b128,
+// 16 LDS-DMA pieces - slot table below.
+//   entry: registers hold (t, k 0-31) = set 0
+//   slots  0-14   reads W(t, k 32-63) -> set 1            | MFMAs 0-63 run on set 0
+//   slot   17/18  lgkmcnt(0), barrier 1: W region of buffer t & 1 is free
+//   slots 19-38   DMA W(t+2) pieces 0-4 alternating with reads A(t, k 32-63)
+//   slot   44/45  lgkmcnt(0), barrier 2: A region free      | MFMAs 64-127 run on set 1
+//   slots 46-66   DMA W(t+2) pieces 5-7, A(t+2) pieces 0-7
+//   slot   86/87  vmcnt(16) [K-tile t+1 landed], barrier 3: K-tile t+1 visible
+//   slots 88-118  reads (t+1, k 0-31) -> set 0;  slot 126 lgkmcnt(0)
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(Q4_THREADS, 1) void gemm_bf16_v4_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
+                                                                     int tiles_n, int GROUP_M) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = tiles_m * tiles_n;
+  const int bid = (int)blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int band_sz = GROUP_M * tiles_n;
+  const int band = lid / band_sz, in_band = lid - band * band_sz;
+  const int first_m = band * GROUP_M;
+  const int gm = min(GROUP_M, tiles_m - first_m);
+  const int mt = first_m + in_band % gm;
+  const int nt = in_band / gm;
+  const int gi = (mt >= mtiles0) ? 1 : 0;
+  const omni_gemm_group G = pick_group(P, gi);
+  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
+  const int n0 = nt * BN;
+  const int M = G.M, N = P.N, K = P.K;
+  if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;
+  asm volatile(OMNI_OWNS_AGPRS ::: OMNI_ALL_AGPRS);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g4 = lane >> 4;
+
+  uint32_t a_off[2][4], w_off[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int lr = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ar = min(m0 + h * 128 + lr, M - 1);
+      if (G.a_row_map) ar = G.a_row_map[ar];
+      const int64_t ae = G.a_k32_rows ? ((int64_t)(c >> 2) * G.a_k32_rows + ar) * 32 + (c & 3) * 8
+                                      : (int64_t)ar * G.lda + c * 8;
+      a_off[h][i] = (uint32_t)(ae * 2);
+      const int wr = min(n0 + h * 128 + lr, N - 1);
+      const int64_t we = P.w_k32_blocked ? ((int64_t)(c >> 2) * N + wr) * 32 + (c & 3) * 8 : (int64_t)wr * K + c * 8;
+      w_off[h][i] = (uint32_t)(we * 2);
+    }
+  }
+  const int64_t astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * 128 : 128;
+  const int64_t wstep = P.w_k32_blocked ? (int64_t)N * 128 : 128;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int nkt = K / PBK;
+  const char* abase = reinterpret_cast<const char*>(G.A);        // K-tile that the NEXT dma() call fetches
+  const char* wbase = reinterpret_cast<const char*>(G.W);
+  const uint32_t m0_wave = lds0 + (uint32_t)wave * 4096;         // + h * PSLOT_BYTES + i * 1024 + parity * 4 * PSLOT_BYTES
+  constexpr uint32_t PAR = 4 * PSLOT_BYTES;
+
+  // piece p = 0..15: p < 8: W half-tile 2 + (p >> 2), else A half-tile (p - 8) >> 2; i = p & 3
+  auto dma = [&](auto pp, uint32_t par_off) {
+    constexpr int p = decltype(pp)::value, i = p & 3;
+    constexpr int h = p < 8 ? 2 + (p >> 2) : ((p - 8) >> 2);
+    const uint32_t m0v = m0_wave + (uint32_t)(h * PSLOT_BYTES + i * 1024);
+    const uint32_t voff = p < 8 ? w_off[(p & 7) >> 2][i] : a_off[(p & 7) >> 2][i];
+    const char* const gb = p < 8 ? wbase : abase;
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                 :: "s"(m0v), "s"(par_off), "v"(voff), "s"(gb) : "memory");
+  };
+  auto dma_tile = [&](uint32_t par_off) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (dma(q4ic<I>{}, par_off), ...); }(std::make_integer_sequence<int, 16>{});
+  };
+
+  uint32_t a_rd[2], w_rd[2];                        // [ks], parity 0
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const uint32_t chunk = ((uint32_t)(ks * 4 + g4) ^ ((l15 >> 1) & 7)) << 4;
+    a_rd[ks] = lds0 + wm * PSLOT_BYTES + l15 * 128 + chunk;
+    w_rd[ks] = lds0 + (2 + wn) * PSLOT_BYTES + l15 * 128 + chunk;
+  }
+
+  // ---- prologue: K-tiles 0 and 1 in flight, accumulators <- bias under the flight
+  dma_tile(0u);
+  abase += astep; wbase += wstep;
+  if (nkt > 1) { dma_tile(PAR); abase += astep; wbase += wstep; }
+  {
+    float bini[8][4];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const int n = n0 + wn * 128 + nb * 16 + g4 * 4;
+      u32x2_t b = {0u, 0u};
+      if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
+      bini[nb][0] = bf16_lo(b[0]); bini[nb][1] = bf16_hi(b[0]); bini[nb][2] = bf16_lo(b[1]); bini[nb][3] = bf16_hi(b[1]);
+    }
+    [&]<int... I>(std::integer_sequence<int, I...>) { (q4_acc_write<I>(bini[I >> 5][I & 3]), ...); }(std::make_integer_sequence<int, 256>{});
+  }
+  bf16x8_t fa[2][8], fw[2][8];                      // [set = ks][block]: the whole K-tile's fragments
+  if (nkt > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  [&]<int... I>(std::integer_sequence<int, I...>) {
+    ((fw[0][I] = lds_read16<I * 2048>(w_rd[0])), ...);
+    ((fa[0][I] = lds_read16<I * 2048>(a_rd[0])), ...);
+  }(std::make_integer_sequence<int, 8>{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  // one K-tile.  po / pn: LDS byte offset of this K-tile's buffer / the other one.  DO_DMA: K-tile t + 2 exists; DO_NEXT: t + 1 does.
+  auto ktile = [&](auto do_dma_c, auto do_next_c, uint32_t po, uint32_t pn) {
+    constexpr bool DO_DMA = decltype(do_dma_c)::value, DO_NEXT = decltype(do_next_c)::value;
+    const uint32_t wr1 = w_rd[1] + po, ar1 = a_rd[1] + po, wr0n = w_rd[0] + pn, ar0n = a_rd[0] + pn;
+    auto slot = [&](auto ii) {
+      constexpr int i = decltype(ii)::value, ks = i >> 6, nb = (i & 63) >> 3, mb = i & 7;
+      q4_mfma<(nb * 8 + mb) * 4>(fw[ks][nb], fa[ks][mb]);
+      if constexpr (i <= 14 && (i & 1) == 0) fw[1][i / 2] = lds_read16<(i / 2) * 2048>(wr1);
+      else if constexpr (i == 17) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else if constexpr (i == 18) asm volatile("s_barrier" ::: "memory");
+      else if constexpr (i >= 19 && i <= 31 && (i - 19) % 3 == 0) { if constexpr (DO_DMA) dma(q4ic<(i - 19) / 3>{}, po); }
+      else if constexpr (i >= 20 && i <= 32 && (i - 20) % 3 == 0) fa[1][(i - 20) / 3] = lds_read16<((i - 20) / 3) * 2048>(ar1);
+      else if constexpr (i == 34 || i == 36 || i == 38) fa[1][5 + (i - 34) / 2] = lds_read16<(5 + (i - 34) / 2) * 2048>(ar1);
+      else if constexpr (i == 44) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else if constexpr (i == 45) asm volatile("s_barrier" ::: "memory");
+      else if constexpr (i >= 46 && i <= 66 && (i & 1) == 0) { if constexpr (DO_DMA) dma(q4ic<5 + (i - 46) / 2>{}, po); }
+      else if constexpr (i == 86) {
+        if constexpr (DO_NEXT) {
+          if constexpr (DO_DMA) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      else if constexpr (i == 87) { if constexpr (DO_NEXT) asm volatile("s_barrier" ::: "memory"); }
+      else if constexpr (i >= 88 && i <= 102 && (i & 1) == 0) { if constexpr (DO_NEXT) fw[0][(i - 88) / 2] = lds_read16<((i - 88) / 2) * 2048>(wr0n); }
+      else if constexpr (i >= 104 && i <= 118 && (i & 1) == 0) { if constexpr (DO_NEXT) fa[0][(i - 104) / 2] = lds_read16<((i - 104) / 2) * 2048>(ar0n); }
+      else if constexpr (i == 126) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    [&]<int... I>(std::integer_sequence<int, I...>) { (slot(q4ic<I>{}), ...); }(std::make_integer_sequence<int, 128>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  __builtin_amdgcn_s_setprio(1);
+  uint32_t po = 0;
+#pragma unroll 1
+  for (int t = 0; t + 2 < nkt; ++t) {
+    ktile(std::true_type{}, std::true_type{}, po, PAR - po);
+    abase += astep; wbase += wstep;
+    po = PAR - po;
+  }
+  if (nkt > 1) {
+    ktile(std::false_type{}, std::true_type{}, po, PAR - po);
+    po = PAR - po;
+  }
+  ktile(std::false_type{}, std::false_type{}, po, PAR - po);
+  __builtin_amdgcn_s_setprio(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results -> v_accvgpr_read: software wait states
+
+  auto write_tile = [&]() {
+    auto one = [&](auto ii) {
+      constexpr int i = decltype(ii)::value, nb = i >> 3, mb = i & 7;
+      float v[4] = {q4_acc_read<i * 4 + 0>(), q4_acc_read<i * 4 + 1>(), q4_acc_read<i * 4 + 2>(), q4_acc_read<i * 4 + 3>()};
+      if (EPI == OMNI_EPI_BIAS_GELU_TANH) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
+      }
+      u32x2_t o;
+      o[0] = pack_bf16x2(v[0], v[1]);
+      o[1] = pack_bf16x2(v[2], v[3]);
+      char* rowp = smem + (wm * 128 + mb * 16 + l15) * EPI_LDS_STRIDE + (wn * 128 + nb * 16 + g4 * 4) * 2;
+      *reinterpret_cast<u32x2_t*>(rowp) = o;
+    };
+    [&]<int... I>(std::integer_sequence<int, I...>) { (one(q4ic<I>{}), ...); }(std::make_integer_sequence<int, 64>{});
+  };
+  gemm_epilogue_lds_impl<EPI, decltype(write_tile), EpiFromLds, Q4_THREADS>(P, G, m0, n0, smem, tid, write_tile);
+}
+#endif  // OMNI_DEV (V4)
+
 int gemm_group_m() {
   // dev knob: OMNI_GEMM_GROUP_M = row-tiles per L2 band
   static int v = -1;
@@ -2103,6 +2291,8 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_w4_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_q4_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_v4_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
 #endif
@@ -2156,6 +2346,13 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
   }
 #endif
 #ifdef OMNI_DEV
+  if (gemm_variant(p) == 7 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p) &&
+      splitk_factor(p, tiles_m, tiles_n) == 1) {
+    hipLaunchKernelGGL((gemm_bf16_v4_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(Q4_THREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
+                       tiles_n, gemm_group_m());
+    OMNI_CHECK_LAUNCH();
+    return OMNI_OK;
+  }
   if (gemm_variant(p) == 4 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p) &&
       splitk_factor(p, tiles_m, tiles_n) == 1) {
     hipLaunchKernelGGL((gemm_bf16_q4_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(Q4_THREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
