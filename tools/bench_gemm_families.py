@@ -34,6 +34,9 @@ SHAPES = {  # name: (N, K, epilogue, blocked operands?, two groups?)
     "out_proj": (D, D, ops.EPI_BIAS, True, True),
     "mlp_down": (D, 4 * D, ops.EPI_BIAS, True, True),
     "sq8192": (8192, 8192, ops.EPI_BIAS, False, False),
+    # the real epilogues of the two N = 3072 GEMMs of a block: res + gate[item] * (acc + bias), in place on the residual stream
+    "out_gate": (D, D, ops.EPI_BIAS_GATE_RES, True, True),
+    "down_gate": (D, 4 * D, ops.EPI_BIAS_GATE_RES, True, True),
 }
 for name in args.shapes.split(","):
     N, K, epi, blk, two = SHAPES[name]
@@ -46,11 +49,16 @@ for name in args.shapes.split(","):
     outs = {}
     for f in fams:
         oi = torch.zeros(m_i, N, dtype=BF16, device=dev)
-        grp = [ops.GemmGroupArgs(xi, wi, b, oi, a_k32_blocked=blk, out_k32_blocked=blk and epi == ops.EPI_BIAS_GELU_TANH)]
+        extra_i, extra_t = {}, {}
+        if epi == ops.EPI_BIAS_GATE_RES:                 # 10 items: rows_per_item 4096 / 64; the residual is a separate buffer so
+            gate = rn(10, N, sc=0.3)                     # that repeated launches compute the same thing
+            extra_i = dict(res=rn(m_i, N), gate=gate, gate_item_stride=N, rows_per_item=4096)
+            extra_t = dict(res=rn(m_t, N), gate=gate, gate_item_stride=N, rows_per_item=64)
+        grp = [ops.GemmGroupArgs(xi, wi, b, oi, a_k32_blocked=blk, out_k32_blocked=blk and epi == ops.EPI_BIAS_GELU_TANH, **extra_i)]
         if two:
             xt, wt = ops.w_to_k32_blocked(rn(m_t, K)), ops.w_to_k32_blocked(rn(N, K, sc=0.02))
             grp.append(ops.GemmGroupArgs(xt, wt, b, torch.zeros(m_t, N, dtype=BF16, device=dev), a_k32_blocked=blk,
-                                         out_k32_blocked=blk and epi == ops.EPI_BIAS_GELU_TANH))
+                                         out_k32_blocked=blk and epi == ops.EPI_BIAS_GELU_TANH, **extra_t))
         outs[f] = (oi, grp)
     flops = 2.0 * (m_i + m_t) * N * K
     run = {f: (lambda f=f: ops.gemm(outs[f][1], epi, w_k32_blocked=blk, kernel_hint=16 + f)) for f in fams}
@@ -63,7 +71,7 @@ for name in args.shapes.split(","):
     ref = (xi_rm[:512].float() @ wi_rm.float().t() + b.float())
     if epi == ops.EPI_BIAS_GELU_TANH:
         ref = torch.nn.functional.gelu(ref, approximate="tanh")
-    got = base[:512].float() if not (blk and epi == ops.EPI_BIAS_GELU_TANH) else None
+    got = base[:512].float() if epi == ops.EPI_BIAS else None
     err = float((got - ref).norm() / ref.norm()) if got is not None else float("nan")
     res = {k: [] for k in run}
     for _ in range(args.rounds):
