@@ -679,3 +679,18 @@ def test_layered_host_pieces_match_the_reference_run():
     assert torch.equal(ts_, t(z["timesteps"])) and torch.equal(sch.sigmas, t(z["sigmas"]))
     with pytest.raises(ValueError):
         preprocess((100, 100), 512)
+    # the engine-side pre-process (registry): PIL -> resized [-1, 1] tensor, generated size set, captioner picture kept
+    from PIL import Image
+
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.registry import get_diffusion_pre_process_func
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    fn = get_diffusion_pre_process_func(OmniDiffusionConfig(model_class_name="QwenImageLayeredPipeline"))
+    req = OmniDiffusionRequest(prompt="x", extra={"image": Image.new("RGB", (1000, 700), (255, 0, 0)), "resolution": 640})
+    fn([req])
+    want = preprocess((1000, 700), 640)
+    img = req.extra["image"]
+    assert tuple(img.shape) == (1, 3, want["calculated_height"], want["calculated_width"]) and (req.height, req.width) == (want["height"], want["width"])
+    assert float(img[0, 0].min()) == 1.0 and float(img[0, 1].max()) == -1.0 and req.extra["prompt_image"].size == (want["calculated_width"], want["calculated_height"])
+    assert get_diffusion_pre_process_func(OmniDiffusionConfig(model_class_name="QwenImagePipeline")) is None

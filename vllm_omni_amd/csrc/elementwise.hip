@@ -43,18 +43,33 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const uint16_t* xr = x + (int64_t)row * ldx;
-  float v[NCH][8];
+  // ALL of the row's loads are issued before the first value is used (round 4: with the load inside `if (e < D) { load; use }`
+  // hipcc waited vmcnt(0) after every chunk - six serial HBM round trips per row and ONE KiB in flight per wave; the kernel ran
+  // at 3.9 TB/s = exactly 16 waves x 1 KiB x 256 CUs per microsecond of latency).  Chunks past D read a clamped address and
+  // are masked afterwards: no branch around a load.  The row stays PACKED (bf16 pairs, NCH x 4 registers) and is unpacked
+  // in each pass, so that the modulation vectors fit beside it at 4 waves per SIMD.
+  int item = 0;                                        // requested FIRST: the modulation loads below wait for it alone (a counted
+  if (MODE == 0) item = row_item_map ? row_item_map[row] : row / rows_per_item;   // vmcnt), not for the row
+  u32x4_t raw[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) raw[c] = *reinterpret_cast<const u32x4_t*>(xr + min((c * 64 + lane) * 8, D - 8));
+  __builtin_amdgcn_sched_barrier(0);                   // keep the first USE of `item` (and its wait) behind the row's loads
+  const int64_t moff = (int64_t)item * item_stride;
+  u32x4_t rsc[NCH], rsh[NCH];                          // the row's modulation vectors (L2-resident), requested with the row
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e = min((c * 64 + lane) * 8, D - 8);
+    rsc[c] = *reinterpret_cast<const u32x4_t*>(scale_or_w + moff + e);
+    if (MODE == 0) rsh[c] = *reinterpret_cast<const u32x4_t*>(shift + moff + e);
+  }
   float sum = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int e = (c * 64 + lane) * 8;
-    if (e < D) {
-      unpack8(*reinterpret_cast<const u32x4_t*>(xr + e), v[c]);
+    if ((c * 64 + lane) * 8 < D) {
+      float v[8];
+      unpack8(raw[c], v);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sum += (MODE == 0) ? v[c][i] : v[c][i] * v[c][i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+      for (int i = 0; i < 8; ++i) sum += (MODE == 0) ? v[i] : v[i] * v[i];
     }
   }
   sum = wave_sum<64>(sum);
@@ -64,11 +79,12 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
     float var = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int e = (c * 64 + lane) * 8;
-      if (e < D) {
+      if ((c * 64 + lane) * 8 < D) {
+        float v[8];
+        unpack8(raw[c], v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float d = v[c][i] - mean;
+          const float d = v[i] - mean;
           var += d * d;
         }
       }
@@ -78,26 +94,22 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
   } else {
     rstd = rsqrtf(sum / D + eps);
   }
-  int64_t moff = 0;
-  if (MODE == 0) {
-    const int item = row_item_map ? row_item_map[row] : row / rows_per_item;
-    moff = (int64_t)item * item_stride;
-  }
   uint16_t* yr = y + (int64_t)row * ldy;
   float amax = 0.0f;                                   // fp8 output: per-row amax of the bf16-ROUNDED result
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int e = (c * 64 + lane) * 8;
     if (e < D) {
-      float sc[8], sh[8], o[8];
-      unpack8(*reinterpret_cast<const u32x4_t*>(scale_or_w + moff + e), sc);
+      float v[8], sc[8], sh[8], o[8];
+      unpack8(raw[c], v);
+      unpack8(rsc[c], sc);
       if (MODE == 0) {
-        unpack8(*reinterpret_cast<const u32x4_t*>(shift + moff + e), sh);
+        unpack8(rsh[c], sh);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mean) * rstd * (1.0f + sc[i]) + sh[i];
+        for (int i = 0; i < 8; ++i) o[i] = (v[i] - mean) * rstd * (1.0f + sc[i]) + sh[i];
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = v[c][i] * rstd * sc[i];
+        for (int i = 0; i < 8; ++i) o[i] = v[i] * rstd * sc[i];
       }
       const u32x4_t pk = pack8(o);
       if (y) {
@@ -105,10 +117,12 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
         uint16_t* dst = y_k32_rows ? y + ((int64_t)(e >> 5) * y_k32_rows + row) * 32 + (e & 31) : yr + e;
         *reinterpret_cast<u32x4_t*>(dst) = pk;
       }
-      if (MODE == 0 && y8) {                           // keep the bf16-rounded values: the same numbers omni_quantize_fp8_rows
-        unpack8(pk, v[c]);                             // would read back from y, so fused == unfused bit for bit
+      if (MODE == 0 && y8) {                           // keep the bf16-ROUNDED values (in the row's registers): the same numbers
+        raw[c] = pk;                                   // omni_quantize_fp8_rows would read back from y: fused == unfused bit for bit
+        float r[8];
+        unpack8(pk, r);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[c][i]));
+        for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(r[i]));
       }
     }
   }
@@ -120,9 +134,11 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
     for (int c = 0; c < NCH; ++c) {
       const int e = (c * 64 + lane) * 8;
       if (e < D) {
+        float r[8];
+        unpack8(raw[c], r);
         u32x2_t o8;
-        o8[0] = cvt_pk_fp8x4(v[c][0] * inv, v[c][1] * inv, v[c][2] * inv, v[c][3] * inv);
-        o8[1] = cvt_pk_fp8x4(v[c][4] * inv, v[c][5] * inv, v[c][6] * inv, v[c][7] * inv);
+        o8[0] = cvt_pk_fp8x4(r[0] * inv, r[1] * inv, r[2] * inv, r[3] * inv);
+        o8[1] = cvt_pk_fp8x4(r[4] * inv, r[5] * inv, r[6] * inv, r[7] * inv);
         *reinterpret_cast<u32x2_t*>(y8 + ((int64_t)(e >> 6) * y8_rows + row) * 64 + (e & 63)) = o8;
       }
     }
@@ -488,17 +504,20 @@ __global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const uint16_t* 
   const int nchunks = K >> 3;
   u32x4_t v[NCH];
   float amax = 0.0f;
+  // every load of the row is issued before the first value is used (see rownorm_kernel: a load inside `if (c < nchunks) { load;
+  // use }` made hipcc wait for each chunk in turn); chunks past K read a clamped address and are masked to zero afterwards
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane + i * 64;
-    v[i] = u32x4_t{0u, 0u, 0u, 0u};
-    if (c < nchunks) {
-      const uint16_t* src = x_k32_rows ? x + ((int64_t)(c >> 2) * x_k32_rows + row) * 32 + (c & 3) * 8
-                                       : x + (int64_t)row * ldx + c * 8;
-      v[i] = *reinterpret_cast<const u32x4_t*>(src);
+    const int c = min(lane + i * 64, nchunks - 1);
+    const uint16_t* src = x_k32_rows ? x + ((int64_t)(c >> 2) * x_k32_rows + row) * 32 + (c & 3) * 8
+                                     : x + (int64_t)row * ldx + c * 8;
+    v[i] = *reinterpret_cast<const u32x4_t*>(src);
+  }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(bf16_lo(v[i][e])), fabsf(bf16_hi(v[i][e]))));
-    }
+  for (int i = 0; i < NCH; ++i) {
+    if (lane + i * 64 >= nchunks) v[i] = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(bf16_lo(v[i][e])), fabsf(bf16_hi(v[i][e]))));
   }
   amax = wave_max<64>(amax);
   const float sc = fmaxf(amax, 1e-12f) * (1.0f / 448.0f);       // e4m3fn: largest finite 448

@@ -39,6 +39,33 @@ def preprocess(image_size: tuple[int, int], resolution: int = 640, vae_scale_fac
     return {"calculated_width": cw, "calculated_height": ch, "width": cw // m * m, "height": ch // m * m}
 
 
+def get_qwen_image_layered_pre_process_func(od_config=None):
+    """The reference's request pre-processing for this pipeline (`get_qwen_image_layered_pre_process_func`, :42-105; run by the
+    engine before the request reaches a worker): a PIL picture in `req.extra["image"]` is resized to ~resolution^2 at its own
+    aspect ratio (`calculate_dimensions`, multiples of 32; diffusers `VaeImageProcessor.resize` -> LANCZOS), kept as
+    `extra["prompt_image"]` (what the captioner sees), converted to a [1, 3, H, W] tensor in [-1, 1] (`VaeImageProcessor.preprocess`)
+    and the generated size `req.height / req.width` is set to the same floored to multiples of 16.  Tensors pass through."""
+    from .text_encoder import resize_picture
+
+    def pre_process_func(requests):
+        for req in requests:
+            extra = req.extra if req.extra is not None else {}
+            img = extra.get("image")
+            if img is None or isinstance(img, torch.Tensor):
+                continue
+            if isinstance(img, (list, tuple)):
+                img = img[0]
+            plan = preprocess(img.size, int(extra.get("resolution") or 640))
+            pic = resize_picture(img.convert("RGB"), plan["calculated_height"], plan["calculated_width"])
+            arr = torch.from_numpy(np.asarray(pic, dtype=np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+            extra.update(image=arr * 2.0 - 1.0, prompt_image=extra.get("prompt_image", pic))
+            req.extra = extra
+            req.height, req.width = plan["height"], plan["width"]
+        return requests
+
+    return pre_process_func
+
+
 class QwenImageLayeredPipeline(QwenImageEditPipeline):
     DEFAULT_LAYERS = 4
 

@@ -19,7 +19,7 @@ _POST_PROCESS = {"QwenImagePipeline": "get_qwen_image_post_process_func",
                  "QwenImageEditPipeline": "get_qwen_image_post_process_func",
                  "QwenImageEditPlusPipeline": "get_qwen_image_post_process_func",
                  "QwenImageLayeredPipeline": "get_qwen_image_post_process_func"}
-_PRE_PROCESS: dict[str, str] = {}
+_PRE_PROCESS: dict[str, str] = {"QwenImageLayeredPipeline": "get_qwen_image_layered_pre_process_func"}
 
 
 def _module(arch: str):
