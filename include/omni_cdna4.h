@@ -295,8 +295,20 @@ typedef struct {
   int32_t y_padded;       /* ABI v8.  1: y is written as a zero-bordered raster too (needs x_padded, Cin % 32 == 0,
                            * Cout % 8 == 0, no up/downsample): the decoder's 3x3 / 1x1 convs run as a GEMM over nine row-shifted
                            * views of x, LDS-DMA fed (vae.hip conv_bordered_kernel) */
+  /* ABI v10: the norm + activation that FOLLOWS this conv in the decoder (QwenImageResidualBlock.forward norm1 / norm2 + SiLU,
+   * autoencoder_kl_qwenimage.py:262-275; norm_out :735-737) as a second output of the same launch:
+   *   y_norm = silu?(F.normalize(y, dim=C) * sqrt(C) * norm_gamma)      computed from y as rounded to bf16
+   * (== omni_vae_rmsnorm_silu(y) bit for bit up to the summation order of the squares).  norm_gamma NULL -> off. */
+  const omni_bf16* norm_gamma; /* [Cout], nullable */
+  omni_bf16* y_norm;           /* same shape as y; required with norm_gamma */
+  int32_t norm_silu;           /* apply SiLU after the norm */
 } omni_conv_params;
+/* With norm_gamma: the conv kernel itself writes y_norm when one workgroup holds all channels of a pixel
+ * (omni_vae_conv2d_fuses_norm(p) == 1: zero-bordered rasters, Cout <= 96, or Cout <= 192 on rasters that fill the chip with
+ * 192-channel tiles); then y may be NULL (only the normed output is wanted).  Otherwise the call runs the conv into y (required)
+ * and omni_vae_rmsnorm_silu from y into y_norm. */
 int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream);
+int omni_vae_conv2d_fuses_norm(const omni_conv_params* p);
 
 /* Nearest-exact x2 upsample (QwenImageUpsample, autoencoder_kl_qwenimage.py:112-124) between zero-bordered rasters:
  * x [B, H + 2, W + 2, C] -> y [B, 2H + 2, 2W + 2, C].  C % 8 == 0.  ABI v8 */

@@ -51,6 +51,49 @@ def test_bordered_conv_matches_torch(cin, cout, ks, hw, B, use_res):
     assert float((got - y_plain).norm() / ref.norm()) <= 4e-3
 
 
+@pytest.mark.parametrize("cin,cout,ks,hw,B,use_res,fused", [
+    (96, 96, 3, (20, 37), 2, True, True),        # 256 px x 96 ch tiles: the lane pair of a pixel holds all channels
+    (192, 64, 3, (33, 18), 1, False, True),      # fewer channels than the tile: the idle channel runs stay out of the sum
+    (96, 96, 3, (256, 1024), 1, True, True),
+    (192, 192, 3, (384, 384), 1, True, True),    # 512 px x 192 ch tiles: two waves share a pixel (LDS exchange)
+    (96, 192, 1, (512, 300), 1, False, True),    # ... 1x1, ragged runs
+    (192, 192, 3, (40, 24), 1, True, False),     # 192 channels on a small raster: 96-channel tiles -> the separate norm pass
+    (192, 384, 3, (64, 64), 1, False, False),    # more channels than any tile
+])
+@pytest.mark.parametrize("silu", [True, False])
+def test_conv_with_the_following_norm_as_second_output(cin, cout, ks, hw, B, use_res, fused, silu):
+    """ABI v10 norm_gamma: y_norm must be what omni_vae_rmsnorm_silu makes of y (same formula from the bf16-rounded y; only the
+    order in which the squares are summed differs), y itself and the zero borders of both unchanged, and with keep_raw=False
+    the kernel writes the normed output alone."""
+    import ctypes
+
+    from vllm_omni_amd import _native as N
+    from vllm_omni_amd import ops
+
+    H, W = hw
+    x, w, b = _border(_rnd((B, H, W, cin), 1)).to(DEV), _rnd((cout, ks, ks, cin), 2, 0.05).to(DEV), _rnd((cout,), 3).to(DEV)
+    res = _border(_rnd((B, H, W, cout), 4)).to(DEV) if use_res else None
+    g = (1.0 + 0.2 * _rnd((cout,), 5).float()).to(torch.bfloat16).to(DEV)
+    kw = dict(res=res, x_bordered=True, y_bordered=True)
+    y0 = ops.vae_conv2d(x, w, b, **kw)
+    n0 = ops.vae_rmsnorm_silu(y0, g, silu=silu)
+    y1, n1 = ops.vae_conv2d(x, w, b, norm_gamma=g, norm_silu=silu, **kw)
+    assert torch.equal(y0, y1)
+    d = (n1.float() - n0.float()).abs()
+    ulp = n0.float().abs() * 2.0 ** -7 + 1e-30
+    assert float((d / ulp).max()) <= 1.0 and float((d > 0).float().mean()) <= 1e-2     # <= 1 bf16 ulp, on <= 1 % of the values
+    for t in (n1,):
+        assert float(t[:, 0].abs().max()) == 0.0 and float(t[:, -1].abs().max()) == 0.0
+        assert float(t[:, :, 0].abs().max()) == 0.0 and float(t[:, :, -1].abs().max()) == 0.0
+    y2, n2 = ops.vae_conv2d(x, w, b, norm_gamma=g, norm_silu=silu, keep_raw=False, **kw)
+    assert torch.equal(n2, n1)
+    assert (y2 is None) == fused                          # the launcher's promise (omni_vae_conv2d_fuses_norm) and what ops did with it
+    p = N.ConvParams()
+    p.B, p.Hin, p.Win, p.Cin, p.Cout, p.ksize, p.x_padded, p.y_padded = B, H, W, cin, cout, ks, 1, 1
+    p.norm_gamma = g.data_ptr()
+    assert bool(N.lib().omni_vae_conv2d_fuses_norm(ctypes.byref(p))) == fused
+
+
 def test_gather_conv_reads_bordered_input():
     """conv_out of the decoder: bordered raster in, plain raster out (3 output channels: the gather kernel)."""
     from vllm_omni_amd import ops

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Launch ONE hot kernel a few times (for rocprofv3 --kernel-trace / --pmc passes).
-   python tools/run_kernel.py roofline|gemm_mlp_up|gemm_mlp_down|gemm_qkv|gemm_out|attention|attention6|attention10 [iters]"""
+   python tools/run_kernel.py roofline|gemm_mlp_up|gemm_mlp_down|gemm_qkv|gemm_out|attention|attention6|attention10|
+                              conv<Cin>_<Cout>_<side>[_n] [iters]     (the VAE's bordered 3x3 conv; _n = with the fused norm output)"""
 import math
 import os
 import sys
@@ -43,6 +44,14 @@ elif which in ("attention", "attention6", "attention10"):
     q, k, v = rn(B * S, H * 128), rn(B * S, H * 128), rn(B * S, H * 128)
     cu = (torch.arange(B + 1, dtype=torch.int32) * S).to(dev)
     fn = lambda: ops.flash_attn_varlen(q, k, v, cu, H, S, 1 / math.sqrt(128))  # noqa: E731
+elif which.startswith("conv"):
+    parts = which[4:].split("_")
+    cin, cout, side = int(parts[0]), int(parts[1]), int(parts[2])
+    x = torch.nn.functional.pad(rn(1, side, side, cin), (0, 0, 1, 1, 1, 1))
+    w, b, gm = rn(cout, 3, 3, cin, s=0.05), rn(cout), rn(cout)
+    res = torch.nn.functional.pad(rn(1, side, side, cout), (0, 0, 1, 1, 1, 1))
+    kw = dict(norm_gamma=gm) if len(parts) > 3 else {}
+    fn = lambda: ops.vae_conv2d(x, w, b, res=res, x_bordered=True, y_bordered=True, **kw)  # noqa: E731
 else:
     raise SystemExit("unknown kernel")
 for _ in range(iters):

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomni_cdna4.so")   # fixed: dev sweeps assign this attribute (tools/devlib.py)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_bf16_p = C.c_void_p  # device pointer to uint16_t bf16 bits
 c_i32_p = C.c_void_p
@@ -56,6 +56,7 @@ class ConvParams(C.Structure):
         ("ksize", C.c_int32), ("upsample2x", C.c_int32), ("silu", C.c_int32),
         ("clamp_lo", C.c_float), ("clamp_hi", C.c_float), ("downsample2x", C.c_int32),
         ("x_padded", C.c_int32), ("y_padded", C.c_int32),
+        ("norm_gamma", c_bf16_p), ("y_norm", c_bf16_p), ("norm_silu", C.c_int32),                 # ABI v10
     ]
 
 
@@ -156,6 +157,7 @@ PROTOTYPES = {
     "omni_cfg_euler_step_ex": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, C.c_int32, C.c_int32, C.c_float, c_f32_p,
                                          C.c_int32, C.c_int32, C.c_void_p]),                      # ABI v9
     "omni_vae_conv2d": (C.c_int, [C.POINTER(ConvParams), C.c_void_p]),
+    "omni_vae_conv2d_fuses_norm": (C.c_int, [C.POINTER(ConvParams)]),                              # ABI v10
     "omni_vae_upsample2x_bordered": (C.c_int, [c_bf16_p, c_bf16_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "omni_vae_rmsnorm_silu": (C.c_int, [c_bf16_p, c_bf16_p, C.c_int64, C.c_int32, c_bf16_p, C.c_int32, C.c_void_p]),
     "omni_softmax_rows": (C.c_int, [c_bf16_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),

@@ -203,28 +203,52 @@ OMNI_DEVINL void conv_dma16(const u32x4_t& srd, uint32_t voff, uint32_t lds_addr
 }
 
 constexpr int CONV_MAX_SEG = 4;                                  // runs per tile
+// tuning knobs of the launcher (tools/build_variants.sh builds alternatives for tools/bench_vae.py)
+#ifndef OMNI_CONV_BIG_KC
+#define OMNI_CONV_BIG_KC 32
+#endif
+#ifndef OMNI_CONV_BIG_NS
+#define OMNI_CONV_BIG_NS 2
+#endif
 // PB = 32-pixel blocks per wave.  PB = 2: K-tile of 32 channels (64-B LDS rows); PB = 4: 16 channels (32-B rows) — the wave
 // tile 128 px x 96 ch reads 7 fragments per 12 MFMAs instead of 5 per 6 (the kernel is LDS-read bound: 8 waves x 5 KiB per
 // 192 MFMA cycles is 83 % of the LDS pipe) at the same 36 MFMAs per wave between barriers.
-template <int WM, int WN, int PB>
+template <int WM, int WN, int PB, int KC, int NS>
 constexpr int conv_lds_bytes() {
-  constexpr int RB = PB == 4 ? 32 : 64, RPP = 1024 / RB;
-  return 2 * ((32 * PB * WM) / RPP + CONV_MAX_SEG + 3 * ((96 * WN) / RPP)) * 1024;
+  constexpr int RB = KC * 2, RPP = 1024 / RB;
+  return NS * ((32 * PB * WM) / RPP + CONV_MAX_SEG + 3 * ((96 * WN) / RPP)) * 1024;
+}
+// wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform, only known at run time: the
+// DMA pieces of a K-tile are dealt round-robin over the waves); a smaller immediate than n is always safe
+OMNI_DEVINL void conv_wait_vm(int n) {
+#define OMNI_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    OMNI_VM(0) OMNI_VM(1) OMNI_VM(2) OMNI_VM(3) OMNI_VM(4) OMNI_VM(5) OMNI_VM(6) OMNI_VM(7) OMNI_VM(8) OMNI_VM(9) OMNI_VM(10)
+    OMNI_VM(11) OMNI_VM(12) OMNI_VM(13) OMNI_VM(14) OMNI_VM(15) OMNI_VM(16) OMNI_VM(17) OMNI_VM(18) OMNI_VM(19) OMNI_VM(20)
+    OMNI_VM(21) OMNI_VM(22) OMNI_VM(23) OMNI_VM(24) OMNI_VM(25) OMNI_VM(26) OMNI_VM(27) OMNI_VM(28) OMNI_VM(29) OMNI_VM(30)
+    OMNI_VM(31) OMNI_VM(32) OMNI_VM(33) OMNI_VM(34) OMNI_VM(35) OMNI_VM(36)
+    default: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+  }
+#undef OMNI_VM
 }
 
 // Tiles are made of RUNS of interior pixels: a run = L consecutive pixels of one image row (L a multiple of the wave's pixel
 // count, chosen by the launcher: the row width when it fits), a tile = MT / L runs.  Border pixels are never computed, so
 // power-of-two images give whole numbers of tiles per round of 256 CUs (over the full bordered raster 258^2 needs 2.02 rounds
 // = 3); the zero border of y is written by the workgroups whose runs touch it.
-template <int WM, int WN, int PB>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_bordered_kernel(const omni_conv_params P, int L) {
+// KC = channels per K-tile (16: 32-B LDS rows, 32: 64-B rows); NS = LDS stages (K-tiles kt + 1 .. kt + NS - 1 in flight while kt is
+// multiplied)
+// FUSE: also write P.y_norm = silu?(rmsnorm(y) * P.norm_gamma) — the launcher guarantees gridDim.y == 1 (all of a pixel's
+// channels in this workgroup: the lane pair of a pixel, times the WN waves that share it)
+template <int WM, int WN, int PB, int KC, int NS, bool FUSE>
+__global__ __launch_bounds__(64 * WM * WN, (conv_lds_bytes<WM, WN, PB, KC, NS>() <= 80 * 1024 && WM * WN == 4 ? 2 : 1)) void conv_bordered_kernel(
+    const omni_conv_params P, int L) {
   constexpr int NW = WM * WN, MT = 32 * PB * WM, NT = 96 * WN;
-  constexpr int KC = PB == 4 ? 16 : 32;                          // channels per K-tile
   constexpr int RB = KC * 2, RPP = 1024 / RB;                    // LDS row bytes; rows per 1-KiB DMA piece
   constexpr int A_MAX = MT / RPP + CONV_MAX_SEG;                 // every run carries L + RPP rows: pixels x0 - 1 .. x0 + L + RPP - 2
   constexpr int W_PIECES = NT / RPP;                             // per kx tap
   constexpr int STAGE = (A_MAX + 3 * W_PIECES) * 1024;
-  static_assert(2 * STAGE <= 160 * 1024, "two stages must fit the CU's LDS");
+  static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "the stages must fit the CU's LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -248,7 +272,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_bor
   // DMA side: lane -> row-in-piece lane / (RB / 16), LDS chunk lane % (RB / 16) holds the logical chunk XORed the same way.
   constexpr int CPR = RB / 16;                                   // chunks per row: 4 or 2
   const int lrow = lane / CPR;
-  const uint32_t lc16 = (uint32_t)(((lane % CPR) ^ (PB == 4 ? (lrow >> 3) & 1 : (lrow >> 2) & 3)) * 16);
+  const uint32_t lc16 = (uint32_t)(((lane % CPR) ^ (KC == 16 ? (lrow >> 3) & 1 : (lrow >> 2) & 3)) * 16);
   const uint32_t a_lane = (uint32_t)(lrow * P.Cin * 2) + lc16;
   const uint32_t w_lane = (uint32_t)(lrow * Ktot * 2) + lc16;
   // raster index of the pixel LEFT of run r's first pixel (runs past the image repeat the last one: computed, never stored)
@@ -260,34 +284,56 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_bor
 
   // K-tile (ky, cc): per run ONE A block — rows origin + (ky - 1) Wp .. of channel chunk cc; the kx = 0, 1, 2 taps read it at
   // row offsets 0, 1, 2 (a third of the L2 -> LDS traffic of one tile per tap) — and the W rows of its nk taps.
+  // The 1-KiB pieces are dealt round-robin over the waves (A pieces g = wave, wave + NW, ..; W pieces likewise); the byte offset
+  // of a piece is a per-piece constant (SGPR, computed ONCE: the run / row divisions cost ~100 scalar instructions per piece,
+  // 12 per MFMA when redone every K-tile) plus a per-K-tile delta that is the same for every piece of an operand.
+  // modulo-2^32 arithmetic: a row before the image wraps to just below 2^32, past the descriptor's range (the launcher keeps
+  // the image 16 MiB short of 4 GiB) -> zeros
+  constexpr int MAXA = (A_MAX + NW - 1) / NW, MAXW = (3 * W_PIECES + NW - 1) / NW;
+  const int w_pieces = nk * W_PIECES;
+  const int cntA = (a_pieces - wave + NW - 1) / NW, cntW = (w_pieces - wave + NW - 1) / NW;
+  uint32_t preA[MAXA], preW[MAXW];
+#pragma unroll
+  for (int i = 0; i < MAXA; ++i) {
+    const int g = min(wave + i * NW, a_pieces - 1), r = g / rp, j = g - r * rp;
+    preA[i] = __builtin_amdgcn_readfirstlane((uint32_t)(run_origin(r) + RPP * j) * (uint32_t)(P.Cin * 2));
+  }
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int q = min(wave + i * NW, w_pieces - 1), kx = q / W_PIECES, rblk = q - kx * W_PIECES;
+    preW[i] = __builtin_amdgcn_readfirstlane((uint32_t)(n0 + RPP * rblk) * (uint32_t)(Ktot * 2) + (uint32_t)(kx * P.Cin * 2));
+  }
   auto issue = [&](int ky, int cc, int slot) {
-    const int shift = nk == 3 ? (ky - 1) * Wp : 0;
-    const uint32_t sbase = lds0 + slot * STAGE;
-    for (int g = wave; g < a_pieces + nk * W_PIECES; g += NW) {
-      if (g < a_pieces) {
-        const int r = g / rp, j = g - r * rp;
-        // modulo-2^32 arithmetic: a row before the image wraps to just below 2^32, past the descriptor's range (the launcher
-        // keeps the image 16 MiB short of 4 GiB) -> zeros
-        const uint32_t row_bytes = (uint32_t)(run_origin(r) + RPP * j + shift) * (uint32_t)(P.Cin * 2) + (uint32_t)(cc * RB);
-        conv_dma16(x_srd, a_lane + row_bytes, sbase + g * 1024);
-      } else {
-        const int q = g - a_pieces, kx = q / W_PIECES, rblk = q - kx * W_PIECES;
-        const uint32_t row_bytes = (uint32_t)(n0 + RPP * rblk) * (uint32_t)(Ktot * 2) + (uint32_t)(((ky * nk + kx) * P.Cin + cc * KC) * 2);
-        conv_dma16(w_srd, w_lane + row_bytes, sbase + (A_MAX + q) * 1024);
-      }
-    }
+    const uint32_t dA = (uint32_t)(nk == 3 ? (ky - 1) * Wp : 0) * (uint32_t)(P.Cin * 2) + (uint32_t)(cc * RB);
+    const uint32_t dW = (uint32_t)((ky * nk * P.Cin + cc * KC) * 2);
+    const uint32_t sA = lds0 + slot * STAGE + wave * 1024, sW = sA + A_MAX * 1024;
+#pragma unroll
+    for (int i = 0; i < MAXA; ++i)
+      if (i < cntA) conv_dma16(x_srd, a_lane + (preA[i] + dA), sA + i * (NW * 1024));
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i)
+      if (i < cntW) conv_dma16(w_srd, w_lane + (preW[i] + dW), sW + i * (NW * 1024));
   };
 
+  // accumulators start at the bias (lane (l31, hi) holds channels n0 + 96 wn + 32 nb + 8 q + 4 hi + j in acc[.][nb][4 q + j]):
+  // the epilogue has no bias traffic
   f32x16_t acc[PB][3];
 #pragma unroll
-  for (int pb = 0; pb < PB; ++pb)
+  for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb)
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + wn * 96 + nb * 32 + q * 8 + hi * 4;
+      u32x2_t b = {0u, 0u};
+      if (P.bias) b = *reinterpret_cast<const u32x2_t*>(P.bias + min(n, P.Cout - 4));
+      const float bf[4] = {bf16_lo(b[0]), bf16_hi(b[0]), bf16_lo(b[1]), bf16_hi(b[1])};
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[pb][nb][i] = 0.f;
+      for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[pb][nb][q * 4 + j] = bf[j];
+    }
 
   auto frag_addr = [&](int r, int c) {
-    return (uint32_t)(r * RB + ((c ^ (PB == 4 ? (r >> 3) & 1 : (r >> 2) & 3)) << 4));
+    return (uint32_t)(r * RB + ((c ^ (KC == 16 ? (r >> 3) & 1 : (r >> 2) & 3)) << 4));
   };
   uint32_t w_rd[3][KC / 16];
 #pragma unroll
@@ -300,15 +346,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_bor
 
   int iky = 0, icc = 0;                                          // (ky, chunk) of the next K-tile to issue
   auto issue_next = [&](int kt) {
-    issue(iky, icc, kt & 1);
+    issue(iky, icc, kt % NS);
     if (++icc == cpt) { icc = 0; ++iky; }
   };
-  issue_next(0);
+  const int my_pieces = cntA + cntW;                              // DMA instructions this wave issues per K-tile
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nkt) issue_next(s);
   for (int kt = 0; kt < nkt; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of K-tile kt (the only ones in flight)
+    conv_wait_vm(min(NS - 2, nkt - 1 - kt) * my_pieces);          // this wave's pieces of K-tile kt have landed (later ones may fly)
     __syncthreads();                                             // K-tile kt is in LDS; everyone is done with K-tile kt-1's slot
-    if (kt + 1 < nkt) issue_next(kt + 1);
-    const char* st = smem + (kt & 1) * STAGE;
+    if (kt + NS - 1 < nkt) issue_next(kt + NS - 1);               // ... which K-tile kt + NS - 1 now fills
+    const char* st = smem + (kt % NS) * STAGE;
     for (int kx = 0; kx < nk; ++kx) {
       const int dx = nk == 3 ? kx : 1;                           // block row 0 is the pixel left of the run
       const char* wst = st + kx * (W_PIECES * 1024);
@@ -327,41 +376,123 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_bor
     }
   }
 
-  // epilogue: lane owns one pixel (column of the swapped product), channels nbase + 8 q + 4 hi + {0..3}
+  // epilogue: lane (l31, hi) owns one pixel (column of the swapped product) and, per 32-channel block, channels 8 q + 4 hi + {0..3}.
+  // v_permlane32_swap between the lane pair of a pixel turns two 8-B quarters into ONE 16-B run (channels 16 h + 8 hi + {0..7}),
+  // so a pixel's bias / residual / output move as 16-B accesses; all of a pixel block's residual loads are issued before the
+  // first use (addresses clamped instead of branched around: a load inside `if (n < Cout)` is waited for on the spot).
   const bool do_clamp = P.clamp_lo < P.clamp_hi;
   const int my_run = run0 + wr;
-  const int ry = my_run / rpr, rx0 = (my_run - ry * rpr) * L;
+  const int crun = min(my_run, nruns - 1);
+  const int ry = crun / rpr, rx0 = (crun - ry * rpr) * L;
+  const int nch0 = n0 + wn * 96 + hi * 8;                         // the lane's 8-channel runs start at nch0 + 32 nb + 16 h
+  u32x4_t kept[FUSE ? PB : 1][3][2];                              // FUSE: the pixel's outputs as rounded to bf16, for the norm pass
+  float ss[PB];
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     const int x = rx0 + wi + pb * 32 + l31;
-    if (my_run >= nruns || x >= P.Win) continue;
-    const int64_t row = ((int64_t)img * npix + (ry + 1) * Wp + x + 1) * P.Cout;
+    const bool live = my_run < nruns && x < P.Win;
+    const int64_t row = ((int64_t)img * npix + (ry + 1) * Wp + min(x, P.Win - 1) + 1) * P.Cout;
+    u32x4_t rs[3][2];
+    if (P.res) {
+#pragma unroll
+      for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)                                  // clamped, not branched around (masked at the store)
+          rs[nb][h] = *reinterpret_cast<const u32x4_t*>(P.res + row + min(nch0 + nb * 32 + h * 16, P.Cout - 8));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ss[pb] = 0.f;
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 96 + nb * 32 + q * 8 + hi * 4;
-        if (n >= P.Cout) continue;
-        float v[4];
+      for (int h = 0; h < 2; ++h) {
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[pb][nb][q * 4 + j];
-        if (P.bias) {
-          const u32x2_t b = *reinterpret_cast<const u32x2_t*>(P.bias + n);
-          v[0] += bf16_lo(b[0]); v[1] += bf16_hi(b[0]); v[2] += bf16_lo(b[1]); v[3] += bf16_hi(b[1]);
+        for (int j = 0; j < 4; ++j) {                              // quarters q = 2h (first operand) and 2h + 1 (second)
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[pb][nb][(2 * h) * 4 + j]),
+                                                           __float_as_uint(acc[pb][nb][(2 * h + 1) * 4 + j]), false, false);
+          v[j] = __uint_as_float(sw[0]);
+          v[4 + j] = __uint_as_float(sw[1]);
         }
         if (P.res) {
-          const u32x2_t r = *reinterpret_cast<const u32x2_t*>(P.res + row + n);
-          v[0] += bf16_lo(r[0]); v[1] += bf16_hi(r[0]); v[2] += bf16_lo(r[1]); v[3] += bf16_hi(r[1]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] += bf16_lo(rs[nb][h][j]);
+            v[2 * j + 1] += bf16_hi(rs[nb][h][j]);
+          }
         }
         if (do_clamp) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], P.clamp_lo), P.clamp_hi);
+          for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf(v[j], P.clamp_lo), P.clamp_hi);
         }
-        u32x2_t o;
-        o[0] = pack_bf16x2(v[0], v[1]);
-        o[1] = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<u32x2_t*>(P.y + row + n) = o;
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+        const int nc = nch0 + nb * 32 + h * 16;
+        if constexpr (FUSE) {
+          if (nc >= P.Cout) o = u32x4_t{0u, 0u, 0u, 0u};
+          kept[pb][nb][h] = o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ss[pb] += bf16_lo(o[j]) * bf16_lo(o[j]) + bf16_hi(o[j]) * bf16_hi(o[j]);
+          if (P.y && live && nc < P.Cout) *reinterpret_cast<u32x4_t*>(P.y + row + nc) = o;
+        } else {
+          if (live && nc < P.Cout) *reinterpret_cast<u32x4_t*>(P.y + row + nc) = o;
+        }
       }
+  }
+  if constexpr (FUSE) {
+    // sum of squares over the pixel's channels: the partner lane (hi ^ 1), then the other waves of the pixel through LDS
+    u32x4_t gm[3][2];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) gm[nb][h] = *reinterpret_cast<const u32x4_t*>(P.norm_gamma + min(nch0 + nb * 32 + h * 16, P.Cout - 8));
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss[pb]), __float_as_uint(ss[pb]), false, false);
+      ss[pb] += __uint_as_float(hi ? sw[0] : sw[1]);
+    }
+    if constexpr (WN > 1) {
+      static_assert(WN == 2, "pixel shared by two waves");
+      float* red = reinterpret_cast<float*>(smem);               // [WN][MT]
+      __syncthreads();                                             // every wave is done with the last K-tile's LDS
+      if (hi == 0) {
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) red[wn * MT + wm * 32 * PB + pb * 32 + l31] = ss[pb];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) ss[pb] += red[(wn ^ 1) * MT + wm * 32 * PB + pb * 32 + l31];
+    }
+    const float sqc = sqrtf((float)P.Cout);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int x = rx0 + wi + pb * 32 + l31;
+      const bool live = my_run < nruns && x < P.Win;
+      const int64_t row = ((int64_t)img * npix + (ry + 1) * Wp + min(x, P.Win - 1) + 1) * P.Cout;
+      const float r = sqc / fmaxf(sqrtf(ss[pb]), 1e-12f);
+#pragma unroll
+      for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u32x4_t o = kept[pb][nb][h], g = gm[nb][h];
+          float f[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f[2 * j] = bf16_lo(o[j]) * r * bf16_lo(g[j]);
+            f[2 * j + 1] = bf16_hi(o[j]) * r * bf16_hi(g[j]);
+          }
+          if (P.norm_silu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+          }
+          u32x4_t w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
+          const int nc = nch0 + nb * 32 + h * 16;
+          if (live && nc < P.Cout) *reinterpret_cast<u32x4_t*>(P.y_norm + row + nc) = w;
+        }
+    }
   }
 
   // the zero border of y, channels [n0, n0 + NT): every run writes the border pixels it touches — the pixel left of a row's
@@ -370,7 +501,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_bor
   auto zero_px = [&](int m_first, int count) {
     for (int i = tid; i < count * c8; i += 64 * NW) {
       const int px = i / c8, c = i - px * c8;
-      *reinterpret_cast<u32x4_t*>(P.y + ((int64_t)img * npix + m_first + px) * P.Cout + n0 + c * 8) = u32x4_t{0u, 0u, 0u, 0u};
+      const int64_t at = ((int64_t)img * npix + m_first + px) * P.Cout + n0 + c * 8;
+      if (!FUSE || P.y) *reinterpret_cast<u32x4_t*>(P.y + at) = u32x4_t{0u, 0u, 0u, 0u};
+      if constexpr (FUSE) *reinterpret_cast<u32x4_t*>(P.y_norm + at) = u32x4_t{0u, 0u, 0u, 0u};
     }
   };
   for (int r = 0; r < seg; ++r) {
@@ -486,9 +619,39 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(uint16_t* __restrict_
 
 }  // namespace
 
+namespace {
+// bordered rasters: tile geometry of the launch (run length: a multiple of the wave's pixel count `gran`, the row width when it
+// fits the tile, tile / L <= CONV_MAX_SEG)
+int conv_run_len(const omni_conv_params* p, int mt, int gran) {
+  int L = (p->Win + gran - 1) / gran * gran;
+  if (L > mt) L = mt;
+  while (mt % L || mt / L > CONV_MAX_SEG) L += gran;              // (mt / gran is a power of two: terminates at mt)
+  return L;
+}
+int64_t conv_tiles_of(const omni_conv_params* p, int mt, int gran) {
+  const int L = conv_run_len(p, mt, gran);
+  const int64_t runs = (int64_t)p->Hin * ((p->Win + L - 1) / L);
+  return (runs + mt / L - 1) / (mt / L);
+}
+// Cout >= 192: 128-pixel waves (8 waves = 512 px x 192 ch, one workgroup per CU) when they fill the chip at least once
+// (+10 % over the small tiles at 258^2 / 514^2); else four-wave workgroups of 256 px x 96 ch, two per CU (for Cout = 96 the
+// 8 x 1 arrangement of 128-pixel waves measured 443 vs 568 TF/s at 1026^2: the K loop is only nine K-tiles long there)
+bool conv_uses_big_tile(const omni_conv_params* p) {
+  return p->Cout >= 192 && conv_tiles_of(p, 512, 128) * ((p->Cout + 191) / 192) * p->B >= 256;
+}
+bool conv_fuses_norm(const omni_conv_params* p) {
+  if (!p->norm_gamma || !p->y_padded || !p->x_padded) return false;
+  return conv_uses_big_tile(p) ? p->Cout <= 192 : p->Cout <= 96;
+}
+}  // namespace
+
+extern "C" int omni_vae_conv2d_fuses_norm(const omni_conv_params* p) { return p && conv_fuses_norm(p) ? 1 : 0; }
+
 extern "C" int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream) {
-  if (!p || !p->x || !p->w || !p->y || p->B <= 0 || p->Hin <= 0 || p->Win <= 0 || p->Cin <= 0 || p->Cout <= 0)
-    return OMNI_ERR_BAD_ARG;
+  if (!p || !p->x || !p->w || p->B <= 0 || p->Hin <= 0 || p->Win <= 0 || p->Cin <= 0 || p->Cout <= 0) return OMNI_ERR_BAD_ARG;
+  if (p->norm_gamma && !p->y_norm) return OMNI_ERR_BAD_ARG;
+  const bool fuse = conv_fuses_norm(p);
+  if (!p->y && !fuse) return OMNI_ERR_BAD_ARG;
   if ((p->ksize != 1 && p->ksize != 3) || p->Cin % 8) return OMNI_ERR_UNSUPPORTED;
   if (p->gamma) return OMNI_ERR_UNSUPPORTED;  // fused norm prologue: not built yet (use omni_vae_rmsnorm_silu)
   if (p->downsample2x && (p->upsample2x || p->ksize != 3 || (p->Hin & 1) || (p->Win & 1))) return OMNI_ERR_UNSUPPORTED;
@@ -497,49 +660,43 @@ extern "C" int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream) {
   const int Wout = p->upsample2x ? 2 * p->Win : (p->downsample2x ? p->Win / 2 : p->Win);
   const int64_t M = (int64_t)p->B * Hout * Wout;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // norm_gamma on a shape the conv kernel cannot norm itself: the separate pass, from y (0 -> 0: a zero border stays zero)
+  auto norm_after = [&]() -> int {
+    if (!p->norm_gamma || fuse) return OMNI_OK;
+    const int64_t rows = (int64_t)p->B * (Hout + 2 * (p->y_padded ? 1 : 0)) * (Wout + 2 * (p->y_padded ? 1 : 0));
+    return omni_vae_rmsnorm_silu(p->y, p->y_norm, rows, p->Cout, p->norm_gamma, p->norm_silu, stream);
+  };
   if (p->y_padded) {
     // zero-bordered rasters in and out: the shifted-GEMM kernel
     if (!p->x_padded || p->upsample2x || p->downsample2x || p->Cin % 32 || p->Cout % 8) return OMNI_ERR_UNSUPPORTED;
-    if (!omni_aligned16(p->y) || (p->bias && (reinterpret_cast<uintptr_t>(p->bias) & 7)) || (p->res && !omni_aligned16(p->res)))
+    if (!omni_aligned16(p->y) || (p->bias && (reinterpret_cast<uintptr_t>(p->bias) & 7)) || (p->res && !omni_aligned16(p->res)) ||
+        (fuse && (!omni_aligned16(p->y_norm) || !omni_aligned16(p->norm_gamma))))
       return OMNI_ERR_ALIGN;
     const int64_t npix = (int64_t)(p->Hin + 2) * (p->Win + 2);
     if (npix * p->Cin * 2 >= (1ll << 32) - (1 << 24) || p->B > 65535) return OMNI_ERR_UNSUPPORTED;   // 32-bit DMA offsets per image
-    constexpr int lds_big2 = conv_lds_bytes<4, 2, 4>(), lds_small = conv_lds_bytes<4, 1, 2>();
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bordered_kernel<4, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              lds_big2) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bordered_kernel<4, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              lds_small) != hipSuccess)
-        return OMNI_ERR_LAUNCH;
-      attr_set = true;
-    }
-    // run length: a multiple of the wave's pixel count `gran`, the row width when it fits the tile, tile / L <= CONV_MAX_SEG
-    auto run_len = [&](int mt, int gran) {
-      int L = (p->Win + gran - 1) / gran * gran;
-      if (L > mt) L = mt;
-      while (mt % L || mt / L > CONV_MAX_SEG) L += gran;          // (mt / gran is a power of two: terminates at mt)
-      return L;
+    auto launch = [&]<int WM, int WN, int PB, int KC, int NS, bool FUSE>() -> int {
+      constexpr int lds = conv_lds_bytes<WM, WN, PB, KC, NS>(), MT = 32 * PB * WM, NT = 96 * WN;
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bordered_kernel<WM, WN, PB, KC, NS, FUSE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+          return OMNI_ERR_LAUNCH;
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((conv_bordered_kernel<WM, WN, PB, KC, NS, FUSE>),
+                         dim3((unsigned)conv_tiles_of(p, MT, 32 * PB), (p->Cout + NT - 1) / NT, p->B), dim3(64 * WM * WN), lds, s, *p,
+                         conv_run_len(p, MT, 32 * PB));
+      return OMNI_OK;
     };
-    auto tiles_of = [&](int mt, int gran) {
-      const int L = run_len(mt, gran);
-      const int64_t runs = (int64_t)p->Hin * ((p->Win + L - 1) / L);
-      return (runs + mt / L - 1) / (mt / L);
-    };
-    // Cout >= 192: 128-pixel waves (8 waves = 512 px x 192 ch, one workgroup per CU) when they fill the chip at least once
-    // (+10 % over the small tiles at 258^2 / 514^2); else four-wave workgroups of 256 px x 96 ch, two per CU (for Cout = 96 the
-    // 8 x 1 arrangement of 128-pixel waves measured 443 vs 568 TF/s at 1026^2: the K loop is only nine K-tiles long there)
-    if (p->Cout >= 192 && p->Cin % 16 == 0 && tiles_of(512, 128) * ((p->Cout + 191) / 192) * p->B >= 256) {
-      const int L = run_len(512, 128);
-      hipLaunchKernelGGL((conv_bordered_kernel<4, 2, 4>), dim3((unsigned)tiles_of(512, 128), (p->Cout + 191) / 192, p->B), dim3(512),
-                         lds_big2, s, *p, L);
-    } else {
-      const int L = run_len(256, 64);
-      hipLaunchKernelGGL((conv_bordered_kernel<4, 1, 2>), dim3((unsigned)tiles_of(256, 64), (p->Cout + 95) / 96, p->B), dim3(256),
-                         lds_small, s, *p, L);
-    }
+    int rc;
+    if (conv_uses_big_tile(p))
+      rc = fuse ? launch.template operator()<4, 2, 4, OMNI_CONV_BIG_KC, OMNI_CONV_BIG_NS, true>()
+                : launch.template operator()<4, 2, 4, OMNI_CONV_BIG_KC, OMNI_CONV_BIG_NS, false>();
+    else
+      rc = fuse ? launch.template operator()<4, 1, 2, 32, 2, true>() : launch.template operator()<4, 1, 2, 32, 2, false>();
+    if (rc != OMNI_OK) return rc;
     OMNI_CHECK_LAUNCH();
-    return OMNI_OK;
+    return norm_after();
   }
   if (p->x_padded && (p->upsample2x || p->downsample2x)) return OMNI_ERR_UNSUPPORTED;
   if (p->Cout % 96 == 0) {
@@ -549,7 +706,7 @@ extern "C" int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream) {
                        *p);
   }
   OMNI_CHECK_LAUNCH();
-  return OMNI_OK;
+  return norm_after();
 }
 
 extern "C" int omni_vae_rmsnorm_silu(const omni_bf16* x, omni_bf16* y, int64_t rows, int32_t C, const omni_bf16* gamma,

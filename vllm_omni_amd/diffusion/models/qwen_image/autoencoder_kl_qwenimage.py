@@ -281,14 +281,19 @@ class AutoencoderKLQwenImage(nn.Module):
     # reference re-creates it with F.pad in front of every conv, autoencoder_kl_qwenimage.py:80-84): a 3x3 conv is then a
     # GEMM over nine row-shifted views of the same matrix, fed by plain LDS-DMA (vae.hip conv_bordered_kernel).  The conv
     # kernel writes zeros at border positions, the norm maps 0 to 0, the upsample kernel writes its own border.
-    def _res_block_b(self, W, pre, x):
+    # The norm + SiLU in front of a conv is produced by the conv BEFORE it (ops.vae_conv2d norm_gamma: a second output of the
+    # same launch where a workgroup holds all channels of a pixel): `xn` is silu(norm1(x)) when the producer of x already made
+    # it, `next_gamma` the norm that will consume this block's output.
+    def _res_block_b(self, W, pre, x, xn=None, next_gamma=None, keep_raw=True):
         kw = dict(x_bordered=True, y_bordered=True)
         h = ops.vae_conv2d(x, W[pre + ".conv_shortcut.weight"], W[pre + ".conv_shortcut.bias"], **kw) \
             if (pre + ".conv_shortcut.weight") in W else x
-        y = ops.vae_rmsnorm_silu(x, W[pre + ".norm1.gamma"])
-        y = ops.vae_conv2d(y, W[pre + ".conv1.weight"], W[pre + ".conv1.bias"], **kw)
-        y = ops.vae_rmsnorm_silu(y, W[pre + ".norm2.gamma"])
-        return ops.vae_conv2d(y, W[pre + ".conv2.weight"], W[pre + ".conv2.bias"], res=h, **kw)
+        if xn is None:
+            xn = ops.vae_rmsnorm_silu(x, W[pre + ".norm1.gamma"])
+        _, y = ops.vae_conv2d(xn, W[pre + ".conv1.weight"], W[pre + ".conv1.bias"], norm_gamma=W[pre + ".norm2.gamma"],
+                              keep_raw=False, **kw)
+        out = ops.vae_conv2d(y, W[pre + ".conv2.weight"], W[pre + ".conv2.bias"], res=h, norm_gamma=next_gamma, keep_raw=keep_raw, **kw)
+        return out if next_gamma is not None else (out, None)
 
     @staticmethod
     def _add_border(x):
@@ -311,18 +316,29 @@ class AutoencoderKLQwenImage(nn.Module):
         x = ops.vae_conv2d(x, W["post_quant_conv.weight"], W["post_quant_conv.bias"])
         x = ops.vae_conv2d(x, W["decoder.conv_in.weight"], W["decoder.conv_in.bias"])      # Cin = z_dim: the gather kernel
         x = self._add_border(x)
-        x = self._res_block_b(W, "decoder.mid_block.resnets.0", x)
+        x, _ = self._res_block_b(W, "decoder.mid_block.resnets.0", x)
         x = self._add_border(self._attn_block(W, "decoder.mid_block.attentions.0", x[:, 1:-1, 1:-1].contiguous()))
-        x = self._res_block_b(W, "decoder.mid_block.resnets.1", x)
+        # the chain of residual blocks / upsamplers behind the attention: every conv that feeds a norm is told its gamma
+        chain = ["decoder.mid_block.resnets.1"]
         n_up = len(c.dim_mult)
         for i in range(n_up):
-            for j in range(c.num_res_blocks + 1):
-                x = self._res_block_b(W, f"decoder.up_blocks.{i}.resnets.{j}", x)
+            chain += [f"decoder.up_blocks.{i}.resnets.{j}" for j in range(c.num_res_blocks + 1)]
             if i != n_up - 1:
-                u = f"decoder.up_blocks.{i}.upsamplers.0.resample.1"
-                x = ops.vae_conv2d(ops.vae_upsample2x_bordered(x), W[u + ".weight"], W[u + ".bias"], x_bordered=True, y_bordered=True)
-        x = ops.vae_rmsnorm_silu(x, W["decoder.norm_out.gamma"])
-        x = ops.vae_conv2d(x, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], clamp=(-1.0, 1.0), x_bordered=True)
+                chain.append(f"decoder.up_blocks.{i}.upsamplers.0.resample.1")
+        xn = None
+        for k, name in enumerate(chain):
+            nxt = chain[k + 1] if k + 1 < len(chain) else None
+            if nxt is None:
+                g = W["decoder.norm_out.gamma"]
+            else:
+                g = W[nxt + ".norm1.gamma"] if "resnets" in nxt else None      # an upsampler takes x raw
+            if "resnets" in name:
+                x, xn = self._res_block_b(W, name, x, xn, next_gamma=g, keep_raw=nxt is not None)
+            else:
+                r = ops.vae_conv2d(ops.vae_upsample2x_bordered(x), W[name + ".weight"], W[name + ".bias"], x_bordered=True,
+                                   y_bordered=True, norm_gamma=g)
+                x, xn = r if g is not None else (r, None)
+        x = ops.vae_conv2d(xn, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], clamp=(-1.0, 1.0), x_bordered=True)
         img = x.permute(0, 3, 1, 2).unsqueeze(2)                       # [B, 3, 1, H, W]
         return (img,)
 

@@ -257,28 +257,38 @@ def cfg_euler_step_(latents, pos, neg, true_cfg_scale: float, dt: torch.Tensor, 
 
 
 def vae_conv2d(x, w, bias=None, *, gamma=None, silu=True, res=None, upsample2x=False, downsample2x=False, clamp=None,
-               out=None, x_bordered=False, y_bordered=False):
+               out=None, x_bordered=False, y_bordered=False, norm_gamma=None, norm_silu=True, keep_raw=True):
     """NHWC bf16 conv (3x3 pad 1 or 1x1): x [B,H,W,Cin], w [Cout,ks,ks,Cin].  downsample2x: the encoder's zero-pad
     (right/bottom) + stride-2 3x3 conv.  x_bordered: x (and res) are zero-bordered rasters [B,H+2,W+2,C]; y_bordered: so is
-    the output (the decoder's LDS-DMA-fed shifted-GEMM kernel; needs x_bordered, Cin % 32 == 0, Cout % 8 == 0)."""
+    the output (the decoder's LDS-DMA-fed shifted-GEMM kernel; needs x_bordered, Cin % 32 == 0, Cout % 8 == 0).
+
+    norm_gamma [Cout]: ALSO return silu?(rmsnorm(y) * norm_gamma) — the norm + activation that follows this conv in the decoder —
+    from the same launch where the kernel holds all channels of a pixel (omni_vae_conv2d_fuses_norm), from a second pass
+    otherwise.  Returns (y, y_norm); with keep_raw=False y is None when the kernel did not have to write it."""
     B, Hin, Win, Cin = x.shape
     if x_bordered:
         Hin, Win = Hin - 2, Win - 2
     Cout, ks = w.shape[0], w.shape[1]
     Hout, Wout = (2 * Hin, 2 * Win) if upsample2x else ((Hin // 2, Win // 2) if downsample2x else (Hin, Win))
-    if out is None:
-        y = torch.empty(B, Hout + 2 * int(y_bordered), Wout + 2 * int(y_bordered), Cout, dtype=BF16, device=x.device)
-    else:
-        y = out
+    shape = (B, Hout + 2 * int(y_bordered), Wout + 2 * int(y_bordered), Cout)
     p = N.ConvParams()
     p.x, p.w, p.bias, p.gamma = _p(x.contiguous(), name="x"), _p(w, name="w"), _p(bias, name="bias"), _p(gamma)
-    p.res, p.y = _p(res, name="res"), _p(y, name="y")
+    p.res = _p(res, name="res")
     p.B, p.Hin, p.Win, p.Cin, p.Cout, p.ksize = B, Hin, Win, Cin, Cout, ks
     p.upsample2x, p.silu, p.downsample2x = int(upsample2x), int(silu), int(downsample2x)
     p.x_padded, p.y_padded = int(x_bordered), int(y_bordered)
     p.clamp_lo, p.clamp_hi = clamp if clamp else (0.0, 0.0)
+    yn = None
+    if norm_gamma is not None:
+        yn = torch.empty(shape, dtype=BF16, device=x.device)
+        p.norm_gamma, p.y_norm, p.norm_silu = _p(norm_gamma, name="norm_gamma"), _p(yn), int(norm_silu)
+        keep_raw = keep_raw or out is not None or not N.lib().omni_vae_conv2d_fuses_norm(C.byref(p))
+    y = None
+    if norm_gamma is None or keep_raw:
+        y = torch.empty(shape, dtype=BF16, device=x.device) if out is None else out
+    p.y = _p(y, name="y")
     N.check(N.lib().omni_vae_conv2d(C.byref(p), _stream()), "omni_vae_conv2d")
-    return y
+    return y if norm_gamma is None else (y, yn)
 
 
 def vae_upsample2x_bordered(x):
