@@ -210,6 +210,12 @@ constexpr int CONV_MAX_SEG = 4;                                  // runs per til
 #ifndef OMNI_CONV_BIG_NS
 #define OMNI_CONV_BIG_NS 2
 #endif
+#ifndef OMNI_CONV_SMALL_KC
+#define OMNI_CONV_SMALL_KC 32
+#endif
+#ifndef OMNI_CONV_SMALL_OCC
+#define OMNI_CONV_SMALL_OCC 2                                    // workgroups per CU the 256 px x 96 ch tile is compiled for when its LDS allows 3
+#endif
 // PB = 32-pixel blocks per wave.  PB = 2: K-tile of 32 channels (64-B LDS rows); PB = 4: 16 channels (32-B rows) — the wave
 // tile 128 px x 96 ch reads 7 fragments per 12 MFMAs instead of 5 per 6 (the kernel is LDS-read bound: 8 waves x 5 KiB per
 // 192 MFMA cycles is 83 % of the LDS pipe) at the same 36 MFMAs per wave between barriers.
@@ -238,10 +244,11 @@ OMNI_DEVINL void conv_wait_vm(int n) {
 // = 3); the zero border of y is written by the workgroups whose runs touch it.
 // KC = channels per K-tile (16: 32-B LDS rows, 32: 64-B rows); NS = LDS stages (K-tiles kt + 1 .. kt + NS - 1 in flight while kt is
 // multiplied)
-// FUSE: also write P.y_norm = silu?(rmsnorm(y) * P.norm_gamma) — the launcher guarantees gridDim.y == 1 (all of a pixel's
+// FUSE: also write P.y_norm = silu?(rmsnorm(y) * P.norm_gamma) — the launcher guarantees ONE channel block (all of a pixel's
 // channels in this workgroup: the lane pair of a pixel, times the WN waves that share it)
 template <int WM, int WN, int PB, int KC, int NS, bool FUSE>
-__global__ __launch_bounds__(64 * WM * WN, (conv_lds_bytes<WM, WN, PB, KC, NS>() <= 80 * 1024 && WM * WN == 4 ? 2 : 1)) void conv_bordered_kernel(
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : conv_lds_bytes<WM, WN, PB, KC, NS>() <= 53 * 1024 ? OMNI_CONV_SMALL_OCC
+                                                              : conv_lds_bytes<WM, WN, PB, KC, NS>() <= 80 * 1024 ? 2 : 1)) void conv_bordered_kernel(
     const omni_conv_params P, int L) {
   constexpr int NW = WM * WN, MT = 32 * PB * WM, NT = 96 * WN;
   constexpr int RB = KC * 2, RPP = 1024 / RB;                    // LDS row bytes; rows per 1-KiB DMA piece
@@ -262,7 +269,16 @@ __global__ __launch_bounds__(64 * WM * WN, (conv_lds_bytes<WM, WN, PB, KC, NS>()
   const int seg = MT / L, rp = L / RPP + 1;                      // runs per tile; DMA pieces per run
   const int rpr = (P.Win + L - 1) / L, nruns = P.Hin * rpr;      // runs per image row; runs per image
   const int a_pieces = seg * rp;
-  const int run0 = blockIdx.x * seg, n0 = blockIdx.y * NT, img = blockIdx.z;
+  // blockIdx.x -> (pixel tile, channel block), XCD-aware: workgroup ids go round-robin over the 8 XCDs (each with its own
+  // L2), so XCD k takes the k-th contiguous BAND of the image's tiles — the three ky taps of vertically adjacent runs and the
+  // channel blocks of one tile (consecutive ids on one XCD) then meet in ONE L2 instead of being fetched by up to three
+  // (measured on 96 -> 96 at 1026^2: 3.3 reads of x from the fabric per element with the plain mapping)
+  const int ntiles = (nruns + seg - 1) / seg, nblk = (P.Cout + NT - 1) / NT;
+  const int chunk = (ntiles + 7) / 8;                              // tiles per XCD; gridDim.x = 8 * chunk * nblk
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int tile = xcd * chunk + idx / nblk;
+  if (tile >= ntiles) return;
+  const int run0 = tile * seg, n0 = (idx % nblk) * NT, img = blockIdx.z;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
   const u32x4_t x_srd = conv_srd(P.x + (int64_t)img * npix * P.Cin, (uint64_t)npix * P.Cin * 2);
@@ -354,12 +370,21 @@ __global__ __launch_bounds__(64 * WM * WN, (conv_lds_bytes<WM, WN, PB, KC, NS>()
   for (int s = 0; s < NS - 1; ++s)
     if (s < nkt) issue_next(s);
   for (int kt = 0; kt < nkt; ++kt) {
+#if defined(OMNI_DEV) && defined(OMNI_CONV_ABL)                  // timing-only ablations (results WRONG): 1 no DMA wait, 2 no DMA after the
+    if (!(OMNI_CONV_ABL & 1))                                     // prologue, 4 no MFMA, 8 no barrier
+#endif
     conv_wait_vm(min(NS - 2, nkt - 1 - kt) * my_pieces);          // this wave's pieces of K-tile kt have landed (later ones may fly)
+#if defined(OMNI_DEV) && defined(OMNI_CONV_ABL)
+    if (!(OMNI_CONV_ABL & 8))
+#endif
     __syncthreads();                                             // K-tile kt is in LDS; everyone is done with K-tile kt-1's slot
+#if defined(OMNI_DEV) && defined(OMNI_CONV_ABL)
+    if (!(OMNI_CONV_ABL & 2))
+#endif
     if (kt + NS - 1 < nkt) issue_next(kt + NS - 1);               // ... which K-tile kt + NS - 1 now fills
     const char* st = smem + (kt % NS) * STAGE;
     for (int kx = 0; kx < nk; ++kx) {
-      const int dx = nk == 3 ? kx : 1;                           // block row 0 is the pixel left of the run
+      const int dx = nk == 3 ? kx : 1;                             // block row 0 is the pixel left of the run
       const char* wst = st + kx * (W_PIECES * 1024);
 #pragma unroll
       for (int ks = 0; ks < KC / 16; ++ks) {
@@ -371,7 +396,12 @@ __global__ __launch_bounds__(64 * WM * WN, (conv_lds_bytes<WM, WN, PB, KC, NS>()
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-          for (int pb = 0; pb < PB; ++pb) acc[pb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], af[pb], acc[pb][nb], 0, 0, 0);
+          for (int pb = 0; pb < PB; ++pb) {
+#if defined(OMNI_DEV) && defined(OMNI_CONV_ABL)
+            if (OMNI_CONV_ABL & 4) { acc[pb][nb][0] += (float)(wf[nb][0] + af[pb][0]); continue; }
+#endif
+            acc[pb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], af[pb], acc[pb][nb], 0, 0, 0);
+          }
       }
     }
   }
@@ -393,6 +423,14 @@ __global__ __launch_bounds__(64 * WM * WN, (conv_lds_bytes<WM, WN, PB, KC, NS>()
     const bool live = my_run < nruns && x < P.Win;
     const int64_t row = ((int64_t)img * npix + (ry + 1) * Wp + min(x, P.Win - 1) + 1) * P.Cout;
     u32x4_t rs[3][2];
+#if defined(OMNI_DEV) && defined(OMNI_CONV_ABL)
+    if (OMNI_CONV_ABL & 16) {                                     // 16: no residual loads
+#pragma unroll
+      for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rs[nb][h] = u32x4_t{1u, 2u, 3u, 4u};
+    } else
+#endif
     if (P.res) {
 #pragma unroll
       for (int nb = 0; nb < 3; ++nb)
@@ -436,6 +474,9 @@ __global__ __launch_bounds__(64 * WM * WN, (conv_lds_bytes<WM, WN, PB, KC, NS>()
           for (int j = 0; j < 4; ++j) ss[pb] += bf16_lo(o[j]) * bf16_lo(o[j]) + bf16_hi(o[j]) * bf16_hi(o[j]);
           if (P.y && live && nc < P.Cout) *reinterpret_cast<u32x4_t*>(P.y + row + nc) = o;
         } else {
+#if defined(OMNI_DEV) && defined(OMNI_CONV_ABL)
+          if ((OMNI_CONV_ABL & 32) && o[0] != 0x12345678u) continue;   // 32: no output stores
+#endif
           if (live && nc < P.Cout) *reinterpret_cast<u32x4_t*>(P.y + row + nc) = o;
         }
       }
@@ -683,9 +724,9 @@ extern "C" int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream) {
           return OMNI_ERR_LAUNCH;
         attr_set = true;
       }
-      hipLaunchKernelGGL((conv_bordered_kernel<WM, WN, PB, KC, NS, FUSE>),
-                         dim3((unsigned)conv_tiles_of(p, MT, 32 * PB), (p->Cout + NT - 1) / NT, p->B), dim3(64 * WM * WN), lds, s, *p,
-                         conv_run_len(p, MT, 32 * PB));
+      const int64_t chunk = (conv_tiles_of(p, MT, 32 * PB) + 7) / 8;    // tiles per XCD (see the kernel's blockIdx mapping)
+      hipLaunchKernelGGL((conv_bordered_kernel<WM, WN, PB, KC, NS, FUSE>), dim3((unsigned)(8 * chunk * ((p->Cout + NT - 1) / NT)), 1, p->B),
+                         dim3(64 * WM * WN), lds, s, *p, conv_run_len(p, MT, 32 * PB));
       return OMNI_OK;
     };
     int rc;
@@ -693,7 +734,7 @@ extern "C" int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream) {
       rc = fuse ? launch.template operator()<4, 2, 4, OMNI_CONV_BIG_KC, OMNI_CONV_BIG_NS, true>()
                 : launch.template operator()<4, 2, 4, OMNI_CONV_BIG_KC, OMNI_CONV_BIG_NS, false>();
     else
-      rc = fuse ? launch.template operator()<4, 1, 2, 32, 2, true>() : launch.template operator()<4, 1, 2, 32, 2, false>();
+      rc = fuse ? launch.template operator()<4, 1, 2, OMNI_CONV_SMALL_KC, 2, true>() : launch.template operator()<4, 1, 2, OMNI_CONV_SMALL_KC, 2, false>();
     if (rc != OMNI_OK) return rc;
     OMNI_CHECK_LAUNCH();
     return norm_after();
