@@ -151,6 +151,11 @@ typedef struct {
 } omni_gemm_params;
 #define OMNI_GEMM_KERNEL_AUTO 0
 #define OMNI_GEMM_KERNEL_RING 1
+/* ABI v10 — automatic kernel choice, and the split-K rule above without its "<= 10 row tiles" clause: for a TALL launch with a
+ * long K and few tiles (the VAE mid-block attention's P.V: 8192 x 384 x 16384 = 64 tiles).  The clause exists so that a batch
+ * and its shards take the same decision; a caller that passes this vouches that nothing compares the result across batch
+ * compositions bit for bit. */
+#define OMNI_GEMM_KERNEL_SPLITK_TALL 2
 
 int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream);
 

@@ -94,14 +94,47 @@ def test_conv_with_the_following_norm_as_second_output(cin, cout, ks, hw, B, use
     assert bool(N.lib().omni_vae_conv2d_fuses_norm(ctypes.byref(p))) == fused
 
 
-def test_gather_conv_reads_bordered_input():
-    """conv_out of the decoder: bordered raster in, plain raster out (3 output channels: the gather kernel)."""
+@pytest.mark.parametrize("rows,cols,pad", [(64, 16384, 0), (7, 3000, 0), (5, 1936 + 48, 48), (4, 65536, 0), (3, 70000, 0)])
+def test_softmax_rows_matches_torch(rows, cols, pad):
+    """omni_softmax_rows (the VAE mid-block attention's softmax, autoencoder_kl_qwenimage.py:319 through GEMM -> this -> GEMM):
+    the register-resident kernels (<= 16384 and <= 65536 columns) and the three-pass one, with masked (-inf) pad keys."""
     from vllm_omni_amd import ops
 
-    x, w, b = _rnd((2, 19, 23, 96), 5), _rnd((3, 3, 3, 96), 6, 0.05), _rnd((3,), 7)
-    ref = ops.vae_conv2d(x.to(DEV), w.to(DEV), b.to(DEV), clamp=(-1.0, 1.0))
-    got = ops.vae_conv2d(_border(x).to(DEV), w.to(DEV), b.to(DEV), clamp=(-1.0, 1.0), x_bordered=True)
-    assert got.shape == ref.shape and torch.equal(got, ref)
+    s = _rnd((rows, cols), 11, 6.0)
+    if pad:
+        s[:, cols - pad:] = float("-inf")
+    scale = 0.051
+    ref = torch.softmax(s.float() * scale, dim=-1)
+    got = ops.softmax_rows_(s.to(DEV).clone(), scale).float().cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= 2.0 ** -8 * float(ref.max()) + 1e-6          # bf16 rounding of the probabilities
+    assert float((got.sum(-1) - 1).abs().max()) <= 2e-2
+    if pad:
+        assert float(got[:, cols - pad:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,hw,cin,cout,clamp", [
+    (2, (19, 23), 96, 3, (-1.0, 1.0)),      # the decoder's conv_out at a ragged size
+    (1, (40, 300), 96, 3, (-1.0, 1.0)),     # rows longer than a workgroup's 256 pixels
+    (1, (8, 70), 64, 16, None),             # all 16 MFMA columns live
+    (1, (5, 33), 128, 4, None),
+    (1, (6, 20), 160, 3, None),             # more input channels than conv_few_kernel holds weights for: the gather kernel
+])
+def test_conv_to_few_channels_reads_bordered_input(B, hw, cin, cout, clamp):
+    """conv_out of the decoder (autoencoder_kl_qwenimage.py:737-739): bordered raster in, plain raster out, <= 16 output
+    channels — vae.hip conv_few_kernel; against torch fp32 and against the gather kernel over the plain raster."""
+    from vllm_omni_amd import ops
+
+    H, W = hw
+    x, w, b = _rnd((B, H, W, cin), 5), _rnd((cout, 3, 3, cin), 6, 0.05), _rnd((cout,), 7)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float(), padding=1).permute(0, 2, 3, 1)
+    if clamp:
+        ref = ref.clamp(*clamp)
+    plain = ops.vae_conv2d(x.to(DEV), w.to(DEV), b.to(DEV), clamp=clamp).float().cpu()
+    got = ops.vae_conv2d(_border(x).to(DEV), w.to(DEV), b.to(DEV), clamp=clamp, x_bordered=True).float().cpu()
+    assert got.shape == ref.shape == plain.shape
+    assert float((got - ref).norm() / ref.norm()) <= 4e-3
+    assert float((got - plain).norm() / ref.norm()) <= 4e-3
 
 
 def test_bordered_upsample_is_nearest_exact():

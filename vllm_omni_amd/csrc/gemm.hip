@@ -2264,7 +2264,9 @@ int splitk_factor(const omni_gemm_params* p, int tiles_m, int tiles_n) {
   }
   if (!knob || !p->splitk_ws || p->splitk_ws_floats <= 0 || !OMNI_PP_MFMA16) return 1;
   const int tiles = tiles_m * tiles_n;
-  if (tiles > 128 || tiles_m > 10 || (p->N % 4) != 0 || (reinterpret_cast<uintptr_t>(p->splitk_ws) & 15)) return 1;
+  if (tiles > 128 || (tiles_m > 10 && p->kernel_hint != OMNI_GEMM_KERNEL_SPLITK_TALL) || (p->N % 4) != 0 ||
+      (reinterpret_cast<uintptr_t>(p->splitk_ws) & 15))
+    return 1;
   const int nkt = p->K / PBK;
   const int64_t mtot = p->g[0].M + (p->ngroups > 1 ? p->g[1].M : 0);
   const int cus = gemm_num_cus();

@@ -559,6 +559,83 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : conv_lds_bytes<WM
   }
 }
 
+// ---- 3x3 convolution from a zero-bordered raster to a FEW output channels (the decoder's conv_out: 96 -> 3 at full image
+// resolution, autoencoder_kl_qwenimage.py:737-739) -------------------------------------------------------------------------
+// 2 * 864 * 3 flop per output pixel against 192 B of input: HBM-bound (202 MB in at 1024^2).  The general kernels pad the
+// three channels to a 32-wide tile and gather A per K-tile through LDS (0.23 ms at 1024^2); here a wave owns 64 consecutive
+// pixels of an image row (four 16-pixel MFMA 16x16x32 row blocks, the <= 16 output channels are the MFMA's 16 columns) and
+// takes its A fragments straight from global memory — a lane's 8 consecutive channels of pixel (y + ky, x + kx) are 16
+// contiguous bytes of the bordered raster, no bounds logic — one tap ahead of the MFMAs; the weights (16 x 9 Cin bf16, zero
+// rows behind Cout) sit in LDS in fragment order.  Output: plain raster [B][H][W][Cout].
+constexpr int CF_MAX_CIN = 128;
+template <int NCC>                                                // Cin / 32
+__global__ __launch_bounds__(256) void conv_few_kernel(const omni_conv_params P) {
+  __shared__ __attribute__((aligned(16))) uint16_t wl[9 * NCC * 64 * 8];   // [tap][chunk][lane][8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  constexpr int ncc = NCC;
+  const int Wp = P.Win + 2;
+  const int segs = (P.Win + 255) / 256;
+  const int seg = blockIdx.x % segs, yrow = blockIdx.x / segs, img = blockIdx.y;
+  // weights -> LDS in B-fragment order: lane (n = l15, g) of step (tap, cc) holds w[n][tap][cc * 32 + 8 g .. + 8]
+  for (int i = tid; i < 9 * ncc * 64; i += 256) {
+    const int ln = i & 63, st = i >> 6, tap = st / ncc, cc = st - tap * ncc, n = ln & 15, gg = ln >> 4;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (n < P.Cout) v = *reinterpret_cast<const u32x4_t*>(P.w + ((int64_t)n * 9 + tap) * P.Cin + cc * 32 + gg * 8);
+    *reinterpret_cast<u32x4_t*>(wl + (int64_t)i * 8) = v;
+  }
+  __syncthreads();
+  const int x0 = seg * 256 + wave * 64;
+  if (x0 >= P.Win) return;
+  const float bv = (P.bias && l15 < P.Cout) ? bf16_bits_to_f32(P.bias[l15]) : 0.f;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4_t{bv, bv, bv, bv};
+  // lane's pixel of row block mb: x0 + 16 mb + l15 (clamped into the row: clamped pixels are computed, never stored)
+  const uint16_t* xb = P.x + ((int64_t)img * (P.Hin + 2) + yrow) * Wp * P.Cin + g * 8;
+  int px[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) px[mb] = min(x0 + mb * 16 + l15, P.Win - 1);
+  constexpr int MAXCC = NCC;
+  bf16x8_t a[2][MAXCC][4];
+  auto load_tap = [&](int tap, bf16x8_t (&dst)[MAXCC][4]) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+    for (int cc = 0; cc < MAXCC; ++cc)
+      if (cc < ncc) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+          dst[cc][mb] = *reinterpret_cast<const bf16x8_t*>(xb + ((int64_t)ky * Wp + px[mb] + kx) * P.Cin + cc * 32);
+      }
+  };
+  load_tap(0, a[0]);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    if (tap + 1 < 9) load_tap(tap + 1, a[(tap + 1) & 1]);
+#pragma unroll
+    for (int cc = 0; cc < MAXCC; ++cc)
+      if (cc < ncc) {
+        const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wl + ((int64_t)(tap * ncc + cc) * 64 + lane) * 8);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tap & 1][cc][mb], wf, acc[mb], 0, 0, 0);
+      }
+  }
+  // D[row = 4 g + j (pixel of the block)][col = l15 (channel)]
+  if (l15 < P.Cout) {
+    const bool do_clamp = P.clamp_lo < P.clamp_hi;
+    uint16_t* yb = P.y + (((int64_t)img * P.Hin + yrow) * P.Win) * P.Cout + l15;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = x0 + mb * 16 + g * 4 + j;
+        float v = acc[mb][j];
+        if (do_clamp) v = fminf(fmaxf(v, P.clamp_lo), P.clamp_hi);
+        if (x < P.Win) yb[(int64_t)x * P.Cout] = f32_to_bf16_bits(v);
+      }
+  }
+}
+
 // nearest-exact x2 upsample between zero-bordered rasters (QwenImageUpsample, autoencoder_kl_qwenimage.py:112-124):
 // y[oy + 1][ox + 1] = x[(oy >> 1) + 1][(ox >> 1) + 1], border zero.  16 B per lane, HBM-bound.
 __global__ __launch_bounds__(256) void upsample2x_bordered_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
@@ -619,6 +696,64 @@ __global__ __launch_bounds__(256) void vae_rmsnorm_kernel(const uint16_t* __rest
 }
 
 // in-place softmax over rows of `cols` bf16 scores: p = exp((s - max) * scale) / sum.  One workgroup per row.
+// softmax_rows_reg_kernel: the row stays in registers between the passes (cols <= 64 * THREADS: 8 chunks of 8 per thread, all
+// loads issued before the first use) — one read and one write of the scores (HBM-bound: the VAE's 16384 x 16384 mid-block
+// attention moves 1 GiB through here); softmax_rows_kernel (any length) re-reads the row for each of its three passes.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void softmax_rows_reg_kernel(uint16_t* __restrict__ s, int64_t ld, int cols, float scale) {
+  constexpr int NW = THREADS / 64, CH = 8;
+  __shared__ float red[2 * NW];
+  uint16_t* row = s + (int64_t)blockIdx.x * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nch = cols / 8;
+  u32x4_t w[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) w[i] = *reinterpret_cast<const u32x4_t*>(row + min(tid + i * THREADS, nch - 1) * 8);
+  __builtin_amdgcn_sched_barrier(0);
+  float e[CH][8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const bool in = tid + i * THREADS < nch;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      e[i][2 * j] = in ? bf16_lo(w[i][j]) : -INFINITY;
+      e[i][2 * j + 1] = in ? bf16_hi(w[i][j]) : -INFINITY;
+      mx = fmaxf(mx, fmaxf(e[i][2 * j], e[i][2 * j + 1]));
+    }
+  }
+  mx = wave_max<64>(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) mx = fmaxf(mx, red[k]);
+  const float c2 = scale * 1.4426950408889634f;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      e[i][j] = __builtin_amdgcn_exp2f((e[i][j] - mx) * c2);     // (-inf - mx) * c2 = -inf -> 0
+      sum += e[i][j];
+    }
+  sum = wave_sum<64>(sum);
+  if (lane == 0) red[NW + wave] = sum;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) tot += red[NW + k];
+  const float inv = 1.0f / tot;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    if (tid + i * THREADS >= nch) continue;
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(e[i][2 * j] * inv, e[i][2 * j + 1] * inv);
+    *reinterpret_cast<u32x4_t*>(row + (tid + i * THREADS) * 8) = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void softmax_rows_kernel(uint16_t* __restrict__ s, int64_t ld, int cols,
                                                            float scale) {
   __shared__ float red[8];
@@ -740,6 +875,18 @@ extern "C" int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream) {
     return norm_after();
   }
   if (p->x_padded && (p->upsample2x || p->downsample2x)) return OMNI_ERR_UNSUPPORTED;
+  if (p->x_padded && p->ksize == 3 && p->Cout <= 16 && p->Cin % 32 == 0 && p->Cin <= CF_MAX_CIN && !p->res && p->B <= 65535 &&
+      (int64_t)p->Hin * ((p->Win + 255) / 256) < (1ll << 31)) {
+    const dim3 grid((unsigned)(p->Hin * ((p->Win + 255) / 256)), p->B);
+    switch (p->Cin / 32) {
+      case 1: hipLaunchKernelGGL(conv_few_kernel<1>, grid, dim3(256), 0, s, *p); break;
+      case 2: hipLaunchKernelGGL(conv_few_kernel<2>, grid, dim3(256), 0, s, *p); break;
+      case 3: hipLaunchKernelGGL(conv_few_kernel<3>, grid, dim3(256), 0, s, *p); break;
+      default: hipLaunchKernelGGL(conv_few_kernel<4>, grid, dim3(256), 0, s, *p); break;
+    }
+    OMNI_CHECK_LAUNCH();
+    return norm_after();
+  }
   if (p->Cout % 96 == 0) {
     hipLaunchKernelGGL(conv2d_kernel<3>, dim3((unsigned)((M + CBM - 1) / CBM), p->Cout / 96), dim3(256), 0, s, *p);
   } else {
@@ -774,8 +921,10 @@ extern "C" int omni_softmax_rows(omni_bf16* s, int64_t ld, int64_t rows, int32_t
   if (!s || rows <= 0 || cols <= 0) return OMNI_ERR_BAD_ARG;
   if (cols % 8) return OMNI_ERR_UNSUPPORTED;
   if (!omni_aligned16(s) || (ld % 8)) return OMNI_ERR_ALIGN;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, static_cast<hipStream_t>(stream), s, ld,
-                     cols, scale);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (cols <= 64 * 256) hipLaunchKernelGGL(softmax_rows_reg_kernel<256>, dim3((unsigned)rows), dim3(256), 0, st, s, ld, cols, scale);
+  else if (cols <= 64 * 1024) hipLaunchKernelGGL(softmax_rows_reg_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, st, s, ld, cols, scale);
+  else hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, ld, cols, scale);
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }

@@ -232,13 +232,16 @@ class AutoencoderKLQwenImage(nn.Module):
             # query rows in chunks: the score buffer is [chunk, tok] bf16 (256 MiB at 1024^2, 1 GiB at 2048^2) instead
             # of [tok, tok] (512 MiB / 8.6 GB)
             o_b = torch.empty(tok, Cc, dtype=BF16, device=x.device)
+            # P V is tall with a long K and few output tiles (8192 x 384 x 16384: 64 workgroups): split-K workspace for it
+            ws = torch.empty(8 * min(tok, self.ATTN_Q_CHUNK) * Cc, dtype=torch.float32, device=x.device)
             for r0 in range(0, tok, self.ATTN_Q_CHUNK):
                 r1 = min(tok, r0 + self.ATTN_Q_CHUNK)
                 s = ops.linear(q[r0:r1], k)                             # [chunk, tokp] scores
                 if tokp != tok:
                     s[:, tok:] = float("-inf")                          # pad keys get probability 0
                 ops.softmax_rows_(s, 1.0 / math.sqrt(Cc))
-                ops.gemm([ops.GemmGroupArgs(s, vt, bqkv[2 * Cc:], o_b[r0:r1])])   # P V + b_v  (rows of P sum to 1)
+                ops.gemm([ops.GemmGroupArgs(s, vt, bqkv[2 * Cc:], o_b[r0:r1])], splitk_ws=ws,
+                         kernel_hint=ops.GEMM_KERNEL_SPLITK_TALL)        # P V + b_v  (rows of P sum to 1)
             outs.append(o_b)
         o = torch.stack(outs).view(B, H, Wd, Cc)
         return ops.vae_conv2d(o, W[pre + ".proj.weight"], W[pre + ".proj.bias"], res=x)

@@ -56,7 +56,7 @@ class GemmGroupArgs:
         self.row_item_map, self.rows_per_item = row_item_map, rows_per_item
 
 
-GEMM_KERNEL_AUTO, GEMM_KERNEL_RING = 0, 1      # omni_gemm_params.kernel_hint
+GEMM_KERNEL_AUTO, GEMM_KERNEL_RING, GEMM_KERNEL_SPLITK_TALL = 0, 1, 2      # omni_gemm_params.kernel_hint
 
 
 def w_to_k32_blocked(w: torch.Tensor) -> torch.Tensor:
@@ -72,7 +72,8 @@ def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0
          w_k32_blocked: bool = False, splitk_ws: torch.Tensor | None = None, kernel_hint: int = 0, fp8: bool = False):
     """Y_g = epilogue(A_g @ W_g.T + bias_g) for up to two groups sharing N, K (omni_gemm_bf16).  `splitk_ws`: optional fp32
     device workspace; with it, launches of at most 128 tiles in at most 10 row tiles split their K loop (ABI v4).
-    `kernel_hint`: 0 = automatic, GEMM_KERNEL_RING = force the fallback (ring) kernel (ABI v6; cross-checks).
+    `kernel_hint`: 0 = automatic, GEMM_KERNEL_RING = force the fallback (ring) kernel (ABI v6; cross-checks),
+    GEMM_KERNEL_SPLITK_TALL = automatic + split-K also for tall launches (ABI v10).
     `fp8`: A and W are uint8 tensors of OCP e4m3 values in the K64-blocked order (`quantize_fp8_rows`), with fp32
     `a_scale` / `w_scale` per group (ABI v7): Y = epilogue((A8 @ W8.T) * a_scale[:, None] * w_scale[None, :] + bias)."""
     p = N.GemmParams()
