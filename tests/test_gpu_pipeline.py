@@ -103,6 +103,23 @@ def test_vae_decode_matches_oracle():
     assert r <= 3e-2 and (img.float().cpu() - ref).abs().mean() <= 2e-2     # the reference's own pixel bar: mean <= 2e-2
 
 
+@pytest.mark.parametrize("hw", [(16, 16), (40, 24)])
+def test_vae_decode_of_a_batch_equals_the_images_decoded_one_by_one(hw):
+    """The pipeline decodes all finished images of one size in ONE VAE call (pipeline_qwen_image.py generate): every kernel of the
+    decoder treats the images independently (conv tiles carry the image in blockIdx.z, attention runs per image), so the batch
+    must reproduce the single-image results bit for bit."""
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import AutoencoderKLQwenImage
+
+    vae = AutoencoderKLQwenImage(device=DEV)
+    vae.init_random_(seed=7)
+    z = (torch.randn(3, 16, 1, *hw, generator=torch.Generator().manual_seed(10)) * 1.5).to(DEV, BF16)
+    batch = vae.decode(z)[0]
+    single = torch.cat([vae.decode(z[i:i + 1])[0] for i in range(3)])
+    torch.cuda.synchronize()
+    assert batch.shape == (3, 3, 1, 8 * hw[0], 8 * hw[1]) and torch.isfinite(batch.float()).all()
+    assert torch.equal(batch, single)
+
+
 def test_pipeline_decode_end_to_end_shapes():
     from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
 

@@ -463,19 +463,33 @@ class QwenImagePipeline(nn.Module):
                                      cfg_normalize=cfg_norm, t_cond=t_cond)
                 for j, o in zip(idxs[s0:s0 + cap], outs):
                     final[j] = o
-        results = []
-        for i, r in enumerate(requests):
-            mine = [j for j, sm in enumerate(samples) if sm["req"] == i]
-            lat = torch.stack([final[j] for j in mine])                           # [n_samples, S, 64]
-            if output_type == "latent" or r.output_type == "latent":
-                results.append(DiffusionOutput(output=lat))
-            else:
-                results.append(DiffusionOutput(output=self._decode_samples(lat, samples[mine[0]])))
-        return results
+        # decode: the images of ALL requests of one size in one VAE call (the decoder's small rasters — 128^2 and 256^2 at 1024^2
+        # — fill a quarter of the chip per image; per image a batch of five decodes 15 % faster than five calls)
+        mine = [[j for j, sm in enumerate(samples) if sm["req"] == i] for i in range(len(requests))]
+        want = [not (output_type == "latent" or r.output_type == "latent") for r in requests]
+        lats = [torch.stack([final[j] for j in m]) for m in mine]                 # per request [n_samples, S, 64]
+        images: list[torch.Tensor | None] = [None] * len(requests)
+        by_size: dict[tuple, list[int]] = {}
+        for i, m in enumerate(mine):
+            if want[i]:
+                by_size.setdefault((samples[m[0]]["height"], samples[m[0]]["width"], lats[i].shape[1]), []).append(i)
+        for _size, reqs in by_size.items():
+            for c0 in range(0, len(reqs), self.DECODE_BATCH):
+                part = reqs[c0:c0 + self.DECODE_BATCH]
+                dec = self._decode_samples(torch.cat([lats[i] for i in part]), samples[mine[part[0]][0]])
+                per = dec.shape[0] // sum(lats[i].shape[0] for i in part)            # images per latent (Layered: one per layer)
+                o = 0
+                for i in part:
+                    n = lats[i].shape[0] * per
+                    images[i] = dec[o:o + n]
+                    o += n
+        return [DiffusionOutput(output=images[i] if want[i] else lats[i]) for i in range(len(requests))]
+
+    DECODE_BATCH = 8                                                 # latents per VAE call (activations: 1 GB per latent at 1024^2)
 
     def _decode_samples(self, lat: torch.Tensor, sample: dict) -> torch.Tensor:
-        """Finished packed latents [n, S, 64] of one request -> images (the Layered pipeline decodes one image per layer)."""
-        return torch.cat([self.decode_latents(lat[k:k + 1], sample["height"], sample["width"]) for k in range(lat.shape[0])])
+        """Finished packed latents [n, S, 64] of one size -> images (the Layered pipeline decodes one image per layer)."""
+        return self.decode_latents(lat, sample["height"], sample["width"])
 
     # ------------------------------------------------------------------ continuous step batching (step_batcher.py)
     def begin_sample(self, a) -> None:

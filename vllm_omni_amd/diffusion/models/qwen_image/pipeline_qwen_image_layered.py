@@ -232,7 +232,7 @@ class QwenImageLayeredPipeline(QwenImageEditPipeline):
     @torch.no_grad()
     def _decode_samples(self, lat: torch.Tensor, sample: dict) -> torch.Tensor:
         """[n, (layers + 1) * S, 64] -> [n * layers, C, H, W]: frame 0 (the recomposed input) is dropped, every layer frame is
-        decoded on its own (:858-871)."""
+        decoded as an image of its own (:858-871), DECODE_BATCH of them per VAE call."""
         L = sample["layers"]
         z = self._unpack_latents(lat, sample["height"], sample["width"], L, self.vae_scale_factor).to(self.vae.dtype)
         mean = self._latents_mean.to(z.device, z.dtype)
@@ -240,7 +240,8 @@ class QwenImageLayeredPipeline(QwenImageEditPipeline):
         z = z / inv_std + mean
         b, c, f, h, w = z.shape
         z = z[:, :, 1:].permute(0, 2, 1, 3, 4).reshape(-1, c, 1, h, w)
-        return torch.cat([self.vae.decode(z[i:i + 1], return_dict=False)[0][:, :, 0] for i in range(z.shape[0])])
+        return torch.cat([self.vae.decode(z[i:i + self.DECODE_BATCH], return_dict=False)[0][:, :, 0]
+                          for i in range(0, z.shape[0], self.DECODE_BATCH)])
 
 
 IMAGE_CAPTION_PROMPT_EN = (  # reference :247-259
