@@ -298,8 +298,11 @@ typedef struct {
   int32_t x_padded;       /* ABI v8.  1: x (and res) are ZERO-BORDERED rasters [B, Hin + 2, Win + 2, C]: the conv's zero padding
                            * (F.pad in QwenImageCausalConv3d.forward, :80-84) is resident in memory instead of re-created per tap */
   int32_t y_padded;       /* ABI v8.  1: y is written as a zero-bordered raster too (needs x_padded, Cin % 32 == 0,
-                           * Cout % 8 == 0, no up/downsample): the decoder's 3x3 / 1x1 convs run as a GEMM over nine row-shifted
-                           * views of x, LDS-DMA fed (vae.hip conv_bordered_kernel) */
+                           * Cout % 8 == 0, no downsample): the decoder's 3x3 / 1x1 convs run as a GEMM over nine row-shifted
+                           * views of x, LDS-DMA fed (vae.hip conv_bordered_kernel).  ABI v10: with upsample2x (3x3, no res) x is
+                           * the half-resolution bordered raster [B, Hin + 2, Win + 2, Cin] and y [B, 2 Hin + 2, 2 Win + 2, Cout]:
+                           * the operand fetch reads source pixel ((Y - 1) / 2 + 1, (X - 1) / 2 + 1) for pixel (Y, X) of the
+                           * upsampled raster — the same result as omni_vae_upsample2x_bordered followed by the conv, bit for bit */
   /* ABI v10: the norm + activation that FOLLOWS this conv in the decoder (QwenImageResidualBlock.forward norm1 / norm2 + SiLU,
    * autoencoder_kl_qwenimage.py:262-275; norm_out :735-737) as a second output of the same launch:
    *   y_norm = silu?(F.normalize(y, dim=C) * sqrt(C) * norm_gamma)      computed from y as rounded to bf16

@@ -137,6 +137,32 @@ def test_conv_to_few_channels_reads_bordered_input(B, hw, cin, cout, clamp):
     assert float((got - plain).norm() / ref.norm()) <= 4e-3
 
 
+@pytest.mark.parametrize("cin,cout,hw,B,with_norm", [
+    (384, 192, (16, 16), 2, False),      # 96-channel tiles
+    (96, 96, (37, 21), 1, True),         # odd source sizes, fused norm (lane pair)
+    (192, 96, (130, 260), 1, True),      # runs shorter than the row
+    (384, 192, (200, 192), 1, True),     # 192-channel tiles (two waves share a pixel), fused norm
+    (192, 384, (64, 300), 2, False),     # two channel blocks per tile
+])
+def test_conv_over_the_upsampled_raster_without_the_upsampled_tensor(cin, cout, hw, B, with_norm):
+    """upsample2x on bordered rasters: the conv's operand fetch maps every pixel of the x2 raster to its source pixel, so the
+    result must equal the conv over the explicitly upsampled raster (omni_vae_upsample2x_bordered) bit for bit — same operands,
+    same order of accumulation."""
+    from vllm_omni_amd import ops
+
+    H, W = hw
+    x, w, b = _border(_rnd((B, H, W, cin), 21)).to(DEV), _rnd((cout, 3, 3, cin), 22, 0.05).to(DEV), _rnd((cout,), 23).to(DEV)
+    g = (1.0 + 0.2 * _rnd((cout,), 24).float()).to(torch.bfloat16).to(DEV) if with_norm else None
+    kw = dict(x_bordered=True, y_bordered=True, norm_gamma=g)
+    want = ops.vae_conv2d(ops.vae_upsample2x_bordered(x), w, b, **kw)
+    got = ops.vae_conv2d(x, w, b, upsample2x=True, **kw)
+    if with_norm:
+        assert got[0].shape == (B, 2 * H + 2, 2 * W + 2, cout)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    else:
+        assert got.shape == (B, 2 * H + 2, 2 * W + 2, cout) and torch.equal(got, want)
+
+
 def test_bordered_upsample_is_nearest_exact():
     from vllm_omni_amd import ops
 

@@ -246,7 +246,11 @@ OMNI_DEVINL void conv_wait_vm(int n) {
 // multiplied)
 // FUSE: also write P.y_norm = silu?(rmsnorm(y) * P.norm_gamma) — the launcher guarantees ONE channel block (all of a pixel's
 // channels in this workgroup: the lane pair of a pixel, times the WN waves that share it)
-template <int WM, int WN, int PB, int KC, int NS, bool FUSE>
+// UP: x is the HALF-resolution bordered raster [B][Hin / 2 + 2][Win / 2 + 2][Cin] and the conv runs over its nearest-exact x2
+// upsample (QwenImageUpsample + the resample conv, autoencoder_kl_qwenimage.py:112-124 / :150-160) without that tensor ever
+// existing: P.Hin / P.Win are the OUTPUT's interior size, and the lane that fetches bordered column X of bordered row Y of the
+// upsampled raster reads source pixel (((Y - 1) >> 1) + 1, ((X - 1) >> 1) + 1) — border maps to border.
+template <int WM, int WN, int PB, int KC, int NS, bool FUSE, bool UP>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : conv_lds_bytes<WM, WN, PB, KC, NS>() <= 53 * 1024 ? OMNI_CONV_SMALL_OCC
                                                               : conv_lds_bytes<WM, WN, PB, KC, NS>() <= 80 * 1024 ? 2 : 1)) void conv_bordered_kernel(
     const omni_conv_params P, int L) {
@@ -281,7 +285,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : conv_lds_bytes<WM
   const int run0 = tile * seg, n0 = (idx % nblk) * NT, img = blockIdx.z;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
-  const u32x4_t x_srd = conv_srd(P.x + (int64_t)img * npix * P.Cin, (uint64_t)npix * P.Cin * 2);
+  const int Wps = UP ? P.Win / 2 + 2 : Wp;                          // the INPUT raster's row length and pixel count
+  const int npix_in = UP ? (P.Hin / 2 + 2) * Wps : npix;
+  const u32x4_t x_srd = conv_srd(P.x + (int64_t)img * npix_in * P.Cin, (uint64_t)npix_in * P.Cin * 2);
   const u32x4_t w_srd = conv_srd(P.w, (uint64_t)P.Cout * Ktot * 2);
   // LDS rows hold RB / 16 chunks of 16 B; chunk index XOR swizzle: 64-B rows (r >> 2) & 3, 32-B rows (r >> 3) & 1 — in both
   // cases 16 consecutive rows (at ANY start: the kx taps read at row offsets 0 / 1 / 2) hit 16 different 16-B bank groups.
@@ -309,10 +315,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : conv_lds_bytes<WM
   const int w_pieces = nk * W_PIECES;
   const int cntA = (a_pieces - wave + NW - 1) / NW, cntW = (w_pieces - wave + NW - 1) / NW;
   uint32_t preA[MAXA], preW[MAXW];
+  uint32_t upx[UP ? MAXA : 1];                                    // UP: per-lane byte offset of the lane's source COLUMN (+ chunk)
+  int upy[UP ? MAXA : 1];                                         // UP: bordered output row of the piece's run (centre tap)
 #pragma unroll
   for (int i = 0; i < MAXA; ++i) {
     const int g = min(wave + i * NW, a_pieces - 1), r = g / rp, j = g - r * rp;
-    preA[i] = __builtin_amdgcn_readfirstlane((uint32_t)(run_origin(r) + RPP * j) * (uint32_t)(P.Cin * 2));
+    if constexpr (UP) {
+      const int run = min(run0 + r, nruns - 1), y = run / rpr, X = (run - y * rpr) * L + RPP * j + lrow;
+      upx[i] = (uint32_t)((((X - 1) >> 1) + 1) * P.Cin * 2) + lc16;
+      upy[i] = __builtin_amdgcn_readfirstlane(y + 1);
+      preA[i] = 0u;
+    } else {
+      preA[i] = __builtin_amdgcn_readfirstlane((uint32_t)(run_origin(r) + RPP * j) * (uint32_t)(P.Cin * 2));
+    }
   }
 #pragma unroll
   for (int i = 0; i < MAXW; ++i) {
@@ -325,7 +340,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : conv_lds_bytes<WM
     const uint32_t sA = lds0 + slot * STAGE + wave * 1024, sW = sA + A_MAX * 1024;
 #pragma unroll
     for (int i = 0; i < MAXA; ++i)
-      if (i < cntA) conv_dma16(x_srd, a_lane + (preA[i] + dA), sA + i * (NW * 1024));
+      if (i < cntA) {
+        if constexpr (UP) {
+          const int sy = ((upy[i] + (nk == 3 ? ky - 1 : 0) - 1) >> 1) + 1;
+          conv_dma16(x_srd, upx[i] + ((uint32_t)(sy * Wps) * (uint32_t)(P.Cin * 2) + (uint32_t)(cc * RB)), sA + i * (NW * 1024));
+        } else {
+          conv_dma16(x_srd, a_lane + (preA[i] + dA), sA + i * (NW * 1024));
+        }
+      }
 #pragma unroll
     for (int i = 0; i < MAXW; ++i)
       if (i < cntW) conv_dma16(w_srd, w_lane + (preW[i] + dW), sW + i * (NW * 1024));
@@ -821,12 +843,29 @@ bool conv_fuses_norm(const omni_conv_params* p) {
 }
 }  // namespace
 
-extern "C" int omni_vae_conv2d_fuses_norm(const omni_conv_params* p) { return p && conv_fuses_norm(p) ? 1 : 0; }
+namespace {
+// bordered rasters with upsample2x: the kernel (and the tile geometry) see the OUTPUT's interior size in Hin / Win
+omni_conv_params conv_output_sized(const omni_conv_params* p) {
+  omni_conv_params q = *p;
+  if (p->upsample2x && p->x_padded && p->y_padded) {
+    q.Hin = 2 * p->Hin;
+    q.Win = 2 * p->Win;
+  }
+  return q;
+}
+}  // namespace
+
+extern "C" int omni_vae_conv2d_fuses_norm(const omni_conv_params* p) {
+  if (!p) return 0;
+  const omni_conv_params q = conv_output_sized(p);
+  return conv_fuses_norm(&q) ? 1 : 0;
+}
 
 extern "C" int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream) {
   if (!p || !p->x || !p->w || p->B <= 0 || p->Hin <= 0 || p->Win <= 0 || p->Cin <= 0 || p->Cout <= 0) return OMNI_ERR_BAD_ARG;
   if (p->norm_gamma && !p->y_norm) return OMNI_ERR_BAD_ARG;
-  const bool fuse = conv_fuses_norm(p);
+  const omni_conv_params q = conv_output_sized(p);
+  const bool fuse = conv_fuses_norm(&q);
   if (!p->y && !fuse) return OMNI_ERR_BAD_ARG;
   if ((p->ksize != 1 && p->ksize != 3) || p->Cin % 8) return OMNI_ERR_UNSUPPORTED;
   if (p->gamma) return OMNI_ERR_UNSUPPORTED;  // fused norm prologue: not built yet (use omni_vae_rmsnorm_silu)
@@ -843,33 +882,34 @@ extern "C" int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream) {
     return omni_vae_rmsnorm_silu(p->y, p->y_norm, rows, p->Cout, p->norm_gamma, p->norm_silu, stream);
   };
   if (p->y_padded) {
-    // zero-bordered rasters in and out: the shifted-GEMM kernel
-    if (!p->x_padded || p->upsample2x || p->downsample2x || p->Cin % 32 || p->Cout % 8) return OMNI_ERR_UNSUPPORTED;
+    // zero-bordered rasters in and out: the shifted-GEMM kernel (upsample2x: over the x2 upsample of x, 3x3 only, no residual)
+    if (!p->x_padded || p->downsample2x || p->Cin % 32 || p->Cout % 8) return OMNI_ERR_UNSUPPORTED;
+    if (p->upsample2x && (p->ksize != 3 || p->res)) return OMNI_ERR_UNSUPPORTED;
     if (!omni_aligned16(p->y) || (p->bias && (reinterpret_cast<uintptr_t>(p->bias) & 7)) || (p->res && !omni_aligned16(p->res)) ||
         (fuse && (!omni_aligned16(p->y_norm) || !omni_aligned16(p->norm_gamma))))
       return OMNI_ERR_ALIGN;
-    const int64_t npix = (int64_t)(p->Hin + 2) * (p->Win + 2);
+    const int64_t npix = (int64_t)(p->Hin + 2) * (p->Win + 2);       // the INPUT raster
     if (npix * p->Cin * 2 >= (1ll << 32) - (1 << 24) || p->B > 65535) return OMNI_ERR_UNSUPPORTED;   // 32-bit DMA offsets per image
-    auto launch = [&]<int WM, int WN, int PB, int KC, int NS, bool FUSE>() -> int {
+    auto launch = [&]<int WM, int WN, int PB, int KC, int NS, bool FUSE, bool UP>() -> int {
       constexpr int lds = conv_lds_bytes<WM, WN, PB, KC, NS>(), MT = 32 * PB * WM, NT = 96 * WN;
       static bool attr_set = false;
       if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bordered_kernel<WM, WN, PB, KC, NS, FUSE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bordered_kernel<WM, WN, PB, KC, NS, FUSE, UP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
           return OMNI_ERR_LAUNCH;
         attr_set = true;
       }
-      const int64_t chunk = (conv_tiles_of(p, MT, 32 * PB) + 7) / 8;    // tiles per XCD (see the kernel's blockIdx mapping)
-      hipLaunchKernelGGL((conv_bordered_kernel<WM, WN, PB, KC, NS, FUSE>), dim3((unsigned)(8 * chunk * ((p->Cout + NT - 1) / NT)), 1, p->B),
-                         dim3(64 * WM * WN), lds, s, *p, conv_run_len(p, MT, 32 * PB));
+      const int64_t chunk = (conv_tiles_of(&q, MT, 32 * PB) + 7) / 8;   // tiles per XCD (see the kernel's blockIdx mapping)
+      hipLaunchKernelGGL((conv_bordered_kernel<WM, WN, PB, KC, NS, FUSE, UP>), dim3((unsigned)(8 * chunk * ((q.Cout + NT - 1) / NT)), 1, q.B),
+                         dim3(64 * WM * WN), lds, s, q, conv_run_len(&q, MT, 32 * PB));
       return OMNI_OK;
     };
-    int rc;
-    if (conv_uses_big_tile(p))
-      rc = fuse ? launch.template operator()<4, 2, 4, OMNI_CONV_BIG_KC, OMNI_CONV_BIG_NS, true>()
-                : launch.template operator()<4, 2, 4, OMNI_CONV_BIG_KC, OMNI_CONV_BIG_NS, false>();
-    else
-      rc = fuse ? launch.template operator()<4, 1, 2, OMNI_CONV_SMALL_KC, 2, true>() : launch.template operator()<4, 1, 2, OMNI_CONV_SMALL_KC, 2, false>();
+    auto pick = [&]<bool FUSE, bool UP>() -> int {
+      return conv_uses_big_tile(&q) ? launch.template operator()<4, 2, 4, OMNI_CONV_BIG_KC, OMNI_CONV_BIG_NS, FUSE, UP>()
+                                    : launch.template operator()<4, 1, 2, OMNI_CONV_SMALL_KC, 2, FUSE, UP>();
+    };
+    const int rc = p->upsample2x ? (fuse ? pick.template operator()<true, true>() : pick.template operator()<false, true>())
+                                 : (fuse ? pick.template operator()<true, false>() : pick.template operator()<false, false>());
     if (rc != OMNI_OK) return rc;
     OMNI_CHECK_LAUNCH();
     return norm_after();

@@ -338,8 +338,8 @@ class AutoencoderKLQwenImage(nn.Module):
             if "resnets" in name:
                 x, xn = self._res_block_b(W, name, x, xn, next_gamma=g, keep_raw=nxt is not None)
             else:
-                r = ops.vae_conv2d(ops.vae_upsample2x_bordered(x), W[name + ".weight"], W[name + ".bias"], x_bordered=True,
-                                   y_bordered=True, norm_gamma=g)
+                r = ops.vae_conv2d(x, W[name + ".weight"], W[name + ".bias"], upsample2x=True, x_bordered=True,
+                                   y_bordered=True, norm_gamma=g)      # the x2 upsample happens in the conv's operand fetch
                 x, xn = r if g is not None else (r, None)
         x = ops.vae_conv2d(xn, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], clamp=(-1.0, 1.0), x_bordered=True)
         img = x.permute(0, 3, 1, 2).unsqueeze(2)                       # [B, 3, 1, H, W]
