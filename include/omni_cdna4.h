@@ -327,6 +327,15 @@ int omni_vae_upsample2x_bordered(const omni_bf16* x, omni_bf16* y, int32_t B, in
 int omni_vae_rmsnorm_silu(const omni_bf16* x, omni_bf16* y, int64_t rows, int32_t C, const omni_bf16* gamma,
                           int32_t silu, omni_stream stream);
 
+/* ABI v10 — the single-head attention of the VAE mid block (QwenImageAttentionBlock.forward,
+ * autoencoder_kl_qwenimage.py:305-330: F.scaled_dot_product_attention over all tokens of an image, ONE head of C = 384 channels)
+ * as one flash kernel: q, k, v [B][tokens][C] bf16 with row strides ldq / ldk / ldv (elements; images tokens * ld apart, so the
+ * three may be column slices of one fused [B * tokens, 3 C] projection), out [B][tokens][C] with row stride ldo;
+ * out = softmax(scale * q k^T) v per image.  C must be 384 (OMNI_ERR_UNSUPPORTED otherwise: callers fall back to
+ * GEMM -> omni_softmax_rows -> GEMM); any token count (ragged tails are masked); tokens * ld * 2 < 4 GiB. */
+int omni_vae_attention(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int32_t B, int32_t tokens,
+                       int32_t C, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, omni_stream stream);
+
 /* In-place row softmax p = softmax(scale * s) over rows of `cols` bf16 scores (row stride ld).  Used for the
  * single-head mid-block attention of the VAE (F.scaled_dot_product_attention at
  * autoencoder_kl_qwenimage.py:319), which runs as GEMM(QK^T) -> this -> GEMM(PV).  cols % 8 == 0. */

@@ -94,6 +94,43 @@ def test_conv_with_the_following_norm_as_second_output(cin, cout, ks, hw, B, use
     assert bool(N.lib().omni_vae_conv2d_fuses_norm(ctypes.byref(p))) == fused
 
 
+@pytest.mark.parametrize("B,tok", [(2, 1024), (1, 1936), (3, 200), (1, 16384)])
+def test_vae_attention_matches_torch(B, tok):
+    """omni_vae_attention (one head of 384 channels, QwenImageAttentionBlock.forward :305-330) against fp32 attention computed by
+    torch on the GPU from the same bf16 inputs; q, k, v are column slices of one fused projection (row stride 3 C), token counts
+    include ragged tails (1936 = 44 x 44, 200)."""
+    import math
+
+    from vllm_omni_amd import ops
+
+    Cc = 384
+    qkv = _rnd((B, tok, 3 * Cc), 31, 1.0).to(DEV)
+    qkv[..., :Cc] *= 2.0                                               # sharper rows than unit-variance scores
+    q, k, v = qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:]
+    got = ops.vae_attention(q, k, v, 1.0 / math.sqrt(Cc)).float()
+    ref = torch.empty_like(got)
+    for b in range(B):
+        for r0 in range(0, tok, 4096):
+            s = (q[b, r0:r0 + 4096].float() @ k[b].float().T) / math.sqrt(Cc)
+            ref[b, r0:r0 + 4096] = torch.softmax(s, dim=-1) @ v[b].float()
+    torch.cuda.synchronize()
+    err = float((got - ref).norm() / ref.norm())
+    assert torch.isfinite(got).all() and err <= 8e-3, err              # bf16 P and bf16 output rounding
+
+
+def test_vae_mid_attention_flash_equals_the_gemm_softmax_gemm_path():
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import AutoencoderKLQwenImage
+
+    vae = AutoencoderKLQwenImage(device=DEV)
+    vae.init_random_(seed=3)
+    W = vae._pack()
+    x = _rnd((2, 24, 20, 384), 41, 1.0).to(DEV)
+    a = vae._attn_block(W, "decoder.mid_block.attentions.0", x).float()
+    vae.flash_mid_attention = False
+    b = vae._attn_block(W, "decoder.mid_block.attentions.0", x).float()
+    assert float((a - b).norm() / b.norm()) <= 8e-3
+
+
 @pytest.mark.parametrize("rows,cols,pad", [(64, 16384, 0), (7, 3000, 0), (5, 1936 + 48, 48), (4, 65536, 0), (3, 70000, 0)])
 def test_softmax_rows_matches_torch(rows, cols, pad):
     """omni_softmax_rows (the VAE mid-block attention's softmax, autoencoder_kl_qwenimage.py:319 through GEMM -> this -> GEMM):

@@ -33,7 +33,7 @@ for _ in range(2): vae.decode(z)
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(3): vae.decode(z)
 torch.cuda.synchronize(); print(f"decode {res}^2 B={B}: {(time.time()-t0)/3*1e3:.2f} ms per call")
-for n in ("vae_conv2d", "vae_rmsnorm_silu", "gemm", "softmax_rows_", "vae_upsample2x_bordered"): wrap(n)
+for n in ("vae_conv2d", "vae_rmsnorm_silu", "gemm", "softmax_rows_", "vae_upsample2x_bordered", "vae_attention"): wrap(n)
 vae.decode(z)
 tot = sum(v[0] for v in T.values())
 for k, (t, n, fl) in T.items():

@@ -161,6 +161,8 @@ PROTOTYPES = {
     "omni_vae_upsample2x_bordered": (C.c_int, [c_bf16_p, c_bf16_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "omni_vae_rmsnorm_silu": (C.c_int, [c_bf16_p, c_bf16_p, C.c_int64, C.c_int32, c_bf16_p, C.c_int32, C.c_void_p]),
     "omni_softmax_rows": (C.c_int, [c_bf16_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "omni_vae_attention": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                     C.c_int64, C.c_int64, C.c_float, C.c_void_p]),                 # ABI v10
     "omni_dit_workspace_bytes": (C.c_size_t, [C.POINTER(DitWeights), C.c_int32, C.c_int32, C.c_int32]),
     "omni_dit_modulation_table_workspace_bytes": (C.c_size_t, [C.POINTER(DitWeights), C.c_int32]),
     "omni_dit_modulation_table": (C.c_int, [C.POINTER(DitWeights), c_bf16_p, C.c_int32, c_bf16_p, C.c_void_p, C.c_size_t,

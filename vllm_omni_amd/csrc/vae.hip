@@ -717,6 +717,251 @@ __global__ __launch_bounds__(256) void vae_rmsnorm_kernel(const uint16_t* __rest
   }
 }
 
+// ---- single-head attention of the VAE mid block (head dim = channels = 384) as ONE flash kernel ----------------------------
+// QwenImageAttentionBlock.forward (autoencoder_kl_qwenimage.py:305-330): F.scaled_dot_product_attention over all H*W tokens of an
+// image with one head of 384 channels.  As GEMM -> softmax -> GEMM the 16384 x 16384 (1024^2) score matrix crosses HBM four
+// times (1 GiB per image; 17 GB at 2048^2); here it never leaves the registers.
+// Workgroup = 4 waves = 128 queries of one image, ONE wave per SIMD with the whole register file: a wave owns 32 queries, its
+// O^T accumulators are 12 MFMA 32x32 blocks (384 channels x 32 queries = 192 registers), Q~ (24 fragments = 96 registers) stays
+// in registers for the whole kernel.  KV tile = 32 keys (K 24 KiB + V 24 KiB per LDS stage, two stages): per tile 24 MFMA
+// 32x32x16 for S^T = K Q^T (two accumulator chains) and 24 for O^T += V^T P^T.  Operands swapped so that a lane owns ONE query:
+// online softmax is lane-local (one v_permlane32_swap for the cross-half max), P^T stays in registers as the B operand, V^T
+// fragments come from hardware-transposed reads (ds_read_b64_tr_b16), K fragments from 64-B column blocks with XOR-swizzled
+// 16-B chunks (conflict-free ds_read_b128).  Tiles are staged by LDS-DMA one tile ahead
+// (landing under the tile's MFMAs); fragment reads are hand-issued with counted waits (hipcc retires every read
+// with lgkmcnt(0)).  Same structure as round 1's flash_attn_fwd_kernel (attention.hip), widened to 384.
+constexpr int VA_DH = 384, VA_KV = 32, VA_NW = 4;
+constexpr int VA_K_BYTES = VA_KV * VA_DH * 2;                      // 24 KiB
+constexpr int VA_STAGE = 2 * VA_K_BYTES;                           // K + V
+constexpr int VA_LDS = 2 * VA_STAGE;                               // 96 KiB
+
+template <int OFF>
+OMNI_DEVINL bf16x8_t va_read16(uint32_t addr) {                    // invisible to hipcc's waitcnt pass: waits are counted by hand
+  bf16x8_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+template <int OFF>
+OMNI_DEVINL u32x2_t va_tr_read8(uint32_t addr) {                    // ds_read_b64_tr_b16: hardware 4x4 transpose read
+  u32x2_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+
+__global__ __launch_bounds__(VA_NW * 64, 1) void vae_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                                    const uint16_t* __restrict__ v, uint16_t* __restrict__ out,
+                                                                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int seq_len,
+                                                                    float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  constexpr int QBLK = 32 * VA_NW;
+  const int qb = blockIdx.x, img = blockIdx.y;
+  q += (int64_t)img * seq_len * ldq;
+  out += (int64_t)img * seq_len * ldo;
+  const uint16_t* kbase = k + (int64_t)img * seq_len * ldk;
+  const uint16_t* vbase = v + (int64_t)img * seq_len * ldv;
+
+  // ---- Q fragments (B operand): lane holds q = l31, d = ks*16 + hi*8 .. +8 ----------------------------------------------------
+  bf16x8_t qf[24];
+  {
+    const int qrow = min(qb * QBLK + wave * 32 + l31, seq_len - 1);
+    const uint16_t* qp = q + (int64_t)qrow * ldq + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+    // Q~ lives in AGPRs: the MFMAs below are asm statements whose B operand has the "a" constraint.  (hipcc's own MFMAs take A / B
+    // from arch VGPRs only: it kept all of Q~ in the 256 VGPRs, spilled half of it, and the scratch reloads' vmcnt waits drained
+    // the LDS-DMA in flight every tile: 10x slower.)
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) asm volatile("" : "+a"(qf[ks]));
+  }
+  // register file of a wave (512): AGPRs = Q~ (96) + O^T blocks 0..9 (160); VGPRs = O^T blocks 10, 11 (32), S (48), fragments, addresses
+
+  // ---- staging by LDS-DMA (buffer_load ... lds: lane L of piece p lands at LDS bytes p * 1024 + 16 L of the operand's image).
+  // Both images are made of 64-B (32-channel) column blocks: piece p = column block p / 2, keys (p % 2) * 16 + L / 4, 16-B chunk
+  // L % 4 of the block — so a lane's source offset is ONE per-lane constant plus a per-piece uniform, for K and for V alike:
+  //   K image [12 column blocks][32 keys][64 B], the chunk index XORed with (key >> 2) & 3 (on the source side): a ds_read_b128
+  //           fragment read (16 lanes = 16 keys, 64 B apart) then hits 16 different 16-B bank groups;
+  //   V image [12 column blocks][8 groups of 4 keys][4 keys][64 B]: the tr-read layout of attention.hip, 32 keys per block.
+  // rows past the end of the image are outside the descriptors' range and land as 0 (those keys are masked to -inf)
+  const int dkey = lane >> 2, dpos = lane & 3;
+  const uint32_t k_ld_lane = (uint32_t)(dkey * ldk * 2 + ((dpos ^ ((dkey >> 2) & 3)) << 4));
+  const uint32_t v_ld_lane = (uint32_t)(dkey * ldv * 2 + (dpos << 4));
+  const u32x4_t k_srd = conv_srd(kbase, (uint64_t)((int64_t)(seq_len - 1) * ldk * 2 + VA_DH * 2));
+  const u32x4_t v_srd = conv_srd(vbase, (uint64_t)((int64_t)(seq_len - 1) * ldv * 2 + VA_DH * 2));
+  const uint32_t k_tile_stride = (uint32_t)(VA_KV * ldk * 2), v_tile_stride = (uint32_t)(VA_KV * ldv * 2);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  // piece j of this wave's twelve per tile (j < 6: K piece 6 wave + j, else V piece 6 wave + j - 6) of tile t -> stage t & 1
+  auto dma_piece = [&](int t, int j) {
+    const int i = j < 6 ? j : j - 6, p = wave * 6 + i;
+    const uint32_t dst = lds0 + (t & 1) * VA_STAGE + (wave * 6 + i) * 1024;
+    if (j < 6) {
+      const uint32_t ku = __builtin_amdgcn_readfirstlane((uint32_t)t * k_tile_stride + (uint32_t)((p & 1) * 16) * (uint32_t)(ldk * 2) + (uint32_t)((p >> 1) * 64));
+      conv_dma16(k_srd, k_ld_lane + ku, dst);
+    } else {
+      const uint32_t vu = __builtin_amdgcn_readfirstlane((uint32_t)t * v_tile_stride + (uint32_t)((p & 1) * 16) * (uint32_t)(ldv * 2) + (uint32_t)((p >> 1) * 64));
+      conv_dma16(v_srd, v_ld_lane + vu, dst + VA_K_BYTES);
+    }
+  };
+  auto dma_tile = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) dma_piece(t, j);
+  };
+
+  // ---- fragment read addresses ---------------------------------------------------------------------------------------------
+  // K, k-step ks (chunk ks * 2 + hi of row l31): column block ks >> 1 (an immediate: 2048 B each), chunk (ks & 1) * 2 + hi swizzled
+  uint32_t k_addr[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) k_addr[e] = l31 * 64 + ((((uint32_t)(e * 2 + hi)) ^ ((l31 >> 2) & 3)) << 4);
+  // V (tr read): m = lane & 15, g = lane >> 4:  (m >> 2) * 64 + (g & 1) * 32 + (m & 3) * 8 + hi * 256
+  const uint32_t v_lane_off = VA_K_BYTES + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + hi * 256;
+
+  f32x16_t o[12];
+#pragma unroll
+  for (int d = 0; d < 12; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+
+  const int ntiles = (seq_len + VA_KV - 1) / VA_KV;
+  dma_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    const int kv0 = t * VA_KV;
+    const bool more = t + 1 < ntiles;                              // tile t + 1's DMA pieces go out one per two MFMAs of the S phase (a
+                                                                   // piece costs its wave ~60 issue cycles: twelve in a burst idle the pipe)
+
+    // ---- S^T = K Q^T: 24 MFMAs on two accumulator chains; K fragments are read 4 deep ahead of their MFMA
+    f32x16_t s0, s1;                                               // (the chains open with C = 0 as an inline constant: no VALU
+                                                                   //  write of an accumulator right in front of an asm MFMA)
+    {
+      const uint32_t kst = lds0 + cur * VA_STAGE;
+      bf16x8_t kf[4];
+#define OMNI_VA_KREAD(i) kf[(i) & 3] = va_read16<0>(k_addr[(i) & 1] + kst + (uint32_t)(((i) >> 1) * 2048))
+      OMNI_VA_KREAD(0); OMNI_VA_KREAD(1); OMNI_VA_KREAD(2); OMNI_VA_KREAD(3);
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        if (i <= 20) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else if (i == 21) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if (i == 22) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (i == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s0) : "v"(kf[i & 3]), "a"(qf[i]));
+        else if (i == 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s1) : "v"(kf[i & 3]), "a"(qf[i]));
+        else if (i & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s1) : "v"(kf[i & 3]), "a"(qf[i]));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s0) : "v"(kf[i & 3]), "a"(qf[i]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 4 < 24) OMNI_VA_KREAD(i + 4);
+        if ((i & 1) && more) dma_piece(t + 1, i >> 1);               // (its stage was drained one barrier ago)
+      }
+#undef OMNI_VA_KREAD
+    }
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));     // the last MFMAs' passes before a VALU reader (no interlock)
+    f32x16_t s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = s0[i] + s1[i];
+    // ---- mask the ragged tail (last tile only; wave-uniform branch): row r of the block = key (r & 3) + 8 (r >> 2) + 4 hi
+    if (kv0 + VA_KV > seq_len) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= seq_len) s[r] = -INFINITY;
+    }
+    // ---- online softmax, lane-local (one cross-half exchange for the max); defer-max as in attention.hip
+    bf16x8_t pf[2];
+    {
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      constexpr float DEFER = 6.0f;
+      if (!__all((mx - m_run) * scale_log2e <= DEFER)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = m_run == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 12; ++d) {                             // one block at a time: all 192 values at once in VGPR temporaries
+#pragma unroll                                                     // push the loop's long-lived values (the DMA offsets) to scratch
+          for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      const float mneg = -m_run * scale_log2e;
+      float psum = 0.0f;
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ss * 8 + e], scale_log2e, mneg));
+          psum += p;
+          pf[ss][e] = (__bf16)p;
+        }
+      l_run += psum;
+    }
+    // ---- O^T += V^T P^T: 24 MFMAs, i -> (ss = i / 12, d = i % 12); a V^T fragment = two transposed reads, fetched three ahead
+    {
+      const uint32_t vb = lds0 + cur * VA_STAGE + v_lane_off;
+      u32x2_t vlo[4], vhi[4];
+#define OMNI_VA_VOFF(i) (((i) % 12) * (VA_KV / 4 * 256) + ((i) / 12) * 1024)
+#define OMNI_VA_VREAD(i)                                        \
+  do {                                                          \
+    vlo[(i) & 3] = va_tr_read8<OMNI_VA_VOFF(i)>(vb);            \
+    vhi[(i) & 3] = va_tr_read8<OMNI_VA_VOFF(i) + 512>(vb);      \
+  } while (0)
+#define OMNI_VA_PV(i)                                                                                            \
+  do {                                                                                                           \
+    if ((i) <= 21) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                            \
+    else if ((i) == 22) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                                       \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    {                                                                                                            \
+      const u32x4_t w_ = {vlo[(i) & 3][0], vlo[(i) & 3][1], vhi[(i) & 3][0], vhi[(i) & 3][1]};                   \
+      if ((i) % 12 < 10) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[(i) % 12]) : "v"(w_), "v"(pf[(i) / 12])); \
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(o[(i) % 12]) : "v"(w_), "v"(pf[(i) / 12]));       \
+    }                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+  } while (0)
+      OMNI_VA_VREAD(0); OMNI_VA_VREAD(1); OMNI_VA_VREAD(2);
+      asm volatile("s_nop 3" : "+v"(pf[0]), "+v"(pf[1]));           // P^T was written by VALU converts: wait states before an asm MFMA reads it
+      OMNI_VA_PV(0);  OMNI_VA_VREAD(3);  OMNI_VA_PV(1);  OMNI_VA_VREAD(4);  OMNI_VA_PV(2);  OMNI_VA_VREAD(5);
+      OMNI_VA_PV(3);  OMNI_VA_VREAD(6);  OMNI_VA_PV(4);  OMNI_VA_VREAD(7);  OMNI_VA_PV(5);  OMNI_VA_VREAD(8);
+      OMNI_VA_PV(6);  OMNI_VA_VREAD(9);  OMNI_VA_PV(7);  OMNI_VA_VREAD(10); OMNI_VA_PV(8);  OMNI_VA_VREAD(11);
+      OMNI_VA_PV(9);  OMNI_VA_VREAD(12); OMNI_VA_PV(10); OMNI_VA_VREAD(13); OMNI_VA_PV(11); OMNI_VA_VREAD(14);
+      OMNI_VA_PV(12); OMNI_VA_VREAD(15); OMNI_VA_PV(13); OMNI_VA_VREAD(16); OMNI_VA_PV(14); OMNI_VA_VREAD(17);
+      OMNI_VA_PV(15); OMNI_VA_VREAD(18); OMNI_VA_PV(16); OMNI_VA_VREAD(19); OMNI_VA_PV(17); OMNI_VA_VREAD(20);
+      OMNI_VA_PV(18); OMNI_VA_VREAD(21); OMNI_VA_PV(19); OMNI_VA_VREAD(22); OMNI_VA_PV(20); OMNI_VA_VREAD(23);
+      OMNI_VA_PV(21); OMNI_VA_PV(22); OMNI_VA_PV(23);
+#undef OMNI_VA_PV
+#undef OMNI_VA_VREAD
+#undef OMNI_VA_VOFF
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's pieces of tile t + 1
+    __syncthreads();
+  }
+
+  // ---- epilogue: O[q][d] = O^T / l; lane holds q = l31, d = dblk*32 + 8*qd + 4*hi + {0..3}
+  asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");                 // the last P.V MFMAs' passes before the VALU reads O^T
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = qb * QBLK + wave * 32 + l31;
+  if (qrow < seq_len) {
+    uint16_t* op = out + (int64_t)qrow * ldo + hi * 4;
+#pragma unroll
+    for (int d = 0; d < 12; ++d)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        u32x2_t w;
+        w[0] = pack_bf16x2(o[d][qd * 4 + 0] * inv, o[d][qd * 4 + 1] * inv);
+        w[1] = pack_bf16x2(o[d][qd * 4 + 2] * inv, o[d][qd * 4 + 3] * inv);
+        *reinterpret_cast<u32x2_t*>(op + d * 32 + qd * 8) = w;
+      }
+  }
+}
+
 // in-place softmax over rows of `cols` bf16 scores: p = exp((s - max) * scale) / sum.  One workgroup per row.
 // softmax_rows_reg_kernel: the row stays in registers between the passes (cols <= 64 * THREADS: 8 chunks of 8 per thread, all
 // loads issued before the first use) — one read and one write of the scores (HBM-bound: the VAE's 16384 x 16384 mid-block
@@ -965,6 +1210,28 @@ extern "C" int omni_softmax_rows(omni_bf16* s, int64_t ld, int64_t rows, int32_t
   if (cols <= 64 * 256) hipLaunchKernelGGL(softmax_rows_reg_kernel<256>, dim3((unsigned)rows), dim3(256), 0, st, s, ld, cols, scale);
   else if (cols <= 64 * 1024) hipLaunchKernelGGL(softmax_rows_reg_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, st, s, ld, cols, scale);
   else hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, ld, cols, scale);
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+extern "C" int omni_vae_attention(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int32_t B,
+                                  int32_t tokens, int32_t C, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+                                  omni_stream stream) {
+  if (!q || !k || !v || !out || B <= 0 || tokens <= 0) return OMNI_ERR_BAD_ARG;
+  if (C != VA_DH || B > 65535) return OMNI_ERR_UNSUPPORTED;
+  if (!omni_aligned16(q) || !omni_aligned16(k) || !omni_aligned16(v) || (reinterpret_cast<uintptr_t>(out) & 7) || (ldq % 8) ||
+      (ldk % 8) || (ldv % 8) || (ldo % 4))
+    return OMNI_ERR_ALIGN;
+  if ((int64_t)tokens * ldk * 2 >= (1ll << 32) || (int64_t)tokens * ldv * 2 >= (1ll << 32)) return OMNI_ERR_UNSUPPORTED;   // 32-bit offsets
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(vae_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, VA_LDS) !=
+        hipSuccess)
+      return OMNI_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(vae_attn_fwd_kernel, dim3((unsigned)((tokens + 32 * VA_NW - 1) / (32 * VA_NW)), B), dim3(VA_NW * 64), VA_LDS,
+                     static_cast<hipStream_t>(stream), q, k, v, out, ldq, ldk, ldv, ldo, tokens, scale * 1.4426950408889634f);
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }

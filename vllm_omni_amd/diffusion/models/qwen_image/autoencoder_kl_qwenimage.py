@@ -200,6 +200,7 @@ class AutoencoderKLQwenImage(nn.Module):
         return out
 
     ATTN_Q_CHUNK = 8192
+    flash_mid_attention = True        # False: the GEMM -> softmax -> GEMM path (any channel count; the flash kernel's cross-check)
 
     # ------------------------------------------------------------------ blocks (NHWC bf16)
     def _res_block(self, W, pre, x):
@@ -221,6 +222,12 @@ class AutoencoderKLQwenImage(nn.Module):
         xn = ops.vae_rmsnorm_silu(x, W[pre + ".norm.gamma"], silu=False)
         wqkv = W[pre + ".to_qkv.weight"].reshape(3 * Cc, Cc)
         bqkv = W[pre + ".to_qkv.bias"]
+        if Cc == ops.VAE_ATTENTION_CHANNELS and self.flash_mid_attention:
+            # one fused q / k / v projection over all images, then the flash kernel on its column slices: the tok x tok score
+            # matrix (1 GiB per 1024^2 image through HBM four times on the path below) never leaves the registers
+            qkv = ops.linear(xn.reshape(B * tok, Cc), wqkv, bqkv).view(B, tok, 3 * Cc)
+            o = ops.vae_attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], 1.0 / math.sqrt(Cc)).view(B, H, Wd, Cc)
+            return ops.vae_conv2d(o, W[pre + ".proj.weight"], W[pre + ".proj.bias"], res=x)
         outs = []
         for b in range(B):
             t = xn[b].reshape(tok, Cc)

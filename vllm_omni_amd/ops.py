@@ -309,6 +309,22 @@ def vae_rmsnorm_silu(x, gamma, silu: bool = True):
     return y
 
 
+VAE_ATTENTION_CHANNELS = 384          # the head dim omni_vae_attention is built for
+
+
+def vae_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+    """Single-head attention per image: q, k, v [B, tokens, 384] (row-strided views of one fused projection are fine: the last
+    dim must be contiguous, images must be tokens * row_stride apart) -> [B, tokens, 384] = softmax(scale q k^T) v."""
+    B, tok, Cc = q.shape
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if t.shape != q.shape or t.stride(2) != 1 or (B > 1 and t.stride(0) != tok * t.stride(1)):
+            raise N.OmniNativeError(f"{n}: expected [B, tokens, C] with contiguous channels and images tokens * row_stride apart")
+    out = torch.empty(B, tok, Cc, dtype=BF16, device=q.device)
+    N.check(N.lib().omni_vae_attention(_p(q, name="q"), _p(k, name="k"), _p(v, name="v"), _p(out), B, tok, Cc, q.stride(1),
+                                       k.stride(1), v.stride(1), Cc, float(scale), _stream()), "omni_vae_attention")
+    return out
+
+
 def softmax_rows_(s: torch.Tensor, scale: float):
     rows, cols, ld = _rows2d(s, "scores")
     N.check(N.lib().omni_softmax_rows(_p(s, name="scores"), ld, rows, cols, scale, _stream()), "omni_softmax_rows")
