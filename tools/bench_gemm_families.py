@@ -30,6 +30,7 @@ D, Mi, Mt = 3072, 40960, 640                      # the bench step-batch: 10 x (
 
 SHAPES = {  # name: (N, K, epilogue, blocked operands?, two groups?)
     "mlp_up": (4 * D, D, ops.EPI_BIAS_GELU_TANH, True, True),
+    "mlp_up_k32out_bias": (4 * D, D, ops.EPI_BIAS, True, True),        # the same launch without the GELU arithmetic (K32-blocked out)
     "qkv_plain": (3 * D, D, ops.EPI_BIAS, True, True),
     "out_proj": (D, D, ops.EPI_BIAS, True, True),
     "mlp_down": (D, 4 * D, ops.EPI_BIAS, True, True),
@@ -40,6 +41,7 @@ SHAPES = {  # name: (N, K, epilogue, blocked operands?, two groups?)
 }
 for name in args.shapes.split(","):
     N, K, epi, blk, two = SHAPES[name]
+    k32out = blk and (epi == ops.EPI_BIAS_GELU_TANH or "k32out" in name)
     m_i, m_t = (Mi, Mt) if two else (8192, 0)
     xi_rm = rn(m_i, K)
     wi_rm = rn(N, K, sc=0.02)
@@ -54,11 +56,11 @@ for name in args.shapes.split(","):
             gate = rn(10, N, sc=0.3)                     # that repeated launches compute the same thing
             extra_i = dict(res=rn(m_i, N), gate=gate, gate_item_stride=N, rows_per_item=4096)
             extra_t = dict(res=rn(m_t, N), gate=gate, gate_item_stride=N, rows_per_item=64)
-        grp = [ops.GemmGroupArgs(xi, wi, b, oi, a_k32_blocked=blk, out_k32_blocked=blk and epi == ops.EPI_BIAS_GELU_TANH, **extra_i)]
+        grp = [ops.GemmGroupArgs(xi, wi, b, oi, a_k32_blocked=blk, out_k32_blocked=k32out, **extra_i)]
         if two:
             xt, wt = ops.w_to_k32_blocked(rn(m_t, K)), ops.w_to_k32_blocked(rn(N, K, sc=0.02))
             grp.append(ops.GemmGroupArgs(xt, wt, b, torch.zeros(m_t, N, dtype=BF16, device=dev), a_k32_blocked=blk,
-                                         out_k32_blocked=blk and epi == ops.EPI_BIAS_GELU_TANH, **extra_t))
+                                         out_k32_blocked=k32out, **extra_t))
         outs[f] = (oi, grp)
     flops = 2.0 * (m_i + m_t) * N * K
     run = {f: (lambda f=f: ops.gemm(outs[f][1], epi, w_k32_blocked=blk, kernel_hint=16 + f)) for f in fams}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch ONE hot kernel a few times (for rocprofv3 --kernel-trace / --pmc passes).
-   python tools/run_kernel.py roofline|gemm_mlp_up|gemm_mlp_down|gemm_qkv|gemm_out|attention|attention6|attention10|
+   python tools/run_kernel.py roofline|torchmm_mlp_up|gemm_mlp_up|gemm_mlp_down|gemm_qkv|gemm_out|attention|attention6|attention10|
                               conv<Cin>_<Cout>_<side>[_n] [iters]     (the VAE's bordered 3x3 conv; _n = with the fused norm output)"""
 import math
 import os
@@ -39,6 +39,13 @@ elif which == "roofline":
     fn = lambda: ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi, a_k32_blocked=True, out_k32_blocked=True),  # noqa: E731
                            ops.GemmGroupArgs(xt, wt, b, ot, a_k32_blocked=True, out_k32_blocked=True)],
                           ops.EPI_BIAS_GELU_TANH, w_k32_blocked=True)
+elif which == "torchmm_mlp_up":
+    # the vendor kernel (hipBLASLt through torch.mm: no bias, no GELU) on the roofline launch's shape, for counter passes
+    R = int(os.environ.get("BENCH_R", "5"))
+    M, N, K = 2 * R * 4160, 4 * D, D
+    xa, wa = rn(M, K), rn(N, K, s=0.02)
+    oa = torch.empty(M, N, dtype=BF16, device=dev)
+    fn = lambda: torch.mm(xa, wa.t(), out=oa)  # noqa: E731
 elif which in ("attention", "attention6", "attention10"):
     B, H, S = {"attention": 2, "attention6": 6, "attention10": 10}[which], 24, 4160      # attention10 = the bench's step-batch
     q, k, v = rn(B * S, H * 128), rn(B * S, H * 128), rn(B * S, H * 128)

@@ -28,6 +28,7 @@
 //   GROUP_M row-tiles at a time: neighbours share A/W panels in that XCD's private L2.
 //
 // Roofline: MFMA-bound.  Algorithmic work = 2*M*N*K flop per launch.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -966,6 +967,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
 #ifndef OMNI_PP_DMA_IN_MMA
 #define OMNI_PP_DMA_IN_MMA 0   // 1: a phase's two DMA pieces are issued inside its MFMA cluster instead of its load section
 #endif
+#ifndef OMNI_PP_EARLY_BARRIER
+#define OMNI_PP_EARLY_BARRIER 0   // n > 0: a cluster's closing s_barrier sits n MFMA pairs (of 8) before its end (see OMNI_PP_MMA); must be even for fp8
+#endif
 #ifndef OMNI_PP_BALANCED
 #define OMNI_PP_BALANCED 0     // 1: second A-fragment register set; fragment reads per phase 4 / 4 / 8 / 8 instead of 12 / 4 / 8 / 0
 #endif
@@ -1204,19 +1208,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
       wf[nq][1][ks_] = lds_read16<16 * 128, OMNI_PP_ABL == 7>(w_rd[ks_] + (sb));           \
     }                                                                                      \
   } while (0)
-// the quadrant's 16 MFMAs: 8 accumulators round-robin, each touched again 8 instructions (128 pipe cycles) later
-#define OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1)                                                            \
+// the quadrant's 16 MFMAs: 8 accumulators round-robin, each touched again 8 instructions (128 pipe cycles) later.
+// OMNI_PP_CLUSTER_PART issues the MFMA PAIRS [p0, p1) of the cluster's 8 (bf16; pair p = (ks, mb) = (p / 4, p % 4)) or 4 (fp8;
+// pair p = mb) in the same order as the whole cluster: OMNI_PP_EARLY_BARRIER splits it around the closing barrier.
+#define OMNI_PP_CLUSTER_PART(nq, mq, AF, p0, p1)                                                           \
   if (FP8) {                                                                                               \
-    _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_) {                                                  \
+    _Pragma("unroll") for (int mb_ = (p0) / 2; mb_ < (p1) / 2; ++mb_) {                                    \
       pp_mfma_fp8(acc[2 * (nq)][4 * (mq) + mb_], wf[nq][0][0], wf[nq][0][1], AF[mb_][0], AF[mb_][1], mx_one);     \
       pp_mfma_fp8(acc[2 * (nq) + 1][4 * (mq) + mb_], wf[nq][1][0], wf[nq][1][1], AF[mb_][0], AF[mb_][1], mx_one); \
     }                                                                                                      \
   } else                                                                                                   \
-  _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                      \
-    _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_) {                                                  \
-      pp_mfma16(acc[2 * (nq)][4 * (mq) + mb_], wf[nq][0][ks_], AF[mb_][ks_]);                              \
-      pp_mfma16(acc[2 * (nq) + 1][4 * (mq) + mb_], wf[nq][1][ks_], AF[mb_][ks_]);                          \
+  _Pragma("unroll") for (int p_ = (p0); p_ < (p1); ++p_) {                                                 \
+      pp_mfma16(acc[2 * (nq)][4 * (mq) + (p_ & 3)], wf[nq][0][p_ >> 2], AF[p_ & 3][p_ >> 2]);              \
+      pp_mfma16(acc[2 * (nq) + 1][4 * (mq) + (p_ & 3)], wf[nq][1][p_ >> 2], AF[p_ & 3][p_ >> 2]);          \
     }
+#define OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1) OMNI_PP_CLUSTER_PART(nq, mq, AF, 0, 8)
 #else
   bf16x8_t wf[2][4], afx[2][4];
 #if OMNI_PP_BALANCED
@@ -1235,6 +1241,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   do {                                                                                     \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) wf[nq][ks_] = lds_read16<0, OMNI_PP_ABL == 7>(w_rd[ks_] + (sb)); \
   } while (0)
+#define OMNI_PP_CLUSTER_PART(nq, mq, AF, p0, p1) OMNI_PP_CLUSTER(nq, mq, AF, (void)0, (void)0)   /* (16x16x32 build only) */
 #define OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1)                                                            \
   _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                    \
     pp_mfma(acc[nq][2 * (mq)], wf[nq][ks_], AF[0][ks_]);                                                   \
@@ -1258,10 +1265,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                    \
-    OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1)                                                                \
-    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                     \
-    if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                                \
+    if (OMNI_PP_EARLY_BARRIER && OMNI_PP_MFMA16) {                                                         \
+      /* the closing barrier is SIGNALLED OMNI_PP_EARLY_BARRIER MFMA pairs before the cluster's end: the partner group's */ \
+      /* release (barrier latency + its first issue slots) then overlaps this wave's last MFMAs instead of an idle pipe */ \
+      OMNI_PP_CLUSTER_PART(nq, mq, AF, 0, 8 - OMNI_PP_EARLY_BARRIER)                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      OMNI_PP_CLUSTER_PART(nq, mq, AF, 8 - OMNI_PP_EARLY_BARRIER, 8)                                       \
+      if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } else {                                                                                               \
+      OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1)                                                              \
+      if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                              \
+    }                                                                                                      \
     asm volatile("" ::: "memory");                                                                         \
   } while (0)
 // one phase: DMA of half-tile (h, tile) either in the load section (both pieces) or inside the cluster
@@ -1303,13 +1322,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   }
   if (!wm) __builtin_amdgcn_s_barrier();         // group 0 waits for group 1's last cluster
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // asm MFMA results -> first compiler-visible VALU read
-#undef OMNI_PP_PHASE
-#undef OMNI_PP_MMA
-#undef OMNI_PP_CLUSTER
-#undef OMNI_PP_READ_W
-#undef OMNI_PP_READ_A
-#undef OMNI_PP_ISSUE
-#undef OMNI_PP_ISSUE_PIECE
+  // (the OMNI_PP_* loop macros stay defined for the persistent variant below, which repeats this loop; #undef'd behind it)
 
 #if OMNI_PP_MFMA16
   if (SPLITK) {
@@ -1341,6 +1354,303 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 #endif
 }
 
+
+#ifdef OMNI_DEV   // dev-only kernel family 8 (kernel_hint 16 + 8): measured NEUTRAL (round 4), kept for A/B runs and its ablations
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT form of the ping-pong kernel for launches whose epilogue is the direct K32 store (MLP-up / GELU: the roofline
+// kernel).  One workgroup per CU walks the tiles the one-shot grid would have given that CU (same XCD-aware order: tile k of
+// workgroup b is the one-shot block b + k * gridDim).  What it buys: in the one-shot kernel a CU sits idle between the last
+// MFMA of tile i and the first of tile i + 1 for the epilogue, the workgroup's exit, the dispatch of the next one (the LDS is
+// whole-CU: it cannot start earlier), its address set-up and one DMA round trip.  Here, at the seam, the NEXT tile's bias
+// loads and its six prologue half-tiles are issued first (the ring is drained: every wave is behind the K-loop's last
+// barrier) and fly while the accumulators of the finished tile go through GELU and out to HBM straight from the registers
+// (no LDS: the direct epilogue).  Waits are counted: the seam's VMEM stream is [4 bias loads] [12 DMA pieces] [16 stores] per
+// wave, the stores issued as buffer stores whose out-of-range lanes are dropped by the descriptor instead of by an exec-mask
+// branch, so their NUMBER is the same for every tile and vmcnt(8 + 16) means "bias and half-tiles 0 / 1 have landed".  Same
+// K-loop (the OMNI_PP_* macros), same accumulation order: bit-identical to gemm_bf16_pp_kernel (tools/check_ppp.py: ragged M / N,
+// two groups, no bias, two K-tiles, skipped row tiles).
+// MEASURED (same box, M = 40960 + 640, N = 12288, K = 3072, profiles/r04_persistent_gemm_and_epilogue_decomposition.log):
+//   one-shot ping-pong 1359-1372 TF/s | this kernel 1373 (+0.2 %) | its epilogue arithmetic with every store dropped 1415 (+3.2 %)
+//   | all stores into one L2-resident 64-KiB window 1412 | no epilogue at all 1478 (+7.9 %) | K-loop waits that never cover the
+//   stores 1374 | the same launch without the GELU arithmetic 1414 (one-shot 1409).
+// Reading: workgroup exit / dispatch / address set-up / the first DMA round trip are NOT what a tile boundary costs (hidden
+// here: +0.2 %); neither is vmcnt's in-order retirement behind the store acknowledgements.  The 7.9 % are 4.6 % of VALU time
+// with the matrix pipe idle (GELU 2.9 %, convert / permlane / addresses 1.7 %: all eight waves reach the seam together) and
+// 3.1 % for the GIGABYTE the launch writes to HBM (gone when the stores stay in L2: it is the drain of 256 simultaneous
+// 128-KiB bursts, not their issue).  Overlapping the arithmetic needs workgroups in different tile phases on one CU (two
+// 4-wave workgroups per CU); smoothing the write bursts needs the XCDs phase-shifted against each other (DESIGN.md "Open leads").
+// ------------------------------------------------------------------------------------------------
+OMNI_DEVINL u32x4_t gemm_srd(const void* base, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  u32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);     // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+#ifndef OMNI_PPP_ABL
+#define OMNI_PPP_ABL 0   // dev-only timing ablations (results wrong by construction): 1 no epilogue at all, 2 epilogue arithmetic with every store dropped, 3 stores into one 64-KiB window, 5 K-loop waits never cover the stores
+#endif
+constexpr uint32_t PPP_DROP = 0xC0000000u;   // a byte offset no output reaches (the host keeps outputs below 2 GiB): the store is dropped
+
+// gemm_epilogue_direct_k32 with descriptor-checked stores: exactly 16 store instructions per wave, whatever M and N are
+template <int EPI>
+OMNI_DEVINL void gemm_epilogue_direct_k32_buf(const u32x4_t& srd, int M, int N, int64_t R, f32x4_t (&acc)[4][8], int m0, int n0,
+                                              int wm, int wn, int l15, int g) {
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const int row = m0 + wm * 128 + mb * 16 + l15;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      uint32_t a[2], b[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int nb = 2 * sl + h;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[nb][mb][j];
+          if (EPI == OMNI_EPI_BIAS_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
+        }
+        (h ? b : a)[0] = pack_bf16x2(v[0], v[1]);
+        (h ? b : a)[1] = pack_bf16x2(v[2], v[3]);
+      }
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+      const u32x4_t o = {a[0], a[1], b[0], b[1]};
+      const int n = n0 + wn * 64 + sl * 32 + (g & 1) * 16 + (g >> 1) * 8;
+      const int64_t off = (((int64_t)(n >> 5) * R + row) * 32 + (n & 31)) * 2;
+#if OMNI_PPP_ABL == 2
+      const uint32_t voff = PPP_DROP | ((uint32_t)off & 0xff0u);   // timing ablation: the arithmetic, no byte written
+#elif OMNI_PPP_ABL == 3
+      const uint32_t voff = (uint32_t)off & 0xfff0u;               // timing ablation: every store lands in one 64-KiB window (L2-resident)
+#else
+      const uint32_t voff = (row < M && n < N) ? (uint32_t)off : PPP_DROP;
+#endif
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" OMNI_EPI_STORE_POLICY "\n\ts_nop 2" ::"v"(o), "v"(voff), "s"(srd) : "memory");
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ppp_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
+                                                                      int tiles_n, int GROUP_M) {
+  static_assert(EPI == OMNI_EPI_BIAS || EPI == OMNI_EPI_BIAS_GELU_TANH, "direct K32 epilogues only");
+  static_assert(OMNI_PP_MFMA16 && !OMNI_PP_BALANCED && !OMNI_PP_DMA_IN_MMA, "built on the 16x16x32 loop");
+  constexpr int FP8 = 0;                           // (named by the loop macros)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = tiles_m * tiles_n;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int N = P.N, K = P.K;
+  const int nkt = K / PBK;                         // >= 2 (host)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int64_t wstep = P.w_k32_blocked ? (int64_t)N * 128 : 128;
+  // this workgroup's tiles: slots (blockIdx >> 3) + k * (gridDim >> 3) of its XCD's contiguous range of the tile list
+  const int xcd = (int)blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int xbase = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
+  const int xcount = qq + (xcd < rr ? 1 : 0);
+  const int slot_step = (int)gridDim.x >> 3;
+  const int band_sz = GROUP_M * tiles_n;
+
+  // ---- state of the tile whose K-loop runs (re-assigned at every seam) ----
+  int gi = 0, m0 = 0, n0 = 0;
+  const char *Ab = nullptr, *Wb = nullptr;
+  int64_t astep = 128;
+  uint32_t a_off[2][2], w_off[2][2];
+  u32x2_t bq[4];                                   // its bias: 4 bf16 per 16-column block, loaded by asm at the seam
+  bool has_bias = false;
+
+  auto decode = [&](int slot, int& gi_, int& mt_, int& nt_) {
+    const int lid = xbase + slot;
+    const int band = lid / band_sz, in_band = lid - band * band_sz;
+    const int first_m = band * GROUP_M;
+    const int gm = min(GROUP_M, tiles_m - first_m);
+    mt_ = first_m + in_band % gm;
+    nt_ = in_band / gm;
+    gi_ = (mt_ >= mtiles0) ? 1 : 0;
+  };
+  auto skipped = [&](int slot) -> bool {           // device-side predicate (omni_teacache)
+    int gi_, mt_, nt_;
+    decode(slot, gi_, mt_, nt_);
+    const int32_t* sk = gi_ ? P.g[1].tile_skip : P.g[0].tile_skip;
+    return sk && sk[gi_ ? mt_ - mtiles0 : mt_];
+  };
+  // tile `slot` becomes the K-loop's tile: operand bases, per-lane DMA offsets, and its bias loads IN FLIGHT (asm: hipcc would
+  // retire a load of its own with vmcnt(0), draining the DMA stream)
+  auto setup = [&](int slot) {
+    int mt, nt;
+    decode(slot, gi, mt, nt);
+    const omni_gemm_group G = pick_group(P, gi);
+    m0 = (gi ? mt - mtiles0 : mt) * BM;
+    n0 = nt * BN;
+    const int M = G.M;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int lr = (wave * 2 + i) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        int ar = min(m0 + (lr >> 6) * 128 + q * 64 + (lr & 63), M - 1);
+        if (G.a_row_map) ar = G.a_row_map[ar];
+        const int64_t ae = G.a_k32_rows ? ((int64_t)(c >> 2) * G.a_k32_rows + ar) * 32 + (c & 3) * 8
+                                        : (int64_t)ar * G.lda + c * 8;
+        a_off[q][i] = (uint32_t)(ae * 2);
+        const int wr = min(n0 + (lr >> 5) * 64 + q * 32 + (lr & 31), N - 1);
+        const int64_t we = P.w_k32_blocked ? ((int64_t)(c >> 2) * N + wr) * 32 + (c & 3) * 8 : (int64_t)wr * K + c * 8;
+        w_off[q][i] = (uint32_t)(we * 2);
+      }
+    }
+    astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * 128 : 128;
+    Ab = reinterpret_cast<const char*>(G.A);
+    Wb = reinterpret_cast<const char*>(G.W);
+    // branch-free: a diamond here would let hipcc resolve the phi with register copies BEFORE the counted wait (copies of
+    // registers whose loads are still in flight).  No bias: any readable address, the value is replaced by 0 behind the wait.
+    has_bias = G.bias != nullptr;
+    const uint16_t* const bsrc = has_bias ? G.bias : reinterpret_cast<const uint16_t*>(G.W);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const uint16_t* bp = bsrc + min(n0 + wn * 64 + nb * 16 + g4 * 4, N - 4);   // (columns >= N are never stored)
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(bq[nb]) : "v"(bp) : "memory");
+    }
+  };
+
+  const int l15_ = l15;
+  uint32_t a_rd[2], w_rd[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const uint32_t chunk = ((uint32_t)(ks * 4 + g4) ^ ((l15_ >> 1) & 7)) << 4;
+    a_rd[ks] = lds0 + (wm * 64 + l15) * 128 + chunk;
+    w_rd[ks] = lds0 + (wn * 32 + l15) * 128 + chunk;
+  }
+  f32x4_t acc[4][8];
+  bf16x8_t wf[2][2][2], afx[4][2];
+  bf16x8_t (&afy)[4][2] = afx;
+  uint32_t mx_one = 0x7f7f7f7fu;
+  asm volatile("" : "+v"(mx_one));
+
+  int slot = (int)blockIdx.x >> 3;
+  while (slot < xcount && skipped(slot)) slot += slot_step;
+  if (slot >= xcount) return;
+  setup(slot);
+  OMNI_PP_ISSUE(0, 0); OMNI_PP_ISSUE(1, 0); OMNI_PP_ISSUE(2, 0); OMNI_PP_ISSUE(3, 0);
+  OMNI_PP_ISSUE(0, 1); OMNI_PP_ISSUE(1, 1);
+  // bias and half-tiles 0 / 1 of the first tile have landed: 8 DMA pieces and 16 (dropped) stores are younger.  (The bias registers are tied to every
+  // counted wait so that no use moves above it; the registers are printed in the listing: tests/test_host_logic.py checks
+  // that they are the very registers the loads wrote, i.e. that hipcc put no copy in between.)
+  {
+    // the first tile has no epilogue in front of it: 16 stores that the descriptor drops (every lane out of range) give its
+    // VMEM stream the shape of a seam's, so that ONE set of counted waits serves every tile
+    const u32x4_t srd0 = gemm_srd(P.g[0].out, 16u);
+    const u32x4_t z = {0u, 0u, 0u, 0u};
+    const uint32_t voff = PPP_DROP;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(z), "v"(voff), "s"(srd0) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(24) ; omni ppp bias %0 %1 %2 %3" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : : "memory");
+  for (;;) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const uint32_t b0 = has_bias ? bq[nb][0] : 0u, b1 = has_bias ? bq[nb][1] : 0u;
+      const f32x4_t bini = {bf16_lo(b0), bf16_hi(b0), bf16_lo(b1), bf16_hi(b1)};
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = bini;
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wm) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
+    asm volatile("" ::: "memory");
+    // K-tile 0, peeled: its four counted waits leave the epilogue's 16 stores in flight as well.  Per wave the VMEM stream is
+    // [12 prologue pieces: half-tiles 0..5] [16 stores] [2 pieces per phase]; phase g needs half-tiles <= g + 2, behind which
+    // are (5 - (g + 2)) * 2 prologue pieces + 16 stores + 2 (g + 1) new pieces = 24, for every g.  (vmcnt retires in order:
+    // with the steady-state vmcnt(8) the FIRST load section of a tile would wait for the acknowledgement of the last store.)
+    // From K-tile 1 on the stores are older than everything a wait still needs: vmcnt(8).
+    {
+      const bool n2 = 2 < nkt;
+#undef OMNI_PP_VMCNT_LOOP
+#define OMNI_PP_VMCNT_LOOP "s_waitcnt vmcnt(24)"
+      OMNI_PP_READ_A(afx, 0u);
+      OMNI_PP_READ_W(0, (uint32_t)PSLOT_BYTES);
+      OMNI_PP_PHASE(0, 0, afx, true, true, 2, 1);
+      OMNI_PP_READ_W(1, (uint32_t)(2 * PSLOT_BYTES));
+      OMNI_PP_PHASE(1, 0, afx, true, true, 3, 1);
+      OMNI_PP_READ_A(afy, (uint32_t)(3 * PSLOT_BYTES));
+      OMNI_PP_PHASE(1, 1, afy, n2, true, 0, 2);
+      OMNI_PP_PHASE(0, 1, afy, n2, n2, 1, 2);
+#undef OMNI_PP_VMCNT_LOOP
+#if OMNI_PPP_ABL == 5   // timing ablation: no wait of the whole K-loop ever covers the stores (needed loads may still be in flight)
+#define OMNI_PP_VMCNT_LOOP "s_waitcnt vmcnt(24)"
+#else
+#define OMNI_PP_VMCNT_LOOP OMNI_PP_VMCNT
+#endif
+    }
+#pragma unroll 1
+    for (int t = 1; t < nkt; ++t) {
+      const uint32_t sb = (uint32_t)((t & 1) * 4 * PSLOT_BYTES);
+      const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;
+      OMNI_PP_READ_A(afx, sb);
+      OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
+      OMNI_PP_PHASE(0, 0, afx, n1, n1, 2, t + 1);
+      OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
+      OMNI_PP_PHASE(1, 0, afx, n1, n1, 3, t + 1);
+      OMNI_PP_READ_A(afy, sb + 3 * PSLOT_BYTES);
+      OMNI_PP_PHASE(1, 1, afy, n2, n1, 0, t + 2);
+      OMNI_PP_PHASE(0, 1, afy, n2, n2, 1, t + 2);
+      // asm MFMA results -> first compiler-visible VALU read: INSIDE the loop body, because hipcc moves accumulators between
+      // register sets on the loop's exit edge (v_mov of registers the last cluster has just written)
+      if (!n1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    }
+    if (!wm) __builtin_amdgcn_s_barrier();         // every wave is behind the last fragment read: the ring may be refilled
+    asm volatile("" ::: "memory");
+
+    // ---- seam: the finished tile's coordinates, then the next tile's loads, then the finished tile's epilogue ----
+    const int e_m0 = m0, e_n0 = n0;
+    uint16_t* const eo = gi ? P.g[1].out : P.g[0].out;
+    const int eM = gi ? P.g[1].M : P.g[0].M;
+    const int64_t eR = gi ? P.g[1].out_k32_rows : P.g[0].out_k32_rows;
+    const u32x4_t srd = gemm_srd(eo, (uint32_t)((int64_t)(N >> 5) * eR * 64));
+    int nslot = slot + slot_step;
+    while (nslot < xcount && skipped(nslot)) nslot += slot_step;
+    if (nslot >= xcount) {                         // last tile of this workgroup
+      gemm_epilogue_direct_k32_buf<EPI>(srd, eM, N, eR, acc, e_m0, e_n0, wm, wn, l15, g4);
+      return;
+    }
+    // straight-line from the bias loads to the counted wait (no control flow: see setup())
+    setup(nslot);
+    OMNI_PP_ISSUE(0, 0); OMNI_PP_ISSUE(1, 0); OMNI_PP_ISSUE(2, 0); OMNI_PP_ISSUE(3, 0);
+    OMNI_PP_ISSUE(0, 1); OMNI_PP_ISSUE(1, 1);
+#if OMNI_PPP_ABL == 1
+    {
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      const uint32_t voff = PPP_DROP;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(z), "v"(voff), "s"(srd) : "memory");
+    }
+#else
+    gemm_epilogue_direct_k32_buf<EPI>(srd, eM, N, eR, acc, e_m0, e_n0, wm, wn, l15, g4);
+#endif
+    // bias and half-tiles 0 / 1 of the next tile have landed: 8 DMA pieces and the 16 stores are younger
+    asm volatile("s_waitcnt vmcnt(24) ; omni ppp bias %0 %1 %2 %3" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : : "memory");
+    slot = nslot;
+  }
+}
+
+#undef OMNI_PP_VMCNT_LOOP
+#define OMNI_PP_VMCNT_LOOP OMNI_PP_VMCNT
+#endif  // OMNI_DEV (family 8)
+#undef OMNI_PP_PHASE
+#undef OMNI_PP_MMA
+#undef OMNI_PP_CLUSTER
+#undef OMNI_PP_CLUSTER_PART
+#undef OMNI_PP_READ_W
+#undef OMNI_PP_READ_A
+#undef OMNI_PP_ISSUE
+#undef OMNI_PP_ISSUE_PIECE
 
 // Split-K finish: one workgroup per output tile (the same workgroup -> tile map as the ping-pong kernel), phase 2 of the
 // row-coalesced epilogue with C taken from the fp32 partials.
@@ -2252,6 +2562,23 @@ bool gemm_persistent() {
   return v != 0;
 }
 
+#ifdef OMNI_DEV
+// The persistent ping-pong kernel (gemm_bf16_ppp_kernel) takes a launch when every group's output is K32-blocked without a row
+// map (the direct epilogue), the grid is deeper than one round of the CUs, K has at least two K-tiles and the outputs stay
+// below 2 GiB (32-bit descriptor offsets; PPP_DROP must be out of range).
+constexpr int OMNI_PPP_FAMILY = 8;
+bool gemm_persistent_direct(const omni_gemm_params* p, int tiles_m, int tiles_n) {
+  if (gemm_variant(p) != OMNI_PPP_FAMILY || p->fp8 || p->K / PBK < 2) return false;
+  if (tiles_m * tiles_n <= (gemm_num_cus() & ~7) || p->N % 32 != 0) return false;
+  for (int g = 0; g < p->ngroups; ++g) {
+    const omni_gemm_group& G = p->g[g];
+    if (!G.out_k32_rows || G.out_row_map || G.out_k32_rows < G.M) return false;
+    if ((int64_t)(p->N / 32) * G.out_k32_rows * 64 >= (1ll << 31)) return false;
+  }
+  return true;
+}
+#endif
+
 // Split-K factor for a launch of the ping-pong kernel, 1 = off.  On when the caller gave a workspace and the grid would leave
 // at least half of the chip idle (<= 128 tiles in <= 10 row tiles: a forward over one or two small images): the
 // largest s in {8, 6, 4, 3, 2} that divides the K-tile count, keeps tiles * s within one round of the CUs and fits the
@@ -2311,6 +2638,13 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI, 0, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
+#ifdef OMNI_DEV
+    if constexpr (EPI == OMNI_EPI_BIAS || EPI == OMNI_EPI_BIAS_GELU_TANH) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ppp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              RLDS_BYTES) != hipSuccess)
+        return OMNI_ERR_LAUNCH;
+    }
+#endif
     attr_set = true;
   }
   if (p->fp8) {
@@ -2361,6 +2695,17 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
                        tiles_n, gemm_group_m());
     OMNI_CHECK_LAUNCH();
     return OMNI_OK;
+  }
+#endif
+#ifdef OMNI_DEV
+  if constexpr (EPI == OMNI_EPI_BIAS || EPI == OMNI_EPI_BIAS_GELU_TANH) {
+    if (gemm_persistent_direct(p, tiles_m, tiles_n) && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
+      if (omni_dev_env_int("OMNI_PPP_TRACE", 0)) fprintf(stderr, "omni: persistent ping-pong launch, %d tiles\n", tiles_m * tiles_n);
+      hipLaunchKernelGGL((gemm_bf16_ppp_kernel<EPI>), dim3(gemm_num_cus() & ~7), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
+                         tiles_n, gemm_group_m());
+      OMNI_CHECK_LAUNCH();
+      return OMNI_OK;
+    }
   }
 #endif
   if (false) {

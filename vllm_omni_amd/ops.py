@@ -46,7 +46,7 @@ class GemmGroupArgs:
     def __init__(self, a, w, bias=None, out=None, *, a_row_map=None, out_row_map=None, out1=None, out2=None,
                  res=None, gate=None, gate_item_stride=0, row_item_map=None, rows_per_item=0,
                  a_k32_blocked=False, out_k32_blocked=False, qk_norm_q_w=None, qk_norm_k_w=None, qk_rope_cos=None,
-                 qk_rope_sin=None, qk_row_pos=None, qk_eps=1e-6, a_scale=None, w_scale=None):
+                 qk_rope_sin=None, qk_row_pos=None, qk_eps=1e-6, a_scale=None, w_scale=None, tile_skip=None):
         self.a_k32_blocked, self.out_k32_blocked = a_k32_blocked, out_k32_blocked
         self.a_scale, self.w_scale = a_scale, w_scale            # fp8 operands (gemm(..., fp8=True)): fp32 row / channel scales
         self.qk = (qk_norm_q_w, qk_norm_k_w, qk_rope_cos, qk_rope_sin, qk_row_pos, qk_eps)
@@ -54,6 +54,7 @@ class GemmGroupArgs:
         self.a_row_map, self.out_row_map, self.out1, self.out2 = a_row_map, out_row_map, out1, out2
         self.res, self.gate, self.gate_item_stride = res, gate, gate_item_stride
         self.row_item_map, self.rows_per_item = row_item_map, rows_per_item
+        self.tile_skip = tile_skip                                # int32 [ceil(M / 256)] device flags: non-zero = that row tile is skipped
 
 
 GEMM_KERNEL_AUTO, GEMM_KERNEL_RING, GEMM_KERNEL_SPLITK_TALL = 0, 1, 2      # omni_gemm_params.kernel_hint
@@ -117,6 +118,7 @@ def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0
         G.qk_row_pos, G.qk_eps = _p(pos, torch.int32, "qk_row_pos"), eps
         G.a_k32_rows = g.a.shape[0] if g.a_k32_blocked else 0       # blocked tensors keep their [rows, K] shape
         G.out_k32_rows = g.out.shape[0] if g.out_k32_blocked else 0
+        G.tile_skip = _p(g.tile_skip, torch.int32, "tile_skip")
     N.check(N.lib().omni_gemm_bf16(C.byref(p), _stream()), "omni_gemm_bf16")
 
 
