@@ -83,6 +83,32 @@ def test_a_failing_finish_request_answers_that_request_and_no_other():
     assert not b.has_work() and not b._pending
 
 
+def test_a_failing_sample_of_a_two_sample_request_aborts_it_once_and_spares_the_rest():
+    """Two samples of ONE request (num_outputs_per_prompt = 2) finish in the same step and the first one's `sample_result`
+    raises: the abort removes the sibling from `active` and the request from `_pending` — the loop over the step's group must
+    skip that sibling (it used to raise ValueError out of step(), which the worker answers by aborting EVERY request)."""
+    from _fake_pipeline import FakePipeline
+    from vllm_omni_amd.diffusion.step_batcher import ContinuousStepBatcher
+
+    class Flaky(FakePipeline):
+        def sample_result(self, a):
+            if a.tag == "boom" and a.sample["k"] == 0:
+                raise RuntimeError("device fault")
+            return super().sample_result(a)
+
+    b = ContinuousStepBatcher(Flaky(), max_items=4)
+    reqs = {"boom": _req(1, 2, n=2), "ok": _req(2, 2), "late": _req(3, 3)}
+    for k, r in reqs.items():
+        b.add(r, k)
+    done = b.drain()
+    assert sorted(t for t, _ in done) == sorted(reqs)                    # one answer per request, none twice
+    done = dict(done)
+    assert done["boom"].error and "device fault" in done["boom"].error
+    for k in ("ok", "late"):
+        assert done[k].error is None and torch.equal(done[k].output, _solo(reqs[k])), k
+    assert not b.has_work() and not b._pending
+
+
 def test_batch_keys_are_served_round_robin():
     """Mixed-resolution traffic: the forwards alternate between the keys instead of finishing the head group's whole loop first
     (round-3 verdict item 13), and more samples than `max_samples` of one key queue FIFO for the first free slot."""

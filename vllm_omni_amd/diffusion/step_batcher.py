@@ -144,6 +144,8 @@ class ContinuousStepBatcher:
             return self.abort({a.tag for a in group}, f"{type(e).__name__}: {e}")
         finished = []
         for a in group:
+            if a.tag not in self._pending:                  # a sibling sample's failure aborted this request earlier in the loop
+                continue
             a.step += 1
             if a.step >= a.n_steps:
                 self.active.remove(a)
