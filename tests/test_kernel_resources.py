@@ -1,0 +1,107 @@
+"""CPU: what the code-object loader will see for every product kernel — registers, scratch, LDS — read from the
+`.amdgpu_metadata` of the device assembly hipcc produces for each translation unit (no GPU needed; the same flags as the build).
+
+Why a test: the hot kernels are written against a register budget: the ping-pong GEMM needs both wave groups of
+its 512-thread workgroup resident (<= 256 registers per lane), the 64-queries-per-wave attention kernel and the VAE mid-block
+attention kernel own a whole SIMD's 512-entry file, the 4-wave conv tile runs two workgroups per CU.  A change that pushes a
+kernel over its budget still compiles and still passes every parity test — it just spills to scratch inside the K-loop and
+runs several times slower (the VAE attention kernel did exactly that before its Q fragments moved to AGPRs).  Without a GPU
+in the authoring container this listing is the only early warning."""
+import concurrent.futures as cf
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "vllm_omni_amd", "csrc")
+
+
+def _short(sym: str) -> str:
+    name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip() or sym
+    return re.sub(r"\(anonymous namespace\)::", "", name).split("(omni_")[0].split("(unsigned")[0].replace("void ", "")
+
+
+@pytest.fixture(scope="module")
+def listing():
+    from vllm_omni_amd.csrc import build as B
+
+    srcs = [os.path.join(CSRC, s) for s in B.SOURCES]
+    with cf.ThreadPoolExecutor(len(srcs)) as ex:
+        asms = list(ex.map(B.device_asm, srcs))
+    res, loops = {}, {}
+    for src, asm in zip(srcs, asms):
+        for sym, r in B.kernel_resources(asm).items():
+            res[_short(sym)] = dict(r, tu=os.path.basename(src))
+        for sym, lp in B.mfma_loops(asm).items():
+            loops[_short(sym)] = lp
+    return res, loops
+
+
+def _alloc(r):
+    """Registers per lane the hardware allocates: VGPRs and AGPRs share one 512-entry file per SIMD, granule 8
+    (MI355X_MICROARCH.md "Register files"); the metadata's `.vgpr_count` is the unified total (arch VGPRs up to the accum
+    offset + `.agpr_count` AGPRs: 208 + 256 = 464 for the w64 attention kernel)."""
+    assert r["agpr_count"] <= r["vgpr_count"]
+    return (r["vgpr_count"] + 7) // 8 * 8
+
+
+def test_every_kernel_is_found_and_fits_its_workgroup(listing):
+    res, _ = listing
+    assert len(res) >= 90, len(res)                                   # 35 GEMM + 3 attention + 36 elementwise + 23 VAE kernels today
+    for name, r in res.items():
+        waves_per_simd = -(-r["max_flat_workgroup_size"] // 64 // 4)   # one workgroup must fit on a CU
+        assert 512 // _alloc(r) >= waves_per_simd, (name, r)
+        assert r["group_segment_fixed_size"] <= 160 * 1024, (name, r)
+
+
+def test_no_kernel_spills_inside_its_mfma_loop(listing):
+    """Scratch is tolerated only OUTSIDE the innermost MFMA loops (today: a few dwords in the per-tile prologue / epilogue of the
+    small-grid attention kernel and in the norm-fusing epilogue of the 192-channel conv tile), and stays small."""
+    res, loops = listing
+    hot = {k: [lp for lp in v if lp["innermost"]] for k, v in loops.items()}
+    assert sum(len(v) for v in hot.values()) >= 40                     # GEMM K-loops, attention KV loops, conv K-loops
+    bad = {k: [lp for lp in v if lp["scratch"]] for k, v in hot.items()}
+    assert not {k: v for k, v in bad.items() if v}, bad
+    for name, r in res.items():
+        assert r["private_segment_fixed_size"] <= 128, (name, r["private_segment_fixed_size"])
+    allowed = ("flash_attn_fwd_pipe_kernel", "conv_bordered_kernel<4, 2, 4, 32, 2, true")
+    spilling = sorted(k for k, r in res.items() if r["private_segment_fixed_size"] or r["vgpr_spill_count"])
+    assert all(k.startswith(allowed) for k in spilling), spilling
+
+
+@pytest.mark.parametrize("prefix,max_regs,threads,why", [
+    ("gemm_bf16_pp_kernel", 256, 512, "8 waves = both ping-pong groups of a workgroup resident: 2 waves per SIMD"),
+    ("gemm_bf16_ring_kernel", 256, 512, "the fallback GEMM: the same 8-wave workgroup"),
+    ("flash_attn_fwd_w64_kernel", 512, 256, "one wave per SIMD owning the whole file (O / Q / K in literal AGPRs)"),
+    ("vae_attn_fwd_kernel", 512, 256, "one wave per SIMD: Q (96) + O^T (192) resident"),
+    ("flash_attn_fwd_pipe_kernel<8", 256, 512, "two waves per SIMD"),
+    ("conv_bordered_kernel<4, 1,", 256, 256, "the 4-wave tile runs TWO workgroups per CU"),
+    ("conv_bordered_kernel<4, 2,", 256, 512, "the 8-wave 192-channel tile"),
+    ("rownorm_kernel<6,", 168, 256, "AdaLN at D = 3072: three waves per SIMD keep the row loads of 12 rows per CU in flight"),
+])
+def test_hot_kernels_keep_their_register_budget(listing, prefix, max_regs, threads, why):
+    res, _ = listing
+    mine = {k: r for k, r in res.items() if k.startswith(prefix)}
+    assert mine, prefix
+    for name, r in mine.items():
+        assert r["max_flat_workgroup_size"] == threads, (name, r["max_flat_workgroup_size"], why)
+        assert _alloc(r) <= max_regs, (name, r["vgpr_count"], r["agpr_count"], why)
+
+
+def test_hot_loops_carry_the_instruction_mix_the_design_states(listing):
+    """a K-tile of the ping-pong GEMM = four clusters of 16 x v_mfma_f32_16x16x32_bf16 per wave (64 per loop trip,
+    32 scaled MFMAs in the fp8 build); the w64 attention KV tile = 2 x 32 MFMAs; the VAE attention tile = 24 + 24."""
+    _, loops = listing
+
+    def inner(prefix):
+        got = {k: [lp["mfma"] for lp in v if lp["innermost"]] for k, v in loops.items() if k.startswith(prefix)}
+        assert got, prefix
+        return got
+
+    for k, v in inner("gemm_bf16_pp_kernel").items():
+        fp8 = k.rstrip(">").endswith(", 1")
+        assert (32 if fp8 else 64) in v, (k, v)
+    assert any(m and m % 64 == 0 for v in inner("flash_attn_fwd_w64_kernel").values() for m in v)   # (the loop is unrolled over ring slots)
+    assert any(48 in v for v in inner("vae_attn_fwd_kernel").values())

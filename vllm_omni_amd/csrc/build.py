@@ -96,13 +96,97 @@ def mfma_loop_lane_spills(asm_lines) -> dict[str, int]:
     return out
 
 
+def kernel_resources(asm_lines) -> dict[str, dict[str, int]]:
+    """{kernel symbol: {vgpr_count, agpr_count, sgpr_count, vgpr_spill_count, sgpr_spill_count, private_segment_fixed_size,
+    group_segment_fixed_size, max_flat_workgroup_size}} from the `.amdgpu_metadata` block of a device-assembly listing — what
+    the code-object loader will see.  `tests/test_kernel_resources.py` holds every product kernel to its budget (no scratch,
+    the occupancy its launch bounds promise) without a GPU."""
+    out: dict[str, dict[str, int]] = {}
+    inmeta, cur = False, None
+    keys = ("vgpr_count", "agpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size",
+            "group_segment_fixed_size", "max_flat_workgroup_size")
+    for line in asm_lines:
+        if ".amdgpu_metadata" in line and ".end_amdgpu_metadata" not in line:
+            inmeta = True
+            continue
+        if ".end_amdgpu_metadata" in line:
+            inmeta = False
+        if not inmeta:
+            continue
+        if re.match(r"^\s*- \.agpr_count:", line) or re.match(r"^\s*- \.args:", line):      # first key of a kernel entry
+            if cur and "name" in cur:
+                out[cur.pop("name")] = cur
+            cur = {}
+        m = re.match(r"^\s*(?:- )?\.(\w+):\s*(\S+)\s*$", line)
+        if m and cur is not None:
+            k, v = m.group(1), m.group(2)
+            if k == "name" and "name" not in cur and v.startswith("_Z"):
+                cur["name"] = v
+            elif k in keys and k not in cur:
+                try:
+                    cur[k] = int(v)
+                except ValueError:
+                    pass
+    if cur and "name" in cur:
+        out[cur.pop("name")] = cur
+    return out
+
+
+_ASM_CACHE: dict[tuple[str, float], list[str]] = {}
+
+
 def device_asm(src: str) -> list[str]:
-    """Device assembly listing of one translation unit (for the build checks and their tests)."""
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "k.s")
-        subprocess.run([HIPCC, *FLAGS, "--cuda-device-only", "-S", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
-        with open(out) as f:
-            return f.read().splitlines()
+    """Device assembly listing of one translation unit (for the build checks and their tests); cached per (file, mtime) for
+    the life of the process — several tests look at the same listing."""
+    key = (os.path.abspath(src), os.path.getmtime(src))
+    if key not in _ASM_CACHE:
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "k.s")
+            subprocess.run([HIPCC, *FLAGS, "--cuda-device-only", "-S", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
+            with open(out) as f:
+                _ASM_CACHE[key] = f.read().splitlines()
+    return _ASM_CACHE[key]
+
+
+def mfma_loops(asm_lines) -> dict[str, list[dict]]:
+    """{function: [{"start", "end", "mfma", "scratch", "innermost"}, ...]} — every loop (backward branch) of a device-assembly
+    listing that issues MFMAs, with the number of scratch (spill) accesses inside it.  `innermost`: no other MFMA loop lies
+    inside — the K-loop / KV-loop proper, where a spill reload is per-iteration VMEM traffic whose `vmcnt` wait drains the
+    LDS-DMA in flight (the VAE attention kernel ran 10x slower that way before its Q fragments moved to AGPRs)."""
+    out: dict[str, list[dict]] = {}
+    fn, body = None, []
+    for line in asm_lines:
+        m = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if m and not m.group(1).startswith(".L"):
+            fn, body = m.group(1), []
+            continue
+        if fn is None:
+            continue
+        if not line.startswith(".Lfunc_end"):
+            body.append(line)
+            continue
+        labels = {}
+        for j, ln in enumerate(body):
+            lm = re.match(r"^(\.LBB\d+_\d+):", ln)
+            if lm:
+                labels[lm.group(1)] = j
+        loops = []
+        for j, ln in enumerate(body):
+            bm = re.search(r"\bs_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
+            if bm and labels.get(bm.group(1), j) < j:
+                a = labels[bm.group(1)]
+                if any("s_endpgm" in x for x in body[a:j]):            # an out-of-line entry block behind the kernel's end that
+                    continue                                          # jumps back into it: a backward branch, not a loop
+                nm = sum(1 for x in body[a:j] if "v_mfma" in x)
+                if nm:
+                    loops.append({"start": a, "end": j, "mfma": nm,
+                                  "scratch": sum(1 for x in body[a:j] if re.search(r"\b(scratch_|buffer_(load|store)\w* .*offen.*s\[0:3\])", x))})
+        for lp in loops:
+            lp["innermost"] = not any(o is not lp and o["start"] >= lp["start"] and o["end"] <= lp["end"] for o in loops)
+        if loops:
+            out[fn] = loops
+        fn = None
+    return out
 
 
 def check_agpr_ownership(src: str, verbose: bool = True) -> None:
