@@ -181,6 +181,13 @@ def mfma_loops(asm_lines) -> dict[str, list[dict]]:
                 if nm:
                     loops.append({"start": a, "end": j, "mfma": nm,
                                   "scratch": sum(1 for x in body[a:j] if re.search(r"\b(scratch_|buffer_(load|store)\w* .*offen.*s\[0:3\])", x))})
+        # several backward branches to ONE header are one natural loop (hipcc rotates loops: a conditional latch plus an
+        # out-of-line block that jumps back): keep the widest extent per header
+        widest: dict[int, dict] = {}
+        for lp in loops:
+            if lp["start"] not in widest or lp["end"] > widest[lp["start"]]["end"]:
+                widest[lp["start"]] = lp
+        loops = sorted(widest.values(), key=lambda d: (d["start"], d["end"]))
         for lp in loops:
             lp["innermost"] = not any(o is not lp and o["start"] >= lp["start"] and o["end"] <= lp["end"] for o in loops)
         if loops:
