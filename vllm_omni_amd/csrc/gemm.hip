@@ -1039,6 +1039,40 @@ OMNI_DEVINL void pp_mfma_fp8(f32x4_t& acc, const bf16x8_t& a_lo, const bf16x8_t&
   asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(one));
 #endif
 }
+// Dev-only timing probe (-DOMNI_DEV -DOMNI_PP_PROBE=1; tools/probe/pp_probe.cpp reads it back): every wave stamps s_memtime
+// (one tick = one shader cycle) at five points of every phase -
+//   T1 load section issued (fragment reads + this phase's two DMA pieces)   T2 counted DMA wait passed   T3 barrier + lgkmcnt(0)
+//   passed = first MFMA may issue   T4 last MFMA of the cluster issued   T5 closing barrier passed (= the next phase's start)
+// - and keeps the SUMS of each stamp over all phases in SGPRs (differences of the sums = cycles per segment; 32-bit wrap-around
+// cancels), plus the T3 / T4 of the four phases of the middle K-tile (the hand-off between the two waves of a SIMD: partner's T3
+// minus this wave's T4).  A stamp is consumed one phase later, at a point where the wave's lgkm queue holds nothing else (the end
+// of a cluster), so the probe adds no wait to the load sections: ~11 scalar instructions per phase.  Output: 16 uint32 per wave at
+// P.splitk_ws (the non-split launch does not use it; the harness passes splitk_ws_floats = 0).  Product builds: all of it is empty.
+#ifndef OMNI_PP_PROBE
+#define OMNI_PP_PROBE 0
+#endif
+#if OMNI_PP_PROBE
+#define OMNI_PP_STAMP(v) do { (v) = __builtin_amdgcn_s_memtime(); } while (0)
+// The additions are pinned between two empty volatile asm statements that "modify" the accumulators: as free C code hipcc sank
+// them below the closing barrier (and waited for the T5 stamp at the head of the next load section) or could hoist them to the
+// head of the cluster (a wait for T3 in front of the first MFMA).  Stamps and sums are 64-bit so that no half of a stamp's SGPR
+// pair is dead while its s_memtime is in flight (the allocator re-used the high half at once: a write-after-write wait).
+// Phase index of a quadrant: (mq, nq) = (0,0) (0,1) (1,1) (1,0) -> 0 1 2 3.
+#define OMNI_PP_PROBE_ACCUM(nq, mq)                                                                        \
+  do {                                                                                                     \
+    constexpr int ph_ = (mq) ? 3 - (nq) : (nq);                                                            \
+    asm volatile("" : "+s"(pb_s[0]), "+s"(pb_s[1]), "+s"(pb_s[2]), "+s"(pb_s[3]), "+s"(pb_s[4]));          \
+    pb_s[0] += pb_t1; pb_s[1] += pb_t2; pb_s[2] += pb_t3; pb_s[3] += pb_t4; pb_s[4] += pb_t5;              \
+    pb_snap3[ph_] = pb_snap ? (uint32_t)pb_t3 : pb_snap3[ph_];                                             \
+    pb_snap4[(ph_ + 3) & 3] = pb_snap ? (uint32_t)pb_t4 : pb_snap4[(ph_ + 3) & 3];                         \
+    asm volatile("" : "+s"(pb_s[0]), "+s"(pb_s[1]), "+s"(pb_s[2]), "+s"(pb_s[3]), "+s"(pb_s[4]),           \
+                      "+s"(pb_snap3[ph_]), "+s"(pb_snap4[(ph_ + 3) & 3]));                                  \
+    ++pb_ph;                                                                                               \
+  } while (0)
+#else
+#define OMNI_PP_STAMP(v) ((void)0)
+#define OMNI_PP_PROBE_ACCUM(nq, mq) ((void)0)
+#endif
 constexpr int PBK = 64;
 constexpr int PSLOT_BYTES = 128 * PBK * 2;    // 16 KiB per half-tile
 constexpr int PLDS_BYTES = 8 * PSLOT_BYTES;   // 128 KiB ring
@@ -1261,9 +1295,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
       if (landed_ok) asm volatile(OMNI_PP_VMCNT_LOOP ::: "memory");                                        \
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
     }                                                                                                      \
+    OMNI_PP_STAMP(pb_t2);                                                                                  \
     if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                                \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
+    OMNI_PP_STAMP(pb_t3);                                                                                  \
     if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                    \
     if (OMNI_PP_EARLY_BARRIER && OMNI_PP_MFMA16) {                                                         \
       /* the closing barrier is SIGNALLED OMNI_PP_EARLY_BARRIER MFMA pairs before the cluster's end: the partner group's */ \
@@ -1277,9 +1313,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
       __builtin_amdgcn_sched_barrier(0);                                                                   \
     } else {                                                                                               \
       OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1)                                                              \
+      OMNI_PP_PROBE_ACCUM(nq, mq); /* T1..T3 of this phase, T4 / T5 of the previous one: all landed long ago */ \
+      OMNI_PP_STAMP(pb_t4);                                                                                \
       if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                              \
+      OMNI_PP_STAMP(pb_t5);                                                                                \
     }                                                                                                      \
     asm volatile("" ::: "memory");                                                                         \
   } while (0)
@@ -1288,6 +1327,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   do {                                                                                                     \
     if (!OMNI_PP_DMA_IN_MMA) {                                                                             \
       if (do_issue) OMNI_PP_ISSUE(h, tile);                                                                \
+      OMNI_PP_STAMP(pb_t1);                                                                                \
       OMNI_PP_MMA(nq, mq, AF, do_issue, (void)0, (void)0);                                                 \
     } else {                                                                                               \
       OMNI_PP_MMA(nq, mq, AF, prev_issued, if (do_issue) OMNI_PP_ISSUE_PIECE(h, tile, 0),                  \
@@ -1298,8 +1338,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 #if OMNI_PP_BALANCED
   OMNI_PP_READ_A(afx, 0u);                      // mq-0 rows of K-tile 0 (half-tile 0 has landed)
 #endif
+#if OMNI_PP_PROBE
+  uint64_t pb_t1, pb_t2, pb_t3, pb_t4, pb_t5, pb_s[5] = {0u, 0u, 0u, 0u, 0u};
+  uint32_t pb_snap3[4] = {0u, 0u, 0u, 0u}, pb_snap4[4] = {0u, 0u, 0u, 0u};
+  uint32_t pb_ph = 0;
+  bool pb_snap = false;
+  OMNI_PP_STAMP(pb_t5);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const uint64_t pb_init = pb_t5;
+  pb_t4 = pb_t5;                               // the "previous phase" of phase 0: its T4 / T5 sums start with this stamp
+#endif
 #pragma unroll 1
   for (int t = 0; t < nkt; ++t) {
+#if OMNI_PP_PROBE
+    pb_snap = t == (nkt >> 1);                   // the middle K-tile: T3 of its four phases, T4 of its phases 0-2 (slot 3: the T4 before it)
+#endif
     const uint32_t sb = (uint32_t)((t & 1) * 4 * PSLOT_BYTES);
     const uint32_t sbn = (uint32_t)(((t + 1) & 1) * 4 * PSLOT_BYTES);
     const bool n1 = OMNI_PP_ABL != 2 && OMNI_PP_ABL != 6 && OMNI_PP_ABL != 7 && t + 1 < nkt,
@@ -1323,6 +1376,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   if (!wm) __builtin_amdgcn_s_barrier();         // group 0 waits for group 1's last cluster
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // asm MFMA results -> first compiler-visible VALU read
   // (the OMNI_PP_* loop macros stay defined for the persistent variant below, which repeats this loop; #undef'd behind it)
+#if OMNI_PP_PROBE
+  if (!SPLITK && P.splitk_ws) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    pb_s[3] += pb_t4; pb_s[4] += pb_t5;          // the last phase's T4 / T5 (every other one was added one phase late)
+    if (lane == 0) {
+      uint32_t* const o = reinterpret_cast<uint32_t*>(P.splitk_ws) + ((int64_t)blockIdx.x * 8 + wave) * 16;
+      o[0] = (uint32_t)pb_s[0]; o[1] = (uint32_t)pb_s[1]; o[2] = (uint32_t)pb_s[2]; o[3] = (uint32_t)pb_s[3]; o[4] = (uint32_t)pb_s[4];
+      o[5] = (uint32_t)pb_init; o[6] = (uint32_t)pb_t5; o[7] = pb_ph;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { o[8 + i] = pb_snap3[i]; o[12 + i] = pb_snap4[i]; }
+    }
+  }
+#endif
 
 #if OMNI_PP_MFMA16
   if (SPLITK) {
@@ -1354,6 +1420,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 #endif
 }
 
+
+#if OMNI_PP_PROBE   // the probe instruments the one-shot kernel only: the persistent variant below expands the same loop macros
+#undef OMNI_PP_STAMP
+#undef OMNI_PP_PROBE_ACCUM
+#define OMNI_PP_STAMP(v) ((void)0)
+#define OMNI_PP_PROBE_ACCUM(nq, mq) ((void)0)
+#endif
 
 #ifdef OMNI_DEV   // dev-only kernel family 8 (kernel_hint 16 + 8): measured NEUTRAL (round 4), kept for A/B runs and its ablations
 // ------------------------------------------------------------------------------------------------
