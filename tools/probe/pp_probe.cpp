@@ -7,6 +7,7 @@
 //
 //   build:  tools/probe/build_pp_probe.sh            (hipcc; also builds the probe variant of the library)
 //   run:    tools/probe/pp_probe [--iters 20] [--m 40960] lib1.so [lib2.so ...]
+//           tools/probe/pp_probe --sweep ref.so other.so ...     (bit-identity of the builds over ragged / small / large shapes)
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,14 +41,27 @@ __global__ void fill_bf16(uint16_t* p, size_t n, uint32_t seed, float scale) {
   }
 }
 
+// order-independent 64-bit digest of a buffer (sum of per-word hashes): equal digests of two builds = bit-identical outputs
+__global__ void digest_u32(const uint32_t* p, size_t n, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long h = (unsigned long long)p[i] * 0x9E3779B97F4A7C15ull + (unsigned long long)i * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 29;
+    acc += h * 0xBF58476D1CE4E5B9ull;
+  }
+  atomicAdd(out, acc);
+}
+
 typedef int (*gemm_fn)(const omni_gemm_params*, omni_stream);
 
 int main(int argc, char** argv) {
   int iters = 20, m_img = 40960, m_txt = 640, N = 12288, K = 3072;
+  bool sweep = false;
   std::vector<std::string> libs;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--m") && i + 1 < argc) m_img = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--sweep")) sweep = true;
     else libs.push_back(argv[i]);
   }
   if (libs.empty()) {
@@ -56,6 +70,8 @@ int main(int argc, char** argv) {
   }
   uint16_t *a0, *a1, *w0, *w1, *bias, *o0, *o1;
   uint32_t* probe;
+  unsigned long long* dig;
+  HIP_OK(hipMalloc(&dig, 8));
   const size_t tiles = ((size_t)(m_img + 255) / 256 + (size_t)(m_txt + 255) / 256) * ((N + 255) / 256);
   const size_t probe_words = tiles * 8 * 16;
   HIP_OK(hipMalloc(&a0, (size_t)m_img * K * 2));
@@ -84,6 +100,56 @@ int main(int argc, char** argv) {
   p.splitk_ws_floats = 0;
   const double flop = 2.0 * (m_img + m_txt) * (double)N * K;
 
+  if (sweep) {
+    // correctness sweep: every build must produce the digest of the FIRST one on every configuration (ragged M / N, one to many
+    // K-tiles, row-major and K32-blocked operands, bias and GELU epilogues, one and two groups)
+    struct Cfg { int m0, m1, n, k, epi, blocked; };
+    const Cfg cfgs[] = {
+        {40960, 640, 12288, 3072, 1, 1}, {40960, 640, 3072, 3072, 0, 1}, {20480, 320, 3072, 12288, 0, 1}, {40960, 640, 9216, 3072, 0, 1},
+        {4160, 0, 3072, 3072, 0, 0},     {4099, 77, 3072, 3072, 0, 0},   {1000, 0, 64, 3072, 0, 0},        {640, 0, 3072, 3584, 0, 0},
+        {2048, 64, 3072, 64, 0, 0},      {2048, 64, 3072, 128, 0, 0},    {2048, 64, 3072, 192, 0, 0},      {2048, 64, 3072, 256, 0, 0},
+        {2048, 64, 3072, 320, 0, 0},     {2048, 64, 3072, 384, 0, 1},    {2048, 64, 12288, 448, 1, 1},     {8192, 0, 4096, 8192, 0, 0},
+        {300, 0, 264, 3072, 1, 0},       {256, 256, 256, 512, 0, 1},
+    };
+    std::vector<gemm_fn> fns;
+    for (const std::string& path : libs) {
+      void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (!h) { fprintf(stderr, "dlopen %s: %s\n", path.c_str(), dlerror()); return 2; }
+      fns.push_back((gemm_fn)dlsym(h, "omni_gemm_bf16"));
+    }
+    int bad = 0;
+    for (const Cfg& c : cfgs) {
+      if ((size_t)c.m0 * c.k > (size_t)m_img * K || (size_t)c.n * c.k > (size_t)N * K || (size_t)c.m0 * c.n > (size_t)m_img * N ||
+          c.m1 > m_txt) { printf("skip %d+%d x %d x %d (buffers)\n", c.m0, c.m1, c.n, c.k); continue; }
+      omni_gemm_params q;
+      memset(&q, 0, sizeof(q));
+      q.ngroups = c.m1 ? 2 : 1; q.N = c.n; q.K = c.k; q.epilogue = c.epi; q.w_k32_blocked = c.blocked;
+      q.g[0].A = a0; q.g[0].lda = c.k; q.g[0].M = c.m0; q.g[0].W = w0; q.g[0].bias = bias; q.g[0].out = o0; q.g[0].ldo = c.n;
+      q.g[1].A = a1; q.g[1].lda = c.k; q.g[1].M = c.m1; q.g[1].W = w1; q.g[1].bias = bias; q.g[1].out = o1; q.g[1].ldo = c.n;
+      if (c.blocked) { q.g[0].a_k32_rows = c.m0; q.g[1].a_k32_rows = c.m1; }
+      if (c.blocked && c.n % 32 == 0) { q.g[0].out_k32_rows = c.m0; q.g[1].out_k32_rows = c.m1; }
+      unsigned long long first = 0;
+      printf("%6d+%-4d x %5d x %5d epi %d %s:", c.m0, c.m1, c.n, c.k, c.epi, c.blocked ? "k32-blocked" : "row-major  ");
+      for (size_t li = 0; li < fns.size(); ++li) {
+        HIP_OK(hipMemset(o0, 0x5a, (size_t)c.m0 * c.n * 2));
+        if (c.m1) HIP_OK(hipMemset(o1, 0x5a, (size_t)c.m1 * c.n * 2));
+        const int st = fns[li](&q, nullptr);
+        unsigned long long hd = 0;
+        HIP_OK(hipMemset(dig, 0, 8));
+        digest_u32<<<2048, 256>>>(reinterpret_cast<const uint32_t*>(o0), (size_t)c.m0 * c.n / 2, dig);
+        if (c.m1) digest_u32<<<64, 256>>>(reinterpret_cast<const uint32_t*>(o1), (size_t)c.m1 * c.n / 2, dig);
+        HIP_OK(hipMemcpy(&hd, dig, 8, hipMemcpyDeviceToHost));
+        if (li == 0) first = hd;
+        const bool ok = st == 0 && hd == first;
+        bad += !ok;
+        printf("  [%zu] st %d %016llx %s", li, st, hd, ok ? "ok" : "DIFFERS");
+      }
+      printf("\n");
+    }
+    printf("sweep: %s\n", bad ? "FAILED" : "all builds bit-identical to the first on every configuration");
+    return bad ? 3 : 0;
+  }
+
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
@@ -106,7 +172,13 @@ int main(int argc, char** argv) {
       float ms = 0;
       HIP_OK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / iters;
-      printf("round %d  %-60s %8.1f us  %7.1f TF/s\n", round, path.c_str(), us, flop / (us * 1e-6) / 1e12);
+      unsigned long long hd = 0;
+      HIP_OK(hipMemset(dig, 0, 8));
+      digest_u32<<<4096, 256>>>(reinterpret_cast<const uint32_t*>(o0), (size_t)m_img * N / 2, dig);
+      digest_u32<<<256, 256>>>(reinterpret_cast<const uint32_t*>(o1), (size_t)m_txt * N / 2, dig);
+      HIP_OK(hipMemcpy(&hd, dig, 8, hipMemcpyDeviceToHost));
+      printf("round %d  %-58s %8.1f us  %7.1f TF/s  out %016llx\n", round, path.c_str(), us, flop / (us * 1e-6) / 1e12, hd);
+      HIP_OK(hipMemset(o0, 0, (size_t)m_img * N * 2));   // the next build must write every element itself
       if (round == 1) {
         HIP_OK(hipMemset(probe, 0, probe_words * 4));
         gemm(&p, nullptr);

@@ -1051,6 +1051,9 @@ OMNI_DEVINL void pp_mfma_fp8(f32x4_t& acc, const bf16x8_t& a_lo, const bf16x8_t&
 #ifndef OMNI_PP_PROBE
 #define OMNI_PP_PROBE 0
 #endif
+#ifndef OMNI_PP_SCHED
+#define OMNI_PP_SCHED 1      // 1: the steady state of the K-loop runs the restructured loop (see gemm_bf16_pp_kernel); 0: the round-2..4 loop only
+#endif
 #if OMNI_PP_PROBE
 #define OMNI_PP_STAMP(v) do { (v) = __builtin_amdgcn_s_memtime(); } while (0)
 // The additions are pinned between two empty volatile asm statements that "modify" the accumulators: as free C code hipcc sank
@@ -1348,8 +1351,87 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   const uint64_t pb_init = pb_t5;
   pb_t4 = pb_t5;                               // the "previous phase" of phase 0: its T4 / T5 sums start with this stamp
 #endif
+  int t_first = 0;
+#if OMNI_PP_SCHED
+  // Dev variant (-DOMNI_DEV -DOMNI_PP_SCHED=<bits>; the default loop below is untouched): the steady state of the K-loop with
+  // everything the scalar unit decides per phase in the default loop made compile-time — the loop is unrolled by two K-tiles
+  // (ring parity = a constant), `t + 1 < nkt` / `t + 2 < nkt` hold by construction (the last two or three K-tiles run through
+  // the default loop), one running pointer per operand instead of `base + t * step` per phase, M0 = one s_add of a per-wave
+  // constant.  Static census (tools/loop_census.py): 75 SALU + 10 branches + 20 nop / setprio per K-tile -> see DESIGN item 29.
+  //   bit 0 (1): the restructured loop        bit 1 (2): a phase's DMA pieces are issued BEFORE its fragment reads
+  //   bit 2 (4): ... only by the waves with odd wn (the four load-group waves of a CU hit the TA in two batches, not one)
+  if constexpr (!SPLITK && !FP8 && OMNI_PP_MFMA16 && !OMNI_PP_BALANCED && !OMNI_PP_DMA_IN_MMA && OMNI_PP_ABL == 0) {
+    const uint32_t lds_w = lds0 + (uint32_t)(wave * 2048);           // this wave's two pieces inside a half-tile slot
+    const char* a_nx = Ab + astep;                                  // K-tile t + 1 of either operand (t = 0)
+    const char* w_nx = Wb + wstep;
+    const bool dma_first_rt = (OMNI_PP_SCHED & 4) ? (wn & 1) != 0 : (OMNI_PP_SCHED & 2) != 0;
+#define OMNI_PP_ISSUE_C(h, base, par)                                                                      \
+  do {                                                                                                     \
+    constexpr uint32_t so_ = (uint32_t)(((par) * 4 + (h)) * PSLOT_BYTES);                                  \
+    const uint32_t v0_ = ((h) == 0 || (h) == 3) ? a_off[(h) == 3][0] : w_off[(h) == 2][0];                 \
+    const uint32_t v1_ = ((h) == 0 || (h) == 3) ? a_off[(h) == 3][1] : w_off[(h) == 2][1];                 \
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                      \
+                 :: "s"(lds_w), "i"(so_), "v"(v0_), "s"(base) : "memory");                                 \
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                      \
+                 :: "s"(lds_w), "i"(so_ + 1024u), "v"(v1_), "s"(base) : "memory");                         \
+  } while (0)
+    // one K-tile of ring parity PAR whose successors t + 1 and t + 2 both exist; DF: DMA first
+    auto ktile = [&](auto par_c, auto df_c) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(par_c)::value;
+      constexpr bool DF = decltype(df_c)::value;
+      constexpr uint32_t sb = (uint32_t)(PAR * 4 * PSLOT_BYTES);
+      // phase 0: quadrant (mq 0, nq 0); DMA: half-tile 2 (W rows of nq 1) of K-tile t + 1
+      if (DF) OMNI_PP_ISSUE_C(2, w_nx, PAR ^ 1);
+      OMNI_PP_READ_A(afx, sb);
+      OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
+      if (!DF) OMNI_PP_ISSUE_C(2, w_nx, PAR ^ 1);
+      OMNI_PP_STAMP(pb_t1);
+      OMNI_PP_MMA(0, 0, afx, true, (void)0, (void)0);
+      // phase 1: quadrant (mq 0, nq 1); DMA: half-tile 3 (A rows of mq 1) of K-tile t + 1
+      if (DF) OMNI_PP_ISSUE_C(3, a_nx, PAR ^ 1);
+      OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
+      if (!DF) OMNI_PP_ISSUE_C(3, a_nx, PAR ^ 1);
+      OMNI_PP_STAMP(pb_t1);
+      OMNI_PP_MMA(1, 0, afx, true, (void)0, (void)0);
+      a_nx += astep;                                                // K-tile t + 2
+      w_nx += wstep;
+      // phase 2: quadrant (mq 1, nq 1); DMA: half-tile 0 (A rows of mq 0) of K-tile t + 2
+      if (DF) OMNI_PP_ISSUE_C(0, a_nx, PAR);
+      OMNI_PP_READ_A(afy, sb + 3 * PSLOT_BYTES);
+      if (!DF) OMNI_PP_ISSUE_C(0, a_nx, PAR);
+      OMNI_PP_STAMP(pb_t1);
+      OMNI_PP_MMA(1, 1, afy, true, (void)0, (void)0);
+      // phase 3: quadrant (mq 1, nq 0); DMA: half-tile 1 (W rows of nq 0) of K-tile t + 2
+      OMNI_PP_ISSUE_C(1, w_nx, PAR);
+      OMNI_PP_STAMP(pb_t1);
+      OMNI_PP_MMA(0, 1, afy, true, (void)0, (void)0);
+    };
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    if (dma_first_rt) {
 #pragma unroll 1
-  for (int t = 0; t < nkt; ++t) {
+      for (; t_first + 3 < nkt; t_first += 2) {
+#if OMNI_PP_PROBE
+        pb_snap = (t_first | 1) == ((nkt >> 1) | 1);
+#endif
+        ktile(c0{}, std::true_type{});
+        ktile(c1{}, std::true_type{});
+      }
+    } else {
+#pragma unroll 1
+      for (; t_first + 3 < nkt; t_first += 2) {
+#if OMNI_PP_PROBE
+        pb_snap = (t_first | 1) == ((nkt >> 1) | 1);
+#endif
+        ktile(c0{}, std::false_type{});
+        ktile(c1{}, std::false_type{});
+      }
+    }
+#undef OMNI_PP_ISSUE_C
+  }
+#endif
+#pragma unroll 1
+  for (int t = t_first; t < nkt; ++t) {
 #if OMNI_PP_PROBE
     pb_snap = t == (nkt >> 1);                   // the middle K-tile: T3 of its four phases, T4 of its phases 0-2 (slot 3: the T4 before it)
 #endif
