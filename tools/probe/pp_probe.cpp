@@ -6,7 +6,7 @@
 // (a fresh box pays 1-2 minutes for `import torch` alone).
 //
 //   build:  tools/probe/build_pp_probe.sh            (hipcc; also builds the probe variant of the library)
-//   run:    tools/probe/pp_probe [--iters 20] [--m 40960] lib1.so [lib2.so ...]
+//   run:    tools/probe/pp_probe [--iters 20] [--m 40960] [--n 12288] [--k 3072] [--epi 1] lib1.so [lib2.so ...]
 //           tools/probe/pp_probe --sweep ref.so other.so ...     (bit-identity of the builds over ragged / small / large shapes)
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -57,11 +57,15 @@ typedef int (*gemm_fn)(const omni_gemm_params*, omni_stream);
 int main(int argc, char** argv) {
   int iters = 20, m_img = 40960, m_txt = 640, N = 12288, K = 3072;
   bool sweep = false;
+  int epi = OMNI_EPI_BIAS_GELU_TANH;
   std::vector<std::string> libs;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--m") && i + 1 < argc) m_img = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--sweep")) sweep = true;
+    else if (!strcmp(argv[i], "--n") && i + 1 < argc) N = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--k") && i + 1 < argc) K = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--epi") && i + 1 < argc) epi = atoi(argv[++i]);
     else libs.push_back(argv[i]);
   }
   if (libs.empty()) {
@@ -91,7 +95,7 @@ int main(int argc, char** argv) {
 
   omni_gemm_params p;
   memset(&p, 0, sizeof(p));
-  p.ngroups = 2; p.N = N; p.K = K; p.epilogue = OMNI_EPI_BIAS_GELU_TANH; p.w_k32_blocked = 1;
+  p.ngroups = 2; p.N = N; p.K = K; p.epilogue = epi; p.w_k32_blocked = 1;
   p.g[0].A = a0; p.g[0].lda = K; p.g[0].M = m_img; p.g[0].W = w0; p.g[0].bias = bias; p.g[0].out = o0; p.g[0].ldo = N;
   p.g[0].a_k32_rows = m_img; p.g[0].out_k32_rows = m_img;
   p.g[1].A = a1; p.g[1].lda = K; p.g[1].M = m_txt; p.g[1].W = w1; p.g[1].bias = bias; p.g[1].out = o1; p.g[1].ldo = N;

@@ -959,7 +959,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
 // Same accumulator layout and the same k order as the ring kernel: results are bit-identical to it.
 // ------------------------------------------------------------------------------------------------
 #ifndef OMNI_PP_SETPRIO
-#define OMNI_PP_SETPRIO 1
+#define OMNI_PP_SETPRIO 0   // 1: s_setprio 1 / 0 around every MFMA cluster.  Off since round 4: with the restructured K-loop the same box measured
+                            // 0 .. +5 % without it on all four DiT shapes (profiles/r04_pp_sched_per_shape_timing.log; +0.5 % on the round-2 loop),
+                            // bit-identical either way — the load sections carry no VALU work the clusters would have to outrank
 #endif
 #ifndef OMNI_PP_VMCNT
 #define OMNI_PP_VMCNT "s_waitcnt vmcnt(8)"   // 4 half-tiles x 2 pieces per wave may stay in flight across a barrier
@@ -1072,9 +1074,11 @@ OMNI_DEVINL void pp_mfma_fp8(f32x4_t& acc, const bf16x8_t& a_lo, const bf16x8_t&
                       "+s"(pb_snap3[ph_]), "+s"(pb_snap4[(ph_ + 3) & 3]));                                  \
     ++pb_ph;                                                                                               \
   } while (0)
+#define OMNI_PP_PROBE_T5_FROM_EARLY() do { pb_t5 = pb_t5e; } while (0)
 #else
 #define OMNI_PP_STAMP(v) ((void)0)
 #define OMNI_PP_PROBE_ACCUM(nq, mq) ((void)0)
+#define OMNI_PP_PROBE_T5_FROM_EARLY() ((void)0)
 #endif
 constexpr int PBK = 64;
 constexpr int PSLOT_BYTES = 128 * PBK * 2;    // 16 KiB per half-tile
@@ -1310,8 +1314,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
       OMNI_PP_CLUSTER_PART(nq, mq, AF, 0, 8 - OMNI_PP_EARLY_BARRIER)                                       \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                              \
+      OMNI_PP_STAMP(pb_t5e);      /* (probe: T5 precedes T4 in this form: "barrier 2" = -(the tail MFMAs' issue time)) */ \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       OMNI_PP_CLUSTER_PART(nq, mq, AF, 8 - OMNI_PP_EARLY_BARRIER, 8)                                       \
+      OMNI_PP_PROBE_ACCUM(nq, mq);                                                                         \
+      OMNI_PP_PROBE_T5_FROM_EARLY();                                                                       \
+      OMNI_PP_STAMP(pb_t4);                                                                                \
       if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
     } else {                                                                                               \
@@ -1342,7 +1350,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   OMNI_PP_READ_A(afx, 0u);                      // mq-0 rows of K-tile 0 (half-tile 0 has landed)
 #endif
 #if OMNI_PP_PROBE
-  uint64_t pb_t1, pb_t2, pb_t3, pb_t4, pb_t5, pb_s[5] = {0u, 0u, 0u, 0u, 0u};
+  uint64_t pb_t1, pb_t2, pb_t3, pb_t4, pb_t5, pb_t5e = 0, pb_s[5] = {0u, 0u, 0u, 0u, 0u};
   uint32_t pb_snap3[4] = {0u, 0u, 0u, 0u}, pb_snap4[4] = {0u, 0u, 0u, 0u};
   uint32_t pb_ph = 0;
   bool pb_snap = false;
@@ -1506,8 +1514,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 #if OMNI_PP_PROBE   // the probe instruments the one-shot kernel only: the persistent variant below expands the same loop macros
 #undef OMNI_PP_STAMP
 #undef OMNI_PP_PROBE_ACCUM
+#undef OMNI_PP_PROBE_T5_FROM_EARLY
 #define OMNI_PP_STAMP(v) ((void)0)
 #define OMNI_PP_PROBE_ACCUM(nq, mq) ((void)0)
+#define OMNI_PP_PROBE_T5_FROM_EARLY() ((void)0)
 #endif
 
 #ifdef OMNI_DEV   // dev-only kernel family 8 (kernel_hint 16 + 8): measured NEUTRAL (round 4), kept for A/B runs and its ablations
