@@ -1214,7 +1214,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   }
 #endif
   if (nkt > 1) {
-    asm volatile(OMNI_PP_VMCNT ::: "memory");
+    if ((OMNI_PP_SCHED & 8) && !SPLITK && !FP8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // big phase A reads half-tiles 0-2 at once
+    else asm volatile(OMNI_PP_VMCNT ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -1360,7 +1361,95 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   pb_t4 = pb_t5;                               // the "previous phase" of phase 0: its T4 / T5 sums start with this stamp
 #endif
   int t_first = 0;
-#if OMNI_PP_SCHED
+#if (OMNI_PP_SCHED & 8)
+  // Dev variant (-DOMNI_DEV -DOMNI_PP_SCHED=9, NOT yet run on hardware): TWO big phases per K-tile instead of four — 32 MFMAs per
+  // cluster, half the barrier hand-offs per MFMA (with the short load section a slot is cluster + hand-off, and
+  // the hand-off is 45-100 cycles per 256-cycle cluster).
+  //   big phase A(t): issue h0, h1, h2 of K-tile t + 1 (t = 0: h2 only, the prologue has sent h0 / h1) | read h0, h1, h2 of K-tile t
+  //                   (16 fragment reads) | vmcnt(6) | B | quadrants (mq 0, nq 0), (mq 0, nq 1) | B
+  //   big phase B(t): issue h3 of K-tile t + 1 | read h3 of K-tile t (8 reads, into the registers of h0) | vmcnt(2) | B | quadrants
+  //                   (mq 1, nq 1), (mq 1, nq 0) | B
+  // Slots (group 0 loads in even slots, group 1 one slot later): h0-2(t) are read in slots 4t / 4t + 1, h3(t) in 4t + 2 / 4t + 3.
+  //   RAW: a wave's pieces of h0-2(t + 1) (sent in its L_A(t)) are covered by its wait at the end of its L_B(t): vmcnt(2) leaves only
+  //        h3(t + 1) in flight; the first read is group 0's in slot 4t + 4, behind both groups' covering waits (slots 4t + 2, 4t + 3) and
+  //        a barrier.  h3(t + 1) (sent in L_B(t)) is covered at the end of L_A(t + 1): vmcnt(6) leaves h0-2(t + 2) in flight; first read
+  //        in slot 4t + 6, the waits sit in slots 4t + 4 / 4t + 5.  t = 0: the prologue's order is h0-3(0), h0(1), h1(1) and L_A(0)
+  //        adds h2(1): vmcnt(6) again covers h3(0).  Last K-tile: nothing is sent, the waits are vmcnt(0).
+  //   WAR: h0-2(t + 1) overwrite h0-2(t - 1), last read in slot 4t - 3 (complete behind the barrier into 4t - 2), sent in slots 4t /
+  //        4t + 1; h3(t + 1) overwrites h3(t - 1), last read in slot 4t - 1, sent in slots 4t + 2 / 4t + 3: at least two barriers apart.
+  // Same MFMA order per accumulator as the four-phase loop: bit-identical results expected (check: tools/probe/pp_probe --sweep).
+  if constexpr (!SPLITK && !FP8 && OMNI_PP_MFMA16 && !OMNI_PP_BALANCED && !OMNI_PP_DMA_IN_MMA && OMNI_PP_ABL == 0 && !OMNI_PP_EARLY_BARRIER) {
+    const uint32_t lds_w = lds0 + (uint32_t)(wave * 2048);
+    const char* a_nx = Ab + astep;                                  // K-tile t + 1 of either operand
+    const char* w_nx = Wb + wstep;
+#define OMNI_PP_ISSUE_C(h, base, par)                                                                      \
+  do {                                                                                                     \
+    constexpr uint32_t so_ = (uint32_t)(((par) * 4 + (h)) * PSLOT_BYTES);                                  \
+    const uint32_t v0_ = ((h) == 0 || (h) == 3) ? a_off[(h) == 3][0] : w_off[(h) == 2][0];                 \
+    const uint32_t v1_ = ((h) == 0 || (h) == 3) ? a_off[(h) == 3][1] : w_off[(h) == 2][1];                 \
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                      \
+                 :: "s"(lds_w), "i"(so_), "v"(v0_), "s"(base) : "memory");                                 \
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                      \
+                 :: "s"(lds_w), "i"(so_ + 1024u), "v"(v1_), "s"(base) : "memory");                         \
+  } while (0)
+// two quadrants behind ONE barrier pair; `nxt`: pieces were sent in this load section (the counted wait is valid)
+#define OMNI_PP_BIGMMA(nqa, nqb, mq, AF, nxt, WAITSTR)                                                     \
+  do {                                                                                                     \
+    if (nxt) asm volatile(WAITSTR ::: "memory");                                                           \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+    OMNI_PP_STAMP(pb_t2);                                                                                  \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    OMNI_PP_STAMP(pb_t3);                                                                                  \
+    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                    \
+    OMNI_PP_CLUSTER(nqa, mq, AF, (void)0, (void)0)                                                         \
+    OMNI_PP_CLUSTER(nqb, mq, AF, (void)0, (void)0)                                                         \
+    OMNI_PP_PROBE_ACCUM(nqa, mq);                                                                          \
+    OMNI_PP_STAMP(pb_t4);                                                                                  \
+    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    OMNI_PP_STAMP(pb_t5);                                                                                  \
+    asm volatile("" ::: "memory");                                                                         \
+  } while (0)
+    auto bigtile = [&](auto par_c, const int t) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(par_c)::value;
+      constexpr uint32_t sb = (uint32_t)(PAR * 4 * PSLOT_BYTES);
+      const bool nxt = t + 1 < nkt;
+      // ---- big phase A
+      if (nxt) {
+        if (t > 0) { OMNI_PP_ISSUE_C(0, a_nx, PAR ^ 1); OMNI_PP_ISSUE_C(1, w_nx, PAR ^ 1); }
+        OMNI_PP_ISSUE_C(2, w_nx, PAR ^ 1);
+      }
+      OMNI_PP_READ_A(afx, sb);
+      OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
+      OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
+      OMNI_PP_STAMP(pb_t1);
+      OMNI_PP_BIGMMA(0, 1, 0, afx, nxt, "s_waitcnt vmcnt(6)");
+      // ---- big phase B
+      if (nxt) OMNI_PP_ISSUE_C(3, a_nx, PAR ^ 1);
+      OMNI_PP_READ_A(afy, sb + 3 * PSLOT_BYTES);
+      OMNI_PP_STAMP(pb_t1);
+      OMNI_PP_BIGMMA(1, 0, 1, afy, nxt, "s_waitcnt vmcnt(2)");
+      a_nx += astep;
+      w_nx += wstep;
+    };
+    if (nkt >= 2) {
+#pragma unroll 1
+      for (; t_first < nkt; t_first += 2) {
+#if OMNI_PP_PROBE
+        pb_snap = (t_first | 1) == ((nkt >> 1) | 1);
+#endif
+        bigtile(std::integral_constant<int, 0>{}, t_first);
+        if (t_first + 1 < nkt) bigtile(std::integral_constant<int, 1>{}, t_first + 1);
+      }
+      t_first = nkt;
+    }
+#undef OMNI_PP_BIGMMA
+#undef OMNI_PP_ISSUE_C
+  }
+#elif OMNI_PP_SCHED
   // Dev variant (-DOMNI_DEV -DOMNI_PP_SCHED=<bits>; the default loop below is untouched): the steady state of the K-loop with
   // everything the scalar unit decides per phase in the default loop made compile-time — the loop is unrolled by two K-tiles
   // (ring parity = a constant), `t + 1 < nkt` / `t + 2 < nkt` hold by construction (the last two or three K-tiles run through
