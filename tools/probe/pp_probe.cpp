@@ -6,7 +6,8 @@
 // (a fresh box pays 1-2 minutes for `import torch` alone).
 //
 //   build:  tools/probe/build_pp_probe.sh            (hipcc; also builds the probe variant of the library)
-//   run:    tools/probe/pp_probe [--iters 20] [--m 40960] [--n 12288] [--k 3072] [--epi 1] lib1.so [lib2.so ...]
+//   run:    tools/probe/pp_probe [--iters 20] [--m 40960] [--n 12288] [--k 3072] [--epi 0|1|2|4] lib1.so [lib2.so ...]
+//           (--epi 2: gated residual as out-proj / MLP-down run it; --epi 4 with --n 9216: the QKV projection with q/k norm + RoPE)
 //           tools/probe/pp_probe --sweep ref.so other.so ...     (bit-identity of the builds over ragged / small / large shapes)
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -100,6 +101,47 @@ int main(int argc, char** argv) {
   p.g[0].a_k32_rows = m_img; p.g[0].out_k32_rows = m_img;
   p.g[1].A = a1; p.g[1].lda = K; p.g[1].M = m_txt; p.g[1].W = w1; p.g[1].bias = bias; p.g[1].out = o1; p.g[1].ldo = N;
   p.g[1].a_k32_rows = m_txt; p.g[1].out_k32_rows = m_txt;
+  if (epi == OMNI_EPI_BIAS_GATE_RES) {
+    // out-proj / MLP-down as the DiT block runs them: res + gate[item] * (acc + bias), row-major output, one gate row per item
+    uint16_t *res0, *res1, *gate;
+    HIP_OK(hipMalloc(&res0, (size_t)m_img * N * 2));
+    HIP_OK(hipMalloc(&res1, (size_t)m_txt * N * 2));
+    HIP_OK(hipMalloc(&gate, (size_t)64 * N * 2));
+    fill_bf16<<<2048, 256>>>(res0, (size_t)m_img * N, 5u, 1.0f);
+    fill_bf16<<<256, 256>>>(res1, (size_t)m_txt * N, 6u, 1.0f);
+    fill_bf16<<<256, 256>>>(gate, (size_t)64 * N, 7u, 1.0f);
+    for (int g = 0; g < 2; ++g) {
+      p.g[g].out_k32_rows = 0;
+      p.g[g].res = g ? res1 : res0; p.g[g].ldres = N; p.g[g].gate = gate; p.g[g].gate_item_stride = N;
+      p.g[g].rows_per_item = g ? 64 : 4096;
+    }
+  }
+  if (epi == OMNI_EPI_BIAS_SPLIT3 || epi == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE) {
+    // the fused QKV projection: three row-major outputs of N / 3 columns; q / k additionally per-head RMS-normed and rotated
+    if (N % 384) { fprintf(stderr, "--epi 3 / 4 need N = 3 x (a multiple of 128)\n"); return 1; }
+    const int sn = N / 3, npos = 4160;
+    uint16_t *ob0, *ob1, *nw, *cs;
+    int32_t* pos;
+    HIP_OK(hipMalloc(&ob0, (size_t)m_img * sn * 2 * 2));            // out1, out2 of group 0
+    HIP_OK(hipMalloc(&ob1, (size_t)m_txt * sn * 2 * 2));
+    HIP_OK(hipMalloc(&nw, 2 * 128 * 2));
+    HIP_OK(hipMalloc(&cs, (size_t)2 * npos * 64 * 2));
+    HIP_OK(hipMalloc(&pos, (size_t)(m_img + m_txt) * 4));
+    fill_bf16<<<1, 256>>>(nw, 256, 8u, 1.0f);
+    fill_bf16<<<256, 256>>>(cs, (size_t)2 * npos * 64, 9u, 1.0f);
+    std::vector<int32_t> hp((size_t)m_img + m_txt);
+    for (size_t i = 0; i < hp.size(); ++i) hp[i] = (int32_t)(i % npos);
+    HIP_OK(hipMemcpy(pos, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+    p.split_n = sn;
+    for (int g = 0; g < 2; ++g) {
+      const size_t mg = g ? m_txt : m_img;
+      uint16_t* extra = g ? ob1 : ob0;
+      p.g[g].out_k32_rows = 0; p.g[g].ldo = sn;
+      p.g[g].out1 = extra; p.g[g].out2 = extra + mg * sn;
+      p.g[g].qk_norm_q_w = nw; p.g[g].qk_norm_k_w = nw + 128; p.g[g].qk_rope_cos = cs; p.g[g].qk_rope_sin = cs + (size_t)npos * 64;
+      p.g[g].qk_row_pos = pos + (g ? m_img : 0); p.g[g].qk_eps = 1e-6f;
+    }
+  }
   p.splitk_ws = reinterpret_cast<float*>(probe);      // read by probe builds only (splitk_ws_floats = 0: never a split-K workspace)
   p.splitk_ws_floats = 0;
   const double flop = 2.0 * (m_img + m_txt) * (double)N * K;
