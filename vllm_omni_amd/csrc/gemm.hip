@@ -1457,7 +1457,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   // constant.  Static census (tools/loop_census.py): 75 SALU + 10 branches + 20 nop / setprio per K-tile -> see DESIGN item 29.
   //   bit 0 (1): the restructured loop        bit 1 (2): a phase's DMA pieces are issued BEFORE its fragment reads
   //   bit 2 (4): ... only by the waves with odd wn (the four load-group waves of a CU hit the TA in two batches, not one)
-  if constexpr (!SPLITK && !FP8 && OMNI_PP_MFMA16 && !OMNI_PP_BALANCED && !OMNI_PP_DMA_IN_MMA && OMNI_PP_ABL == 0) {
+  if constexpr (!SPLITK && (!FP8 || (OMNI_PP_SCHED & 16)) && OMNI_PP_MFMA16 && !OMNI_PP_BALANCED && !OMNI_PP_DMA_IN_MMA && OMNI_PP_ABL == 0) {   // bit 4 (16): dev builds, also the fp8 instance (same LDS image and loop; not yet run)
     const uint32_t lds_w = lds0 + (uint32_t)(wave * 2048);           // this wave's two pieces inside a half-tile slot
     const char* a_nx = Ab + astep;                                  // K-tile t + 1 of either operand (t = 0)
     const char* w_nx = Wb + wstep;
