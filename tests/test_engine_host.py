@@ -235,3 +235,34 @@ def test_unseeded_request_gets_one_seed_before_the_sequence_parallel_fan_out():
     r3 = OmniDiffusionRequest(height=64, width=64, num_inference_steps=2, prompt_embeds=torch.zeros(1, 1, 8))
     eng.submit(r3)
     assert r3.seed is None
+
+
+def test_request_accepts_the_reference_spellings_of_picture_and_variant_inputs():
+    """A caller written against the reference passes `pil_image=`, `layers=`, `resolution=`, `cfg_normalize=`, `use_en_prompt=`
+    (vllm_omni/diffusion/request.py:33-38,70-79; read at pipeline_qwen_image_edit.py:64, pipeline_qwen_image_layered.py:69,668-671)
+    and the reference's default `prompt_embeds=[]`; this build's pipelines read `extra[...]`.  Both spellings must reach the same
+    code, an explicit `extra` entry wins, and the entry points keep the fields instead of dropping them as unknown kwargs."""
+    from PIL import Image
+
+    from vllm_omni_amd.diffusion.diffusion_engine import _request_to_cpu
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image_edit_plus import QwenImageEditPlusPipeline
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+    from vllm_omni_amd.entrypoints.omni_diffusion import prepare_requests
+
+    pic = Image.new("RGB", (640, 400))
+    r = prepare_requests("a prompt", pil_image=pic, layers=3, resolution=1024, cfg_normalize=True, use_en_prompt=True,
+                         prompt_embeds=[], no_such_field=1)
+    assert r.extra == {"image": pic, "layers": 3, "resolution": 1024, "cfg_normalize": True, "use_en_prompt": True}
+    assert r.prompt_embeds is None and r.pil_image is pic
+    assert OmniDiffusionRequest(pil_image=pic, extra={"image": "explicit"}).extra["image"] == "explicit"
+    t = torch.zeros(1, 3, 8, 8)
+    assert OmniDiffusionRequest(pil_image=pic, preprocessed_image=t).extra["image"] is t      # the pre-processed picture wins
+    one = torch.zeros(1, 4, 8)
+    assert OmniDiffusionRequest(prompt_embeds=[one]).prompt_embeds is one
+    # Edit-Plus: a LIST of pictures in `pil_image` is what `_prompt_pictures` resizes for the vision tower
+    shell = QwenImageEditPlusPipeline.__new__(QwenImageEditPlusPipeline)
+    got = shell._prompt_pictures(OmniDiffusionRequest(prompt="x", pil_image=[pic, Image.new("RGB", (300, 300))]))
+    assert len(got) == 2
+    # the engine sends host objects only: pictures pass through, tensors (also inside lists in `extra`) stay host tensors
+    q = _request_to_cpu(OmniDiffusionRequest(prompt="x", pil_image=[pic], extra={"image_latents": [torch.zeros(2, 64)]}))
+    assert q.pil_image == [pic] and not q.extra["image_latents"][0].is_cuda

@@ -25,11 +25,22 @@ from .request import OmniDiffusionRequest
 from .worker.gpu_worker import SHUTDOWN, WorkerProc
 
 
+def _cpu(v):
+    """Device tensors (also inside lists / tuples) -> host tensors; everything else unchanged."""
+    if isinstance(v, torch.Tensor):
+        return v.cpu() if v.is_cuda else v
+    if isinstance(v, (list, tuple)):
+        return type(v)(_cpu(x) for x in v)
+    return v
+
+
 def _request_to_cpu(req: OmniDiffusionRequest) -> OmniDiffusionRequest:
-    for f in ("latents", "prompt_embeds", "prompt_embeds_mask", "negative_prompt_embeds", "negative_prompt_embeds_mask"):
-        v = getattr(req, f, None)
-        if isinstance(v, torch.Tensor) and v.is_cuda:
-            setattr(req, f, v.cpu())
+    """Only host objects cross the process boundary to a worker (queues pickle their payload)."""
+    for f in ("latents", "prompt_embeds", "prompt_embeds_mask", "negative_prompt_embeds", "negative_prompt_embeds_mask",
+              "pil_image", "preprocessed_image", "prompt_image"):
+        setattr(req, f, _cpu(getattr(req, f, None)))
+    if req.extra:
+        req.extra = {k: _cpu(v) for k, v in req.extra.items()}
     if isinstance(req.generator, torch.Generator):          # generators do not pickle: carry the seed instead
         req.seed, req.generator = (req.seed if req.seed is not None else req.generator.initial_seed()), None
     return req
