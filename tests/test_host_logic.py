@@ -694,3 +694,30 @@ def test_layered_host_pieces_match_the_reference_run():
     assert tuple(img.shape) == (1, 3, want["calculated_height"], want["calculated_width"]) and (req.height, req.width) == (want["height"], want["width"])
     assert float(img[0, 0].min()) == 1.0 and float(img[0, 1].max()) == -1.0 and req.extra["prompt_image"].size == (want["calculated_width"], want["calculated_height"])
     assert get_diffusion_pre_process_func(OmniDiffusionConfig(model_class_name="QwenImagePipeline")) is None
+
+
+def test_request_and_config_accept_the_reference_field_names():
+    """Drop-in at the dataclass level: every field of the reference's OmniDiffusionConfig / DiffusionParallelConfig exists here
+    under the same name (a config written for the reference constructs unchanged; fields whose effect would change results are
+    refused when set, not ignored), and so does every OmniDiffusionRequest field the reference's Qwen-Image pipelines read.
+    Names: tests/golden/reference_field_names.json, generated from the reference sources by oracle/gen_field_names.py."""
+    import dataclasses
+    import json
+
+    from vllm_omni_amd.diffusion.data import DiffusionParallelConfig, OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_field_names.json")))
+    have = lambda cls: {f.name for f in dataclasses.fields(cls)}  # noqa: E731
+    assert not set(ref["OmniDiffusionConfig"]) - have(OmniDiffusionConfig)
+    assert not set(ref["DiffusionParallelConfig"]) - have(DiffusionParallelConfig)
+    assert not set(ref["request_fields_read_by_the_qwen_image_pipelines"]) - have(OmniDiffusionRequest)
+    # a reference-style config: server / offload / compile knobs are accepted and inert ...
+    cfg = OmniDiffusionConfig(model="Qwen/Qwen-Image", dit_cpu_offload=False, vae_use_slicing=True, enable_torch_compile=True,
+                              host="0.0.0.0", port=8091, log_level="debug", parallel_config={"ulysses_degree": 2})
+    assert cfg.num_gpus == 2 and cfg.parallel_config.ulysses_degree == 2
+    # ... and what would change the results is refused
+    for kw in (dict(lora_path="/adapters/x"), dict(vae_use_tiling=True), dict(VSA_sparsity=0.5), dict(use_fsdp_inference=True),
+               dict(override_transformer_cls_name="Other")):
+        with pytest.raises(NotImplementedError):
+            OmniDiffusionConfig(**kw)

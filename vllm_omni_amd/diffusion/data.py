@@ -103,8 +103,58 @@ class OmniDiffusionConfig:
                                      # of weights in every forward
     max_steps_in_flight: int = 2     # NEW: how many denoising steps a worker's host may enqueue ahead of the device
                                      # (step_batcher.py: bounded run-ahead, so that a newcomer joins within this many steps)
+    # ---- the reference's remaining fields (data.py:255-360), so that a config written for it constructs here unchanged.
+    # Inert here (nothing on this path depends on them, results are the same either way): executor / server plumbing, HF hub
+    # options, CPU-offload and pinning switches (41 GB of weights stay resident in 288 GB of HBM), VAE slicing, torch.compile
+    # (there is no tracing compiler: kernels are hand-written), logging.  Fields that would CHANGE results if honoured — LoRA,
+    # FSDP / HSDP sharding, the sparse-attention variants, VAE tiling, another transformer class, the Wan-only schedule knobs —
+    # are refused when set away from the reference's defaults (`__post_init__`), never silently ignored.
+    cache_strategy: str = "none"
+    distributed_executor_backend: str = "mp"
+    nccl_port: int | None = None
+    trust_remote_code: bool = False
+    revision: str | None = None
+    hsdp_replicate_dim: int = 1
+    hsdp_shard_dim: int = -1
+    lora_path: str | None = None
+    lora_nickname: str = "default"
+    lora_target_modules: list[str] | None = None
+    dit_cpu_offload: bool = True
+    use_fsdp_inference: bool = False
+    text_encoder_cpu_offload: bool = True
+    image_encoder_cpu_offload: bool = True
+    vae_cpu_offload: bool = True
+    pin_cpu_memory: bool = True
+    vae_use_slicing: bool = False
+    vae_use_tiling: bool = False
+    mask_strategy_file_path: str | None = None
+    skip_time_steps: int = 15
+    enable_torch_compile: bool = False
+    disable_autocast: bool = False
+    VSA_sparsity: float = 0.0
+    moba_config_path: str | None = None
+    host: str | None = None
+    port: int | None = None
+    scheduler_port: int = 5555
+    enable_stage_verification: bool = True
+    prompt_file_path: str | None = None
+    model_paths: dict[str, str] = field(default_factory=dict)
+    model_loaded: dict[str, bool] = field(default_factory=lambda: {"transformer": True, "vae": True})
+    override_transformer_cls_name: str | None = None
+    boundary_ratio: float | None = None
+    flow_shift: float | None = None
+    supports_multimodal_inputs: bool = False
+    log_level: str = "info"
+
+    _REFUSED = {"lora_path": None, "use_fsdp_inference": False, "hsdp_replicate_dim": 1, "hsdp_shard_dim": -1,
+                "mask_strategy_file_path": None, "VSA_sparsity": 0.0, "moba_config_path": None, "vae_use_tiling": False,
+                "override_transformer_cls_name": None, "boundary_ratio": None, "flow_shift": None}
 
     def __post_init__(self):
+        changed = sorted(k for k, dflt in self._REFUSED.items() if getattr(self, k) != dflt)
+        if changed:
+            raise NotImplementedError(f"{changed}: not built on the MI355X path, and honouring them would change the results — "
+                                      "refused instead of ignored")
         if isinstance(self.parallel_config, dict):
             self.parallel_config = DiffusionParallelConfig.from_dict(self.parallel_config)
         if not isinstance(self.tf_model_config, TransformerConfig):

@@ -46,6 +46,17 @@ def _request_to_cpu(req: OmniDiffusionRequest) -> OmniDiffusionRequest:
     return req
 
 
+def _free_port() -> int:
+    """A TCP port nobody listens on right now (the reference probes upwards from a base port, data.py:360-391 `settle_port`;
+    here the kernel picks one): the workers' rendezvous port when `od_config.master_port` is not given.  Two engines started in
+    the same millisecond — `bench.py --gpus N` next to another job — no longer meet on a clock-derived port."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
 class DiffusionEngine:
     def __init__(self, od_config: OmniDiffusionConfig, pipeline_factory: Callable[[], Any] | None = None,
                  post_process_func: Callable | None | str = "default", pre_process_func: Callable | None = None,
@@ -73,7 +84,7 @@ class DiffusionEngine:
         self._results: dict[int, DiffusionOutput] = {}
         self._rpc_results: dict[int, dict[int, Any]] = {}
         self._closed = False
-        port = od_config.master_port or (29600 + (int(time.time() * 1000) % 2000))
+        port = od_config.master_port or _free_port()
         self._processes = [self._ctx.Process(target=WorkerProc.worker_main, name=f"DiffusionWorker-{r}", daemon=True,
                                              args=(r, self.num_gpus, od_config, self._inbox[r], self._outbox, self._ready,
                                                    pipeline_factory, port))
