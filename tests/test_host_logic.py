@@ -721,3 +721,34 @@ def test_request_and_config_accept_the_reference_field_names():
                dict(override_transformer_cls_name="Other")):
         with pytest.raises(NotImplementedError):
             OmniDiffusionConfig(**kw)
+
+
+def test_small_surface_pieces_a_reference_side_caller_may_touch():
+    """Names a caller or plug-in written against the reference uses next to the big contracts: OmniRequestOutput's counters and
+    `to_dict` (the image endpoint serialises them, outputs.py:119-152), `from_pipeline`, the cache selector's keyword names
+    (cache/selector.py:9), the parallel-strategy Protocol (attention/parallel/base.py:25-58), the backend's builder hook
+    (backends/abstract.py:31-34), `GPUWorker.generate` / `shutdown` (gpu_worker.py:109-140)."""
+    from vllm_omni_amd.diffusion.attention.backends.cdna4_flash import CDNA4FlashBackend
+    from vllm_omni_amd.diffusion.attention.parallel.base import NoParallelAttention, ParallelAttentionStrategy
+    from vllm_omni_amd.diffusion.attention.parallel.ulysses import UlyssesParallelAttention
+    from vllm_omni_amd.diffusion.cache.selector import get_cache_backend
+    from vllm_omni_amd.diffusion.distributed.comm import SeqAllToAll4D, SeqAllToAll5D
+    from vllm_omni_amd.diffusion.worker.gpu_worker import GPUWorker
+    from vllm_omni_amd.outputs import OmniRequestOutput
+
+    o = OmniRequestOutput.from_diffusion("r1", images=["a", "b"], prompt="p", metrics={"steps": 20})
+    assert o.num_images == 2 and o.is_diffusion_output and not o.is_pipeline_output
+    assert o.to_dict() == {"request_id": "r1", "finished": True, "final_output_type": "image", "num_images": 2, "prompt": "p",
+                           "metrics": {"steps": 20}}
+    assert "2 images" in repr(o)
+    stage = type("RO", (), {"request_id": "r2"})()
+    p = OmniRequestOutput.from_pipeline(stage_id=1, final_output_type="text", request_output=stage)
+    assert p.request_id == "r2" and p.is_pipeline_output and p.to_dict()["stage_id"] == 1 and not p.is_diffusion_output
+    assert get_cache_backend(cache_backend="none", cache_config={}) is None and get_cache_backend(None, None) is None
+    assert type(get_cache_backend(cache_backend="tea_cache", cache_config={"rel_l1_thresh": 0.2})).__name__ == "TeaCacheBackend"
+    assert isinstance(NoParallelAttention(), ParallelAttentionStrategy) and isinstance(UlyssesParallelAttention(), ParallelAttentionStrategy)
+    assert CDNA4FlashBackend.get_builder_cls() is None and CDNA4FlashBackend.get_supported_head_sizes() == [128]
+    x = torch.arange(24.0).reshape(1, 2, 3, 4)
+    assert torch.equal(SeqAllToAll4D.forward(None, None, x, 2, 1), x)             # no process group: the identity
+    assert torch.equal(SeqAllToAll5D.forward(None, None, x.unsqueeze(2), 3, 1), x.unsqueeze(2))
+    assert callable(GPUWorker.generate) and callable(GPUWorker.shutdown)

@@ -67,6 +67,12 @@ class AttentionBackend(abc.ABC):
         return AttentionMetadata
 
     @classmethod
+    def get_builder_cls(cls):
+        """The reference declares a metadata-builder hook (abstract.py:31-34) that nothing on the diffusion path calls; a
+        backend has none unless it says so."""
+        return None
+
+    @classmethod
     def get_supported_head_sizes(cls) -> list[int]:
         return list(cls.HEAD_SIZES)
 

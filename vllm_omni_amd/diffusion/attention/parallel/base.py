@@ -3,11 +3,23 @@ backend — `pre_attention` reshards q/k/v before the kernel, `post_attention` r
 from __future__ import annotations
 
 from dataclasses import dataclass
+from typing import Any, Protocol, runtime_checkable
 
 
 @dataclass(frozen=True)
 class ParallelAttentionContext:
     name: str
+
+
+@runtime_checkable
+class ParallelAttentionStrategy(Protocol):
+    """What a strategy object offers (typing contract; `UlyssesParallelAttention` and `NoParallelAttention` satisfy it)."""
+    enabled: bool
+    name: str
+
+    def pre_attention(self, query: Any, key: Any, value: Any, attn_metadata: Any) -> tuple: ...
+
+    def post_attention(self, attn_output: Any, ctx: Any) -> Any: ...
 
 
 class NoParallelAttention:

@@ -6,7 +6,8 @@ from __future__ import annotations
 from .base import CacheBackend
 
 
-def get_cache_backend(name: str | None, config) -> CacheBackend | None:
+def get_cache_backend(cache_backend: str | None, cache_config=None) -> CacheBackend | None:
+    name, config = cache_backend, cache_config            # (the reference's parameter names: keyword callers keep working)
     if name in (None, "", "none"):
         return None
     if name in ("tea_cache", "teacache"):

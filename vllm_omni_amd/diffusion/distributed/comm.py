@@ -62,8 +62,16 @@ class SeqAllToAll4D:
     def apply(group, input, scatter_idx: int, gather_idx: int, use_sync: bool = False):
         return all_to_all_4D(input, scatter_idx, gather_idx, group=group, use_sync=use_sync)
 
+    @staticmethod
+    def forward(ctx, group, input, scatter_idx: int, gather_idx: int, use_sync: bool = False):
+        return all_to_all_4D(input, scatter_idx, gather_idx, group=group, use_sync=use_sync)
+
 
 class SeqAllToAll5D:
     @staticmethod
     def apply(group, input, scatter_idx: int = 3, gather_idx: int = 1, use_sync: bool = False):
+        return all_to_all_5D(input, scatter_idx, gather_idx, group=group, use_sync=use_sync)
+
+    @staticmethod
+    def forward(ctx, group, input, scatter_idx: int = 3, gather_idx: int = 1, use_sync: bool = False):
         return all_to_all_5D(input, scatter_idx, gather_idx, group=group, use_sync=use_sync)

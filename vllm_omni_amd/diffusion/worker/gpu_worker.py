@@ -65,6 +65,15 @@ class GPUWorker:
     def is_ready(self) -> bool:
         return self.pipeline is not None
 
+    def generate(self, requests: list[OmniDiffusionRequest]) -> DiffusionOutput:
+        """Reference name for `execute_model(requests, self.od_config)` (gpu_worker.py:109-119)."""
+        return self.execute_model(requests, self.od_config)
+
+    def shutdown(self) -> None:
+        """Leave the process group (reference :139-140 `destroy_distributed_env`)."""
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+
     @torch.inference_mode()
     def execute_model(self, reqs: list[OmniDiffusionRequest], od_config: OmniDiffusionConfig | None = None,
                       output_rank: int = 0, decode: bool = True) -> DiffusionOutput:
