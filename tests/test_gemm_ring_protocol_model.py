@@ -1,0 +1,132 @@
+"""CPU: the LDS-ring protocol of the ping-pong GEMM as an epoch model — every read of a half-tile happens behind a counted wait
+of EVERY wave that sent a piece of it plus a barrier (RAW), and no piece of the next occupant of a ring slot is sent before every
+wave's reads of the previous occupant have completed (WAR).  The kernel comments derive both by hand (csrc/gemm.hip
+"Ping-pong variant": RAW / WAR; the two-big-phase dev variant `-DOMNI_PP_SCHED=9` has its own derivation); this test replays the
+schedules mechanically for 1..12 K-tiles, both wave groups, first and last tiles included.
+
+Model.  A wave's program is a list of actions; `B` is the workgroup barrier.  Epoch k of a wave = after its k-th barrier, before
+its (k+1)-th; actions of different waves in the same epoch are concurrent.  Group 1 executes one extra barrier before the loop
+(it runs one slot behind), group 0 one after it.  `ISSUE (t, h)`: two LDS-DMA pieces of half-tile h of K-tile t into ring slot
+(t & 1) * 4 + h; they land at an unknown time before the wave's first later `WAIT n` that leaves at most n younger pieces in
+flight (vmcnt retires in order).  `READ (t, h)`: fragment reads, complete at the `lgkmcnt(0)` that follows the NEXT barrier.
+  RAW: a READ in epoch kr needs, for every wave group, a covering WAIT in an epoch kw < kr (own pieces: earlier in the program).
+  WAR: an ISSUE in epoch ki into the slot of X needs every other wave's reads of X issued in epochs kr <= ki - 2 (own: kr < ki).
+The schedules below restate the kernel's loops (what is sent / read in which phase); if a loop changes, this table changes with it."""
+import pytest
+
+
+def four_phase(nkt: int, group: int):
+    """The product loop (steady state and tail send / read the same half-tiles in the same phases)."""
+    prog = [("ISSUE", (0, h)) for h in range(4)]
+    if nkt > 1:
+        prog += [("ISSUE", (1, 0)), ("ISSUE", (1, 1))]
+    prog += [("WAIT", 8 if nkt > 1 else 0), ("B",)]
+    if group == 1:
+        prog.append(("B",))
+    for t in range(nkt):
+        n1, n2 = t + 1 < nkt, t + 2 < nkt
+        phases = [([(t, 0), (t, 1)], (t + 1, 2) if n1 else None),
+                  ([(t, 2)], (t + 1, 3) if n1 else None),
+                  ([(t, 3)], (t + 2, 0) if n2 else None),
+                  ([], (t + 2, 1) if n2 else None)]
+        for reads, send in phases:
+            prog += [("READ", r) for r in reads]
+            if send is not None:
+                prog.append(("ISSUE", send))
+            prog += [("WAIT", 8 if send is not None else 0), ("B",), ("MFMA",), ("B",)]
+    if group == 0:
+        prog.append(("B",))
+    return prog
+
+
+def two_big_phases(nkt: int, group: int):
+    """-DOMNI_PP_SCHED=9: big phase A sends h0-2 of the next K-tile and reads h0-2, big phase B sends and reads h3."""
+    if nkt < 2:
+        return four_phase(nkt, group)
+    prog = [("ISSUE", (0, h)) for h in range(4)] + [("ISSUE", (1, 0)), ("ISSUE", (1, 1)), ("WAIT", 6), ("B",)]
+    if group == 1:
+        prog.append(("B",))
+    for t in range(nkt):
+        nxt = t + 1 < nkt
+        if nxt:
+            if t > 0:
+                prog += [("ISSUE", (t + 1, 0)), ("ISSUE", (t + 1, 1))]
+            prog.append(("ISSUE", (t + 1, 2)))
+        prog += [("READ", (t, 0)), ("READ", (t, 1)), ("READ", (t, 2)), ("WAIT", 6 if nxt else 0), ("B",), ("MFMA",), ("B",)]
+        if nxt:
+            prog.append(("ISSUE", (t + 1, 3)))
+        prog += [("READ", (t, 3)), ("WAIT", 2 if nxt else 0), ("B",), ("MFMA",), ("B",)]
+    if group == 0:
+        prog.append(("B",))
+    return prog
+
+
+def analyse(prog):
+    """-> (epoch of every action, {half-tile: epoch + position of its covering wait}, barrier count)."""
+    epoch, pos, issued, covered, sends, reads = 0, 0, [], {}, {}, {}
+    for act in prog:
+        if act[0] == "B":
+            epoch += 1
+        elif act[0] == "ISSUE":
+            issued += [act[1], act[1]]                                   # two pieces
+            sends[act[1]] = (epoch, pos)
+        elif act[0] == "WAIT":
+            landed = issued[: len(issued) - act[1]] if act[1] else issued
+            for ht in landed:
+                covered.setdefault(ht, (epoch, pos))
+        elif act[0] == "READ":
+            reads.setdefault(act[1], []).append((epoch, pos))
+        pos += 1
+    return sends, covered, reads, epoch
+
+
+@pytest.mark.parametrize("schedule", [four_phase, two_big_phases], ids=["product_four_phase", "dev_two_big_phases"])
+@pytest.mark.parametrize("nkt", list(range(1, 13)))
+def test_ring_protocol_has_no_raw_or_war_hazard(schedule, nkt):
+    groups = [analyse(schedule(nkt, g)) for g in (0, 1)]
+    assert groups[0][3] == groups[1][3], "both wave groups must execute the same number of barriers"
+    for w, (sends_w, covered_w, reads_w, _) in enumerate(groups):
+        assert set(reads_w) == {(t, h) for t in range(nkt) for h in range(4)}, "every half-tile is read"
+        assert all(len(v) == 1 for v in reads_w.values()), "every half-tile is read in exactly one phase"
+        assert set(sends_w) == set(reads_w), "every half-tile is sent exactly once"
+        for ht, [(kr, pr)] in reads_w.items():
+            for v, (_s, covered_v, _r, _) in enumerate(groups):
+                assert ht in covered_v, (ht, "never covered by a wait of group", v)
+                kw, pw = covered_v[ht]
+                ok = (kw < kr) if v != w else (kw < kr or (kw == kr and pw < pr))
+                assert ok, f"RAW: {schedule.__name__} nkt={nkt}: group {w} reads {ht} in epoch {kr}, group {v}'s wait is in epoch {kw}"
+        for (t, h), (ki, pi) in sends_w.items():
+            if t < 2:
+                continue                                                  # first occupants of their slots
+            prev = (t - 2, h)
+            for v, (_s, _c, reads_v, _) in enumerate(groups):
+                [(kr, pr)] = reads_v[prev]
+                ok = (kr <= ki - 2) if v != w else (kr < ki)
+                assert ok, f"WAR: {schedule.__name__} nkt={nkt}: group {w} sends {(t, h)} in epoch {ki}, group {v} read {prev} in epoch {kr}"
+        # nothing may still be in flight when the K-loop is over (the epilogue reuses the ring's LDS)
+        assert set(covered_w) == set(sends_w)
+
+
+def test_the_model_catches_a_broken_schedule():
+    """Sanity of the checker itself: sending h0 / h1 of K-tile t + 2 in big phase B (one slot after the partner group read their
+    previous occupants) is the WAR hazard the two-big-phase schedule avoids by sending them in phase A of the next K-tile."""
+    def broken(nkt, group):
+        prog = [("ISSUE", (0, h)) for h in range(4)] + [("ISSUE", (1, 0)), ("ISSUE", (1, 1)), ("WAIT", 6), ("B",)]
+        if group == 1:
+            prog.append(("B",))
+        for t in range(nkt):
+            nxt, nx2 = t + 1 < nkt, t + 2 < nkt
+            if nxt:
+                prog.append(("ISSUE", (t + 1, 2)))
+            prog += [("READ", (t, 0)), ("READ", (t, 1)), ("READ", (t, 2)), ("WAIT", 2 if nxt else 0), ("B",), ("MFMA",), ("B",)]
+            if nxt:
+                prog.append(("ISSUE", (t + 1, 3)))
+            if nx2:
+                prog += [("ISSUE", (t + 2, 0)), ("ISSUE", (t + 2, 1))]
+            prog += [("READ", (t, 3)), ("WAIT", 4 if nx2 else 0), ("B",), ("MFMA",), ("B",)]
+        if group == 0:
+            prog.append(("B",))
+        return prog
+
+    with pytest.raises(AssertionError, match="WAR"):
+        test_ring_protocol_has_no_raw_or_war_hazard(broken, 6)
