@@ -1413,37 +1413,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
     OMNI_PP_STAMP(pb_t5);                                                                                  \
     asm volatile("" ::: "memory");                                                                         \
   } while (0)
-    auto bigtile = [&](auto par_c, const int t) __attribute__((always_inline)) {
+    // A K-tile that has a successor (everything but the last): ring parity compile-time, `first` (K-tile 0: the prologue has
+    // already sent h0 / h1 of K-tile 1) one uniform branch.  (Six fully compile-time instances — first / steady x 2 / single /
+    // last x 2 — made hipcc spill 200+ VGPRs: too many merge points for 128 accumulators; this form allocates 221, no spill.)
+    auto bigtile = [&](auto par_c, const bool first) __attribute__((always_inline)) {
       constexpr int PAR = decltype(par_c)::value;
       constexpr uint32_t sb = (uint32_t)(PAR * 4 * PSLOT_BYTES);
-      const bool nxt = t + 1 < nkt;
       // ---- big phase A
-      if (nxt) {
-        if (t > 0) { OMNI_PP_ISSUE_C(0, a_nx, PAR ^ 1); OMNI_PP_ISSUE_C(1, w_nx, PAR ^ 1); }
-        OMNI_PP_ISSUE_C(2, w_nx, PAR ^ 1);
-      }
+      if (!first) { OMNI_PP_ISSUE_C(0, a_nx, PAR ^ 1); OMNI_PP_ISSUE_C(1, w_nx, PAR ^ 1); }
+      OMNI_PP_ISSUE_C(2, w_nx, PAR ^ 1);
       OMNI_PP_READ_A(afx, sb);
       OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
       OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
       OMNI_PP_STAMP(pb_t1);
-      OMNI_PP_BIGMMA(0, 1, 0, afx, nxt, "s_waitcnt vmcnt(6)");
+      OMNI_PP_BIGMMA(0, 1, 0, afx, true, "s_waitcnt vmcnt(6)");
       // ---- big phase B
-      if (nxt) OMNI_PP_ISSUE_C(3, a_nx, PAR ^ 1);
+      OMNI_PP_ISSUE_C(3, a_nx, PAR ^ 1);
       OMNI_PP_READ_A(afy, sb + 3 * PSLOT_BYTES);
       OMNI_PP_STAMP(pb_t1);
-      OMNI_PP_BIGMMA(1, 0, 1, afy, nxt, "s_waitcnt vmcnt(2)");
+      OMNI_PP_BIGMMA(1, 0, 1, afy, true, "s_waitcnt vmcnt(2)");
       a_nx += astep;
       w_nx += wstep;
     };
+    // the last K-tile: nothing to send, every wait is vmcnt(0); ring parity at run time (one instance)
+    auto lasttile = [&](const uint32_t sb) __attribute__((always_inline)) {
+      OMNI_PP_READ_A(afx, sb);
+      OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
+      OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
+      OMNI_PP_STAMP(pb_t1);
+      OMNI_PP_BIGMMA(0, 1, 0, afx, false, "s_waitcnt vmcnt(0)");
+      OMNI_PP_READ_A(afy, sb + 3 * PSLOT_BYTES);
+      OMNI_PP_STAMP(pb_t1);
+      OMNI_PP_BIGMMA(1, 0, 1, afy, false, "s_waitcnt vmcnt(0)");
+    };
     if (nkt >= 2) {
 #pragma unroll 1
-      for (; t_first < nkt; t_first += 2) {
+      for (; t_first + 1 < nkt; t_first += 2) {                     // K-tiles with a successor, in pairs (parities 0, 1)
 #if OMNI_PP_PROBE
         pb_snap = (t_first | 1) == ((nkt >> 1) | 1);
 #endif
-        bigtile(std::integral_constant<int, 0>{}, t_first);
-        if (t_first + 1 < nkt) bigtile(std::integral_constant<int, 1>{}, t_first + 1);
+        bigtile(std::integral_constant<int, 0>{}, t_first == 0);
+        if (t_first + 2 < nkt) bigtile(std::integral_constant<int, 1>{}, false);
       }
+      // t_first is the first K-tile not handled above: nkt - 1 (even nkt ran 0 .. nkt - 2 as pairs + one single) — its parity:
+      lasttile((uint32_t)(((nkt - 1) & 1) * 4 * PSLOT_BYTES));
       t_first = nkt;
     }
 #undef OMNI_PP_BIGMMA
