@@ -130,3 +130,85 @@ def test_the_model_catches_a_broken_schedule():
 
     with pytest.raises(AssertionError, match="WAR"):
         test_ring_protocol_has_no_raw_or_war_hazard(broken, 6)
+
+
+def long_lead_big_phases(nkt: int, group: int):
+    """A CANDIDATE schedule (not built): two big phases per K-tile with ~4 epochs of DMA lead instead of SCHED=9's two, bought with
+    different programs for the two wave groups (group 1 runs one slot behind, so group 0 needs its pieces one slot "earlier"):
+      group 0: sends h0-2(t+1) in L_A(t) and h3(t+1) in L_B(t) like SCHED=9, but retires them at the END of the following cluster
+               (h0-2(t+1) behind cluster B(t), h3(t+1) behind cluster A(t+1)) — its partner reads them one slot later still;
+      group 1: sends h3(t+1) in L_A(t) and h0-2(t+2) in L_B(t) (its partner finished with those slots two slots ago), retires at
+               the end of its load sections.
+    The counted waits are derived here: vmcnt(n) with n = pieces sent after the youngest piece that must have landed."""
+    if nkt < 3:
+        return two_big_phases(nkt, group)
+    prog, sent = [], []
+
+    def send(t, h):
+        prog.append(("ISSUE", (t, h)))
+        sent.extend([(t, h), (t, h)])
+
+    def cover(need):
+        need = [ht for ht in need if ht in sent]
+        if not need:
+            return
+        last = max(len(sent) - 1 - sent[::-1].index(ht) for ht in need)
+        prog.append(("WAIT", len(sent) - 1 - last))
+
+    for h in range(4):
+        send(0, h)
+    if group == 1:
+        for h in range(3):
+            send(1, h)
+    cover([(0, 0), (0, 1), (0, 2)])
+    prog.append(("B",))
+    if group == 1:
+        prog.append(("B",))
+    for t in range(nkt):
+        if group == 0:
+            if t + 1 < nkt:
+                for h in range(3):
+                    send(t + 1, h)
+            prog += [("READ", (t, 0)), ("READ", (t, 1)), ("READ", (t, 2)), ("B",), ("MFMA",)]
+            cover([(t, 3)])                                               # behind cluster A(t): h3 of THIS K-tile, read next
+            prog.append(("B",))
+            if t + 1 < nkt:
+                send(t + 1, 3)
+            prog += [("READ", (t, 3)), ("B",), ("MFMA",)]
+            cover([(t + 1, 0), (t + 1, 1), (t + 1, 2)])                   # behind cluster B(t)
+            prog.append(("B",))
+        else:
+            if t + 1 < nkt:
+                send(t + 1, 3)
+            prog += [("READ", (t, 0)), ("READ", (t, 1)), ("READ", (t, 2))]
+            cover([(t, 3)])
+            prog += [("B",), ("MFMA",), ("B",)]
+            if t + 2 < nkt:
+                for h in range(3):
+                    send(t + 2, h)
+            prog.append(("READ", (t, 3)))
+            cover([(t + 1, 0), (t + 1, 1), (t + 1, 2)])
+            prog += [("B",), ("MFMA",), ("B",)]
+    prog.append(("WAIT", 0))
+    if group == 0:
+        prog.append(("B",))
+    return prog
+
+
+@pytest.mark.parametrize("nkt", [3, 4, 5, 6, 7, 12, 48])
+def test_a_long_lead_two_big_phase_schedule_exists_on_the_eight_slot_ring(nkt):
+    """Design aid for round 5 (DESIGN.md "Open leads"): the asymmetric schedule above passes the same RAW / WAR checks, and its
+    DMA lead (epochs between a send and its covering wait) is >= 3 for every steady-state half-tile, against 2 for SCHED=9."""
+    test_ring_protocol_has_no_raw_or_war_hazard(long_lead_big_phases, nkt)
+
+    def leads(schedule):
+        out = []
+        for g in (0, 1):
+            sends, covered, _reads, _ = analyse(schedule(nkt, g))
+            out += [covered[ht][0] - sends[ht][0] for ht in sends if 2 <= ht[0] < nkt - 1]     # steady-state K-tiles
+        return out
+
+    if nkt >= 6:
+        assert min(leads(long_lead_big_phases)) >= 3 and max(leads(two_big_phases)) <= 2
+        steady = sorted({w[1] for g in (0, 1) for w in long_lead_big_phases(nkt, g)[40:-40] if w[0] == "WAIT"})
+        assert steady in ([2, 6, 8], [2, 6], [8], [6, 8], [2, 8]), steady      # the vmcnt immediates the kernel would carry
