@@ -105,3 +105,39 @@ def test_hot_loops_carry_the_instruction_mix_the_design_states(listing):
         assert (32 if fp8 else 64) in v, (k, v)
     assert any(m and m % 64 == 0 for v in inner("flash_attn_fwd_w64_kernel").values() for m in v)   # (the loop is unrolled over ring slots)
     assert any(48 in v for v in inner("vae_attn_fwd_kernel").values())
+
+
+def test_the_queued_two_big_phase_gemm_variant_still_compiles_clean():
+    """`-DOMNI_DEV -DOMNI_PP_SCHED=9` (DESIGN.md "Open leads": 32 MFMAs per cluster, half the barrier hand-offs; queued for the first
+    GPU call of round 5) must stay measurable: no scratch, within the two-waves-per-SIMD budget, and its steady-state loop really
+    has 4 barriers per K-tile.  hipcc's allocator is fragile here — a version of the same loop with six fully compile-time tile
+    instances spilled 200+ VGPRs — and without a GPU this listing is the only place that shows."""
+    import importlib
+
+    B = importlib.import_module("vllm_omni_amd.csrc.build")
+    saved = list(B.FLAGS)
+    try:
+        B.FLAGS = saved + ["-DOMNI_DEV", "-DOMNI_PP_SCHED=9"]
+        B._ASM_CACHE.pop((os.path.join(CSRC, "gemm.hip"), os.path.getmtime(os.path.join(CSRC, "gemm.hip"))), None)
+        asm = B.device_asm(os.path.join(CSRC, "gemm.hip"))
+    finally:
+        B.FLAGS = saved
+        B._ASM_CACHE.pop((os.path.join(CSRC, "gemm.hip"), os.path.getmtime(os.path.join(CSRC, "gemm.hip"))), None)
+    res = {_short(k): v for k, v in B.kernel_resources(asm).items()}
+    pp = {k: v for k, v in res.items() if k.startswith("gemm_bf16_pp_kernel") and k.rstrip(">").endswith(", 0, 0")}
+    assert len(pp) == 5, sorted(pp)
+    for name, r in pp.items():
+        assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0 and r["vgpr_count"] <= 256, (name, r)
+    # the steady-state loop: two K-tiles per trip = 128 MFMAs with 8 barriers (the product loop: 16)
+    body, fn = {}, None
+    for line in asm:
+        m = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if m and not m.group(1).startswith(".L"):
+            fn, body[m.group(1)] = m.group(1), []
+        elif fn is not None:
+            body[fn].append(line)
+    sym = next(s for s in body if "gemm_bf16_pp_kernelILi1ELi0ELi0" in s)
+    loops = [lp for lp in B.mfma_loops(asm)[sym] if lp["innermost"] and lp["mfma"] == 128]
+    assert loops, [lp["mfma"] for lp in B.mfma_loops(asm)[sym]]
+    seg = body[sym][loops[0]["start"]:loops[0]["end"] + 1]
+    assert sum(1 for ln in seg if re.search(r"^\s*s_barrier\b", ln)) == 8
