@@ -254,7 +254,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _dp_worker(rank, world, port, q, fail_rank=-1, mixed=False):
+def _dp_worker(rank, world, port, q, fail_rank=-1, mixed=False, decode_fail_rank=-1, layered=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     from vllm_omni_amd.diffusion.data import DiffusionOutput, OmniDiffusionConfig
@@ -277,11 +277,44 @@ def _dp_worker(rank, world, port, q, fail_rank=-1, mixed=False):
                                                       dtype=torch.bfloat16)) for r in reqs]
 
         def decode_latents(self, lat, h, w):
+            if rank == decode_fail_rank:
+                raise RuntimeError("injected decode failure")
             self.decoded = getattr(self, "decoded", 0) + 1
             return lat[:, :1, :1].reshape(1, 1, 1, 1).expand(1, 3, h, w).clone()
 
-    w = GPUWorker(rank, rank, OmniDiffusionConfig(dist_timeout=60), pipeline=FakePipeline())
+    class FakeLayeredPipeline(FakePipeline):
+        """A pipeline whose finished sample is (layers + 1) frames of (h/16)(w/16) rows and decodes to `layers` images."""
+
+        def latent_rows(self, r):
+            return (r.extra["layers"] + 1) * (r.height // 16) * (r.width // 16)
+
+        def images_per_sample(self, r):
+            return r.extra["layers"]
+
+        def generate(self, reqs, output_type="latent"):
+            outs = []
+            for r in reqs:
+                S, L = (r.height // 16) * (r.width // 16), r.extra["layers"]
+                frames = torch.arange(L + 1, dtype=torch.float32).repeat_interleave(S).view(1, -1, 1) + 10.0 * r.seed
+                outs.append(DiffusionOutput(output=frames.expand(1, (L + 1) * S, 64).to(torch.bfloat16).contiguous()))
+            return outs
+
+        def decode_request(self, r, lat):
+            self.decoded = getattr(self, "decoded", 0) + 1
+            S, L = (r.height // 16) * (r.width // 16), r.extra["layers"]
+            per = lat.view(1, L + 1, S, 64)[0, 1:, 0, 0]                      # frame 0 dropped, one image per layer
+            return per.view(L, 1, 1, 1).expand(L, 3, r.height, r.width).clone()
+
+    w = GPUWorker(rank, rank, OmniDiffusionConfig(dist_timeout=60), pipeline=FakeLayeredPipeline() if layered else FakePipeline())
     w.init_device_and_model()
+    if layered:
+        reqs = [OmniDiffusionRequest(height=64, width=64, num_inference_steps=4, seed=i, prompt_embeds=torch.zeros(1, 1, 8),
+                                     extra={"layers": L}) for i, L in enumerate([2, 3, 2])]
+        out = w.execute_model(reqs, decode=True)
+        vals = None if out.output is None else [(tuple(t.shape), t.float().mean(dim=(1, 2, 3)).tolist()) for t in out.output]
+        q.put((rank, out.error, vals))
+        torch.distributed.destroy_process_group()
+        return
     reqs = [OmniDiffusionRequest(height=64, width=64, num_inference_steps=s, seed=i, prompt_embeds=torch.zeros(1, 1, 8))
             for i, s in enumerate([4, 20, 4, 4, 20])]
     if mixed:
@@ -290,7 +323,7 @@ def _dp_worker(rank, world, port, q, fail_rank=-1, mixed=False):
                 for i, hw in enumerate([64, 128, 64, 128, 64])]
         out = w.execute_model(reqs, decode=True)
         vals = None if out.output is None else [(tuple(t.shape), float(t.float().mean())) for t in out.output]
-        q.put((rank, out.error, (vals, w.pipeline.decoded)))
+        q.put((rank, out.error, (vals, getattr(w.pipeline, "decoded", 0))))
     else:
         out = w.execute_model(reqs, decode=False)
         q.put((rank, out.error, None if out.output is None else out.output[:, 0, 0].float().tolist()))
@@ -356,6 +389,56 @@ def test_dp_worker_one_rank_failing_aborts_all_ranks_without_hanging():
         assert p.exitcode == 0
     assert res[1][0] is not None and "injected failure" in res[1][0] and res[1][1] is None
     assert res[0][0] is not None and "another data-parallel rank failed" in res[0][0] and res[0][1] is None
+
+
+def test_dp_worker_one_rank_failing_in_the_vae_decode_aborts_all_ranks_without_hanging():
+    """the decodes are dealt over the ranks and followed by a second collective (the pixel gather); a rank whose
+    decode raises must not strand the others there: the ranks agree on a failure flag before the pixel gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, -1, True, 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(2):
+        rank, err, vals = q.get(timeout=60)          # would time out if rank 0 were stuck in the pixel gather
+        res[rank] = (err, vals)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1][0] is not None and "injected decode failure" in res[1][0]
+    assert res[0][0] is not None and "another data-parallel rank failed to decode" in res[0][0]
+
+
+def test_dp_worker_serves_a_pipeline_whose_samples_are_several_frames():
+    """the Layered pipeline finishes with (layers + 1) x (h/16)(w/16) rows per sample and one image per layer; the DP
+    path keys its gathers on the pipeline's own row / image counts and decodes through `decode_request`."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, -1, False, -1, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(2):
+        rank, err, vals = q.get(timeout=120)
+        res[rank] = (err, vals)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] is None and res[1] == (None, None)
+    assert res[0][1] == [((2, 3, 64, 64), [1.0, 2.0]), ((3, 3, 64, 64), [11.0, 12.0, 13.0]), ((2, 3, 64, 64), [21.0, 22.0])]
+
+
+def test_worker_results_are_moved_to_the_host_through_lists():
+    """a mixed-resolution execute_model returns a LIST of tensors; `_to_cpu` must recurse into it."""
+    from vllm_omni_amd.diffusion.data import DiffusionOutput
+    from vllm_omni_amd.diffusion.worker.gpu_worker import _to_cpu
+
+    out = _to_cpu(DiffusionOutput(output=[torch.ones(2), (torch.zeros(1), torch.ones(1))]))
+    assert isinstance(out.output, list) and isinstance(out.output[1], tuple)
+    assert all(t.device.type == "cpu" for t in (out.output[0], *out.output[1]))
 
 
 def test_transformer_state_dict_and_apply_are_layout_safe():

@@ -228,6 +228,23 @@ class QwenImageLayeredPipeline(QwenImageEditPipeline):
                      lat=lat_all[k if lat_all.shape[0] > 1 else 0].to(self.device, BF16), pos=pos[k],
                      neg=neg[k] if do_cfg else None) for k in range(len(pos))]
 
+    # ------------------------------------------------------------------ data-parallel worker hooks (GPUWorker.execute_model)
+    def _layers_of(self, req: OmniDiffusionRequest) -> int:
+        return int((req.extra or {}).get("layers") or self.DEFAULT_LAYERS)
+
+    def latent_rows(self, req: OmniDiffusionRequest) -> int:
+        """Packed-latent rows of one finished sample: (layers + 1) frames of (h/16)(w/16) tokens."""
+        height, width, *_ = self._req_params(req)
+        return (self._layers_of(req) + 1) * (height // 16) * (width // 16)
+
+    def images_per_sample(self, req: OmniDiffusionRequest) -> int:
+        return self._layers_of(req)
+
+    def decode_request(self, req: OmniDiffusionRequest, lat: torch.Tensor) -> torch.Tensor:
+        """[n, (layers + 1) * S, 64] of `req` -> [n * layers, 3, H, W] (one image per layer, frame 0 dropped)."""
+        height, width, *_ = self._req_params(req)
+        return self._decode_samples(lat, dict(layers=self._layers_of(req), height=height, width=width))
+
     # ------------------------------------------------------------------ decode
     @torch.no_grad()
     def _decode_samples(self, lat: torch.Tensor, sample: dict) -> torch.Tensor:

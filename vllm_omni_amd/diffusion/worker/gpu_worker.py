@@ -89,8 +89,17 @@ class GPUWorker:
                 self.pipeline._req_params(r)
                 if self.world > 1 and ((r.num_outputs_per_prompt or 1) != 1 or (isinstance(r.prompt, list) and len(r.prompt) != 1)):
                     raise NotImplementedError("a data-parallel batch carries one sample per request (one gather row each)")
-            shape_of = [((r.height or 1024), (r.width or 1024)) for r in reqs]
-            costs = [float((r.num_inference_steps or 50) * (h // 16) * (w // 16)) for r, (h, w) in zip(reqs, shape_of)]
+            pl = self.pipeline
+            # gather key of a request: (height, width, packed-latent rows per sample, images per sample).  The text-to-image
+            # and Edit pipelines finish with (h/16)(w/16) rows and one image; the Layered pipeline with (layers + 1) frames of
+            # that many rows and one image per layer — every rank derives the key from the request alone.
+            shape_of = []
+            for r in reqs:
+                h, w = (r.height or 1024), (r.width or 1024)
+                rows = int(pl.latent_rows(r)) if hasattr(pl, "latent_rows") else (h // 16) * (w // 16)
+                n_img = int(pl.images_per_sample(r)) if hasattr(pl, "images_per_sample") else 1
+                shape_of.append((h, w, rows, n_img))
+            costs = [float((r.num_inference_steps or 50) * rows) for r, (_h, _w, rows, _n) in zip(reqs, shape_of)]
             # requests are sharded over the data-parallel GROUPS; the ranks of a sequence-parallel group run the same share in
             # lockstep and only the group's first rank contributes rows to the gather
             dp_assign = dp.shard_requests(costs, self.dp_world)
@@ -117,11 +126,11 @@ class GPUWorker:
             mine_out = dict(zip(mine_idx, outs)) if contributes else {}
             lat: list[torch.Tensor | None] = [None] * len(reqs)
             imgs: list[torch.Tensor | None] = [None] * len(reqs)
-            # one gather per resolution (a gather needs one row shape), in sorted order: the same sequence of collectives on
-            # every rank.  Mixed-resolution batches are legal (the reference has no collective here, so no such constraint).
-            for (h, w) in sorted(set(shape_of)):
-                S = (h // 16) * (w // 16)
-                sub = [[i for i in a if shape_of[i] == (h, w)] for a in assign]
+            # one gather per key (a gather needs one row shape), in sorted order: the same sequence of collectives on every
+            # rank.  Mixed-resolution batches are legal (the reference has no collective here, so no such constraint).
+            for key in sorted(set(shape_of)):
+                h, w, S, n_img = key
+                sub = [[i for i in a if shape_of[i] == key] for a in assign]
                 my = sub[self.rank]
                 local = (torch.cat([mine_out[i].output.reshape(-1, S, 64) for i in my]) if my
                          else torch.empty((0, S, 64), dtype=torch.bfloat16, device=dev))
@@ -131,15 +140,25 @@ class GPUWorker:
                     lat[i] = t
                 if not decode:
                     continue
-                # every rank now holds every latent of this resolution: the VAE decodes are dealt round-robin over the ranks
-                # (round 3: `output_rank` decoded all of them serially) and the pixels return in one more gather
+                # every rank now holds every latent of this key: the VAE decodes are dealt round-robin over the ranks
+                # (round 3: `output_rank` decoded all of them serially) and the pixels return in one more gather.  The decode
+                # is fallible (a 1024^2 decode needs ~1 GB of activations): like the denoise phase above, the ranks agree on
+                # a failure flag BEFORE anyone enters the pixel gather, so a rank whose decode raised cannot strand the others
+                # inside the collective.
                 order = sorted(rows)
                 deal = [[i for n, i in enumerate(order) if n % self.world == r] for r in range(self.world)]
-                px = [self.pipeline.decode_latents(lat[i].unsqueeze(0), h, w) for i in deal[self.rank]]
-                loc = (torch.cat(px).reshape(len(px), 1, -1) if px else torch.empty((0, 1, 3 * h * w), dtype=torch.bfloat16, device=dev))
+                px, derr = [], None
+                try:
+                    px = [self._decode_one(reqs[i], lat[i].unsqueeze(0), h, w) for i in deal[self.rank]]
+                except Exception as e:  # noqa: BLE001
+                    derr = f"rank {self.rank}: decode failed: {type(e).__name__}: {e}"
+                if dp.any_rank_failed(derr is not None, dev):
+                    return DiffusionOutput(error=derr or "another data-parallel rank failed to decode; batch aborted on all ranks")
+                loc = (torch.cat(px).reshape(len(px), 1, -1) if px
+                       else torch.empty((0, 1, n_img * 3 * h * w), dtype=torch.bfloat16, device=dev))
                 allpx = dp.gather_latents(loc.to(torch.bfloat16).contiguous(), [len(d) for d in deal])
                 for i, t in dp.unshard_indexed(allpx, deal).items():
-                    imgs[i] = t.reshape(3, h, w)
+                    imgs[i] = t.reshape(3, h, w) if n_img == 1 else t.reshape(n_img, 3, h, w)
             if self.rank != output_rank:
                 return DiffusionOutput(output=None)
             res = lat if not decode else imgs
@@ -148,6 +167,13 @@ class GPUWorker:
             return DiffusionOutput(output=res)              # mixed resolutions: a list, request order
         except Exception as e:
             return DiffusionOutput(error=f"{type(e).__name__}: {e}")
+
+    def _decode_one(self, req: OmniDiffusionRequest, lat: torch.Tensor, h: int, w: int) -> torch.Tensor:
+        """Packed latents of ONE sample [1, rows, 64] -> its image(s) [n_img, 3, h, w] through the pipeline's own decode
+        (`decode_request` where a pipeline's samples are not one (h/16)(w/16)-row image: the Layered variant)."""
+        if hasattr(self.pipeline, "decode_request"):
+            return self.pipeline.decode_request(req, lat)
+        return self.pipeline.decode_latents(lat, h, w)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -161,8 +187,12 @@ SHUTDOWN = {"type": "shutdown"}
 
 
 def _to_cpu(x):
+    """Device tensors -> host tensors, through lists / tuples / DiffusionOutput (a mixed-resolution `execute_model` returns a LIST
+    of device tensors; only CPU tensors may cross the process boundary)."""
     if isinstance(x, torch.Tensor):
         return x.detach().to("cpu")
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_cpu(v) for v in x)
     if isinstance(x, DiffusionOutput):
         return DiffusionOutput(output=_to_cpu(x.output), error=x.error, trajectory_timesteps=x.trajectory_timesteps,
                                trajectory_latents=_to_cpu(x.trajectory_latents))
