@@ -83,7 +83,7 @@ def cpu_baseline(layers_sample: int = 4) -> dict:
             enc, hidden = O.dit_block(P, i, hidden, enc, temb, vid, txt, 24)
         dt = (time.perf_counter() - t0) / layers_sample
     sec_per_image = dt * LAYERS * STEPS_DENOISE * 2          # 2 forwards per step (true-CFG), blocks dominate
-    return {"value": 1.0 / sec_per_image, "unit": "images/sec", "cores": cores, "kind": "port",
+    return {"value": 1.0 / sec_per_image, "unit": "images/sec", "cores": cores, "cores_available": os.cpu_count(), "kind": "port",
             "sample": f"{layers_sample} full-width DiT block(s) (S_img=4096, T=64, fp32) = {dt:.2f} s/block, "
                       f"extrapolated x{LAYERS} layers x{STEPS_DENOISE * 2} forwards"}
 
@@ -290,19 +290,33 @@ def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
     pipe.od_config.max_step_batch = old_cap
     out["config1_256px_4step_stepbatched16_images_per_sec"] = 16 / t
     # BASELINE config 5 geometry in bf16: 2048x2048 (16384 image tokens per item: attention is 47 % of the FLOPs), one
-    # request with true-CFG.  3 denoise steps are timed and scaled to the config's 50; the VAE decode (2048^2) is timed once.
-    big = reqs(1, 2048, 3, cfg=True)
-    t3 = timed(lambda: pipe.generate(big, output_type="latent"))
-    lat = pipe.generate(big, output_type="latent")[0].output
-    tv = timed(lambda: pipe.decode_latents(lat, 2048, 2048))
+    # request with true-CFG, THE CONFIG'S 50 STEPS run for real (round 4 timed 3 steps and extrapolated) + its VAE decode.
+    # Warm-up = the same request with 2 steps (same launch shapes), then ONE timed 50-step generation.
+    def run2048():
+        pipe.generate(reqs(1, 2048, 2, cfg=True), output_type="latent")
+        big50 = reqs(1, 2048, 50, cfg=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = pipe.generate(big50, output_type="latent")[0].output
+        torch.cuda.synchronize()
+        t_loop = time.perf_counter() - t0
+        img = pipe.decode_latents(o, 2048, 2048)                          # warm-up of the 2048^2 decode shapes
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img = pipe.decode_latents(o, 2048, 2048)
+        torch.cuda.synchronize()
+        return t_loop, time.perf_counter() - t0, bool(torch.isfinite(img.float()).all())
+
+    t50, tv, ok = run2048()
     flop_step = 2 * 423.01e12                       # 423.01 TFLOP per forward at 2048^2, two forwards per step
-    out["res2048_bf16_ms_per_denoise_step"] = t3 / 3 * 1e3
+    out["res2048_bf16_ms_per_denoise_step"] = t50 / 50 * 1e3
     out["res2048_bf16_vae_decode_ms"] = tv * 1e3
-    out["res2048_bf16_50step_images_per_sec_extrapolated"] = 1.0 / (50 * t3 / 3 + tv)
-    out["res2048_bf16_dit_mfma_roofline_frac"] = flop_step / (t3 / 3) / 2.5e15
-    out["res2048_note"] = ("2048x2048, true-CFG, batch 1, bf16 (the fp8-weight variant of BASELINE config 5 is not built): 3 steps "
-                           "timed, images/s extrapolated to 50 steps + one measured VAE decode")
-    del lat
+    out["res2048_bf16_50step_seconds_per_image"] = t50 + tv
+    out["res2048_bf16_50step_images_per_sec"] = 1.0 / (t50 + tv)
+    out["res2048_bf16_dit_mfma_roofline_frac"] = flop_step / (t50 / 50) / 2.5e15
+    out["res2048_finite_outputs"] = ok
+    out["res2048_note"] = ("2048x2048, 50 steps, true-CFG, batch 1: ONE full 50-step generation timed (the modulation table of the "
+                           "request included) + one measured VAE decode; *_50step_images_per_sec = 1 / (loop + decode)")
     # BASELINE config 5 proper: the same request with the block GEMMs in fp8 (e4m3 weights per output channel, activations
     # quantised per token in front of each GEMM, scaled MFMA at twice the bf16 rate; attention, norms, residuals stay bf16).
     # Every fp8 throughput figure carries its accuracy: the final latent of ONE headline request (1024^2, 20 steps, true-CFG)
@@ -325,13 +339,15 @@ def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
             out[f"{tag}_1024px_images_per_sec"] = R / t
             out[f"{tag}_final_latent_rel_l2_vs_bf16"] = drift()
         tr.enable_fp8()
-        t3f = timed(lambda: pipe.generate(big, output_type="latent"))
-        out["res2048_fp8_ms_per_denoise_step"] = t3f / 3 * 1e3
-        out["res2048_fp8_50step_images_per_sec_extrapolated"] = 1.0 / (50 * t3f / 3 + tv)
+        t50f, tvf, okf = run2048()
+        out["res2048_fp8_ms_per_denoise_step"] = t50f / 50 * 1e3
+        out["res2048_fp8_50step_seconds_per_image"] = t50f + tvf
+        out["res2048_fp8_50step_images_per_sec"] = 1.0 / (t50f + tvf)
+        out["res2048_fp8_finite_outputs"] = okf
         # roofline of the mixed-precision step: GEMM flops against the fp8 peak (5 PF), attention flops against the bf16 peak
         gemm_flop = 2 * (423.01e12 - 4.0 * 24 * (16384 + T_TXT) ** 2 * 128 * layers)
         attn_flop = 2 * 4.0 * 24 * (16384 + T_TXT) ** 2 * 128 * layers
-        out["res2048_fp8_roofline_frac"] = (gemm_flop / 5.0e15 + attn_flop / 2.5e15) / (t3f / 3)
+        out["res2048_fp8_roofline_frac"] = (gemm_flop / 5.0e15 + attn_flop / 2.5e15) / (t50f / 50)
         out["res2048_fp8_note"] = ("transformer.enable_fp8(): OCP e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4), bf16 attention / "
                                    "norms / residual streams; the reference has no fp8 path.  fp8_* = all four block-GEMM classes, "
                                    "fp8_accurate_* = qkv + out-proj only; *_final_latent_rel_l2_vs_bf16 = final latent of one headline "
@@ -450,7 +466,8 @@ def main():
     elapsed = time.perf_counter() - t0
     parts = [sum(ev[k].elapsed_time(ev[k + 1]) for ev in marks) * 1e-3 for k in range(3)]   # denoise, gather, decode
     stats = torch.tensor([elapsed, mine] + parts + [float(numa["node"]) if numa["node"] is not None else -1.0,
-                                                    1.0 if numa["pinned"] else 0.0, float(numa["cpus"])], dtype=torch.float64)
+                                                    1.0 if numa["pinned"] else 0.0, float(numa["cpus"]), float(local)],
+                         dtype=torch.float64)
     if world > 1:
         allstats = [torch.zeros_like(stats) for _ in range(world)]
         torch.distributed.all_gather(allstats, stats, group=cpu_group)
@@ -458,9 +475,37 @@ def main():
     else:
         allstats = [stats]
     per_rank = [{"rank": r, "seconds": float(t[1]), "denoise_s": float(t[2]), "gather_s": float(t[3]), "vae_decode_s": float(t[4]),
-                 "numa_node": int(t[5]), "numa_pinned": bool(t[6]), "host_cpus": int(t[7])}
+                 "numa_node": int(t[5]), "numa_pinned": bool(t[6]), "host_cpus": int(t[7]), "device": int(t[8])}
                 for r, t in enumerate(allstats)]
     ok = bool(torch.isfinite(img.float()).all()) and bool(torch.isfinite(gathered.float()).all())
+
+    # N > 1: make the record prove that the collective carried N ranks' data.  Every rank digests (a) the latents it contributed
+    # in the last step and (b) each rank-sized slice of what the all-gather returned to it; the digests travel over the CPU (gloo)
+    # group, and rank 0 checks that every rank received, in slot r, exactly what rank r sent (different seeds per rank: a gather
+    # that returned local data N times, or skipped a rank, cannot pass).
+    collective = None
+    if world > 1:
+        def digest(t):                                     # order-sensitive 62-bit digest of the bf16 bits
+            v = t.contiguous().view(torch.int16).to(torch.int64).flatten() & 0xFFFF
+            w = (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 65521) + 1
+            return int(((v * w).sum() % ((1 << 61) - 1)).item())
+
+        sent = digest(gathered[rank * R:(rank + 1) * R])   # == this rank's own `lat` of the last step (checked below via slot `rank`)
+        got = [digest(gathered[r * R:(r + 1) * R]) for r in range(world)]
+        mine_t = torch.tensor([sent] + got, dtype=torch.int64)
+        alld = [torch.zeros_like(mine_t) for _ in range(world)]
+        torch.distributed.all_gather(alld, mine_t, group=cpu_group)
+        sent_by = [int(alld[r][0]) for r in range(world)]
+        match = all(int(alld[q][1 + r]) == sent_by[r] for q in range(world) for r in range(world))
+        distinct = len(set(sent_by)) == world
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            ver = None
+        collective = {"backend": torch.distributed.get_backend(), "world": world, "rccl_version": ver,
+                      "op": f"all_gather_into_tensor of [{R}, {S_img}, 64] bf16 per rank and step",
+                      "gathered_checksum_matches_all_ranks": bool(match), "per_rank_payloads_distinct": bool(distinct),
+                      "devices": sorted({int(t[8]) for t in allstats}) if allstats[0].numel() > 8 else None}
 
     sp_line = None
     if args.sp:
@@ -505,6 +550,7 @@ def main():
                                    f"{R} requests step-batched per rank",
                        "global_batch": world * R, "parallelism": f"dp{world}", "images_per_step": world * R},
             "finite_outputs": ok, "per_rank": per_rank,
+            **({"collective": collective} if collective is not None else {}),
             "dit_mfma_roofline_frac": (value / world) * PFLOP_PER_IMAGE * (args.layers / LAYERS) / PEAK_BF16,
             "roofline": measure_roofline(dev, R),
         }

@@ -33,12 +33,35 @@ def test_bench_two_ranks_on_one_device_over_gloo():
     for r in pr:
         assert r["denoise_s"] > 0 and r["vae_decode_s"] > 0 and r["gather_s"] >= 0 and r["seconds"] <= j["ms_per_step"] * 1e-3 * 1.001
     assert "roofline" in j and j["roofline"]["bound"] == "mfma"
+    # the record proves what the collective carried: every rank received, in slot r, exactly the rows rank r contributed
+    col = j["collective"]
+    assert col["world"] == 2 and col["backend"] == "gloo" and col["gathered_checksum_matches_all_ranks"] and col["per_rank_payloads_distinct"]
     # the serving topology at N = 2: two worker processes, dispatched requests, per-worker device-busy fractions
     sec = j.get("secondary", {})
     assert "engine_error" not in sec, sec.get("engine_error")
     assert sec["engine_images_per_sec"] > 0 and len(sec["engine_workers"]) == 2
     for w in sec["engine_workers"]:
         assert w["steps"] > 0 and 0 < w["busy_frac"] <= 1.0 + 1e-6 and 1.0 <= w["mean_batch"] <= 2.0
+
+
+def test_bench_eight_ranks_on_one_device_over_gloo():
+    """The REAL width of the driver's scaling run (8 ranks: ports, spawn, NUMA pinning, the 8-way gather and its checksum proof,
+    max-over-ranks timing) on one device with one layer; the serving line is skipped (eight worker processes x their own weights
+    add nothing the 2-rank test does not cover).  Reference spawn shape: vllm_omni/diffusion/diffusion_engine.py:211-270."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--layers", "1", "--steps", "1", "--warmup", "1",
+           "--requests", "1", "--no-cpu-baseline", "--no-engine", "--dist-backend", "gloo", "--share-device"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["global_batch"] == 8 and j["config"]["parallelism"] == "dp8" and j["finite_outputs"]
+    assert [r["rank"] for r in j["per_rank"]] == list(range(8))
+    assert all(r["denoise_s"] > 0 and r["vae_decode_s"] > 0 for r in j["per_rank"])
+    col = j["collective"]
+    assert col["world"] == 8 and col["gathered_checksum_matches_all_ranks"] and col["per_rank_payloads_distinct"]
+    assert abs(j["value"] - 8 * 1 * 1 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
 
 
 def test_engine_two_workers_share_one_device():

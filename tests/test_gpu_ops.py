@@ -664,3 +664,17 @@ def test_adaln_modulate_fp8_fused_equals_adaln_then_quantize():
     torch.cuda.synchronize()
     assert none is None and torch.equal(yb, y)
     assert torch.equal(sc, sc_ref) and torch.equal(y8, y8_ref) and torch.equal(y8b, y8_ref) and torch.equal(scb, sc_ref)
+
+
+def test_torch_sdpa_backend_refuses_device_tensors():
+    """Round-4 verdict (hygiene): DIFFUSION_ATTENTION_BACKEND=TORCH_SDPA must not swap the HIP attention kernel for a torch op on
+    a GPU box — the host backend serves CPU tensors (plug-in surface tests) and raises for device tensors."""
+    from vllm_omni_amd import _native
+    from vllm_omni_amd.diffusion.attention.backends.sdpa import SDPAImpl
+
+    impl = SDPAImpl(num_heads=2, head_size=128, softmax_scale=128 ** -0.5)
+    q = torch.randn(1, 16, 2, 128, device=dev(), dtype=torch.bfloat16)
+    with pytest.raises(_native.OmniNativeError, match="CDNA4_FLASH"):
+        impl.forward(q, q, q)
+    out = impl.forward(q.cpu().float(), q.cpu().float(), q.cpu().float())      # host tensors: served
+    assert out.shape == (1, 16, 2, 128)

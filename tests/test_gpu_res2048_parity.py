@@ -1,0 +1,114 @@
+"""GPU parity at BASELINE config 5's GEOMETRY (2048x2048: 16384 image tokens per item, joint sequence 16448; VAE decode of a
+256x256 latent), with the fp32 oracle run on the GPU as the checker.
+
+Round 4 quoted throughput at this size (bench.py `secondary.res2048_*`) while the only test at it compared the path with
+itself (item-swap equivariance, tests/test_gpu_fullsize_properties.py).  What exists only at this size: 258 key tiles per
+attention query block (the w64 flash kernel), 65 row tiles per item in every GEMM, a RoPE table of 16384 + text rows, and the
+VAE mid-block attention over 65536 tokens (`vae_attn_fwd_kernel`: 2048 key tiles) with 2050x2050x96 bordered rasters.
+
+Reference shapes: qwen_image_transformer.py:692-802 (forward), autoencoder_kl_qwenimage.py:305-330 (mid-block attention),
+:839-863 (decode).  Tolerances, as at 1024^2 (tests/test_gpu_bench_shape_parity.py): forward of <= 4 layers rel_l2 <= 1e-2 and
+cosine >= 0.9995 vs the fp32 oracle on the same bf16-rounded weights; the ACCURATE fp8 recipe (qkv + out-proj in e4m3) within
+2.5x of the bf16 path's own distance on the same forward (tests/test_gpu_fp8.py states the bar); VAE image rel_l2 <= 3e-2,
+mean |err| <= 2e-2, max |err| <= 2e-1 (the reference's pixel bar, tests/e2e/offline_inference/test_sequence_parallel.py:128-147).
+
+Memory of the checker: fp32 scores of ONE item 24 x 16448^2 x 4 B = 26 GB (+ the softmax copy), the VAE's 65536^2 x 4 B = 17 GB:
+fits the 288 GB part, item by item."""
+import pytest
+import torch
+
+import qwen_image_oracle as O
+from _util import cosine, rel_l2
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+DEV = "cuda:0"
+GRID, S, T = (1, 128, 128), 16384, 64
+
+
+def _model(layers: int, seed: int):
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+
+    m = QwenImageTransformer2DModel(num_layers=layers, device=DEV)
+    m.init_random_(seed=seed)
+    g = torch.Generator(device=DEV).manual_seed(seed + 1)
+    for n, p in m.named_parameters():                       # non-zero biases, jittered norm weights
+        if p.dim() == 1 and "norm" in n:
+            p.data.add_(0.1 * torch.randn(p.shape, device=DEV, generator=g).to(BF16))
+        elif p.dim() == 1:
+            p.data.copy_((0.02 * torch.randn(p.shape, device=DEV, generator=g)).to(BF16))
+    return m
+
+
+def test_two_fullwidth_layers_at_2048px_bf16_and_fp8_accurate():
+    """(a) of round-4 verdict item 1: two full-width layers, ONE item of 16384 + 64 rows, product (bf16, then the accurate fp8
+    recipe) vs `O.dit_forward` in fp32 on the GPU."""
+    torch.backends.cuda.matmul.allow_tf32 = False
+    m = _model(2, seed=2048)
+    P = {n: p.detach().float() for n, p in m.named_parameters()}          # BEFORE the first forward (row-major layout)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    lat = torch.randn(1, S, 64, device=DEV, generator=g).to(BF16)
+    txt = torch.randn(1, T, 3584, device=DEV, generator=g).to(BF16)
+    sig = torch.full((1,), 0.6015625, device=DEV)
+    kw = dict(hidden_states=lat, encoder_hidden_states=txt, timestep=sig, img_shapes=[[GRID]], txt_seq_lens=[T], return_dict=False)
+    out = m(**kw)[0].clone()
+    m.enable_fp8(m.FP8_RECIPE_ACCURATE)
+    out8 = m(**kw)[0].clone()
+    m.enable_fp8(False)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.dit_forward(P, lat.float(), txt.float(), sig, GRID, num_heads=24)
+    r, c = rel_l2(out, ref), cosine(out, ref)
+    r8, c8 = rel_l2(out8, ref), cosine(out8, ref)
+    print(f"2 full-width layers @ 16384+64 rows: bf16 rel_l2 {r:.3e} cos {c:.6f}; fp8-accurate rel_l2 {r8:.3e} cos {c8:.6f} "
+          f"({r8 / r:.2f}x bf16)")
+    assert torch.isfinite(out.float()).all() and torch.isfinite(out8.float()).all()
+    assert r <= 1e-2 and c >= 0.9995
+    assert r8 <= 2.5 * r and c8 >= 0.999
+
+
+def test_ragged_pair_at_2048px_each_item_matches_its_own_oracle_forward():
+    """A CFG pair as the 2048^2 bench step runs it (two items with different text lengths in ONE ragged forward, 130 row tiles
+    of image rows): every item vs its own B = 1 fp32-oracle forward."""
+    from vllm_omni_amd.diffusion.batch import build_ragged_batch
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    m = _model(1, seed=4096)
+    P = {n: p.detach().float() for n, p in m.named_parameters()}
+    g = torch.Generator(device=DEV).manual_seed(12)
+    lens = [64, 19]
+    lat = [torch.randn(S, 64, device=DEV, generator=g).to(BF16) for _ in lens]
+    txt = [torch.randn(t, 3584, device=DEV, generator=g).to(BF16) for t in lens]
+    sig = torch.full((2,), 0.37109375, device=DEV)
+    out = m.forward_ragged(m.prepare_batch(build_ragged_batch(lens, GRID)), torch.cat(lat), torch.cat(txt), sig).clone()
+    torch.cuda.synchronize()
+    for i in range(2):
+        with torch.no_grad():
+            ref = O.dit_forward(P, lat[i][None].float(), txt[i][None].float(), sig[i:i + 1], GRID, num_heads=24)[0]
+        r, c = rel_l2(out[i * S:(i + 1) * S], ref), cosine(out[i * S:(i + 1) * S], ref)
+        print(f"   item {i} (T = {lens[i]}): rel_l2 {r:.3e} cos {c:.6f}")
+        assert r <= 1e-2 and c >= 0.9995
+        del ref
+
+
+def test_vae_decode_at_2048px():
+    """(b): VAE decode of a 256x256 latent (2048^2 image; mid-block attention over 65536 tokens) vs `O.vae_decode` in fp32."""
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import AutoencoderKLQwenImage
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    hw = 256
+    Pv = O.make_vae_params()
+    vae = AutoencoderKLQwenImage(device=DEV)
+    vae.load_weights(Pv.items())
+    Pg = {k: v.to(BF16).float().to(DEV) for k, v in Pv.items()}
+    z = (torch.randn(1, 16, 1, hw, hw, generator=torch.Generator().manual_seed(9)) * 1.5).to(BF16)
+    img = vae.decode(z.to(DEV))[0]
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.vae_decode(Pg, z.float().to(DEV))
+    assert img.shape == ref.shape == (1, 3, 1, 8 * hw, 8 * hw)
+    r = rel_l2(img, ref)
+    d = (img.float() - ref).abs()
+    print(f"vae decode {8 * hw}px: rel_l2 {r:.3e} mean|err| {float(d.mean()):.3e} max|err| {float(d.max()):.3e}")
+    assert r <= 3e-2 and float(d.mean()) <= 2e-2 and float(d.max()) <= 2e-1

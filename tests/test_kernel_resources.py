@@ -107,37 +107,26 @@ def test_hot_loops_carry_the_instruction_mix_the_design_states(listing):
     assert any(48 in v for v in inner("vae_attn_fwd_kernel").values())
 
 
-def test_the_queued_two_big_phase_gemm_variant_still_compiles_clean():
-    """`-DOMNI_DEV -DOMNI_PP_SCHED=9` (DESIGN.md "Open leads": 32 MFMAs per cluster, half the barrier hand-offs; queued for the first
-    GPU call of round 5) must stay measurable: no scratch, within the two-waves-per-SIMD budget, and its steady-state loop really
-    has 4 barriers per K-tile.  hipcc's allocator is fragile here — a version of the same loop with six fully compile-time tile
-    instances spilled 200+ VGPRs — and without a GPU this listing is the only place that shows."""
-    import importlib
+def test_product_translation_units_carry_no_dev_kernel_families():
+    """Round-4 verdict (hygiene): the rejected kernel families and their ablation switches live under csrc/dev/ as fragments that
+    only a -DOMNI_DEV build includes; the product translation units stay readable (size bound) and the dev builds stay
+    compilable (a syntax-only device pass of every family, seconds)."""
+    import subprocess
 
-    B = importlib.import_module("vllm_omni_amd.csrc.build")
-    saved = list(B.FLAGS)
-    try:
-        B.FLAGS = saved + ["-DOMNI_DEV", "-DOMNI_PP_SCHED=9"]
-        B._ASM_CACHE.pop((os.path.join(CSRC, "gemm.hip"), os.path.getmtime(os.path.join(CSRC, "gemm.hip"))), None)
-        asm = B.device_asm(os.path.join(CSRC, "gemm.hip"))
-    finally:
-        B.FLAGS = saved
-        B._ASM_CACHE.pop((os.path.join(CSRC, "gemm.hip"), os.path.getmtime(os.path.join(CSRC, "gemm.hip"))), None)
-    res = {_short(k): v for k, v in B.kernel_resources(asm).items()}
-    pp = {k: v for k, v in res.items() if k.startswith("gemm_bf16_pp_kernel") and k.rstrip(">").endswith(", 0, 0")}
-    assert len(pp) == 5, sorted(pp)
-    for name, r in pp.items():
-        assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0 and r["vgpr_count"] <= 256, (name, r)
-    # the steady-state loop: two K-tiles per trip = 128 MFMAs with 8 barriers (the product loop: 16)
-    body, fn = {}, None
-    for line in asm:
-        m = re.match(r"^([A-Za-z_][\w$.]*):", line)
-        if m and not m.group(1).startswith(".L"):
-            fn, body[m.group(1)] = m.group(1), []
-        elif fn is not None:
-            body[fn].append(line)
-    sym = next(s for s in body if "gemm_bf16_pp_kernelILi1ELi0ELi0" in s)
-    loops = [lp for lp in B.mfma_loops(asm)[sym] if lp["innermost"] and lp["mfma"] == 128]
-    assert loops, [lp["mfma"] for lp in B.mfma_loops(asm)[sym]]
-    seg = body[sym][loops[0]["start"]:loops[0]["end"] + 1]
-    assert sum(1 for ln in seg if re.search(r"^\s*s_barrier\b", ln)) == 8
+    B = __import__("vllm_omni_amd.csrc.build", fromlist=["x"])
+    limits = {"gemm.hip": 1900, "attention.hip": 900}
+    for name, cap in limits.items():
+        src = open(os.path.join(CSRC, name)).read()
+        n = src.count("\n") + 1
+        assert n <= cap, f"{name}: {n} lines (bound {cap})"
+        # whatever is guarded by OMNI_DEV in a product TU is an include of a dev fragment (or a few lines of host-side family
+        # selection), never a kernel
+        for m in re.finditer(r"#ifdef OMNI_DEV[^\n]*\n(.*?)#endif", src, flags=re.S):
+            body = [ln for ln in m.group(1).splitlines() if ln.strip()]
+            assert body and (all(ln.startswith('#include "dev/') for ln in body) or
+                             (len(body) <= 6 and "__global__" not in m.group(1))), (name, body[:3])
+        for old in ("OMNI_PP_ABL", "OMNI_PP_SCHED", "OMNI_PP_EARLY_BARRIER", "OMNI_PP_BALANCED", "OMNI_PP_DMA_IN_MMA", "OMNI_FP8_PROBE"):
+            assert old not in src or name != "gemm.hip", f"{name} still carries the ablation switch {old}"
+        r = subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-std=c++20", "-DOMNI_DEV", "-DOMNI_PP_PROBE=1", "--cuda-device-only",
+                            "-fsyntax-only", os.path.join(CSRC, name)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]

@@ -61,269 +61,9 @@ OMNI_DEVINL bf16x8_t tr_read_pair(uint32_t lds_addr_a, uint32_t lds_addr_b) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-#ifdef OMNI_DEV   // round-1 register-staged kernels (OMNI_ATTN_PIPE=0): dev builds only
-// NQ = 32-query blocks per wave.  NQ = 1: 4 waves x 32 queries, 2 workgroups / CU (two waves per SIMD overlap each other).
-// NQ = 2: 4 waves x 64 queries, ONE wave per SIMD with ~400 registers: every K / V^T fragment read from LDS feeds TWO
-// MFMAs, and staging traffic + barriers per query halve (the NQ = 1 loop is LDS-traffic-bound: each wave re-reads all
-// of K and V for only 32 queries).
-template <int NQ>
-__global__ __launch_bounds__(NWAVES * 64, (NQ == 1 ? 2 : 1)) void flash_attn_fwd_kernel(
-    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
-    uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-    const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-
-  // heads fastest -> block b runs on XCD b%8, so every q-block of a head lands on the same XCD's L2
-  const int hb = blockIdx.x % n_heads_total;
-  const int qb = blockIdx.x / n_heads_total;
-  const int b = hb / H, h = hb - b * H;
-  const int seq_start = cu_seqlens[b];
-  const int seq_len = cu_seqlens[b + 1] - seq_start;
-  constexpr int QBLK = 32 * NWAVES * NQ;   // queries per workgroup
-  if (qb * QBLK >= seq_len) return;
-
-  const uint16_t* kbase = k + (int64_t)seq_start * ldk + h * DH;
-  const uint16_t* vbase = v + (int64_t)seq_start * ldv + h * DH;
-
-  // ---- Q fragments (B operand): lane holds q = l31, d = ks*16 + hi*8 .. +8 ---------------------
-  bf16x8_t qf[NQ][8];
-#pragma unroll
-  for (int bq = 0; bq < NQ; ++bq) {
-    const int qrow = min(qb * QBLK + (wave * NQ + bq) * 32 + l31, seq_len - 1);
-    const uint16_t* qp = q + (int64_t)(seq_start + qrow) * ldq + h * DH + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[bq][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
-    // make the fragments opaque: otherwise hipcc REMATERIALISES these global loads inside the KV loop (to save
-    // VGPRs) and every QK^T MFMA then waits on an L2 round trip (seen as vmcnt(7..0) waits in the loop)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[bq][ks]));
-  }
-
-  // ---- staging: thread t moves 16-B chunks id = t + 256*i; key = id>>4, c = id&15 -----------------------
-  // Loads go through buffer descriptors: the per-thread byte offset is loop-invariant (voffset), the tile
-  // offset is an SGPR (soffset) -> ZERO per-tile address VALU (the flat-address form cost ~90 VALU per tile,
-  // much of it quarter-rate 64-bit multiplies), and rows past the sequence end are out of the descriptor's range
-  // and read as 0 (no clamp; those keys are masked to -inf anyway).
-  u32x4_t kreg[4], vreg[4];
-  uint32_t k_wr_off[4], v_wr_off[4], k_ld_off[4], v_ld_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int id = tid + 256 * i;
-    const int key = id >> 4, c = id & 15;
-    k_wr_off[i] = key * 256 + ((c ^ (key & 15)) << 4);
-    v_wr_off[i] = K_TILE_BYTES + (c >> 2) * 4096 + (key >> 2) * 256 + (key & 3) * 64 + (c & 3) * 16;
-    k_ld_off[i] = (uint32_t)(key * ldk * 2 + c * 16);
-    v_ld_off[i] = (uint32_t)(key * ldv * 2 + c * 16);
-  }
-  const uint32_t k_bytes = (uint32_t)((int64_t)(seq_len - 1) * ldk * 2 + DH * 2);
-  const uint32_t v_bytes = (uint32_t)((int64_t)(seq_len - 1) * ldv * 2 + DH * 2);
-  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, k_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, v_bytes, 0x00020000);
-  const uint32_t k_tile_stride = (uint32_t)(KVBLK * ldk * 2), v_tile_stride = (uint32_t)(KVBLK * ldv * 2);
-  auto load_tile = [&](int t) {
-    const uint32_t ks_ = __builtin_amdgcn_readfirstlane(t * k_tile_stride);
-    const uint32_t vs_ = __builtin_amdgcn_readfirstlane(t * v_tile_stride);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_ld_off[i], ks_, 0);
-      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_ld_off[i], vs_, 0);
-    }
-  };
-  auto store_tile = [&](int stage) {
-    char* sb = smem + stage * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4_t*>(sb + k_wr_off[i]) = kreg[i];
-      *reinterpret_cast<u32x4_t*>(sb + v_wr_off[i]) = vreg[i];
-    }
-  };
-
-  // ---- fragment read addresses ------------------------------------------------------------------
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  // K: row key = j*32 + l31, chunk (ks*2+hi) ^ (key&15)      (j*32 keeps key&15 = l31&15)
-  uint32_t k_addr[8];   // per k-step: key-row offset + swizzled 16-B chunk (sub-block j adds 32*256 as an immediate)
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) k_addr[ks] = l31 * 256 + ((((uint32_t)(ks * 2 + hi)) ^ (l31 & 15)) << 4);
-  // V (tr read): g = lane>>4, m = lane&15:  base = (m>>2)*64 + (g&1)*32 + (m&3)*8 + hi*256
-  const uint32_t v_lane_off = K_TILE_BYTES + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + hi * 256;
-
-  f32x16_t o[NQ][4];
-  float m_run[NQ], l_run[NQ];
-#pragma unroll
-  for (int bq = 0; bq < NQ; ++bq) {
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[bq][d][i] = 0.0f;
-    m_run[bq] = -INFINITY;
-    l_run[bq] = 0.0f;
-  }
-
-  const int ntiles = (seq_len + KVBLK - 1) / KVBLK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    const int kv0 = t * KVBLK;
-    if (t + 1 < ntiles) load_tile(t + 1);  // in flight under this tile's MFMAs
-    const char* sb = smem + cur * STAGE_BYTES;
-
-    // ---- Sᵀ = K Qᵀ : two 32-key sub-blocks = 16 MFMAs; K fragments are read 4 deep ahead of their MFMA
-    // (hand-issued ds_read_b128 + counted lgkmcnt: hipcc otherwise waits lgkmcnt(0) before every single MFMA).
-    f32x16_t s[NQ][2];
-#pragma unroll
-    for (int bq = 0; bq < NQ; ++bq)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[bq][j][i] = 0.0f;
-    {
-      const uint32_t kst = lds0 + cur * STAGE_BYTES;
-      bf16x8_t kf[4];
-#define OMNI_KREAD(i) \
-  kf[(i) & 3] = (((i) >> 3) ? lds_read16<32 * 256>(k_addr[(i) & 7] + kst) : lds_read16<0>(k_addr[(i) & 7] + kst))
-      OMNI_KREAD(0); OMNI_KREAD(1); OMNI_KREAD(2); OMNI_KREAD(3);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (i <= 12) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-        else if (i == 13) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-        else if (i == 14) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int bq = 0; bq < NQ; ++bq)
-          s[bq][i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 3], qf[bq][i & 7], s[bq][i >> 3], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 4 < 16) OMNI_KREAD(i + 4);
-      }
-      __builtin_amdgcn_s_setprio(0);
-#undef OMNI_KREAD
-    }
-    // ---- mask the ragged tail (last tile only; wave-uniform branch) ---------------------------
-    if (kv0 + KVBLK > seq_len) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= seq_len) {
-#pragma unroll
-            for (int bq = 0; bq < NQ; ++bq) s[bq][j][r] = -INFINITY;
-          }
-        }
-    }
-    // ---- online softmax (lane-local; one cross-half exchange for the max), per 32-query block -----------
-    bf16x8_t pf[NQ][2][2];
-#pragma unroll
-    for (int bq = 0; bq < NQ; ++bq) {
-      float mx = s[bq][0][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[bq][0][r]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[bq][1][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // defer-max (cdna guide T13): while the row max grows by less than 2^DEFER (in the exponent's log2 units) keep
-      // the OLD reference max — P is then bounded by 2^DEFER instead of 1 (harmless in bf16/fp32) and the 64-register
-      // rescale of O is skipped.  The decision is taken AFTER the previous tile's P·V is complete and BEFORE this
-      // tile's P is exponentiated, so O, l and P always share one reference max.
-      constexpr float DEFER = 6.0f;
-      if (!__all((mx - m_run[bq]) * scale_log2e <= DEFER)) {
-        const float m_new = fmaxf(m_run[bq], mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run[bq] - m_new) * scale_log2e);
-        m_run[bq] = m_new;
-        l_run[bq] *= alpha;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) o[bq][d][i] *= alpha;
-      }
-      const float mneg = -m_run[bq] * scale_log2e;
-      float psum = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[bq][j][ss * 8 + e], scale_log2e, mneg));
-            psum += p;
-            pf[bq][j][ss][e] = (__bf16)p;
-          }
-      l_run[bq] += psum;
-    }
-
-    // 16 MFMAs, i -> (j = i>>3, ss = (i>>2)&1, d = i&3); each needs one Vᵀ fragment = two transposed reads.
-    // Fragments are fetched THREE MFMAs ahead (hand-issued + counted lgkmcnt; hipcc keeps only one ahead and
-    // every MFMA then eats an LDS round trip).
-    {
-      const uint32_t vb = lds0 + cur * STAGE_BYTES + v_lane_off;
-      u32x2_t vlo[4], vhi[4];
-#define OMNI_VOFF(i) (((i) & 3) * 4096 + ((((i) >> 3) * 8 + (((i) >> 2) & 1) * 4) * 256))
-#define OMNI_VREAD(i)                                   \
-  do {                                                  \
-    vlo[(i) & 3] = lds_tr_read8<OMNI_VOFF(i)>(vb);      \
-    vhi[(i) & 3] = lds_tr_read8<OMNI_VOFF(i) + 512>(vb); \
-  } while (0)
-#define OMNI_PV(i)                                                                                             \
-  do {                                                                                                         \
-    if ((i) <= 13) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                          \
-    else if ((i) == 14) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                                     \
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    {                                                                                                          \
-      typedef __attribute__((ext_vector_type(4))) uint32_t u4_;                                                \
-      const u4_ w_ = {vlo[(i) & 3][0], vlo[(i) & 3][1], vhi[(i) & 3][0], vhi[(i) & 3][1]};                     \
-      _Pragma("unroll") for (int bq = 0; bq < NQ; ++bq)                                                         \
-        o[bq][(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w_),             \
-                                                  pf[bq][(i) >> 3][((i) >> 2) & 1], o[bq][(i) & 3], 0, 0, 0);  \
-    }                                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-  } while (0)
-      OMNI_VREAD(0); OMNI_VREAD(1); OMNI_VREAD(2);
-      __builtin_amdgcn_s_setprio(1);
-      OMNI_PV(0);  OMNI_VREAD(3);  OMNI_PV(1);  OMNI_VREAD(4);  OMNI_PV(2);  OMNI_VREAD(5);  OMNI_PV(3);  OMNI_VREAD(6);
-      OMNI_PV(4);  OMNI_VREAD(7);  OMNI_PV(5);  OMNI_VREAD(8);  OMNI_PV(6);  OMNI_VREAD(9);  OMNI_PV(7);  OMNI_VREAD(10);
-      OMNI_PV(8);  OMNI_VREAD(11); OMNI_PV(9);  OMNI_VREAD(12); OMNI_PV(10); OMNI_VREAD(13); OMNI_PV(11); OMNI_VREAD(14);
-      OMNI_PV(12); OMNI_VREAD(15); OMNI_PV(13); OMNI_PV(14); OMNI_PV(15);
-      __builtin_amdgcn_s_setprio(0);
-#undef OMNI_PV
-#undef OMNI_VREAD
-#undef OMNI_VOFF
-    }
-
-    if (t + 1 < ntiles) store_tile(cur ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: O[q][d] = Oᵀ / l ; lane holds q = l31, d = dblk*32 + 8*qd + 4*hi + {0..3} -------
-#pragma unroll
-  for (int bq = 0; bq < NQ; ++bq) {
-    const float l_tot = l_run[bq] + __shfl_xor(l_run[bq], 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int qrow = qb * QBLK + (wave * NQ + bq) * 32 + l31;
-    if (qrow < seq_len) {
-      uint16_t* op = out + (int64_t)(seq_start + qrow) * ldo + h * DH + hi * 4;
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          u32x2_t w;
-          w[0] = pack_bf16x2(o[bq][d][qd * 4 + 0] * inv, o[bq][d][qd * 4 + 1] * inv);
-          w[1] = pack_bf16x2(o[bq][d][qd * 4 + 2] * inv, o[bq][d][qd * 4 + 3] * inv);
-          *reinterpret_cast<u32x2_t*>(op + d * 32 + qd * 8) = w;
-        }
-    }
-  }
-}
-
-#endif  // OMNI_DEV
+#ifdef OMNI_DEV
+#include "dev/attention_family_round1_register_staged.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Software-pipelined variant (default).  Same tiling and LDS images as flash_attn_fwd_kernel<1>, but
@@ -872,423 +612,8 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && NQ == 1) ? 2 : 1)) void flash
 
 
 #ifdef OMNI_DEV
-// ------------------------------------------------------------------------------------------------
-// 16x16x32 MFMA form of the software-pipelined kernel (dev builds, OMNI_ATTN_MFMA=16; measured -2.4 %: see below).  The same tile stream, K image, skewed loop, DMA and
-// barrier structure as flash_attn_fwd_pipe_kernel<NW, 1>; what changes is the instruction shape and the layouts that follow
-// from it.  v_mfma_f32_16x16x32_bf16 does the same flops per matrix-pipe cycle as 32x32x16 with 32 k per instruction: half
-// the accumulator read-modify-write traffic per flop.  On this power-limited part that is clock: swapping only the
-// instruction in the 32x32 kernel (results wrong) measured 900 -> 997 TF/s at B=6, S=4160 (profiles/r02_attention_mfma_shape.log).
-//   A wave owns 32 queries as TWO 16-query blocks (qb): lane = (q = lane & 15, g = lane >> 4).
-//   Sᵀ = K·Qᵀ: A = K fragment (16 keys x 32 d: key l15, d 32*ks + 8g..), B = Q fragment in registers (d 32*ks + 8g.. of query
-//        l15).  Each K fragment feeds both query blocks.  C layout: S[qb][kb][i] = key kb*16 + 4g + i of query qb*16 + l15:
-//        softmax max / sum are lane-local over 16 keys, then reduced over the four g groups with two permlane swaps.
-//   Oᵀ = Vᵀ·Pᵀ: B = Pᵀ taken straight from the S registers of TWO key blocks: k slots 0..3 = keys 4g + i of block 2c, slots
-//        4..7 = the same of block 2c+1 (the MFMA k order is simply defined that way); A = Vᵀ fragment (16 d x those 32 keys)
-//        from two ds_read_b64_tr_b16 (keys 4g.. of key group c*8 + g, and of c*8 + g + 4).
-//   V image: [d/32 (4)][key-group pair (8)][d-block parity (2)][key-group parity (2)][key & 3 (4)][16 d] — the 32 lanes of a
-//        tr-read half cover 256 contiguous bytes (conflict-free), and a 1-KiB DMA piece still fetches 16 keys x 64 B.
-// The rescale decision is taken per wave over both query blocks, i.e. over the same 32 queries as in the 32x32 kernel.
-// MEASURED (B=6, S=4160, same box, profiles/r02_attention_mfma_shape.log): 883 TF/s against 904 for the 32x32x16 kernel.
-// PMC: the clock does rise (GRBM_GUI_ACTIVE / duration: 1.74 -> 1.96 GHz) but the kernel needs 17 % more cycles: SQ_INSTS_VALU
-// 208 M -> 265 M (the MFMA count doubles: 32 more issues per wave and tile, +13 other VALU), and with two waves per SIMD this
-// loop is bound by its per-wave instruction issue (~8 cycles per instruction), not by the matrix pipe (busy 42-49 %).
-// ------------------------------------------------------------------------------------------------
-OMNI_DEVINL float xquad_max(float x) {   // max over the four 16-lane groups
-  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return xhalf_max(fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)));
-}
-OMNI_DEVINL float xquad_sum(float x) {
-  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return xhalf_sum(__builtin_bit_cast(float, a) + __builtin_bit_cast(float, b));
-}
-
-// max of TWO per-lane values over the four 16-lane groups in three swaps (the plain form needs four): after the 16-swap of
-// (x0, x1) lane groups hold [x0 g0, x1 g0, x0 g2, x1 g2] / [x0 g1, x1 g1, x0 g3, x1 g3]; their max, 32-swapped with itself,
-// gives the full max of x0 in groups 0 / 2 and of x1 in groups 1 / 3; a last 16-swap of that with itself spreads both to
-// every lane.  v_max_f32 from asm: fmaxf() adds two canonicalising v_max x, x, x per call.
-OMNI_DEVINL float vmaxf(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-OMNI_DEVINL void xquad_max2(float x0, float x1, float& r0, float& r1) {
-  uint32_t a = __builtin_bit_cast(uint32_t, x0), b = __builtin_bit_cast(uint32_t, x1);
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  const float y = vmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
-  uint32_t c = __builtin_bit_cast(uint32_t, y), d = c;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));
-  const float z = vmaxf(__builtin_bit_cast(float, c), __builtin_bit_cast(float, d));
-  uint32_t e = __builtin_bit_cast(uint32_t, z), f = e;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(e), "+v"(f));
-  r0 = __builtin_bit_cast(float, e);
-  r1 = __builtin_bit_cast(float, f);
-}
-#ifndef OMNI_ATTN16_VIMG
-#define OMNI_ATTN16_VIMG 1   // V image: 1 = [d/32][key group][key & 3][32 d] with the two 16-d halves XOR (key group & 1):
-                             // four CONSECUTIVE lanes of a DMA piece fetch one key's 64 contiguous bytes; 0 = paired image
+#include "dev/attention_family_pipe16_mfma16x16x32.inc"
 #endif
-#ifndef OMNI_ATTN16_RED2
-#define OMNI_ATTN16_RED2 1   // 1 = xquad_max2 (three swaps for both query blocks), 0 = two xquad_max
-#endif
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void flash_attn_fwd_pipe16_kernel(
-    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
-    uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-    const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e, int out_k32_rows,
-    int block_order, const int32_t* __restrict__ item_skip) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, g = lane >> 4;
-
-  int hb, qblk;                                  // block -> (item*head, q-block): see flash_attn_fwd_pipe_kernel
-  if (block_order == 1) {
-    const int nwg = gridDim.x, bid = blockIdx.x, qblocks = nwg / n_heads_total;
-    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    hb = lid / qblocks;
-    qblk = lid - hb * qblocks;
-  } else {
-    hb = blockIdx.x % n_heads_total;
-    qblk = blockIdx.x / n_heads_total;
-  }
-  const int b = hb / H, h = hb - b * H;
-  if (item_skip && item_skip[b]) return;          // device-side predicate: this item's block stack is skipped (omni_teacache)
-  const int seq_start = cu_seqlens[b];
-  const int seq_len = cu_seqlens[b + 1] - seq_start;
-  constexpr int QBLK = 32 * NW;
-  constexpr int NPIECE = 16 / NW;                 // DMA pieces (1 KiB) per wave per operand per tile
-  if (qblk * QBLK >= seq_len) return;
-
-  const char* kbase = reinterpret_cast<const char*>(k + (int64_t)seq_start * ldk + h * DH);
-  const char* vbase = reinterpret_cast<const char*>(v + (int64_t)seq_start * ldv + h * DH);
-
-  // ---- Q fragments (B operand): qf[qb][ks] = d 32*ks + 8g .. +8 of query qb*16 + l15 ----------------------------
-  bf16x8_t qf[2][4];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int qrow = min(qblk * QBLK + wave * 32 + qb * 16 + l15, seq_len - 1);
-    const uint16_t* qp = q + (int64_t)(seq_start + qrow) * ldq + h * DH + g * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qb][ks]));   // no rematerialisation of the loads inside the loop
-  }
-
-  // ---- DMA sources.  One wave-instruction = 1 KiB of the LDS image, lane L -> byte 16*L of the piece.
-  //  K piece P (keys 4P .. 4P+3): key = 4P + (L>>4), LDS chunk L&15 holds logical chunk (L&15)^(key&15)
-  //  V piece P = (d/32 = P>>2, 16-key group = P&3): L = [key-group pair 1][d-block parity 1][key-group parity 1][key&3 2][8-d half 1]
-  auto k_key_of = [&](int i) { return 4 * (wave + NW * i) + (lane >> 4); };
-  auto k_col_of = [&](int i) { return (uint32_t)(((lane & 15) ^ (k_key_of(i) & 15)) * 16); };
-#if OMNI_ATTN16_VIMG
-  //  V piece P = (d/32 = P>>2, 16-key group = P&3): L = [key group & 3 (2)][key & 3 (2)][16-B chunk of the 64-B row (2)]; the
-  //  chunk's 16-d half is XORed with the key group's parity (= (L>>4) & 1) so that a tr-read's even and odd lane groups
-  //  (key groups g, g+1) fall into different bank halves
-  auto v_key_of = [&](int i) { return 16 * ((wave + NW * i) & 3) + 4 * (lane >> 4) + ((lane >> 2) & 3); };
-  auto v_col_of = [&](int i) { return (uint32_t)((4 * ((wave + NW * i) >> 2) + ((lane & 3) ^ (2 * ((lane >> 4) & 1)))) * 16); };
-#else
-  auto v_key_of = [&](int i) { return 16 * ((wave + NW * i) & 3) + 8 * (lane >> 5) + 4 * ((lane >> 3) & 1) + ((lane >> 1) & 3); };
-  auto v_col_of = [&](int i) { return (uint32_t)(((wave + NW * i) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 1) * 16); };
-#endif
-  uint32_t k_src[NPIECE], v_src[NPIECE];
-#pragma unroll
-  for (int i = 0; i < NPIECE; ++i) {
-    k_src[i] = (uint32_t)(k_key_of(i) * ldk * 2) + k_col_of(i);
-    v_src[i] = (uint32_t)(v_key_of(i) * ldv * 2) + v_col_of(i);
-  }
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const int ntiles = (seq_len + KVBLK - 1) / KVBLK;
-  const int last_valid = seq_len - (ntiles - 1) * KVBLK;          // keys in the last tile (1..64)
-  auto issue_K = [&](int t, int stage) {
-    const char* tb = kbase + (int64_t)t * KVBLK * ldk * 2;          // uniform
-#pragma unroll
-    for (int i = 0; i < NPIECE; ++i) {
-      const uint32_t dst = lds0 + stage * STAGE_BYTES + (wave + NW * i) * 1024;
-      if (t == ntiles - 1 && last_valid < KVBLK)                    // ragged tail: re-read the last valid row
-        attn_glds16(tb, (uint32_t)(min(k_key_of(i), last_valid - 1) * ldk * 2) + k_col_of(i), dst);
-      else
-        attn_glds16(tb, k_src[i], dst);
-    }
-  };
-  auto issue_V = [&](int t, int stage) {
-    const char* tb = vbase + (int64_t)t * KVBLK * ldv * 2;
-#pragma unroll
-    for (int i = 0; i < NPIECE; ++i) {
-      const uint32_t dst = lds0 + stage * STAGE_BYTES + K_TILE_BYTES + (wave + NW * i) * 1024;
-      if (t == ntiles - 1 && last_valid < KVBLK)
-        attn_glds16(tb, (uint32_t)(min(v_key_of(i), last_valid - 1) * ldv * 2) + v_col_of(i), dst);
-      else
-        attn_glds16(tb, v_src[i], dst);
-    }
-  };
-
-  // K fragment (kb, ks): key kb*16 + l15 (256-B rows), logical 16-B chunk 4*ks + g, XOR key & 15 = l15
-  uint32_t k_addr[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) k_addr[ks] = l15 * 256 + ((((uint32_t)(ks * 4 + g)) ^ (uint32_t)l15) << 4);
-  // V^T fragment: 16-lane group g transposes the 4 keys x 16 d block of key group c*8 + g (+4 for the upper k slots)
-#if OMNI_ATTN16_VIMG
-  // key group c*8 + g (256 B each), key l15 >> 2 (64 B), 16-d half (db & 1) ^ (g & 1) (32 B): one lane offset per d-block parity
-  const uint32_t v_lane_off0 = K_TILE_BYTES + g * 256 + (l15 >> 2) * 64 + (g & 1) * 32 + (l15 & 3) * 8;
-  const uint32_t v_lane_off1 = K_TILE_BYTES + g * 256 + (l15 >> 2) * 64 + ((g & 1) ^ 1) * 32 + (l15 & 3) * 8;
-#else
-  const uint32_t v_lane_off = K_TILE_BYTES + (g >> 1) * 512 + (g & 1) * 128 + (l15 >> 2) * 32 + (l15 & 3) * 8;
-#endif
-
-  f32x4_t o[2][8];                               // O^T[qb][d block]: d = db*16 + 4g + i of query qb*16 + l15
-  float m_run[2], l_run[2];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-    for (int d = 0; d < 8; ++d) o[qb][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    m_run[qb] = -INFINITY;
-    l_run[qb] = 0.0f;
-  }
-
-  bf16x8_t kf[4];
-// QK step i (0..15): key block i & 3, k-step i >> 2: consecutive MFMAs never share an accumulator
-#define OMNI_KREAD(i, kst) kf[(i) & 3] = lds_read16<((i) & 3) * 4096>(k_addr[((i) >> 2) & 3] + (kst))
-#define OMNI_QK_STEP(i, SN, kst, CHUNK)                                                          \
-  do {                                                                                           \
-    if ((i) <= 12) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                            \
-    else if ((i) == 13) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                       \
-    else if ((i) == 14) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");                       \
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    SN[0][(i) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[(i) & 3], qf[0][(i) >> 2], SN[0][(i) & 3], 0, 0, 0); \
-    SN[1][(i) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[(i) & 3], qf[1][(i) >> 2], SN[1][(i) & 3], 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    if ((i) + 4 < 16) OMNI_KREAD((i) + 4, kst);                                                  \
-    CHUNK;                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-  } while (0)
-#define OMNI_QK_ALL(SN, kst, CH)                                                                                     \
-  do {                                                                                                               \
-    OMNI_KREAD(0, kst); OMNI_KREAD(1, kst); OMNI_KREAD(2, kst); OMNI_KREAD(3, kst);                                  \
-    OMNI_QK_STEP(0, SN, kst, CH(0));   OMNI_QK_STEP(1, SN, kst, CH(1));   OMNI_QK_STEP(2, SN, kst, CH(2));           \
-    OMNI_QK_STEP(3, SN, kst, CH(3));   OMNI_QK_STEP(4, SN, kst, CH(4));   OMNI_QK_STEP(5, SN, kst, CH(5));           \
-    OMNI_QK_STEP(6, SN, kst, CH(6));   OMNI_QK_STEP(7, SN, kst, CH(7));   OMNI_QK_STEP(8, SN, kst, CH(8));           \
-    OMNI_QK_STEP(9, SN, kst, CH(9));   OMNI_QK_STEP(10, SN, kst, CH(10)); OMNI_QK_STEP(11, SN, kst, CH(11));         \
-    OMNI_QK_STEP(12, SN, kst, CH(12)); OMNI_QK_STEP(13, SN, kst, CH(13)); OMNI_QK_STEP(14, SN, kst, CH(14));         \
-    OMNI_QK_STEP(15, SN, kst, CH(15));                                                                               \
-  } while (0)
-#define OMNI_NOCHUNK(i) (void)0
-
-  auto mask_tail = [&](f32x4_t (&S)[2][4], int kv0) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (kv0 + kb * 16 + 4 * g + i >= seq_len) { S[0][kb][i] = -INFINITY; S[1][kb][i] = -INFINITY; }
-  };
-  auto zero_s = [&](f32x4_t (&S)[2][4]) {
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) S[qb][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  };
-
-  // ---- prologue: tiles 0 (K, V) and 1 (K) in flight, S(0) and its row max -------------------------------------
-  issue_K(0, 0);
-  issue_V(0, 0);
-  if (ntiles > 1) issue_K(1, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  f32x4_t sA[2][4], sB[2][4];
-  float mxA[2], mxB[2];
-  zero_s(sA);
-  OMNI_QK_ALL(sA, lds0, OMNI_NOCHUNK);
-  if (KVBLK > seq_len) mask_tail(sA, 0);
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    float mx = sA[qb][0][0];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sA[qb][kb][i]);
-    mxA[qb] = mx;
-    mxB[qb] = 0.0f;
-  }
-  xquad_max2(mxA[0], mxA[1], mxA[0], mxA[1]);
-
-  // One iteration; SC = S(t) (complete, row max mxc known), SN receives S(t+1).
-  auto iteration = [&](auto has_next_c, int t, f32x4_t (&SC)[2][4], f32x4_t (&SN)[2][4], float (&mxc)[2], float (&mxn)[2]) {
-    constexpr bool has_next = decltype(has_next_c)::value;
-    if (t + 2 < ntiles) issue_K(t + 2, t & 1);
-    if (has_next) issue_V(t + 1, (t + 1) & 1);
-
-    // defer-max: rescale only when some query's new tile max exceeds its running max by more than 2^DEFER
-    constexpr float DEFER = 6.0f;
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    const f32x2_t scale2 = {scale_log2e, scale_log2e};
-    f32x2_t mneg2[2], psum2[2];
-    uint32_t pfu[2][2][4];                        // [qb][32-key chunk c][k-slot pair]: bf16 pairs of P^T
-    if (!__all((mxc[0] - m_run[0]) * scale_log2e <= DEFER && (mxc[1] - m_run[1]) * scale_log2e <= DEFER)) {
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const float m_new = fmaxf(m_run[qb], mxc[qb]);
-        const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * scale_log2e);
-        m_run[qb] = m_new;
-        l_run[qb] *= alpha;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) o[qb][d] *= alpha;
-      }
-    }
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const float mneg = -m_run[qb] * scale_log2e;
-      mneg2[qb][0] = mneg; mneg2[qb][1] = mneg;
-      psum2[qb][0] = 0.0f; psum2[qb][1] = 0.0f;
-    }
-    // exp chunk i (0..15): query block i >> 3, key block (i >> 1) & 3, register pair i & 1 -> one packed bf16 pair of P
-#define OMNI_EXP_CHUNK(i)                                                                                        \
-  do {                                                                                                           \
-    const f32x2_t x_ = {SC[(i) >> 3][((i) >> 1) & 3][2 * ((i) & 1)], SC[(i) >> 3][((i) >> 1) & 3][2 * ((i) & 1) + 1]}; \
-    const f32x2_t y_ = __builtin_elementwise_fma(x_, scale2, mneg2[(i) >> 3]);                                   \
-    const float p0_ = __builtin_amdgcn_exp2f(y_[0]), p1_ = __builtin_amdgcn_exp2f(y_[1]);                         \
-    const f32x2_t pp_ = {p0_, p1_};                                                                              \
-    psum2[(i) >> 3] += pp_;                                                                                      \
-    uint32_t pk_ = pack_bf16x2(p0_, p1_);                                                                        \
-    asm volatile("" : "+v"(pk_), "+v"(psum2[(i) >> 3])); /* pin: pure arithmetic is otherwise sunk below the MFMA run */ \
-    pfu[(i) >> 3][((i) >> 2) & 1][(((i) >> 1) & 1) * 2 + ((i) & 1)] = pk_;                                       \
-  } while (0)
-    if (has_next) {
-      const uint32_t kst = lds0 + ((t + 1) & 1) * STAGE_BYTES;
-      zero_s(SN);
-      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(1);
-      OMNI_QK_ALL(SN, kst, OMNI_EXP_CHUNK);
-      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) OMNI_EXP_CHUNK(i);
-    }
-#undef OMNI_EXP_CHUNK
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) l_run[qb] += psum2[qb][0] + psum2[qb][1];
-    if (has_next && (t + 2) * KVBLK > seq_len) mask_tail(SN, (t + 1) * KVBLK);
-
-    // ---- O^T += V^T P^T (tile t), with the row max of S(t+1) in the MFMA shadows
-    float mx[2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) mx[qb] = has_next ? SN[qb][0][0] : 0.0f;
-    {
-      u32x2_t vlo[4], vhi[4];
-// PV step i (0..15): 32-key chunk c = i >> 3, d block db = i & 7
-#if OMNI_ATTN16_VIMG
-      const uint32_t vb0 = lds0 + (t & 1) * STAGE_BYTES + v_lane_off0, vb1 = lds0 + (t & 1) * STAGE_BYTES + v_lane_off1;
-#define OMNI_VOFF(i) ((((i) & 7) >> 1) * 4096 + ((i) >> 3) * 2048)
-#define OMNI_VREAD(i)                                                                      \
-  do {                                                                                     \
-    vlo[(i) & 3] = lds_tr_read8<OMNI_VOFF(i)>(((i) & 1) ? vb1 : vb0);                      \
-    vhi[(i) & 3] = lds_tr_read8<OMNI_VOFF(i) + 1024>(((i) & 1) ? vb1 : vb0);               \
-  } while (0)
-#else
-      const uint32_t vb = lds0 + (t & 1) * STAGE_BYTES + v_lane_off;
-#define OMNI_VOFF(i) ((((i) & 7) >> 1) * 4096 + ((i) >> 3) * 2048 + ((i) & 1) * 256)
-#define OMNI_VREAD(i)                                                                      \
-  do {                                                                                     \
-    vlo[(i) & 3] = lds_tr_read8<OMNI_VOFF(i)>(vb);                                         \
-    vhi[(i) & 3] = lds_tr_read8<OMNI_VOFF(i) + 1024>(vb);                                  \
-  } while (0)
-#endif
-#define OMNI_PV(i)                                                                                             \
-  do {                                                                                                         \
-    if ((i) <= 13) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                          \
-    else if ((i) == 14) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                                     \
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    {                                                                                                          \
-      const u32x4_t w_ = {vlo[(i) & 3][0], vlo[(i) & 3][1], vhi[(i) & 3][0], vhi[(i) & 3][1]};                 \
-      _Pragma("unroll") for (int qb_ = 0; qb_ < 2; ++qb_) {                                                     \
-        const u32x4_t p_ = {pfu[qb_][(i) >> 3][0], pfu[qb_][(i) >> 3][1], pfu[qb_][(i) >> 3][2], pfu[qb_][(i) >> 3][3]}; \
-        o[qb_][(i) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w_),            \
-                                                    __builtin_bit_cast(bf16x8_t, p_), o[qb_][(i) & 7], 0, 0, 0); \
-      }                                                                                                        \
-    }                                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-  } while (0)
-// max chunk c (0..7): query block c >> 2, key block c & 3
-#define OMNI_MAX_CHUNK(c)                                                                                       \
-  do {                                                                                                          \
-    if (has_next) {                                                                                             \
-      mx[(c) >> 2] = fmaxf(fmaxf(mx[(c) >> 2], SN[(c) >> 2][(c) & 3][0]), SN[(c) >> 2][(c) & 3][1]);              \
-      mx[(c) >> 2] = fmaxf(fmaxf(mx[(c) >> 2], SN[(c) >> 2][(c) & 3][2]), SN[(c) >> 2][(c) & 3][3]);              \
-      asm volatile("" : "+v"(mx[(c) >> 2]));                                                                    \
-    }                                                                                                           \
-  } while (0)
-      OMNI_VREAD(0); OMNI_VREAD(1); OMNI_VREAD(2);
-      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(1);
-      OMNI_PV(0);  OMNI_VREAD(3);  OMNI_PV(1);  OMNI_VREAD(4);
-      OMNI_PV(2);  OMNI_VREAD(5);  OMNI_PV(3);  OMNI_VREAD(6);
-      OMNI_PV(4);  OMNI_VREAD(7);  OMNI_MAX_CHUNK(0); OMNI_PV(5);  OMNI_VREAD(8);  OMNI_MAX_CHUNK(1);
-      OMNI_PV(6);  OMNI_VREAD(9);  OMNI_MAX_CHUNK(2); OMNI_PV(7);  OMNI_VREAD(10); OMNI_MAX_CHUNK(3);
-      OMNI_PV(8);  OMNI_VREAD(11); OMNI_MAX_CHUNK(4); OMNI_PV(9);  OMNI_VREAD(12); OMNI_MAX_CHUNK(5);
-      OMNI_PV(10); OMNI_VREAD(13); OMNI_MAX_CHUNK(6); OMNI_PV(11); OMNI_VREAD(14); OMNI_MAX_CHUNK(7);
-      OMNI_PV(12); OMNI_VREAD(15); OMNI_PV(13); OMNI_PV(14); OMNI_PV(15);
-      if (OMNI_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(0);
-#undef OMNI_MAX_CHUNK
-#undef OMNI_PV
-#undef OMNI_VREAD
-#undef OMNI_VOFF
-    }
-    if (has_next) {
-      if (OMNI_ATTN16_RED2) {
-        xquad_max2(mx[0], mx[1], mxn[0], mxn[1]);
-      } else {
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) mxn[qb] = xquad_max(mx[qb]);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this iteration's DMA has landed
-    __syncthreads();                                  // ... for every wave; and every wave is done with K(t+1), V(t)
-  };
-
-  {
-    using yes = std::integral_constant<bool, true>;
-    using no = std::integral_constant<bool, false>;
-    int t = 0;
-    for (; t + 2 < ntiles; t += 2) {
-      iteration(yes{}, t, sA, sB, mxA, mxB);
-      iteration(yes{}, t + 1, sB, sA, mxB, mxA);
-    }
-    if (t + 1 < ntiles) {
-      iteration(yes{}, t, sA, sB, mxA, mxB);
-      iteration(no{}, t + 1, sB, sA, mxB, mxA);
-    } else {
-      iteration(no{}, t, sA, sB, mxA, mxB);
-    }
-  }
-#undef OMNI_QK_ALL
-#undef OMNI_QK_STEP
-#undef OMNI_KREAD
-#undef OMNI_NOCHUNK
-
-  // ---- epilogue: a wave-instruction stores 16 rows x 32 contiguous bytes ------------------------------------------
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const float inv = 1.0f / xquad_sum(l_run[qb]);
-    const int qrow = qblk * QBLK + wave * 32 + qb * 16 + l15;
-    if (qrow < seq_len) {
-      // row-major: out[row][h*128 + db*16 + 4g ..];  K32-blocked: slab h*4 + db/2, [slab][row][(db&1)*16 + 4g ..]
-#pragma unroll
-      for (int db = 0; db < 8; ++db) {
-        uint16_t* op = out_k32_rows
-                           ? out + ((int64_t)(h * 4 + (db >> 1)) * out_k32_rows + seq_start + qrow) * 32 + (db & 1) * 16 + g * 4
-                           : out + (int64_t)(seq_start + qrow) * ldo + h * DH + db * 16 + g * 4;
-        u32x2_t w;
-        w[0] = pack_bf16x2(o[qb][db][0] * inv, o[qb][db][1] * inv);
-        w[1] = pack_bf16x2(o[qb][db][2] * inv, o[qb][db][3] * inv);
-        *reinterpret_cast<u32x2_t*>(op) = w;
-      }
-    }
-  }
-}
-
-#endif  // OMNI_DEV
 
 }  // namespace
 
@@ -1349,63 +674,11 @@ int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
   return OMNI_OK;
 }
 #ifdef OMNI_DEV
-int attn_mfma_shape() {
-  // dev knob: OMNI_ATTN_MFMA = 32 (default: flash_attn_fwd_pipe_kernel, 32x32x16) | 16 (flash_attn_fwd_pipe16_kernel, 16x16x32)
-  static int v = -1;
-  if (v < 0) {
-    v = omni_dev_env_int("OMNI_ATTN_MFMA", 32);
-    if (v != 16) v = 32;
-  }
-  return v;
-}
-int attn_pingpong() {
-  // dev knob: OMNI_ATTN_PP = 0 (default) | 1 (wave groups half an iteration apart in the 8-wave kernel: measured 878 vs 912 TF/s)
-  static int v = -1;
-  if (v < 0) {
-    v = omni_dev_env_int("OMNI_ATTN_PP", 0);
-  }
-  return v;
-}
-template <int NW>
-int launch_pipe16(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
-                  int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
-                  float softmax_scale, int out_k32_rows, hipStream_t s, const int32_t* item_skip) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe16_kernel<NW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return OMNI_ERR_LAUNCH;
-    attr_set = true;
-  }
-  const int qblocks = (max_seqlen + 32 * NW - 1) / (32 * NW);
-  const int nh = B * H;
-  hipLaunchKernelGGL((flash_attn_fwd_pipe16_kernel<NW>), dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
-                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows, attn_block_order(), item_skip);
-  OMNI_CHECK_LAUNCH();
-  return OMNI_OK;
-}
-#endif  // OMNI_DEV
+#include "dev/attention_dev_launch_pipe16.inc"
+#endif
 #ifdef OMNI_DEV
-template <int NQ>
-int launch_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
-                int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
-                float softmax_scale, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel<NQ>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return OMNI_ERR_LAUNCH;
-    attr_set = true;
-  }
-  constexpr int QBLK = 32 * NWAVES * NQ;
-  const int qblocks = (max_seqlen + QBLK - 1) / QBLK;
-  const int nh = B * H;
-  hipLaunchKernelGGL(flash_attn_fwd_kernel<NQ>, dim3(nh * qblocks), dim3(NWAVES * 64), LDS_BYTES, s, q, k, v, out, ldq,
-                     ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f);
-  OMNI_CHECK_LAUNCH();
-  return OMNI_OK;
-}
-#endif  // OMNI_DEV
+#include "dev/attention_dev_launch_round1.inc"
+#endif
 }  // namespace
 
 
@@ -1430,22 +703,7 @@ int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_
                                         out_k32_rows, item_skip, q_prescaled, stream);
 #endif
 #ifdef OMNI_DEV
-  if (q_prescaled && (!attn_pipelined() || attn_mfma_shape() == 16 || !OMNI_ATTN_BAKE)) return OMNI_ERR_UNSUPPORTED;
-  if (!attn_pipelined()) {
-    if (out_k32_rows) return OMNI_ERR_UNSUPPORTED;   // only the pipelined kernel writes the blocked layout
-    if (attn_variant() == 1)
-      return launch_attn<1>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
-    return launch_attn<2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, s);
-  }
-  if (attn_variant() == 2)   // OMNI_ATTN_NQ=2: 4 waves x 64 queries, one wave per SIMD (spills as compiled by hipcc)
-    return launch_pipe<4, 2>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip, q_prescaled);
-  if (attn_mfma_shape() == 16) {
-    if (attn_pipe_waves(B * H, max_seqlen) == 8)
-      return launch_pipe16<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
-    return launch_pipe16<4>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip);
-  }
-  if (attn_pipe_waves(B * H, max_seqlen) == 8 && attn_pingpong())
-    return launch_pipe<8, 1, 1>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip, q_prescaled);
+#include "dev/attention_dev_dispatch.inc"
 #endif
   if (attn_pipe_waves(B * H, max_seqlen) == 8)
     return launch_pipe<8>(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale, out_k32_rows, s, item_skip,

@@ -6,17 +6,13 @@
 //      half a phase apart (one in an MFMA-only cluster while its SIMD partner issues reads and LDS-DMA), see its comment;
 //   1  gemm_bf16_ring_kernel — round 1's kernel, now the fallback for what the ping-pong kernel does not take (K % 64 != 0,
 //      operand offsets beyond 32 bits, outputs that cannot use the row-coalesced epilogue); bit-identical results.
-// The first design (0), the hipcc-scheduled 4-wave kernel (2), the hand-placed 4-wave kernel with the accumulators in the AGPR
-// half (4, "Q4": bit-identical, measured -8 % against the ping-pong kernel — see its comment), the two-phase ping-pong variants
-// (5, 6) and the ablation entry points are compiled only with -DOMNI_DEV (tools/build_variants.sh); there a family is picked by
-// omni_gemm_params.kernel_hint = 16 + family or by OMNI_GEMM_VARIANT.  The product library takes omni_gemm_params.kernel_hint =
-// OMNI_GEMM_KERNEL_RING (force the fallback family) and nothing else: no environment variable, no global setter.  Families:
-//   1  gemm_bf16_ring_kernel — the production kernel: BK = 32 stages in a 5-deep LDS ring (all 160 KiB), a continuous
-//      DMA / fragment-read / MFMA pipeline (see the comment above the kernel), K32-blocked operand layouts for full-line
-//      DMA requests, row-coalesced epilogue through LDS (gemm_epilogue_lds) incl. the fused q/k norm + RoPE.
-//   0  gemm_bf16_kernel — the first design, kept for A/B runs: BK = 64, 2 stages x (A 32 KiB + W 32 KiB) = 128 KiB,
-//      one barrier per K tile (wait own DMA -> barrier -> issue tile t+1 -> 24 ds_read_b128 + 32 MFMA on tile t).
-//   2  gemm_bf16_w4_kernel — 4 waves x (128 x 128), one wave per SIMD (slower: exposes the DMA issue cost).
+// Everything else that was built and measured against them — the first design (family 0), the hipcc-scheduled 4-wave kernel (2),
+// the hand-placed 4-wave kernels with the accumulators in the AGPR half (4 "Q4", 7 "V4": the vendor kernel's schedule), the
+// two-phase ping-pong variants (5, 6), the persistent ping-pong kernel (8), the ablation entry points and the phase probe — lives
+// under dev/ as fragments that ONLY a -DOMNI_DEV build includes (tools/build_variants.sh; a family is then picked by
+// omni_gemm_params.kernel_hint = 16 + family or by OMNI_GEMM_VARIANT).  The product library takes omni_gemm_params.kernel_hint =
+// OMNI_GEMM_KERNEL_RING (force the fallback family) / OMNI_GEMM_KERNEL_SPLITK_TALL and nothing else: no environment variable, no
+// global setter.
 // Common to all:
 //   Staging is direct-to-LDS (global_load_lds_dwordx4, 1 KiB per wave-instruction).  The LDS image is row-major with the
 //   16-byte chunk index XOR-swizzled; because the DMA destination is lane-linear the swizzle is applied to the per-lane
@@ -595,92 +591,9 @@ OMNI_DEVINL void gemm_epilogue_lds_fp8(const omni_gemm_params& P, const omni_gem
   });
 }
 
-#ifdef OMNI_DEV   // dev-only kernel family (OMNI_GEMM_VARIANT=0): built with -DOMNI_DEV, not part of the product library
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
-                                                                  int tiles_n, int GROUP_M) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  // ---- tile id: XCD-aware bijective remap, then GROUP_M banding -------------------------------
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int band_sz = GROUP_M * tiles_n;
-  const int band = lid / band_sz, in_band = lid - band * band_sz;
-  const int first_m = band * GROUP_M;
-  const int gm = min(GROUP_M, tiles_m - first_m);
-  const int mt = first_m + in_band % gm;
-  const int nt = in_band / gm;
-  const int gi = (mt >= mtiles0) ? 1 : 0;
-  const omni_gemm_group G = pick_group(P, gi);
-  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
-  const int n0 = nt * BN;
-  const int M = G.M, N = P.N, K = P.K;
-
-  // ---- per-lane DMA source pointers: 4 A rows + 4 W rows, fixed over the K loop ---------------
-  const uint16_t* a_src[4];
-  const uint16_t* w_src[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = (wave * 4 + j) * 8 + (lane >> 3);            // tile row this lane feeds
-    const int c = (lane & 7) ^ ((r >> 1) & 7);                 // logical k-chunk landing in phys chunk lane&7
-    int ar = min(m0 + r, M - 1);
-    if (G.a_row_map) ar = G.a_row_map[ar];
-    a_src[j] = G.A + (int64_t)ar * G.lda + c * 8;
-    const int wr = min(n0 + r, N - 1);
-    w_src[j] = G.W + (int64_t)wr * K + c * 8;
-  }
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;  // LDS byte address of the dynamic region
-  auto issue_part = [&](int stage, int kt, int part) {   // part 0..3: one A piece + one W piece (1 KiB each)
-    const uint32_t base = lds0 + stage * STAGE_BYTES + (wave * 4) * 1024;
-    const int koff = kt * BK;
-    glds16(a_src[part] + koff, base + part * 1024);
-    glds16(w_src[part] + koff, base + TILE_BYTES + part * 1024);
-  };
-  auto issue_stage = [&](int stage, int kt) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) issue_part(stage, kt, j);
-  };
-
-  // ---- per-lane fragment read offsets ---------------------------------------------------------
-  const int wm = wave >> 2, wn = wave & 3;
-  const int l31 = lane & 31, hi = lane >> 5;
-  // per-lane fragment byte offsets per k-step: row*128 + ((ks*2+hi) ^ swz)*16, swz = (row>>1)&7 = (l31>>1)&7
-  uint32_t a_base[4], w_base[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const uint32_t chunk = ((uint32_t)(ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-    a_base[ks] = (wm * 128 + l31) * 128 + chunk;
-    w_base[ks] = (wn * 64 + l31) * 128 + chunk;
-  }
-
-  f32x16_t acc[2][4];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.0f;
-
-  const int nkt = K / BK;
-  issue_stage(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (ABL != 4 && ABL != 5) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    if (ABL != 1 && ABL != 5 && kt + 1 < nkt) issue_stage(cur ^ 1, kt + 1);
-    mma_stage<4, 32 * 128, TILE_BYTES, ABL>(acc, a_base, w_base, lds0 + cur * STAGE_BYTES, [](int) {});
-  }
-
-  gemm_epilogue<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi);
-}
-
-#endif  // OMNI_DEV
+#ifdef OMNI_DEV
+#include "dev/gemm_family0_first_design.inc"
+#endif
 // ------------------------------------------------------------------------------------------------
 // Ring variant: BK = 32 per stage, 5-deep LDS ring (5 x 32 KiB = the CU's whole 160 KiB), DMA issued FOUR
 // stages (= 2 BK64 tiles, ~2 us) ahead and retired with a COUNTED vmcnt(12); raw s_barrier (a __syncthreads()
@@ -958,64 +871,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ring_kernel(const omni_
 // lines in the row-major layout, 2 x (8 rows x 64 B contiguous) in the K32-blocked layouts.
 // Same accumulator layout and the same k order as the ring kernel: results are bit-identical to it.
 // ------------------------------------------------------------------------------------------------
-#ifndef OMNI_PP_SETPRIO
-#define OMNI_PP_SETPRIO 0   // 1: s_setprio 1 / 0 around every MFMA cluster.  Off since round 4: with the restructured K-loop the same box measured
-                            // 0 .. +5 % without it on all four DiT shapes (profiles/r04_pp_sched_per_shape_timing.log; +0.5 % on the round-2 loop),
-                            // bit-identical either way — the load sections carry no VALU work the clusters would have to outrank
-#endif
-#ifndef OMNI_PP_VMCNT
-#define OMNI_PP_VMCNT "s_waitcnt vmcnt(8)"   // 4 half-tiles x 2 pieces per wave may stay in flight across a barrier
-#endif
-#ifndef OMNI_PP_DMA_IN_MMA
-#define OMNI_PP_DMA_IN_MMA 0   // 1: a phase's two DMA pieces are issued inside its MFMA cluster instead of its load section
-#endif
-#ifndef OMNI_PP_EARLY_BARRIER
-#define OMNI_PP_EARLY_BARRIER 0   // n > 0: a cluster's closing s_barrier sits n MFMA pairs (of 8) before its end (see OMNI_PP_MMA); must be even for fp8
-#endif
-#ifndef OMNI_PP_BALANCED
-#define OMNI_PP_BALANCED 0     // 1: second A-fragment register set; fragment reads per phase 4 / 4 / 8 / 8 instead of 12 / 4 / 8 / 0
-#endif
-// counted wait at the end of a load section inside the k-loop: with the DMA issued from the load sections the youngest FOUR
-// half-tiles may be in flight (vmcnt 8); with the DMA inside the clusters this phase's pieces are not issued yet: THREE (6)
-#if OMNI_PP_DMA_IN_MMA
-#define OMNI_PP_VMCNT_LOOP "s_waitcnt vmcnt(6)"
-#else
+// counted wait at the end of a load section: the youngest FOUR half-tiles (x 2 pieces per wave) may stay in flight across a barrier
+#define OMNI_PP_VMCNT "s_waitcnt vmcnt(8)"
 #define OMNI_PP_VMCNT_LOOP OMNI_PP_VMCNT
-#endif
+// (No s_setprio around the clusters since round 4: with the restructured K-loop the same box measured 0 .. +5 % without it on all
+// four DiT shapes, bit-identical — the load sections carry no VALU work the clusters would have to outrank.  What else was
+// measured on this loop and is NOT in the kernel any more — DMA pieces inside the clusters, a second A-fragment register set
+// (reads 4 / 4 / 8 / 8 per phase), the closing barrier signalled early, 32-MFMA clusters on two big phases per K-tile, the
+// 32x32x16 MFMA shape, and the timing ablations — is in DESIGN.md 7 items 14-18, 28-30 with the logs under profiles/.)
 // The cluster's MFMAs are issued from inline asm: as builtins they are "pure" nodes that hipcc's instruction selection
 // is free to sink below s_setprio 0 / the closing s_barrier and interleave with the NEXT phase's reads (observed) —
 // which destroys exactly the phase separation this kernel is about.  Volatile asm keeps program order with respect to the
 // barriers, waits and reads.  Hazards the compiler can no longer see: the operands come from ds_reads retired by the
 // explicit lgkmcnt(0); consecutive MFMAs alternate between two accumulators, SrcC == vDst exactly (the interlocked case);
 // the epilogue's first VALU read of an accumulator is kept >= 18 wait states away by the s_nops behind the k-loop.
-#ifndef OMNI_PP_ABL
-#define OMNI_PP_ABL 0   // dev-only timing ablations (results wrong by construction): 1 no MFMA, 2 no DMA inside the k-loop,
-                        // 3 no vmcnt waits, 4 no barriers, 6 = 2 + 4, 7 = 2 + no fragment reads
-#endif
-OMNI_DEVINL void pp_mfma(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
-#if OMNI_PP_ABL == 1
-  asm volatile("" : "+v"(acc) : "v"(a), "v"(b));
-#else
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-#endif
-}
-// MFMA shape of the ping-pong kernel.  1: v_mfma_f32_16x16x32_bf16 — the same flops per matrix-pipe cycle as 32x32x16, but
+// MFMA shape of the ping-pong kernel: v_mfma_f32_16x16x32_bf16 — the same flops per matrix-pipe cycle as 32x32x16, but
 // an instruction carries 32 k instead of 16: half the accumulator read-modify-write traffic per flop.  On this power-limited
 // part that is clock: swapping only the instruction shape (same loads, same barriers) measured 1127 -> 1194 TF/s (+6 %,
 // profiles/r02_gemm_mfma_shape.log).  Both shapes add their products to the fp32 accumulator in 8-k groups in ascending k:
 // the results are bit-identical to the 32x32x16 build and to the ring kernel (tests/test_gpu_ops.py asserts it).
-#ifndef OMNI_PP_MFMA16
-#define OMNI_PP_MFMA16 1
-#endif
-#ifndef OMNI_PP_DIRECT_K32
-#define OMNI_PP_DIRECT_K32 1   // K32-blocked outputs are stored straight from the accumulators (gemm_epilogue_direct_k32)
-#endif
 OMNI_DEVINL void pp_mfma16(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
-#if OMNI_PP_ABL == 1
-  asm volatile("" : "+v"(acc) : "v"(a), "v"(b));
-#else
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-#endif
 }
 // fp8 (omni_gemm_params.fp8): ONE v_mfma_scale_f32_16x16x128_f8f6f4 replaces the two 16x16x32 bf16 MFMAs of a (block, block) pair.
 // Its A / B operand is 8 VGPRs = 32 fp8 of one row: bytes 0-15 = k 16g .. 16g+15, bytes 16-31 = k 64+16g .. 64+16g+15 (g = lane >> 4;
@@ -1031,54 +907,19 @@ OMNI_DEVINL void pp_mfma_fp8(f32x4_t& acc, const bf16x8_t& a_lo, const bf16x8_t&
   const u32x4_t bl = __builtin_bit_cast(u32x4_t, b_lo), bh = __builtin_bit_cast(u32x4_t, b_hi);
   const u32x8_t a = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
   const u32x8_t b = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
-#if defined(OMNI_FP8_PROBE) && OMNI_FP8_PROBE == 1     // bisect: the bf16 instruction on the same registers (wrong results)
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(al), "v"(bl));
-#elif defined(OMNI_FP8_PROBE) && OMNI_FP8_PROBE == 2   // bisect: the builtin instead of the asm statement
-  typedef __attribute__((ext_vector_type(8))) int i32x8_t;
-  acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_bit_cast(i32x8_t, a), __builtin_bit_cast(i32x8_t, b), acc, 0, 0, 0,
-                                                         (int)one, 0, (int)one);
-#else
   asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(one));
-#endif
 }
-// Dev-only timing probe (-DOMNI_DEV -DOMNI_PP_PROBE=1; tools/probe/pp_probe.cpp reads it back): every wave stamps s_memtime
-// (one tick = one shader cycle) at five points of every phase -
-//   T1 load section issued (fragment reads + this phase's two DMA pieces)   T2 counted DMA wait passed   T3 barrier + lgkmcnt(0)
-//   passed = first MFMA may issue   T4 last MFMA of the cluster issued   T5 closing barrier passed (= the next phase's start)
-// - and keeps the SUMS of each stamp over all phases in SGPRs (differences of the sums = cycles per segment; 32-bit wrap-around
-// cancels), plus the T3 / T4 of the four phases of the middle K-tile (the hand-off between the two waves of a SIMD: partner's T3
-// minus this wave's T4).  A stamp is consumed one phase later, at a point where the wave's lgkm queue holds nothing else (the end
-// of a cluster), so the probe adds no wait to the load sections: ~11 scalar instructions per phase.  Output: 16 uint32 per wave at
-// P.splitk_ws (the non-split launch does not use it; the harness passes splitk_ws_floats = 0).  Product builds: all of it is empty.
+// Dev-only phase probe (-DOMNI_DEV -DOMNI_PP_PROBE=1, dev/gemm_pp_probe.h; tools/probe/pp_probe.cpp reads it back): s_memtime
+// stamps at five points of every phase.  Product builds: the OMNI_PP_STAMP / OMNI_PP_PROBE_ACCUM hooks below are empty and the
+// device code is byte-identical to a build without them.
 #ifndef OMNI_PP_PROBE
 #define OMNI_PP_PROBE 0
 #endif
-#ifndef OMNI_PP_SCHED
-#define OMNI_PP_SCHED 1      // 1: the steady state of the K-loop runs the restructured loop (see gemm_bf16_pp_kernel); 0: the round-2..4 loop only
-#endif
 #if OMNI_PP_PROBE
-#define OMNI_PP_STAMP(v) do { (v) = __builtin_amdgcn_s_memtime(); } while (0)
-// The additions are pinned between two empty volatile asm statements that "modify" the accumulators: as free C code hipcc sank
-// them below the closing barrier (and waited for the T5 stamp at the head of the next load section) or could hoist them to the
-// head of the cluster (a wait for T3 in front of the first MFMA).  Stamps and sums are 64-bit so that no half of a stamp's SGPR
-// pair is dead while its s_memtime is in flight (the allocator re-used the high half at once: a write-after-write wait).
-// Phase index of a quadrant: (mq, nq) = (0,0) (0,1) (1,1) (1,0) -> 0 1 2 3.
-#define OMNI_PP_PROBE_ACCUM(nq, mq)                                                                        \
-  do {                                                                                                     \
-    constexpr int ph_ = (mq) ? 3 - (nq) : (nq);                                                            \
-    asm volatile("" : "+s"(pb_s[0]), "+s"(pb_s[1]), "+s"(pb_s[2]), "+s"(pb_s[3]), "+s"(pb_s[4]));          \
-    pb_s[0] += pb_t1; pb_s[1] += pb_t2; pb_s[2] += pb_t3; pb_s[3] += pb_t4; pb_s[4] += pb_t5;              \
-    pb_snap3[ph_] = pb_snap ? (uint32_t)pb_t3 : pb_snap3[ph_];                                             \
-    pb_snap4[(ph_ + 3) & 3] = pb_snap ? (uint32_t)pb_t4 : pb_snap4[(ph_ + 3) & 3];                         \
-    asm volatile("" : "+s"(pb_s[0]), "+s"(pb_s[1]), "+s"(pb_s[2]), "+s"(pb_s[3]), "+s"(pb_s[4]),           \
-                      "+s"(pb_snap3[ph_]), "+s"(pb_snap4[(ph_ + 3) & 3]));                                  \
-    ++pb_ph;                                                                                               \
-  } while (0)
-#define OMNI_PP_PROBE_T5_FROM_EARLY() do { pb_t5 = pb_t5e; } while (0)
+#include "dev/gemm_pp_probe.h"
 #else
 #define OMNI_PP_STAMP(v) ((void)0)
 #define OMNI_PP_PROBE_ACCUM(nq, mq) ((void)0)
-#define OMNI_PP_PROBE_T5_FROM_EARLY() ((void)0)
 #endif
 constexpr int PBK = 64;
 constexpr int PSLOT_BYTES = 128 * PBK * 2;    // 16 KiB per half-tile
@@ -1154,7 +995,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
     OMNI_PP_ISSUE_PIECE(h, tile, 1);                                                                        \
   } while (0)
 
-#if OMNI_PP_MFMA16
   // ---- per-lane fragment read offsets (16x16x32: lane = row l15 of a 16-row block, k = 32*ks + 8*g .. +8):
   //      row * 128 + ((ks*4 + g) ^ swz) * 16, swz = (row >> 1) & 7 = (l15 >> 1) & 7; 16-row blocks via the offset immediate.
   //      Every 16-lane group reads 16 consecutive rows at one logical chunk: (row & 1) * 8 + (chunk ^ swz) covers all 16
@@ -1167,23 +1007,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
     a_rd[ks] = lds0 + (wm * 64 + l15) * 128 + chunk;
     w_rd[ks] = lds0 + (wn * 32 + l15) * 128 + chunk;
   }
-#else
-  // ---- per-lane fragment read offsets: row * 128 + ((ks*2 + hi) ^ swz) * 16, swz = (row >> 1) & 7 = (l31 >> 1) & 7 ----
-  uint32_t a_rd[4], w_rd[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const uint32_t chunk = ((uint32_t)(ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-    a_rd[ks] = lds0 + (wm * 64 + l31) * 128 + chunk;
-    w_rd[ks] = lds0 + (wn * 32 + l31) * 128 + chunk;
-  }
-#endif
 
   // ---- prologue: half-tiles 0..5 in flight; 0 and 1 landed before the first read ---------------------------------
   OMNI_PP_ISSUE(0, 0); OMNI_PP_ISSUE(1, 0); OMNI_PP_ISSUE(2, 0); OMNI_PP_ISSUE(3, 0);
   if (nkt > 1) { OMNI_PP_ISSUE(0, 1); OMNI_PP_ISSUE(1, 1); }
   // accumulators start at the bias.  The bias loads sit BEHIND the prologue's DMA issue: hipcc retires them with vmcnt(0)
   // (it cannot see the asm DMAs), which placed between the DMA issues would drain the first pieces before the rest is sent.
-#if OMNI_PP_MFMA16
   f32x4_t acc[4][8];                               // [16-column block][16-row block]: C[mb*16 + l15][nb*16 + 4*g4 + j]
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
@@ -1194,28 +1023,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = bini;
   }
-#else
-  f32x16_t acc[2][4];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    float bini[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = n0 + wn * 64 + hi * 4 + nb * 32 + q * 8;
-      u32x2_t b = {0u, 0u};
-      if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
-      bini[q * 4 + 0] = bf16_lo(b[0]); bini[q * 4 + 1] = bf16_hi(b[0]);
-      bini[q * 4 + 2] = bf16_lo(b[1]); bini[q * 4 + 3] = bf16_hi(b[1]);
-    }
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nb][mb][i] = bini[i];
-  }
-#endif
   if (nkt > 1) {
-    if ((OMNI_PP_SCHED & 8) && !SPLITK && !FP8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // big phase A reads half-tiles 0-2 at once
-    else asm volatile(OMNI_PP_VMCNT ::: "memory");
+    asm volatile(OMNI_PP_VMCNT ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -1224,11 +1033,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   if (wm) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
   asm volatile("" ::: "memory");
 
-  // wf[nq][ks]; afx[mb][ks] holds the A rows of mq 0, afy[mb][ks] those of mq 1 (OMNI_PP_BALANCED: two register sets, so
-  // that the 8 reads of the NEXT K-tile's mq-0 rows move from phase 0 into phase 3, which reads nothing otherwise: the
-  // phases then read 4 / 4 / 8 / 8 fragments instead of 12 / 4 / 8 / 0; without it afy aliases afx)
-#if OMNI_PP_MFMA16
-  static_assert(!OMNI_PP_BALANCED && !OMNI_PP_DMA_IN_MMA, "the placement experiments exist for the 32x32x16 build only");
   // wf[nq][16-row block of the 32 W rows][ks]; afx[16-row block of the 64 A rows][ks] (mq 0 and mq 1 share the registers)
   bf16x8_t wf[2][2][2], afx[4][2];
   bf16x8_t (&afy)[4][2] = afx;
@@ -1237,244 +1041,73 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 #define OMNI_PP_READ_A(AF, sb)                                                             \
   do {                                                                                     \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                  \
-      AF[0][ks_] = lds_read16<0, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));                      \
-      AF[1][ks_] = lds_read16<16 * 128, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));               \
-      AF[2][ks_] = lds_read16<32 * 128, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));               \
-      AF[3][ks_] = lds_read16<48 * 128, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));               \
+      AF[0][ks_] = lds_read16<0>(a_rd[ks_] + (sb));                                        \
+      AF[1][ks_] = lds_read16<16 * 128>(a_rd[ks_] + (sb));                                 \
+      AF[2][ks_] = lds_read16<32 * 128>(a_rd[ks_] + (sb));                                 \
+      AF[3][ks_] = lds_read16<48 * 128>(a_rd[ks_] + (sb));                                 \
     }                                                                                      \
   } while (0)
 #define OMNI_PP_READ_W(nq, sb)                                                             \
   do {                                                                                     \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                  \
-      wf[nq][0][ks_] = lds_read16<0, OMNI_PP_ABL == 7>(w_rd[ks_] + (sb));                  \
-      wf[nq][1][ks_] = lds_read16<16 * 128, OMNI_PP_ABL == 7>(w_rd[ks_] + (sb));           \
+      wf[nq][0][ks_] = lds_read16<0>(w_rd[ks_] + (sb));                                    \
+      wf[nq][1][ks_] = lds_read16<16 * 128>(w_rd[ks_] + (sb));                             \
     }                                                                                      \
   } while (0)
-// the quadrant's 16 MFMAs: 8 accumulators round-robin, each touched again 8 instructions (128 pipe cycles) later.
-// OMNI_PP_CLUSTER_PART issues the MFMA PAIRS [p0, p1) of the cluster's 8 (bf16; pair p = (ks, mb) = (p / 4, p % 4)) or 4 (fp8;
-// pair p = mb) in the same order as the whole cluster: OMNI_PP_EARLY_BARRIER splits it around the closing barrier.
-#define OMNI_PP_CLUSTER_PART(nq, mq, AF, p0, p1)                                                           \
+// the quadrant's 16 MFMAs: 8 accumulators round-robin, each touched again 8 instructions (128 pipe cycles) later; bf16: pair p =
+// (ks, mb) = (p / 4, p % 4); fp8: ONE scaled MFMA per (block, block) pair covers both ks
+#define OMNI_PP_CLUSTER(nq, mq, AF)                                                                        \
   if (FP8) {                                                                                               \
-    _Pragma("unroll") for (int mb_ = (p0) / 2; mb_ < (p1) / 2; ++mb_) {                                    \
+    _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_) {                                                  \
       pp_mfma_fp8(acc[2 * (nq)][4 * (mq) + mb_], wf[nq][0][0], wf[nq][0][1], AF[mb_][0], AF[mb_][1], mx_one);     \
       pp_mfma_fp8(acc[2 * (nq) + 1][4 * (mq) + mb_], wf[nq][1][0], wf[nq][1][1], AF[mb_][0], AF[mb_][1], mx_one); \
     }                                                                                                      \
   } else                                                                                                   \
-  _Pragma("unroll") for (int p_ = (p0); p_ < (p1); ++p_) {                                                 \
+  _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) {                                                       \
       pp_mfma16(acc[2 * (nq)][4 * (mq) + (p_ & 3)], wf[nq][0][p_ >> 2], AF[p_ & 3][p_ >> 2]);              \
       pp_mfma16(acc[2 * (nq) + 1][4 * (mq) + (p_ & 3)], wf[nq][1][p_ >> 2], AF[p_ & 3][p_ >> 2]);          \
     }
-#define OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1) OMNI_PP_CLUSTER_PART(nq, mq, AF, 0, 8)
-#else
-  bf16x8_t wf[2][4], afx[2][4];
-#if OMNI_PP_BALANCED
-  bf16x8_t afy[2][4];
-#else
-  bf16x8_t (&afy)[2][4] = afx;
-#endif
-#define OMNI_PP_READ_A(AF, sb)                                                             \
-  do {                                                                                     \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                  \
-      AF[0][ks_] = lds_read16<0, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));                      \
-      AF[1][ks_] = lds_read16<32 * 128, OMNI_PP_ABL == 7>(a_rd[ks_] + (sb));               \
-    }                                                                                      \
-  } while (0)
-#define OMNI_PP_READ_W(nq, sb)                                                             \
-  do {                                                                                     \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) wf[nq][ks_] = lds_read16<0, OMNI_PP_ABL == 7>(w_rd[ks_] + (sb)); \
-  } while (0)
-#define OMNI_PP_CLUSTER_PART(nq, mq, AF, p0, p1) OMNI_PP_CLUSTER(nq, mq, AF, (void)0, (void)0)   /* (16x16x32 build only) */
-#define OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1)                                                            \
-  _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                    \
-    pp_mfma(acc[nq][2 * (mq)], wf[nq][ks_], AF[0][ks_]);                                                   \
-    pp_mfma(acc[nq][2 * (mq) + 1], wf[nq][ks_], AF[1][ks_]);                                               \
-    if (OMNI_PP_DMA_IN_MMA && ks_ == 0) { DMA0; }                                                          \
-    if (OMNI_PP_DMA_IN_MMA && ks_ == 2) { DMA1; }                                                          \
-  }
-#endif
 // end of a load section: counted DMA wait, barrier, fragments arrived; then the MFMA cluster and the second barrier.
 // `landed_ok`: the counted wait is valid (enough younger pieces were issued behind the ones that must have landed).
-// DMA0 / DMA1: with OMNI_PP_DMA_IN_MMA the phase's two DMA pieces are issued INSIDE the cluster (behind MFMA 2 and 6): a
-// global_load_lds costs its wave ~60 issue cycles among bare MFMAs but 100-185 next to a burst of ds_reads (MI355X_MICROARCH
-// "LDS-DMA piece issue cost"), and the load section is what the partner group's cluster has to cover.
-#define OMNI_PP_MMA(nq, mq, AF, landed_ok, DMA0, DMA1)                                                     \
+#define OMNI_PP_MMA(nq, mq, AF, landed_ok)                                                                 \
   do {                                                                                                     \
-    if (OMNI_PP_ABL != 3) {                                                                                \
-      if (landed_ok) asm volatile(OMNI_PP_VMCNT_LOOP ::: "memory");                                        \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
-    }                                                                                                      \
-    OMNI_PP_STAMP(pb_t2);                                                                                  \
-    if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                                \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                     \
-    OMNI_PP_STAMP(pb_t3);                                                                                  \
-    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                    \
-    if (OMNI_PP_EARLY_BARRIER && OMNI_PP_MFMA16) {                                                         \
-      /* the closing barrier is SIGNALLED OMNI_PP_EARLY_BARRIER MFMA pairs before the cluster's end: the partner group's */ \
-      /* release (barrier latency + its first issue slots) then overlaps this wave's last MFMAs instead of an idle pipe */ \
-      OMNI_PP_CLUSTER_PART(nq, mq, AF, 0, 8 - OMNI_PP_EARLY_BARRIER)                                       \
-      __builtin_amdgcn_sched_barrier(0);                                                                   \
-      if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                              \
-      OMNI_PP_STAMP(pb_t5e);      /* (probe: T5 precedes T4 in this form: "barrier 2" = -(the tail MFMAs' issue time)) */ \
-      __builtin_amdgcn_sched_barrier(0);                                                                   \
-      OMNI_PP_CLUSTER_PART(nq, mq, AF, 8 - OMNI_PP_EARLY_BARRIER, 8)                                       \
-      OMNI_PP_PROBE_ACCUM(nq, mq);                                                                         \
-      OMNI_PP_PROBE_T5_FROM_EARLY();                                                                       \
-      OMNI_PP_STAMP(pb_t4);                                                                                \
-      if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                   \
-    } else {                                                                                               \
-      OMNI_PP_CLUSTER(nq, mq, AF, DMA0, DMA1)                                                              \
-      OMNI_PP_PROBE_ACCUM(nq, mq); /* T1..T3 of this phase, T4 / T5 of the previous one: all landed long ago */ \
-      OMNI_PP_STAMP(pb_t4);                                                                                \
-      if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                   \
-      if (OMNI_PP_ABL != 4 && OMNI_PP_ABL != 6) __builtin_amdgcn_s_barrier();                              \
-      OMNI_PP_STAMP(pb_t5);                                                                                \
-    }                                                                                                      \
-    asm volatile("" ::: "memory");                                                                         \
-  } while (0)
-// one phase: DMA of half-tile (h, tile) either in the load section (both pieces) or inside the cluster
-#define OMNI_PP_PHASE(nq, mq, AF, do_issue, prev_issued, h, tile)                                          \
-  do {                                                                                                     \
-    if (!OMNI_PP_DMA_IN_MMA) {                                                                             \
-      if (do_issue) OMNI_PP_ISSUE(h, tile);                                                                \
-      OMNI_PP_STAMP(pb_t1);                                                                                \
-      OMNI_PP_MMA(nq, mq, AF, do_issue, (void)0, (void)0);                                                 \
-    } else {                                                                                               \
-      OMNI_PP_MMA(nq, mq, AF, prev_issued, if (do_issue) OMNI_PP_ISSUE_PIECE(h, tile, 0),                  \
-                  if (do_issue) OMNI_PP_ISSUE_PIECE(h, tile, 1));                                          \
-    }                                                                                                      \
-  } while (0)
-
-#if OMNI_PP_BALANCED
-  OMNI_PP_READ_A(afx, 0u);                      // mq-0 rows of K-tile 0 (half-tile 0 has landed)
-#endif
-#if OMNI_PP_PROBE
-  uint64_t pb_t1, pb_t2, pb_t3, pb_t4, pb_t5, pb_t5e = 0, pb_s[5] = {0u, 0u, 0u, 0u, 0u};
-  uint32_t pb_snap3[4] = {0u, 0u, 0u, 0u}, pb_snap4[4] = {0u, 0u, 0u, 0u};
-  uint32_t pb_ph = 0;
-  bool pb_snap = false;
-  OMNI_PP_STAMP(pb_t5);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const uint64_t pb_init = pb_t5;
-  pb_t4 = pb_t5;                               // the "previous phase" of phase 0: its T4 / T5 sums start with this stamp
-#endif
-  int t_first = 0;
-#if (OMNI_PP_SCHED & 8)
-  // Dev variant (-DOMNI_DEV -DOMNI_PP_SCHED=9, NOT yet run on hardware): TWO big phases per K-tile instead of four — 32 MFMAs per
-  // cluster, half the barrier hand-offs per MFMA (with the short load section a slot is cluster + hand-off, and
-  // the hand-off is 45-100 cycles per 256-cycle cluster).
-  //   big phase A(t): issue h0, h1, h2 of K-tile t + 1 (t = 0: h2 only, the prologue has sent h0 / h1) | read h0, h1, h2 of K-tile t
-  //                   (16 fragment reads) | vmcnt(6) | B | quadrants (mq 0, nq 0), (mq 0, nq 1) | B
-  //   big phase B(t): issue h3 of K-tile t + 1 | read h3 of K-tile t (8 reads, into the registers of h0) | vmcnt(2) | B | quadrants
-  //                   (mq 1, nq 1), (mq 1, nq 0) | B
-  // Slots (group 0 loads in even slots, group 1 one slot later): h0-2(t) are read in slots 4t / 4t + 1, h3(t) in 4t + 2 / 4t + 3.
-  //   RAW: a wave's pieces of h0-2(t + 1) (sent in its L_A(t)) are covered by its wait at the end of its L_B(t): vmcnt(2) leaves only
-  //        h3(t + 1) in flight; the first read is group 0's in slot 4t + 4, behind both groups' covering waits (slots 4t + 2, 4t + 3) and
-  //        a barrier.  h3(t + 1) (sent in L_B(t)) is covered at the end of L_A(t + 1): vmcnt(6) leaves h0-2(t + 2) in flight; first read
-  //        in slot 4t + 6, the waits sit in slots 4t + 4 / 4t + 5.  t = 0: the prologue's order is h0-3(0), h0(1), h1(1) and L_A(0)
-  //        adds h2(1): vmcnt(6) again covers h3(0).  Last K-tile: nothing is sent, the waits are vmcnt(0).
-  //   WAR: h0-2(t + 1) overwrite h0-2(t - 1), last read in slot 4t - 3 (complete behind the barrier into 4t - 2), sent in slots 4t /
-  //        4t + 1; h3(t + 1) overwrites h3(t - 1), last read in slot 4t - 1, sent in slots 4t + 2 / 4t + 3: at least two barriers apart.
-  // Same MFMA order per accumulator as the four-phase loop: bit-identical results expected (check: tools/probe/pp_probe --sweep).
-  if constexpr (!SPLITK && !FP8 && OMNI_PP_MFMA16 && !OMNI_PP_BALANCED && !OMNI_PP_DMA_IN_MMA && OMNI_PP_ABL == 0 && !OMNI_PP_EARLY_BARRIER) {
-    const uint32_t lds_w = lds0 + (uint32_t)(wave * 2048);
-    const char* a_nx = Ab + astep;                                  // K-tile t + 1 of either operand
-    const char* w_nx = Wb + wstep;
-#define OMNI_PP_ISSUE_C(h, base, par)                                                                      \
-  do {                                                                                                     \
-    constexpr uint32_t so_ = (uint32_t)(((par) * 4 + (h)) * PSLOT_BYTES);                                  \
-    const uint32_t v0_ = ((h) == 0 || (h) == 3) ? a_off[(h) == 3][0] : w_off[(h) == 2][0];                 \
-    const uint32_t v1_ = ((h) == 0 || (h) == 3) ? a_off[(h) == 3][1] : w_off[(h) == 2][1];                 \
-    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                      \
-                 :: "s"(lds_w), "i"(so_), "v"(v0_), "s"(base) : "memory");                                 \
-    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                      \
-                 :: "s"(lds_w), "i"(so_ + 1024u), "v"(v1_), "s"(base) : "memory");                         \
-  } while (0)
-// two quadrants behind ONE barrier pair; `nxt`: pieces were sent in this load section (the counted wait is valid)
-#define OMNI_PP_BIGMMA(nqa, nqb, mq, AF, nxt, WAITSTR)                                                     \
-  do {                                                                                                     \
-    if (nxt) asm volatile(WAITSTR ::: "memory");                                                           \
+    if (landed_ok) asm volatile(OMNI_PP_VMCNT_LOOP ::: "memory");                                          \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
     OMNI_PP_STAMP(pb_t2);                                                                                  \
     __builtin_amdgcn_s_barrier();                                                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     OMNI_PP_STAMP(pb_t3);                                                                                  \
-    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                    \
-    OMNI_PP_CLUSTER(nqa, mq, AF, (void)0, (void)0)                                                         \
-    OMNI_PP_CLUSTER(nqb, mq, AF, (void)0, (void)0)                                                         \
-    OMNI_PP_PROBE_ACCUM(nqa, mq);                                                                          \
+    OMNI_PP_CLUSTER(nq, mq, AF)                                                                            \
+    OMNI_PP_PROBE_ACCUM(nq, mq); /* T1..T3 of this phase, T4 / T5 of the previous one: all landed long ago */ \
     OMNI_PP_STAMP(pb_t4);                                                                                  \
-    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     __builtin_amdgcn_s_barrier();                                                                          \
     OMNI_PP_STAMP(pb_t5);                                                                                  \
     asm volatile("" ::: "memory");                                                                         \
   } while (0)
-    // A K-tile that has a successor (everything but the last): ring parity compile-time, `first` (K-tile 0: the prologue has
-    // already sent h0 / h1 of K-tile 1) one uniform branch.  (Six fully compile-time instances — first / steady x 2 / single /
-    // last x 2 — made hipcc spill 200+ VGPRs: too many merge points for 128 accumulators; this form allocates 221, no spill.)
-    auto bigtile = [&](auto par_c, const bool first) __attribute__((always_inline)) {
-      constexpr int PAR = decltype(par_c)::value;
-      constexpr uint32_t sb = (uint32_t)(PAR * 4 * PSLOT_BYTES);
-      // ---- big phase A
-      if (!first) { OMNI_PP_ISSUE_C(0, a_nx, PAR ^ 1); OMNI_PP_ISSUE_C(1, w_nx, PAR ^ 1); }
-      OMNI_PP_ISSUE_C(2, w_nx, PAR ^ 1);
-      OMNI_PP_READ_A(afx, sb);
-      OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
-      OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
-      OMNI_PP_STAMP(pb_t1);
-      OMNI_PP_BIGMMA(0, 1, 0, afx, true, "s_waitcnt vmcnt(6)");
-      // ---- big phase B
-      OMNI_PP_ISSUE_C(3, a_nx, PAR ^ 1);
-      OMNI_PP_READ_A(afy, sb + 3 * PSLOT_BYTES);
-      OMNI_PP_STAMP(pb_t1);
-      OMNI_PP_BIGMMA(1, 0, 1, afy, true, "s_waitcnt vmcnt(2)");
-      a_nx += astep;
-      w_nx += wstep;
-    };
-    // the last K-tile: nothing to send, every wait is vmcnt(0); ring parity at run time (one instance)
-    auto lasttile = [&](const uint32_t sb) __attribute__((always_inline)) {
-      OMNI_PP_READ_A(afx, sb);
-      OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
-      OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
-      OMNI_PP_STAMP(pb_t1);
-      OMNI_PP_BIGMMA(0, 1, 0, afx, false, "s_waitcnt vmcnt(0)");
-      OMNI_PP_READ_A(afy, sb + 3 * PSLOT_BYTES);
-      OMNI_PP_STAMP(pb_t1);
-      OMNI_PP_BIGMMA(1, 0, 1, afy, false, "s_waitcnt vmcnt(0)");
-    };
-    if (nkt >= 2) {
-#pragma unroll 1
-      for (; t_first + 1 < nkt; t_first += 2) {                     // K-tiles with a successor, in pairs (parities 0, 1)
+// one phase of the GENERAL loop (run-time `do_issue`): both DMA pieces of half-tile (h, tile) in the load section
+#define OMNI_PP_PHASE(nq, mq, AF, do_issue, h, tile)                                                       \
+  do {                                                                                                     \
+    if (do_issue) OMNI_PP_ISSUE(h, tile);                                                                  \
+    OMNI_PP_STAMP(pb_t1);                                                                                  \
+    OMNI_PP_MMA(nq, mq, AF, do_issue);                                                                     \
+  } while (0)
+
 #if OMNI_PP_PROBE
-        pb_snap = (t_first | 1) == ((nkt >> 1) | 1);
+  OMNI_PP_PROBE_DECLS();
 #endif
-        bigtile(std::integral_constant<int, 0>{}, t_first == 0);
-        if (t_first + 2 < nkt) bigtile(std::integral_constant<int, 1>{}, false);
-      }
-      // t_first is the first K-tile not handled above: nkt - 1 (even nkt ran 0 .. nkt - 2 as pairs + one single) — its parity:
-      lasttile((uint32_t)(((nkt - 1) & 1) * 4 * PSLOT_BYTES));
-      t_first = nkt;
-    }
-#undef OMNI_PP_BIGMMA
-#undef OMNI_PP_ISSUE_C
-  }
-#elif OMNI_PP_SCHED
-  // Dev variant (-DOMNI_DEV -DOMNI_PP_SCHED=<bits>; the default loop below is untouched): the steady state of the K-loop with
-  // everything the scalar unit decides per phase in the default loop made compile-time — the loop is unrolled by two K-tiles
-  // (ring parity = a constant), `t + 1 < nkt` / `t + 2 < nkt` hold by construction (the last two or three K-tiles run through
-  // the default loop), one running pointer per operand instead of `base + t * step` per phase, M0 = one s_add of a per-wave
-  // constant.  Static census (tools/loop_census.py): 75 SALU + 10 branches + 20 nop / setprio per K-tile -> see DESIGN item 29.
-  //   bit 0 (1): the restructured loop        bit 1 (2): a phase's DMA pieces are issued BEFORE its fragment reads
-  //   bit 2 (4): ... only by the waves with odd wn (the four load-group waves of a CU hit the TA in two batches, not one)
-  if constexpr (!SPLITK && (!FP8 || (OMNI_PP_SCHED & 16)) && OMNI_PP_MFMA16 && !OMNI_PP_BALANCED && !OMNI_PP_DMA_IN_MMA && OMNI_PP_ABL == 0) {   // bit 4 (16): dev builds, also the fp8 instance (same LDS image and loop; not yet run)
+  int t_first = 0;
+  // STEADY STATE (every K-tile whose successors t + 1 and t + 2 both exist; not the split-K instance): everything the scalar unit
+  // decides per phase in the general loop below is compile-time here — the loop runs two K-tiles per trip (ring parity = a
+  // constant), `t + 1 < nkt` / `t + 2 < nkt` hold by construction, one running pointer per operand instead of `base + t * step`
+  // per phase, M0 = one s_add of a per-wave constant and an immediate: 0.25 scalar instructions per MFMA (1.17 in the general
+  // loop; the vendor kernel: 0.33), load section 246 -> 154 cycles per phase by the phase probe.  The fp8
+  // instance runs the same loop since round 5 (its clusters are half as long: the scalar stream weighed twice as much).
+  if constexpr (!SPLITK) {
     const uint32_t lds_w = lds0 + (uint32_t)(wave * 2048);           // this wave's two pieces inside a half-tile slot
     const char* a_nx = Ab + astep;                                  // K-tile t + 1 of either operand (t = 0)
     const char* w_nx = Wb + wstep;
-    const bool dma_first_rt = (OMNI_PP_SCHED & 4) ? (wn & 1) != 0 : (OMNI_PP_SCHED & 2) != 0;
 #define OMNI_PP_ISSUE_C(h, base, par)                                                                      \
   do {                                                                                                     \
     constexpr uint32_t so_ = (uint32_t)(((par) * 4 + (h)) * PSLOT_BYTES);                                  \
@@ -1485,104 +1118,71 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                      \
                  :: "s"(lds_w), "i"(so_ + 1024u), "v"(v1_), "s"(base) : "memory");                         \
   } while (0)
-    // one K-tile of ring parity PAR whose successors t + 1 and t + 2 both exist; DF: DMA first
-    auto ktile = [&](auto par_c, auto df_c) __attribute__((always_inline)) {
+    // one K-tile of ring parity PAR
+    auto ktile = [&](auto par_c) __attribute__((always_inline)) {
       constexpr int PAR = decltype(par_c)::value;
-      constexpr bool DF = decltype(df_c)::value;
       constexpr uint32_t sb = (uint32_t)(PAR * 4 * PSLOT_BYTES);
       // phase 0: quadrant (mq 0, nq 0); DMA: half-tile 2 (W rows of nq 1) of K-tile t + 1
-      if (DF) OMNI_PP_ISSUE_C(2, w_nx, PAR ^ 1);
       OMNI_PP_READ_A(afx, sb);
       OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
-      if (!DF) OMNI_PP_ISSUE_C(2, w_nx, PAR ^ 1);
+      OMNI_PP_ISSUE_C(2, w_nx, PAR ^ 1);
       OMNI_PP_STAMP(pb_t1);
-      OMNI_PP_MMA(0, 0, afx, true, (void)0, (void)0);
+      OMNI_PP_MMA(0, 0, afx, true);
       // phase 1: quadrant (mq 0, nq 1); DMA: half-tile 3 (A rows of mq 1) of K-tile t + 1
-      if (DF) OMNI_PP_ISSUE_C(3, a_nx, PAR ^ 1);
       OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
-      if (!DF) OMNI_PP_ISSUE_C(3, a_nx, PAR ^ 1);
+      OMNI_PP_ISSUE_C(3, a_nx, PAR ^ 1);
       OMNI_PP_STAMP(pb_t1);
-      OMNI_PP_MMA(1, 0, afx, true, (void)0, (void)0);
+      OMNI_PP_MMA(1, 0, afx, true);
       a_nx += astep;                                                // K-tile t + 2
       w_nx += wstep;
       // phase 2: quadrant (mq 1, nq 1); DMA: half-tile 0 (A rows of mq 0) of K-tile t + 2
-      if (DF) OMNI_PP_ISSUE_C(0, a_nx, PAR);
       OMNI_PP_READ_A(afy, sb + 3 * PSLOT_BYTES);
-      if (!DF) OMNI_PP_ISSUE_C(0, a_nx, PAR);
+      OMNI_PP_ISSUE_C(0, a_nx, PAR);
       OMNI_PP_STAMP(pb_t1);
-      OMNI_PP_MMA(1, 1, afy, true, (void)0, (void)0);
+      OMNI_PP_MMA(1, 1, afy, true);
       // phase 3: quadrant (mq 1, nq 0); DMA: half-tile 1 (W rows of nq 0) of K-tile t + 2
       OMNI_PP_ISSUE_C(1, w_nx, PAR);
       OMNI_PP_STAMP(pb_t1);
-      OMNI_PP_MMA(0, 1, afy, true, (void)0, (void)0);
+      OMNI_PP_MMA(0, 1, afy, true);
     };
-    using c0 = std::integral_constant<int, 0>;
-    using c1 = std::integral_constant<int, 1>;
-    if (dma_first_rt) {
 #pragma unroll 1
-      for (; t_first + 3 < nkt; t_first += 2) {
+    for (; t_first + 3 < nkt; t_first += 2) {
 #if OMNI_PP_PROBE
-        pb_snap = (t_first | 1) == ((nkt >> 1) | 1);
+      pb_snap = (t_first | 1) == ((nkt >> 1) | 1);
 #endif
-        ktile(c0{}, std::true_type{});
-        ktile(c1{}, std::true_type{});
-      }
-    } else {
-#pragma unroll 1
-      for (; t_first + 3 < nkt; t_first += 2) {
-#if OMNI_PP_PROBE
-        pb_snap = (t_first | 1) == ((nkt >> 1) | 1);
-#endif
-        ktile(c0{}, std::false_type{});
-        ktile(c1{}, std::false_type{});
-      }
+      ktile(std::integral_constant<int, 0>{});
+      ktile(std::integral_constant<int, 1>{});
     }
 #undef OMNI_PP_ISSUE_C
   }
-#endif
+  // GENERAL loop: the last two or three K-tiles (their successors may not exist), short K, and the split-K instance
 #pragma unroll 1
   for (int t = t_first; t < nkt; ++t) {
 #if OMNI_PP_PROBE
     pb_snap = t == (nkt >> 1);                   // the middle K-tile: T3 of its four phases, T4 of its phases 0-2 (slot 3: the T4 before it)
 #endif
     const uint32_t sb = (uint32_t)((t & 1) * 4 * PSLOT_BYTES);
-    const uint32_t sbn = (uint32_t)(((t + 1) & 1) * 4 * PSLOT_BYTES);
-    const bool n1 = OMNI_PP_ABL != 2 && OMNI_PP_ABL != 6 && OMNI_PP_ABL != 7 && t + 1 < nkt,
-               n2 = OMNI_PP_ABL != 2 && OMNI_PP_ABL != 6 && OMNI_PP_ABL != 7 && t + 2 < nkt;
-    // with the DMA inside the clusters, the pieces a load section's wait must leave in flight were issued by the
-    // PREVIOUS phase's cluster: phase 0 looks back at phase 3 of tile t-1 (issued iff t + 1 < nkt), etc.
+    const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;
     // phase 0: quadrant (mq 0, nq 0)
-    if (!OMNI_PP_BALANCED) OMNI_PP_READ_A(afx, sb);
+    OMNI_PP_READ_A(afx, sb);
     OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
-    OMNI_PP_PHASE(0, 0, afx, n1, n1, 2, t + 1);
+    OMNI_PP_PHASE(0, 0, afx, n1, 2, t + 1);
     // phase 1: quadrant (mq 0, nq 1)
     OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
-    OMNI_PP_PHASE(1, 0, afx, n1, n1, 3, t + 1);
+    OMNI_PP_PHASE(1, 0, afx, n1, 3, t + 1);
     // phase 2: quadrant (mq 1, nq 1)
     OMNI_PP_READ_A(afy, sb + 3 * PSLOT_BYTES);
-    OMNI_PP_PHASE(1, 1, afy, n2, n1, 0, t + 2);
+    OMNI_PP_PHASE(1, 1, afy, n2, 0, t + 2);
     // phase 3: quadrant (mq 1, nq 0)
-    if (OMNI_PP_BALANCED && t + 1 < nkt) OMNI_PP_READ_A(afx, sbn);
-    OMNI_PP_PHASE(0, 1, afy, n2, n2, 1, t + 2);
+    OMNI_PP_PHASE(0, 1, afy, n2, 1, t + 2);
   }
   if (!wm) __builtin_amdgcn_s_barrier();         // group 0 waits for group 1's last cluster
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // asm MFMA results -> first compiler-visible VALU read
   // (the OMNI_PP_* loop macros stay defined for the persistent variant below, which repeats this loop; #undef'd behind it)
 #if OMNI_PP_PROBE
-  if (!SPLITK && P.splitk_ws) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    pb_s[3] += pb_t4; pb_s[4] += pb_t5;          // the last phase's T4 / T5 (every other one was added one phase late)
-    if (lane == 0) {
-      uint32_t* const o = reinterpret_cast<uint32_t*>(P.splitk_ws) + ((int64_t)blockIdx.x * 8 + wave) * 16;
-      o[0] = (uint32_t)pb_s[0]; o[1] = (uint32_t)pb_s[1]; o[2] = (uint32_t)pb_s[2]; o[3] = (uint32_t)pb_s[3]; o[4] = (uint32_t)pb_s[4];
-      o[5] = (uint32_t)pb_init; o[6] = (uint32_t)pb_t5; o[7] = pb_ph;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { o[8 + i] = pb_snap3[i]; o[12 + i] = pb_snap4[i]; }
-    }
-  }
+  OMNI_PP_PROBE_WRITE();
 #endif
 
-#if OMNI_PP_MFMA16
   if (SPLITK) {
     // fp32 partial tile: lane (l15, g4) holds C[mb*16 + l15][nb*16 + 4*g4 .. +4]: 16-B stores, 64 contiguous bytes per row
     float* const wsp = P.splitk_ws + ((int64_t)split * (P.g[0].M + (P.ngroups > 1 ? P.g[1].M : 0)) + (gi ? P.g[0].M : 0)) * N;
@@ -1598,7 +1198,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
     }
     return;
   }
-  if constexpr ((EPI == OMNI_EPI_BIAS || EPI == OMNI_EPI_BIAS_GELU_TANH) && OMNI_PP_DIRECT_K32) {
+  // K32-blocked outputs are stored straight from the accumulators
+  if constexpr (EPI == OMNI_EPI_BIAS || EPI == OMNI_EPI_BIAS_GELU_TANH) {
     if (G.out_k32_rows && !G.out_row_map) {          // uniform over the workgroup
       gemm_epilogue_direct_k32<EPI, FP8>(P, G, acc, m0, n0, wm, wn, l15, g4);
       return;
@@ -1606,314 +1207,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   }
   if (FP8) gemm_epilogue_lds_fp8<EPI>(P, G, acc, m0, n0, wm, wn, l15, g4, smem, tid);
   else gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l15, g4, smem, tid);
-#else
-  static_assert(!SPLITK, "split-K is built for the 16x16x32 accumulator layout");
-  gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi, smem, tid);
-#endif
 }
 
 
 #if OMNI_PP_PROBE   // the probe instruments the one-shot kernel only: the persistent variant below expands the same loop macros
 #undef OMNI_PP_STAMP
 #undef OMNI_PP_PROBE_ACCUM
-#undef OMNI_PP_PROBE_T5_FROM_EARLY
 #define OMNI_PP_STAMP(v) ((void)0)
 #define OMNI_PP_PROBE_ACCUM(nq, mq) ((void)0)
-#define OMNI_PP_PROBE_T5_FROM_EARLY() ((void)0)
 #endif
 
-#ifdef OMNI_DEV   // dev-only kernel family 8 (kernel_hint 16 + 8): measured NEUTRAL (round 4), kept for A/B runs and its ablations
-// ------------------------------------------------------------------------------------------------
-// PERSISTENT form of the ping-pong kernel for launches whose epilogue is the direct K32 store (MLP-up / GELU: the roofline
-// kernel).  One workgroup per CU walks the tiles the one-shot grid would have given that CU (same XCD-aware order: tile k of
-// workgroup b is the one-shot block b + k * gridDim).  What it buys: in the one-shot kernel a CU sits idle between the last
-// MFMA of tile i and the first of tile i + 1 for the epilogue, the workgroup's exit, the dispatch of the next one (the LDS is
-// whole-CU: it cannot start earlier), its address set-up and one DMA round trip.  Here, at the seam, the NEXT tile's bias
-// loads and its six prologue half-tiles are issued first (the ring is drained: every wave is behind the K-loop's last
-// barrier) and fly while the accumulators of the finished tile go through GELU and out to HBM straight from the registers
-// (no LDS: the direct epilogue).  Waits are counted: the seam's VMEM stream is [4 bias loads] [12 DMA pieces] [16 stores] per
-// wave, the stores issued as buffer stores whose out-of-range lanes are dropped by the descriptor instead of by an exec-mask
-// branch, so their NUMBER is the same for every tile and vmcnt(8 + 16) means "bias and half-tiles 0 / 1 have landed".  Same
-// K-loop (the OMNI_PP_* macros), same accumulation order: bit-identical to gemm_bf16_pp_kernel (tools/check_ppp.py: ragged M / N,
-// two groups, no bias, two K-tiles, skipped row tiles).
-// MEASURED (same box, M = 40960 + 640, N = 12288, K = 3072, profiles/r04_persistent_gemm_and_epilogue_decomposition.log):
-//   one-shot ping-pong 1359-1372 TF/s | this kernel 1373 (+0.2 %) | its epilogue arithmetic with every store dropped 1415 (+3.2 %)
-//   | all stores into one L2-resident 64-KiB window 1412 | no epilogue at all 1478 (+7.9 %) | K-loop waits that never cover the
-//   stores 1374 | the same launch without the GELU arithmetic 1414 (one-shot 1409).
-// Reading: workgroup exit / dispatch / address set-up / the first DMA round trip are NOT what a tile boundary costs (hidden
-// here: +0.2 %); neither is vmcnt's in-order retirement behind the store acknowledgements.  The 7.9 % are 4.6 % of VALU time
-// with the matrix pipe idle (GELU 2.9 %, convert / permlane / addresses 1.7 %: all eight waves reach the seam together) and
-// 3.1 % for the GIGABYTE the launch writes to HBM (gone when the stores stay in L2: it is the drain of 256 simultaneous
-// 128-KiB bursts, not their issue).  Overlapping the arithmetic needs workgroups in different tile phases on one CU (two
-// 4-wave workgroups per CU); smoothing the write bursts needs the XCDs phase-shifted against each other (DESIGN.md "Open leads").
-// ------------------------------------------------------------------------------------------------
-OMNI_DEVINL u32x4_t gemm_srd(const void* base, uint32_t bytes) {
-  const uint64_t a = reinterpret_cast<uint64_t>(base);
-  u32x4_t r;
-  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
-  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);     // stride 0: raw buffer
-  r[2] = __builtin_amdgcn_readfirstlane(bytes);
-  r[3] = 0x00020000u;
-  return r;
-}
-#ifndef OMNI_PPP_ABL
-#define OMNI_PPP_ABL 0   // dev-only timing ablations (results wrong by construction): 1 no epilogue at all, 2 epilogue arithmetic with every store dropped, 3 stores into one 64-KiB window, 5 K-loop waits never cover the stores
+#ifdef OMNI_DEV
+#include "dev/gemm_family8_persistent_pingpong.inc"
 #endif
-constexpr uint32_t PPP_DROP = 0xC0000000u;   // a byte offset no output reaches (the host keeps outputs below 2 GiB): the store is dropped
-
-// gemm_epilogue_direct_k32 with descriptor-checked stores: exactly 16 store instructions per wave, whatever M and N are
-template <int EPI>
-OMNI_DEVINL void gemm_epilogue_direct_k32_buf(const u32x4_t& srd, int M, int N, int64_t R, f32x4_t (&acc)[4][8], int m0, int n0,
-                                              int wm, int wn, int l15, int g) {
-#pragma unroll
-  for (int mb = 0; mb < 8; ++mb) {
-    const int row = m0 + wm * 128 + mb * 16 + l15;
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-      uint32_t a[2], b[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int nb = 2 * sl + h;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = acc[nb][mb][j];
-          if (EPI == OMNI_EPI_BIAS_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
-        }
-        (h ? b : a)[0] = pack_bf16x2(v[0], v[1]);
-        (h ? b : a)[1] = pack_bf16x2(v[2], v[3]);
-      }
-      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1"
-                   : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
-      const u32x4_t o = {a[0], a[1], b[0], b[1]};
-      const int n = n0 + wn * 64 + sl * 32 + (g & 1) * 16 + (g >> 1) * 8;
-      const int64_t off = (((int64_t)(n >> 5) * R + row) * 32 + (n & 31)) * 2;
-#if OMNI_PPP_ABL == 2
-      const uint32_t voff = PPP_DROP | ((uint32_t)off & 0xff0u);   // timing ablation: the arithmetic, no byte written
-#elif OMNI_PPP_ABL == 3
-      const uint32_t voff = (uint32_t)off & 0xfff0u;               // timing ablation: every store lands in one 64-KiB window (L2-resident)
-#else
-      const uint32_t voff = (row < M && n < N) ? (uint32_t)off : PPP_DROP;
-#endif
-      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" OMNI_EPI_STORE_POLICY "\n\ts_nop 2" ::"v"(o), "v"(voff), "s"(srd) : "memory");
-    }
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_ppp_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
-                                                                      int tiles_n, int GROUP_M) {
-  static_assert(EPI == OMNI_EPI_BIAS || EPI == OMNI_EPI_BIAS_GELU_TANH, "direct K32 epilogues only");
-  static_assert(OMNI_PP_MFMA16 && !OMNI_PP_BALANCED && !OMNI_PP_DMA_IN_MMA, "built on the 16x16x32 loop");
-  constexpr int FP8 = 0;                           // (named by the loop macros)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = tiles_m * tiles_n;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int l15 = lane & 15, g4 = lane >> 4;
-  const int N = P.N, K = P.K;
-  const int nkt = K / PBK;                         // >= 2 (host)
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const int64_t wstep = P.w_k32_blocked ? (int64_t)N * 128 : 128;
-  // this workgroup's tiles: slots (blockIdx >> 3) + k * (gridDim >> 3) of its XCD's contiguous range of the tile list
-  const int xcd = (int)blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int xbase = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
-  const int xcount = qq + (xcd < rr ? 1 : 0);
-  const int slot_step = (int)gridDim.x >> 3;
-  const int band_sz = GROUP_M * tiles_n;
-
-  // ---- state of the tile whose K-loop runs (re-assigned at every seam) ----
-  int gi = 0, m0 = 0, n0 = 0;
-  const char *Ab = nullptr, *Wb = nullptr;
-  int64_t astep = 128;
-  uint32_t a_off[2][2], w_off[2][2];
-  u32x2_t bq[4];                                   // its bias: 4 bf16 per 16-column block, loaded by asm at the seam
-  bool has_bias = false;
-
-  auto decode = [&](int slot, int& gi_, int& mt_, int& nt_) {
-    const int lid = xbase + slot;
-    const int band = lid / band_sz, in_band = lid - band * band_sz;
-    const int first_m = band * GROUP_M;
-    const int gm = min(GROUP_M, tiles_m - first_m);
-    mt_ = first_m + in_band % gm;
-    nt_ = in_band / gm;
-    gi_ = (mt_ >= mtiles0) ? 1 : 0;
-  };
-  auto skipped = [&](int slot) -> bool {           // device-side predicate (omni_teacache)
-    int gi_, mt_, nt_;
-    decode(slot, gi_, mt_, nt_);
-    const int32_t* sk = gi_ ? P.g[1].tile_skip : P.g[0].tile_skip;
-    return sk && sk[gi_ ? mt_ - mtiles0 : mt_];
-  };
-  // tile `slot` becomes the K-loop's tile: operand bases, per-lane DMA offsets, and its bias loads IN FLIGHT (asm: hipcc would
-  // retire a load of its own with vmcnt(0), draining the DMA stream)
-  auto setup = [&](int slot) {
-    int mt, nt;
-    decode(slot, gi, mt, nt);
-    const omni_gemm_group G = pick_group(P, gi);
-    m0 = (gi ? mt - mtiles0 : mt) * BM;
-    n0 = nt * BN;
-    const int M = G.M;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int lr = (wave * 2 + i) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((lr >> 1) & 7);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        int ar = min(m0 + (lr >> 6) * 128 + q * 64 + (lr & 63), M - 1);
-        if (G.a_row_map) ar = G.a_row_map[ar];
-        const int64_t ae = G.a_k32_rows ? ((int64_t)(c >> 2) * G.a_k32_rows + ar) * 32 + (c & 3) * 8
-                                        : (int64_t)ar * G.lda + c * 8;
-        a_off[q][i] = (uint32_t)(ae * 2);
-        const int wr = min(n0 + (lr >> 5) * 64 + q * 32 + (lr & 31), N - 1);
-        const int64_t we = P.w_k32_blocked ? ((int64_t)(c >> 2) * N + wr) * 32 + (c & 3) * 8 : (int64_t)wr * K + c * 8;
-        w_off[q][i] = (uint32_t)(we * 2);
-      }
-    }
-    astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * 128 : 128;
-    Ab = reinterpret_cast<const char*>(G.A);
-    Wb = reinterpret_cast<const char*>(G.W);
-    // branch-free: a diamond here would let hipcc resolve the phi with register copies BEFORE the counted wait (copies of
-    // registers whose loads are still in flight).  No bias: any readable address, the value is replaced by 0 behind the wait.
-    has_bias = G.bias != nullptr;
-    const uint16_t* const bsrc = has_bias ? G.bias : reinterpret_cast<const uint16_t*>(G.W);
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      const uint16_t* bp = bsrc + min(n0 + wn * 64 + nb * 16 + g4 * 4, N - 4);   // (columns >= N are never stored)
-      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(bq[nb]) : "v"(bp) : "memory");
-    }
-  };
-
-  const int l15_ = l15;
-  uint32_t a_rd[2], w_rd[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const uint32_t chunk = ((uint32_t)(ks * 4 + g4) ^ ((l15_ >> 1) & 7)) << 4;
-    a_rd[ks] = lds0 + (wm * 64 + l15) * 128 + chunk;
-    w_rd[ks] = lds0 + (wn * 32 + l15) * 128 + chunk;
-  }
-  f32x4_t acc[4][8];
-  bf16x8_t wf[2][2][2], afx[4][2];
-  bf16x8_t (&afy)[4][2] = afx;
-  uint32_t mx_one = 0x7f7f7f7fu;
-  asm volatile("" : "+v"(mx_one));
-
-  int slot = (int)blockIdx.x >> 3;
-  while (slot < xcount && skipped(slot)) slot += slot_step;
-  if (slot >= xcount) return;
-  setup(slot);
-  OMNI_PP_ISSUE(0, 0); OMNI_PP_ISSUE(1, 0); OMNI_PP_ISSUE(2, 0); OMNI_PP_ISSUE(3, 0);
-  OMNI_PP_ISSUE(0, 1); OMNI_PP_ISSUE(1, 1);
-  // bias and half-tiles 0 / 1 of the first tile have landed: 8 DMA pieces and 16 (dropped) stores are younger.  (The bias registers are tied to every
-  // counted wait so that no use moves above it; the registers are printed in the listing: tests/test_host_logic.py checks
-  // that they are the very registers the loads wrote, i.e. that hipcc put no copy in between.)
-  {
-    // the first tile has no epilogue in front of it: 16 stores that the descriptor drops (every lane out of range) give its
-    // VMEM stream the shape of a seam's, so that ONE set of counted waits serves every tile
-    const u32x4_t srd0 = gemm_srd(P.g[0].out, 16u);
-    const u32x4_t z = {0u, 0u, 0u, 0u};
-    const uint32_t voff = PPP_DROP;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(z), "v"(voff), "s"(srd0) : "memory");
-  }
-  asm volatile("s_waitcnt vmcnt(24) ; omni ppp bias %0 %1 %2 %3" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : : "memory");
-  for (;;) {
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      const uint32_t b0 = has_bias ? bq[nb][0] : 0u, b1 = has_bias ? bq[nb][1] : 0u;
-      const f32x4_t bini = {bf16_lo(b0), bf16_hi(b0), bf16_lo(b1), bf16_hi(b1)};
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = bini;
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (wm) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
-    asm volatile("" ::: "memory");
-    // K-tile 0, peeled: its four counted waits leave the epilogue's 16 stores in flight as well.  Per wave the VMEM stream is
-    // [12 prologue pieces: half-tiles 0..5] [16 stores] [2 pieces per phase]; phase g needs half-tiles <= g + 2, behind which
-    // are (5 - (g + 2)) * 2 prologue pieces + 16 stores + 2 (g + 1) new pieces = 24, for every g.  (vmcnt retires in order:
-    // with the steady-state vmcnt(8) the FIRST load section of a tile would wait for the acknowledgement of the last store.)
-    // From K-tile 1 on the stores are older than everything a wait still needs: vmcnt(8).
-    {
-      const bool n2 = 2 < nkt;
-#undef OMNI_PP_VMCNT_LOOP
-#define OMNI_PP_VMCNT_LOOP "s_waitcnt vmcnt(24)"
-      OMNI_PP_READ_A(afx, 0u);
-      OMNI_PP_READ_W(0, (uint32_t)PSLOT_BYTES);
-      OMNI_PP_PHASE(0, 0, afx, true, true, 2, 1);
-      OMNI_PP_READ_W(1, (uint32_t)(2 * PSLOT_BYTES));
-      OMNI_PP_PHASE(1, 0, afx, true, true, 3, 1);
-      OMNI_PP_READ_A(afy, (uint32_t)(3 * PSLOT_BYTES));
-      OMNI_PP_PHASE(1, 1, afy, n2, true, 0, 2);
-      OMNI_PP_PHASE(0, 1, afy, n2, n2, 1, 2);
-#undef OMNI_PP_VMCNT_LOOP
-#if OMNI_PPP_ABL == 5   // timing ablation: no wait of the whole K-loop ever covers the stores (needed loads may still be in flight)
-#define OMNI_PP_VMCNT_LOOP "s_waitcnt vmcnt(24)"
-#else
-#define OMNI_PP_VMCNT_LOOP OMNI_PP_VMCNT
-#endif
-    }
-#pragma unroll 1
-    for (int t = 1; t < nkt; ++t) {
-      const uint32_t sb = (uint32_t)((t & 1) * 4 * PSLOT_BYTES);
-      const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;
-      OMNI_PP_READ_A(afx, sb);
-      OMNI_PP_READ_W(0, sb + PSLOT_BYTES);
-      OMNI_PP_PHASE(0, 0, afx, n1, n1, 2, t + 1);
-      OMNI_PP_READ_W(1, sb + 2 * PSLOT_BYTES);
-      OMNI_PP_PHASE(1, 0, afx, n1, n1, 3, t + 1);
-      OMNI_PP_READ_A(afy, sb + 3 * PSLOT_BYTES);
-      OMNI_PP_PHASE(1, 1, afy, n2, n1, 0, t + 2);
-      OMNI_PP_PHASE(0, 1, afy, n2, n2, 1, t + 2);
-      // asm MFMA results -> first compiler-visible VALU read: INSIDE the loop body, because hipcc moves accumulators between
-      // register sets on the loop's exit edge (v_mov of registers the last cluster has just written)
-      if (!n1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-    }
-    if (!wm) __builtin_amdgcn_s_barrier();         // every wave is behind the last fragment read: the ring may be refilled
-    asm volatile("" ::: "memory");
-
-    // ---- seam: the finished tile's coordinates, then the next tile's loads, then the finished tile's epilogue ----
-    const int e_m0 = m0, e_n0 = n0;
-    uint16_t* const eo = gi ? P.g[1].out : P.g[0].out;
-    const int eM = gi ? P.g[1].M : P.g[0].M;
-    const int64_t eR = gi ? P.g[1].out_k32_rows : P.g[0].out_k32_rows;
-    const u32x4_t srd = gemm_srd(eo, (uint32_t)((int64_t)(N >> 5) * eR * 64));
-    int nslot = slot + slot_step;
-    while (nslot < xcount && skipped(nslot)) nslot += slot_step;
-    if (nslot >= xcount) {                         // last tile of this workgroup
-      gemm_epilogue_direct_k32_buf<EPI>(srd, eM, N, eR, acc, e_m0, e_n0, wm, wn, l15, g4);
-      return;
-    }
-    // straight-line from the bias loads to the counted wait (no control flow: see setup())
-    setup(nslot);
-    OMNI_PP_ISSUE(0, 0); OMNI_PP_ISSUE(1, 0); OMNI_PP_ISSUE(2, 0); OMNI_PP_ISSUE(3, 0);
-    OMNI_PP_ISSUE(0, 1); OMNI_PP_ISSUE(1, 1);
-#if OMNI_PPP_ABL == 1
-    {
-      const u32x4_t z = {0u, 0u, 0u, 0u};
-      const uint32_t voff = PPP_DROP;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(z), "v"(voff), "s"(srd) : "memory");
-    }
-#else
-    gemm_epilogue_direct_k32_buf<EPI>(srd, eM, N, eR, acc, e_m0, e_n0, wm, wn, l15, g4);
-#endif
-    // bias and half-tiles 0 / 1 of the next tile have landed: 8 DMA pieces and the 16 stores are younger
-    asm volatile("s_waitcnt vmcnt(24) ; omni ppp bias %0 %1 %2 %3" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : : "memory");
-    slot = nslot;
-  }
-}
-
-#undef OMNI_PP_VMCNT_LOOP
-#define OMNI_PP_VMCNT_LOOP OMNI_PP_VMCNT
-#endif  // OMNI_DEV (family 8)
 #undef OMNI_PP_PHASE
 #undef OMNI_PP_MMA
 #undef OMNI_PP_CLUSTER
-#undef OMNI_PP_CLUSTER_PART
 #undef OMNI_PP_READ_W
 #undef OMNI_PP_READ_A
 #undef OMNI_PP_ISSUE
@@ -1945,799 +1254,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_splitk_finish_kernel(const omni
   gemm_epilogue_lds_impl<EPI>(P, G, m0, n0, nullptr, (int)threadIdx.x, []() {}, src);
 }
 
-#ifdef OMNI_DEV   // dev-only kernel families: two-phase ping-pong (variants 5 / 6: measured <= the four-phase kernel) and
-                  // 4 waves x 128x128 (variant 2)
-// ------------------------------------------------------------------------------------------------
-// Two-phase ping-pong variant (OMNI_GEMM_VARIANT=5): same half-tiles, accumulators and k order as gemm_bf16_pp_kernel, but a
-// K-tile is consumed in TWO phases of 16 MFMAs (512 matrix-pipe cycles): phase a = A rows of mq 0 x both nq (reads h0, h1,
-// h2: 16 ds_read_b128), phase b = mq 1 x both nq (reads h3: 8).  Half the barriers per K-tile, and a load section has 512
-// instead of 256 partner-MFMA cycles to hide its reads and its four DMA pieces.  The LDS ring has 10 half-tile slots (all
-// 160 KiB; half-tile j = 4*tile + h in slot j % 10), which lets the DMA run further ahead:
-//   phase a of tile t issues h2 of tile t+1, then h0 of tile t+2;  phase b issues h3 of tile t+1, then h1 of tile t+2
-//   (leads of 2 / 4 / 2 / 3 phases; within a phase the half-tile that is needed sooner goes first).
-//   RAW: at the end of a load section everything the NEXT phase reads was issued at least one phase ago and FIRST in its
-//        phase; the three half-tiles issued after it may stay in flight: vmcnt(6).
-//   WAR: the previous occupant of a slot (half-tile j - 10) was last read >= 2 phases before the slot is re-issued.
-// ------------------------------------------------------------------------------------------------
-constexpr int P2_SLOTS = 10;
-static_assert(P2_SLOTS * PSLOT_BYTES <= RLDS_BYTES, "10-slot ring must fit the 160 KiB allocation");
-
-template <int EPI, bool DMA_FIRST>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp2_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
-                                                                      int tiles_n, int GROUP_M) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int band_sz = GROUP_M * tiles_n;
-  const int band = lid / band_sz, in_band = lid - band * band_sz;
-  const int first_m = band * GROUP_M;
-  const int gm = min(GROUP_M, tiles_m - first_m);
-  const int mt = first_m + in_band % gm;
-  const int nt = in_band / gm;
-  const int gi = (mt >= mtiles0) ? 1 : 0;
-  const omni_gemm_group G = pick_group(P, gi);
-  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
-  const int n0 = nt * BN;
-  const int M = G.M, N = P.N, K = P.K;
-  if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;   // device-side predicate (omni_teacache)
-  const int wm = wave >> 2, wn = wave & 3;
-  const int l31 = lane & 31, hi = lane >> 5;
-
-  uint32_t a_off[2][2], w_off[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int lr = (wave * 2 + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((lr >> 1) & 7);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      int ar = min(m0 + (lr >> 6) * 128 + q * 64 + (lr & 63), M - 1);
-      if (G.a_row_map) ar = G.a_row_map[ar];
-      const int64_t ae = G.a_k32_rows ? ((int64_t)(c >> 2) * G.a_k32_rows + ar) * 32 + (c & 3) * 8
-                                      : (int64_t)ar * G.lda + c * 8;
-      a_off[q][i] = (uint32_t)(ae * 2);
-      const int wr = min(n0 + (lr >> 5) * 64 + q * 32 + (lr & 31), N - 1);
-      const int64_t we = P.w_k32_blocked ? ((int64_t)(c >> 2) * N + wr) * 32 + (c & 3) * 8 : (int64_t)wr * K + c * 8;
-      w_off[q][i] = (uint32_t)(we * 2);
-    }
-  }
-  const int64_t astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * 128 : 128;
-  const int64_t wstep = P.w_k32_blocked ? (int64_t)N * 128 : 128;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const int nkt = K / PBK;
-  const char* const Ab = reinterpret_cast<const char*>(G.A);
-  const char* const Wb = reinterpret_cast<const char*>(G.W);
-  auto mod10 = [](int x) { return x - (x >= 10 ? 10 : 0) - (x >= 20 ? 10 : 0); };   // x < 30
-  // half-tile h (compile time) of K-tile `tile`, whose ring slot is `slot` (uniform)
-#define OMNI_P2_ISSUE(h, tile, slot)                                                                        \
-  do {                                                                                                      \
-    const int t_ = (tile);                                                                                  \
-    const uint32_t dst_ = lds0 + (uint32_t)(slot) * PSLOT_BYTES + (wave * 2) * 1024;                          \
-    if ((h) == 0 || (h) == 3) {                                                                             \
-      const char* b_ = Ab + t_ * astep;                                                                     \
-      glds16_saddr(b_, a_off[(h) == 3][0], dst_);                                                           \
-      glds16_saddr(b_, a_off[(h) == 3][1], dst_ + 1024);                                                    \
-    } else {                                                                                                \
-      const char* b_ = Wb + t_ * wstep;                                                                     \
-      glds16_saddr(b_, w_off[(h) == 2][0], dst_);                                                           \
-      glds16_saddr(b_, w_off[(h) == 2][1], dst_ + 1024);                                                    \
-    }                                                                                                       \
-  } while (0)
-
-  uint32_t a_rd[4], w_rd[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const uint32_t chunk = ((uint32_t)(ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-    a_rd[ks] = lds0 + (wm * 64 + l31) * 128 + chunk;
-    w_rd[ks] = lds0 + (wn * 32 + l31) * 128 + chunk;
-  }
-
-  // ---- prologue: issue order h0(0) h1(0) h2(0) h0(1) h3(0) h1(1) (= the steady-state schedule of phases -4 .. -1) ----
-  OMNI_P2_ISSUE(0, 0, 0); OMNI_P2_ISSUE(1, 0, 1); OMNI_P2_ISSUE(2, 0, 2);
-  if (nkt > 1) OMNI_P2_ISSUE(0, 1, 4);
-  OMNI_P2_ISSUE(3, 0, 3);
-  if (nkt > 1) OMNI_P2_ISSUE(1, 1, 5);
-  f32x16_t acc[2][4];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    float bini[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = n0 + wn * 64 + hi * 4 + nb * 32 + q * 8;
-      u32x2_t b = {0u, 0u};
-      if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
-      bini[q * 4 + 0] = bf16_lo(b[0]); bini[q * 4 + 1] = bf16_hi(b[0]);
-      bini[q * 4 + 2] = bf16_lo(b[1]); bini[q * 4 + 3] = bf16_hi(b[1]);
-    }
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nb][mb][i] = bini[i];
-  }
-  if (nkt > 1) {
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (wm) __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  bf16x8_t wf[2][4], af[2][4];
-#define OMNI_P2_READ_A(slot)                                                               \
-  do {                                                                                     \
-    const uint32_t sb_ = (uint32_t)(slot) * PSLOT_BYTES;                                   \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                  \
-      af[0][ks_] = lds_read16<0>(a_rd[ks_] + sb_);                                         \
-      af[1][ks_] = lds_read16<32 * 128>(a_rd[ks_] + sb_);                                  \
-    }                                                                                      \
-  } while (0)
-#define OMNI_P2_READ_W(nq, slot)                                                           \
-  do {                                                                                     \
-    const uint32_t sb_ = (uint32_t)(slot) * PSLOT_BYTES;                                   \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) wf[nq][ks_] = lds_read16<0>(w_rd[ks_] + sb_); \
-  } while (0)
-#define OMNI_P2_MMA(mq, steady)                                                                            \
-  do {                                                                                                     \
-    if (steady) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                           \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
-    __builtin_amdgcn_s_barrier();                                                                          \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                     \
-    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                    \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                  \
-      pp_mfma(acc[0][2 * (mq)], wf[0][ks_], af[0][ks_]);                                                   \
-      pp_mfma(acc[0][2 * (mq) + 1], wf[0][ks_], af[1][ks_]);                                               \
-      pp_mfma(acc[1][2 * (mq)], wf[1][ks_], af[0][ks_]);                                                   \
-      pp_mfma(acc[1][2 * (mq) + 1], wf[1][ks_], af[1][ks_]);                                               \
-    }                                                                                                      \
-    if (OMNI_PP_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                     \
-    __builtin_amdgcn_s_barrier();                                                                          \
-    asm volatile("" ::: "memory");                                                                         \
-  } while (0)
-
-  int tb = 0;                                    // (4 * t) % 10: ring slot of half-tile h0 of the current K-tile
-#pragma unroll 1
-  for (int t = 0; t < nkt; ++t) {
-    const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;
-    const int s_h1 = mod10(tb + 1), s_h2 = mod10(tb + 2), s_h3 = mod10(tb + 3);
-    const int s1_h2 = mod10(tb + 6), s1_h3 = mod10(tb + 7), s2_h0 = mod10(tb + 8), s2_h1 = mod10(tb + 9);
-    // phase a: A rows of mq 0 x both nq
-    if (DMA_FIRST) {
-      if (n1) OMNI_P2_ISSUE(2, t + 1, s1_h2);
-      if (n2) OMNI_P2_ISSUE(0, t + 2, s2_h0);
-    }
-    OMNI_P2_READ_A(tb);
-    OMNI_P2_READ_W(0, s_h1);
-    OMNI_P2_READ_W(1, s_h2);
-    if (!DMA_FIRST) {
-      if (n1) OMNI_P2_ISSUE(2, t + 1, s1_h2);
-      if (n2) OMNI_P2_ISSUE(0, t + 2, s2_h0);
-    }
-    OMNI_P2_MMA(0, n2);
-    // phase b: A rows of mq 1 x both nq
-    if (DMA_FIRST) {
-      if (n1) OMNI_P2_ISSUE(3, t + 1, s1_h3);
-      if (n2) OMNI_P2_ISSUE(1, t + 2, s2_h1);
-    }
-    OMNI_P2_READ_A(s_h3);
-    if (!DMA_FIRST) {
-      if (n1) OMNI_P2_ISSUE(3, t + 1, s1_h3);
-      if (n2) OMNI_P2_ISSUE(1, t + 2, s2_h1);
-    }
-    OMNI_P2_MMA(1, n2);
-    tb = mod10(tb + 4);
-  }
-  if (!wm) __builtin_amdgcn_s_barrier();
-  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-#undef OMNI_P2_MMA
-#undef OMNI_P2_READ_W
-#undef OMNI_P2_READ_A
-#undef OMNI_P2_ISSUE
-
-  gemm_epilogue_lds<EPI>(P, G, acc, m0, n0, wm, wn, l31, hi, smem, tid);
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// W4 variant: 4 waves x (128 x 128), ONE wave per SIMD owning the whole 512-entry register file (256 accumulator
-// registers + double-buffered fragments).  Same 5-stage BK=32 LDS ring and continuous pipeline as the ring kernel.
-// Why: the ablation (tools/bench_ablate_ring.py) shows DMA landings and fragment reads fighting for LDS bandwidth on
-// real data; a 128x128 wave tile needs 8 fragment reads per 16 MFMAs instead of 6 per 8 (-33 % LDS read bytes) and
-// the barrier only joins 4 waves.  All latency hiding is intra-wave: reads run two k-steps ahead, one DMA piece and
-// one or two reads ride in the issue shadow of every group of 4 MFMAs.
-// ------------------------------------------------------------------------------------------------
-constexpr int W4_THREADS = 256;
-
-template <int EPI>
-__global__ __launch_bounds__(W4_THREADS, 1) void gemm_bf16_w4_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
-                                                                      int tiles_n, int GROUP_M) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int band_sz = GROUP_M * tiles_n;
-  const int band = lid / band_sz, in_band = lid - band * band_sz;
-  const int first_m = band * GROUP_M;
-  const int gm = min(GROUP_M, tiles_m - first_m);
-  const int mt = first_m + in_band % gm;
-  const int nt = in_band / gm;
-  const int gi = (mt >= mtiles0) ? 1 : 0;
-  const omni_gemm_group G = pick_group(P, gi);
-  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
-  const int n0 = nt * BN;
-  const int M = G.M, N = P.N, K = P.K;
-
-  // DMA sources: a stage is 16 A pieces + 16 W pieces of (16 rows x 64 B); wave w moves pieces w*4 .. w*4+3 of each
-  const uint16_t* a_src[4];
-  const uint16_t* w_src[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = (wave * 4 + j) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((r >> 2) & 3);
-    int ar = min(m0 + r, M - 1);
-    if (G.a_row_map) ar = G.a_row_map[ar];
-    a_src[j] = G.A + (int64_t)ar * G.lda + c * 8;
-    const int wr = min(n0 + r, N - 1);
-    w_src[j] = G.W + (int64_t)wr * K + c * 8;
-  }
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  auto issue_piece = [&](int slot, int st, int piece) {   // piece 0..7 = A0, W0, A1, W1, ...
-    const uint32_t base = lds0 + slot * RSTAGE_BYTES + (wave * 4) * 1024;
-    const int koff = st * RBK, part = piece >> 1;
-    if (piece & 1) glds16(w_src[part] + koff, base + ROP_BYTES + part * 1024);
-    else glds16(a_src[part] + koff, base + part * 1024);
-  };
-  auto issue_stage = [&](int slot, int st) {
-#pragma unroll
-    for (int p = 0; p < 8; ++p) issue_piece(slot, st, p);
-  };
-
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, hi = lane >> 5;
-  uint32_t a_base[2], w_base[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const uint32_t chunk = ((uint32_t)(ks * 2 + hi) ^ ((l31 >> 2) & 3)) << 4;
-    a_base[ks] = (wm * 128 + l31) * 64 + chunk;
-    w_base[ks] = ROP_BYTES + (wn * 128 + l31) * 64 + chunk;
-  }
-
-  f32x16_t acc[4][4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.0f;
-
-  const int nst = K / RBK;
-  constexpr int LEAD = RSTAGES - 1;
-#pragma unroll
-  for (int st = 0; st < LEAD; ++st)
-    if (st < nst) issue_stage(st, st);
-  bf16x8_t wf[2][4], af[2][4];
-  constexpr int BS = 32 * 64;   // bytes between 32-row blocks
-#define W4_ADDR(slot_, ks)                                  \
-  const uint32_t sa_ = lds0 + (slot_) * RSTAGE_BYTES;       \
-  const uint32_t aa_ = a_base[ks] + sa_, wa_ = w_base[ks] + sa_;
-#define W4_READ_ALL(buf, slot_, ks)                         \
-  do {                                                      \
-    W4_ADDR(slot_, ks)                                      \
-    wf[buf][0] = lds_read16<0>(wa_);                        \
-    wf[buf][1] = lds_read16<BS>(wa_);                       \
-    wf[buf][2] = lds_read16<2 * BS>(wa_);                   \
-    wf[buf][3] = lds_read16<3 * BS>(wa_);                   \
-    af[buf][0] = lds_read16<0>(aa_);                        \
-    af[buf][1] = lds_read16<BS>(aa_);                       \
-    af[buf][2] = lds_read16<2 * BS>(aa_);                   \
-    af[buf][3] = lds_read16<3 * BS>(aa_);                   \
-  } while (0)
-#define W4_GROUP(buf, mb)                                                                                     \
-  acc[0][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][0], af[buf][mb], acc[0][mb], 0, 0, 0);         \
-  acc[1][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][1], af[buf][mb], acc[1][mb], 0, 0, 0);         \
-  acc[2][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][2], af[buf][mb], acc[2][mb], 0, 0, 0);         \
-  acc[3][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][3], af[buf][mb], acc[3][mb], 0, 0, 0);         \
-  __builtin_amdgcn_sched_barrier(0);
-// 16 MFMAs of one k-step; in their issue shadows: the 8 reads of k-step g+2 (same buffer) and 4 DMA pieces
-#define W4_MMA(buf, PREFETCH, nslot_, ks, D0, D1, D2, D3)          \
-  do {                                                             \
-    W4_ADDR(nslot_, ks)                                            \
-    __builtin_amdgcn_sched_barrier(0);                             \
-    W4_GROUP(buf, 0)                                               \
-    if (PREFETCH) af[buf][0] = lds_read16<0>(aa_);                 \
-    D0;                                                            \
-    __builtin_amdgcn_sched_barrier(0);                             \
-    W4_GROUP(buf, 1)                                               \
-    if (PREFETCH) af[buf][1] = lds_read16<BS>(aa_);                \
-    D1;                                                            \
-    __builtin_amdgcn_sched_barrier(0);                             \
-    W4_GROUP(buf, 2)                                               \
-    if (PREFETCH) af[buf][2] = lds_read16<2 * BS>(aa_);            \
-    D2;                                                            \
-    __builtin_amdgcn_sched_barrier(0);                             \
-    W4_GROUP(buf, 3)                                               \
-    if (PREFETCH) {                                                \
-      af[buf][3] = lds_read16<3 * BS>(aa_);                        \
-      wf[buf][0] = lds_read16<0>(wa_);                             \
-      wf[buf][1] = lds_read16<BS>(wa_);                            \
-      wf[buf][2] = lds_read16<2 * BS>(wa_);                        \
-      wf[buf][3] = lds_read16<3 * BS>(wa_);                        \
-    }                                                              \
-    D3;                                                            \
-    __builtin_amdgcn_sched_barrier(0);                             \
-  } while (0)
-  // B_0: own pieces of stages 0,1 landed (stages 2,3 = 16 DMAs may stay in flight)
-  if (LEAD - 1 < nst) {
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (LEAD < nst) issue_stage(LEAD, LEAD);
-  W4_READ_ALL(0, 0, 0);
-  W4_READ_ALL(1, 0, 1);
-  int slot = 0, pslot = RSTAGES - 1;
-  for (int st = 0; st + 1 < nst; ++st) {
-    const int nslot = (slot + 1 == RSTAGES) ? 0 : slot + 1;
-    const bool dma = st > 0 && st + LEAD < nst;
-    const int dst = st + LEAD;
-#define W4_D(p) if (dma) issue_piece(pslot, dst, p)
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    W4_MMA(0, true, nslot, 0, W4_D(0), W4_D(1), W4_D(2), W4_D(3));
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    W4_MMA(1, true, nslot, 1, W4_D(4), W4_D(5), W4_D(6), W4_D(7));
-#undef W4_D
-    if (st + LEAD < nst) {
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    pslot = slot;
-    slot = nslot;
-  }
-  asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-  W4_MMA(0, false, 0, 0, (void)0, (void)0, (void)0, (void)0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  W4_MMA(1, false, 0, 1, (void)0, (void)0, (void)0, (void)0);
-#undef W4_MMA
-#undef W4_GROUP
-#undef W4_READ_ALL
-#undef W4_ADDR
-  gemm_epilogue_t<EPI, 4, 4>(P, G, acc, m0 + wm * 128, n0 + wn * 128, l31, hi);
-}
-
-
-#endif  // OMNI_DEV
+#ifdef OMNI_DEV
+#include "dev/gemm_family5_6_two_phase_pingpong_and_2_w4.inc"
+#endif
 
 #ifdef OMNI_DEV
-// ------------------------------------------------------------------------------------------------
-// Q4: 4 waves x (128 x 128), ONE wave per SIMD, the 256 accumulator registers in the AGPR half, named literally in the MFMA
-// statements (never touched by the compiler); both fragment register sets (2 x 64 VGPRs) compiler-allocated.
-//
-// Why: the part runs at its package power limit, what a GEMM achieves is set by energy per
-// flop, and the 8-wave ping-pong kernel reads 48 KiB of fragments per 16-k step where this geometry (the vendor kernel's)
-// reads 32 KiB: 16 ds_read_b128 per 64 MFMAs instead of 24.  Round 1's hipcc-scheduled attempt (gemm_bf16_w4_kernel, -20 %)
-// lost the accumulators to spills and the pipelining to the compiler's waitcnt pass; here every MFMA, read, DMA and wait is
-// placed by hand.
-//
-// K-tile = 64 k = four 16-KiB half-tile slots (A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255; the ping-pong
-// kernel's LDS image: 128-B rows, 16-B chunk index XOR (row >> 1) & 7); ring = 2 K-tiles = 128 KiB.  A wave reads its A
-// half-tile and its W half-tile once per K-tile (32 ds_read_b128 for 128 MFMAs).  Per K-tile t two phases of 64 MFMAs of
-// v_mfma_f32_16x16x32_bf16, each on 64 DIFFERENT accumulators (no dependent chain inside a phase):
-//   X(t): MFMAs on fragment set X = (t, k 0-31)   ||  16 reads: set Y <- (t, k 32-63)
-//         then: my DMA pieces of K-tile t+1 have landed (issued a whole phase ago: vmcnt(0)), Y arrived -> s_barrier
-//               (= every wave has finished reading K-tile t's slots and K-tile t+1 is visible to all)
-//   Y(t): MFMAs on set Y                         ||  16 reads: set X <- (t+1, k 0-31)  ||  16 LDS-DMA pieces: K-tile t+2 into
-//         the slots K-tile t just left (they land during X(t+1))
-// ONE barrier per K-tile (128 MFMAs, ~2100 matrix-pipe cycles).
-// ------------------------------------------------------------------------------------------------
-constexpr int Q4_THREADS = 256;
-#ifndef OMNI_Q4_STAGGER
-#define OMNI_Q4_STAGGER 1
+#include "dev/gemm_family4_q4_four_waves_agpr.inc"
 #endif
-#ifndef OMNI_Q4_ABL
-#define OMNI_Q4_ABL 0   // dev-only timing ablations (results wrong): 1 no DMA in the loop, 2 no fragment reads, 4 no barrier, 8 no MFMA
-#endif
-
-template <int N>
-using q4ic = std::integral_constant<int, N>;
-
-template <int ACC>   // C^T block ACC (4 AGPRs) += W fragment (A operand) x A fragment (B operand)
-OMNI_DEVINL void q4_mfma(const bf16x8_t& wfrag, const bf16x8_t& afrag) {
-  if (OMNI_Q4_ABL & 8) { asm volatile("" ::"v"(wfrag), "v"(afrag)); return; }
-  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wfrag), "v"(afrag), "i"(ACC), "i"(ACC + 3));
-}
-template <int A>
-OMNI_DEVINL void q4_acc_write(float v) { asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "i"(A)); }
-template <int A>
-OMNI_DEVINL float q4_acc_read() {
-  float v;
-  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(A));
-  return v;
-}
-
-template <int EPI>
-__global__ __launch_bounds__(Q4_THREADS, 1) void gemm_bf16_q4_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
-                                                                     int tiles_n, int GROUP_M) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = tiles_m * tiles_n;
-  const int bid = (int)blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int band_sz = GROUP_M * tiles_n;
-  const int band = lid / band_sz, in_band = lid - band * band_sz;
-  const int first_m = band * GROUP_M;
-  const int gm = min(GROUP_M, tiles_m - first_m);
-  const int mt = first_m + in_band % gm;
-  const int nt = in_band / gm;
-  const int gi = (mt >= mtiles0) ? 1 : 0;
-  const omni_gemm_group G = pick_group(P, gi);
-  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
-  const int n0 = nt * BN;
-  const int M = G.M, N = P.N, K = P.K;
-  if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;   // device-side predicate (omni_teacache)
-  asm volatile(OMNI_OWNS_AGPRS ::: OMNI_ALL_AGPRS);                               // allocate a[0:255]
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, g4 = lane >> 4;
-
-  // ---- per-lane DMA source byte offsets (SADDR form).  Slot row lr = (wave * 4 + i) * 8 + (lane >> 3) of half-tile h.
-  uint32_t a_off[2][4], w_off[2][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int lr = (wave * 4 + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((lr >> 1) & 7);               // logical 16-B chunk landing in physical chunk lane & 7
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int ar = min(m0 + h * 128 + lr, M - 1);
-      if (G.a_row_map) ar = G.a_row_map[ar];
-      const int64_t ae = G.a_k32_rows ? ((int64_t)(c >> 2) * G.a_k32_rows + ar) * 32 + (c & 3) * 8
-                                      : (int64_t)ar * G.lda + c * 8;
-      a_off[h][i] = (uint32_t)(ae * 2);
-      const int wr = min(n0 + h * 128 + lr, N - 1);
-      const int64_t we = P.w_k32_blocked ? ((int64_t)(c >> 2) * N + wr) * 32 + (c & 3) * 8 : (int64_t)wr * K + c * 8;
-      w_off[h][i] = (uint32_t)(we * 2);
-    }
-  }
-  const int64_t astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * 128 : 128;
-  const int64_t wstep = P.w_k32_blocked ? (int64_t)N * 128 : 128;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const int nkt = K / PBK;
-  const char* const Ab = reinterpret_cast<const char*>(G.A);
-  const char* const Wb = reinterpret_cast<const char*>(G.W);
-  // piece p = 0..15 of K-tile `tile`: half-tile h = p >> 2 (A0, A1, W0, W1), piece i = p & 3 of this wave
-  auto issue_piece = [&](int tile, auto pp) {
-    constexpr int p = decltype(pp)::value, h = p >> 2, i = p & 3;
-    const uint32_t dst = lds0 + (uint32_t)(((tile & 1) * 4 + h) * PSLOT_BYTES) + (wave * 4 + i) * 1024;
-    if constexpr (h < 2) glds16_saddr(Ab + tile * astep, a_off[h][i], dst);
-    else glds16_saddr(Wb + tile * wstep, w_off[h - 2][i], dst);
-  };
-  auto issue_tile = [&](int tile) {
-    [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(tile, q4ic<I>{}), ...); }(std::make_integer_sequence<int, 16>{});
-  };
-
-  // ---- fragment read addresses: row l15 of a 16-row block (block = offset immediate), logical chunk ks * 4 + g4
-  uint32_t a_rd[2], w_rd[2];                        // [ks], K-tile parity 0 (parity 1: + 4 slots)
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const uint32_t chunk = ((uint32_t)(ks * 4 + g4) ^ ((l15 >> 1) & 7)) << 4;
-    a_rd[ks] = lds0 + wm * PSLOT_BYTES + l15 * 128 + chunk;
-    w_rd[ks] = lds0 + (2 + wn) * PSLOT_BYTES + l15 * 128 + chunk;
-  }
-
-  // ---- prologue: K-tiles 0 and 1 in flight, accumulators <- bias under the flight
-  issue_tile(0);
-  if (nkt > 1) issue_tile(1);
-  {
-    // acc[nb][mb] (4 AGPRs at (nb * 8 + mb) * 4) = C[wm*128 + mb*16 + l15][wn*128 + nb*16 + 4*g4 .. +4]
-    float bini[8][4];
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      const int n = n0 + wn * 128 + nb * 16 + g4 * 4;
-      u32x2_t b = {0u, 0u};
-      if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
-      bini[nb][0] = bf16_lo(b[0]); bini[nb][1] = bf16_hi(b[0]); bini[nb][2] = bf16_lo(b[1]); bini[nb][3] = bf16_hi(b[1]);
-    }
-    [&]<int... I>(std::integer_sequence<int, I...>) { (q4_acc_write<I>(bini[I >> 5][I & 3]), ...); }(std::make_integer_sequence<int, 256>{});
-  }
-  bf16x8_t xa[8], xw[8], ya[8], yw[8];
-  // fragment reads of one set: index r = 0..15: r < 8 -> W block r, else A block r - 8
-  auto read_frag = [&](auto rr_, bf16x8_t (&fa)[8], bf16x8_t (&fw)[8], uint32_t aaddr, uint32_t waddr) {
-    constexpr int r = decltype(rr_)::value;
-    if constexpr (r < 8) fw[r] = lds_read16<r * 2048>(waddr);
-    else fa[r - 8] = lds_read16<(r - 8) * 2048>(aaddr);
-  };
-  if (nkt > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  [&]<int... I>(std::integer_sequence<int, I...>) { (read_frag(q4ic<I>{}, xa, xw, a_rd[0], w_rd[0]), ...); }(std::make_integer_sequence<int, 16>{});
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-
-  // one phase: 64 MFMAs on set (fa, fw) in 16 groups of 4; group g carries read g of the OTHER set (if do_read) and DMA piece g
-  // of K-tile `dtile` (if do_dma).  The four waves leave every barrier together and run the same instruction stream on four
-  // SIMDs: whatever they issue to the CU's ONE texture addresser / LDS pipeline they issue in the same cycle, and three of
-  // them queue (an LDS-DMA piece occupies the addresser ~16 cycles: that queue is the "~60 cycles per piece" of
-  // MI355X_MICROARCH).  STAG (= the wave index when OMNI_Q4_STAGGER) moves the group's memory operations behind its MFMA
-  // number STAG instead of its last one: the waves' requests arrive one MFMA (~16 cycles) apart.
-  auto phase = [&](auto stag_c, bf16x8_t (&fa)[8], bf16x8_t (&fw)[8], bf16x8_t (&oa)[8], bf16x8_t (&ow)[8], bool do_read,
-                   uint32_t raddr_a, uint32_t raddr_w, bool do_dma, int dtile) {
-    constexpr int STAG = decltype(stag_c)::value;
-    auto group = [&](auto gg) {
-      constexpr int g = decltype(gg)::value;        // MFMAs 4g .. 4g+3: (nb, mb) = (i >> 3, i & 7)
-      auto mem = [&] {
-        __builtin_amdgcn_sched_barrier(0);
-        if (do_read && !(OMNI_Q4_ABL & 2)) read_frag(gg, oa, ow, raddr_a, raddr_w);
-        if (do_dma && !(OMNI_Q4_ABL & 1)) issue_piece(dtile, gg);
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      q4_mfma<(4 * g + 0) * 4>(fw[(4 * g + 0) >> 3], fa[(4 * g + 0) & 7]);
-      if constexpr (STAG == 0) mem();
-      q4_mfma<(4 * g + 1) * 4>(fw[(4 * g + 1) >> 3], fa[(4 * g + 1) & 7]);
-      if constexpr (STAG == 1) mem();
-      q4_mfma<(4 * g + 2) * 4>(fw[(4 * g + 2) >> 3], fa[(4 * g + 2) & 7]);
-      if constexpr (STAG == 2) mem();
-      q4_mfma<(4 * g + 3) * 4>(fw[(4 * g + 3) >> 3], fa[(4 * g + 3) & 7]);
-      if constexpr (STAG == 3) mem();
-    };
-    [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (group(q4ic<Gs>{}), ...); }(std::make_integer_sequence<int, 16>{});
-  };
-
-  auto k_loop = [&](auto stag_c) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll 1
-    for (int t = 0; t < nkt; ++t) {
-      const uint32_t po = (uint32_t)((t & 1) * 4 * PSLOT_BYTES), pn = (uint32_t)(4 * PSLOT_BYTES) - po;
-      // X(t): reads Y <- (t, ks 1)
-      phase(stag_c, xa, xw, ya, yw, true, a_rd[1] + po, w_rd[1] + po, false, 0);
-      if (!(OMNI_Q4_ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(OMNI_Q4_ABL & 4)) __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      // Y(t): reads X <- (t+1, ks 0); DMA K-tile t+2 into K-tile t's slots
-      phase(stag_c, ya, yw, xa, xw, t + 1 < nkt, a_rd[0] + pn, w_rd[0] + pn, t + 2 < nkt, t + 2);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-#if OMNI_Q4_STAGGER
-  switch (wave) {
-    case 0: k_loop(q4ic<0>{}); break;
-    case 1: k_loop(q4ic<1>{}); break;
-    case 2: k_loop(q4ic<2>{}); break;
-    default: k_loop(q4ic<3>{}); break;
-  }
-#else
-  k_loop(q4ic<3>{});
-#endif
-  __builtin_amdgcn_s_setprio(0);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results -> v_accvgpr_read: software wait states
-
-  auto write_tile = [&]() {
-    // (the bias is already in the accumulators)
-    auto one = [&](auto ii) {
-      constexpr int i = decltype(ii)::value, nb = i >> 3, mb = i & 7;
-      float v[4] = {q4_acc_read<i * 4 + 0>(), q4_acc_read<i * 4 + 1>(), q4_acc_read<i * 4 + 2>(), q4_acc_read<i * 4 + 3>()};
-      if (EPI == OMNI_EPI_BIAS_GELU_TANH) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
-      }
-      u32x2_t o;
-      o[0] = pack_bf16x2(v[0], v[1]);
-      o[1] = pack_bf16x2(v[2], v[3]);
-      char* rowp = smem + (wm * 128 + mb * 16 + l15) * EPI_LDS_STRIDE + (wn * 128 + nb * 16 + g4 * 4) * 2;
-      *reinterpret_cast<u32x2_t*>(rowp) = o;
-    };
-    [&]<int... I>(std::integer_sequence<int, I...>) { (one(q4ic<I>{}), ...); }(std::make_integer_sequence<int, 64>{});
-  };
-  gemm_epilogue_lds_impl<EPI, decltype(write_tile), EpiFromLds, Q4_THREADS>(P, G, m0, n0, smem, tid, write_tile);
-}
-#endif  // OMNI_DEV (Q4)
 
 #ifdef OMNI_DEV
-// ------------------------------------------------------------------------------------------------
-// V4 (dev family 7): the Q4 geometry (4 waves x 128 x 128, accumulators in literal AGPRs) on the VENDOR kernel's schedule.
-//
-// Round 4 disassembled the hipBLASLt kernel torch.mm picks at the DiT shapes (Custom_Cijk_..._MT256x256x64_MI16x16x1_SK3,
-// DESIGN.md 7 item 24).  Its K-loop is what Q4 tried to be, but: (a) NO branch inside the loop (the tail K-tiles are peeled;
-// Q4's run-time `do_read / do_dma` flags cost 29 scalar branches per K-tile), (b) exactly ONE scalar / memory instruction
-// between two MFMAs, (c) the whole K-tile's fragments live in registers (128 VGPRs), so an LDS buffer is free for the
-// DMA of K-tile t + 2 as soon as its k 32-63 halves have been read: 3-deep pipeline out of 2 LDS buffers, (d) three
-// barriers per K-tile, each right behind the reads that free a region.  Per K-tile and wave: 128 MFMAs, 32 ds_read_b128,
-// 16 LDS-DMA pieces - slot table below.
-//   entry: registers hold (t, k 0-31) = set 0
-//   slots  0-14   reads W(t, k 32-63) -> set 1            | MFMAs 0-63 run on set 0
-//   slot   17/18  lgkmcnt(0), barrier 1: W region of buffer t & 1 is free
-//   slots 19-38   DMA W(t+2) pieces 0-4 alternating with reads A(t, k 32-63)
-//   slot   44/45  lgkmcnt(0), barrier 2: A region free      | MFMAs 64-127 run on set 1
-//   slots 46-66   DMA W(t+2) pieces 5-7, A(t+2) pieces 0-7
-//   slot   86/87  vmcnt(16) [K-tile t+1 landed], barrier 3: K-tile t+1 visible
-//   slots 88-118  reads (t+1, k 0-31) -> set 0;  slot 126 lgkmcnt(0)
-// ------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(Q4_THREADS, 1) void gemm_bf16_v4_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
-                                                                     int tiles_n, int GROUP_M) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = tiles_m * tiles_n;
-  const int bid = (int)blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int band_sz = GROUP_M * tiles_n;
-  const int band = lid / band_sz, in_band = lid - band * band_sz;
-  const int first_m = band * GROUP_M;
-  const int gm = min(GROUP_M, tiles_m - first_m);
-  const int mt = first_m + in_band % gm;
-  const int nt = in_band / gm;
-  const int gi = (mt >= mtiles0) ? 1 : 0;
-  const omni_gemm_group G = pick_group(P, gi);
-  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
-  const int n0 = nt * BN;
-  const int M = G.M, N = P.N, K = P.K;
-  if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;
-  asm volatile(OMNI_OWNS_AGPRS ::: OMNI_ALL_AGPRS);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, g4 = lane >> 4;
-
-  uint32_t a_off[2][4], w_off[2][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int lr = (wave * 4 + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((lr >> 1) & 7);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int ar = min(m0 + h * 128 + lr, M - 1);
-      if (G.a_row_map) ar = G.a_row_map[ar];
-      const int64_t ae = G.a_k32_rows ? ((int64_t)(c >> 2) * G.a_k32_rows + ar) * 32 + (c & 3) * 8
-                                      : (int64_t)ar * G.lda + c * 8;
-      a_off[h][i] = (uint32_t)(ae * 2);
-      const int wr = min(n0 + h * 128 + lr, N - 1);
-      const int64_t we = P.w_k32_blocked ? ((int64_t)(c >> 2) * N + wr) * 32 + (c & 3) * 8 : (int64_t)wr * K + c * 8;
-      w_off[h][i] = (uint32_t)(we * 2);
-    }
-  }
-  const int64_t astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * 128 : 128;
-  const int64_t wstep = P.w_k32_blocked ? (int64_t)N * 128 : 128;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const int nkt = K / PBK;
-  const char* abase = reinterpret_cast<const char*>(G.A);        // K-tile that the NEXT dma() call fetches
-  const char* wbase = reinterpret_cast<const char*>(G.W);
-  const uint32_t m0_wave = lds0 + (uint32_t)wave * 4096;         // + h * PSLOT_BYTES + i * 1024 + parity * 4 * PSLOT_BYTES
-  constexpr uint32_t PAR = 4 * PSLOT_BYTES;
-
-  // piece p = 0..15: p < 8: W half-tile 2 + (p >> 2), else A half-tile (p - 8) >> 2; i = p & 3
-  auto dma = [&](auto pp, uint32_t par_off) {
-    constexpr int p = decltype(pp)::value, i = p & 3;
-    constexpr int h = p < 8 ? 2 + (p >> 2) : ((p - 8) >> 2);
-    const uint32_t m0v = m0_wave + (uint32_t)(h * PSLOT_BYTES + i * 1024);
-    const uint32_t voff = p < 8 ? w_off[(p & 7) >> 2][i] : a_off[(p & 7) >> 2][i];
-    const char* const gb = p < 8 ? wbase : abase;
-    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
-                 :: "s"(m0v), "s"(par_off), "v"(voff), "s"(gb) : "memory");
-  };
-  auto dma_tile = [&](uint32_t par_off) {
-    [&]<int... I>(std::integer_sequence<int, I...>) { (dma(q4ic<I>{}, par_off), ...); }(std::make_integer_sequence<int, 16>{});
-  };
-
-  uint32_t a_rd[2], w_rd[2];                        // [ks], parity 0
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const uint32_t chunk = ((uint32_t)(ks * 4 + g4) ^ ((l15 >> 1) & 7)) << 4;
-    a_rd[ks] = lds0 + wm * PSLOT_BYTES + l15 * 128 + chunk;
-    w_rd[ks] = lds0 + (2 + wn) * PSLOT_BYTES + l15 * 128 + chunk;
-  }
-
-  // ---- prologue: K-tiles 0 and 1 in flight, accumulators <- bias under the flight
-  dma_tile(0u);
-  abase += astep; wbase += wstep;
-  if (nkt > 1) { dma_tile(PAR); abase += astep; wbase += wstep; }
-  {
-    float bini[8][4];
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      const int n = n0 + wn * 128 + nb * 16 + g4 * 4;
-      u32x2_t b = {0u, 0u};
-      if (G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);
-      bini[nb][0] = bf16_lo(b[0]); bini[nb][1] = bf16_hi(b[0]); bini[nb][2] = bf16_lo(b[1]); bini[nb][3] = bf16_hi(b[1]);
-    }
-    [&]<int... I>(std::integer_sequence<int, I...>) { (q4_acc_write<I>(bini[I >> 5][I & 3]), ...); }(std::make_integer_sequence<int, 256>{});
-  }
-  bf16x8_t fa[2][8], fw[2][8];                      // [set = ks][block]: the whole K-tile's fragments
-  if (nkt > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("s_barrier" ::: "memory");
-  [&]<int... I>(std::integer_sequence<int, I...>) {
-    ((fw[0][I] = lds_read16<I * 2048>(w_rd[0])), ...);
-    ((fa[0][I] = lds_read16<I * 2048>(a_rd[0])), ...);
-  }(std::make_integer_sequence<int, 8>{});
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-
-  // one K-tile.  po / pn: LDS byte offset of this K-tile's buffer / the other one.  DO_DMA: K-tile t + 2 exists; DO_NEXT: t + 1 does.
-  auto ktile = [&](auto do_dma_c, auto do_next_c, uint32_t po, uint32_t pn) {
-    constexpr bool DO_DMA = decltype(do_dma_c)::value, DO_NEXT = decltype(do_next_c)::value;
-    const uint32_t wr1 = w_rd[1] + po, ar1 = a_rd[1] + po, wr0n = w_rd[0] + pn, ar0n = a_rd[0] + pn;
-    auto slot = [&](auto ii) {
-      constexpr int i = decltype(ii)::value, ks = i >> 6, nb = (i & 63) >> 3, mb = i & 7;
-      q4_mfma<(nb * 8 + mb) * 4>(fw[ks][nb], fa[ks][mb]);
-      if constexpr (i <= 14 && (i & 1) == 0) fw[1][i / 2] = lds_read16<(i / 2) * 2048>(wr1);
-      else if constexpr (i == 17) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      else if constexpr (i == 18) asm volatile("s_barrier" ::: "memory");
-      else if constexpr (i >= 19 && i <= 31 && (i - 19) % 3 == 0) { if constexpr (DO_DMA) dma(q4ic<(i - 19) / 3>{}, po); }
-      else if constexpr (i >= 20 && i <= 32 && (i - 20) % 3 == 0) fa[1][(i - 20) / 3] = lds_read16<((i - 20) / 3) * 2048>(ar1);
-      else if constexpr (i == 34 || i == 36 || i == 38) fa[1][5 + (i - 34) / 2] = lds_read16<(5 + (i - 34) / 2) * 2048>(ar1);
-      else if constexpr (i == 44) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      else if constexpr (i == 45) asm volatile("s_barrier" ::: "memory");
-      else if constexpr (i >= 46 && i <= 66 && (i & 1) == 0) { if constexpr (DO_DMA) dma(q4ic<5 + (i - 46) / 2>{}, po); }
-      else if constexpr (i == 86) {
-        if constexpr (DO_NEXT) {
-          if constexpr (DO_DMA) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-      }
-      else if constexpr (i == 87) { if constexpr (DO_NEXT) asm volatile("s_barrier" ::: "memory"); }
-      else if constexpr (i >= 88 && i <= 102 && (i & 1) == 0) { if constexpr (DO_NEXT) fw[0][(i - 88) / 2] = lds_read16<((i - 88) / 2) * 2048>(wr0n); }
-      else if constexpr (i >= 104 && i <= 118 && (i & 1) == 0) { if constexpr (DO_NEXT) fa[0][(i - 104) / 2] = lds_read16<((i - 104) / 2) * 2048>(ar0n); }
-      else if constexpr (i == 126) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    [&]<int... I>(std::integer_sequence<int, I...>) { (slot(q4ic<I>{}), ...); }(std::make_integer_sequence<int, 128>{});
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  __builtin_amdgcn_s_setprio(1);
-  uint32_t po = 0;
-#pragma unroll 1
-  for (int t = 0; t + 2 < nkt; ++t) {
-    ktile(std::true_type{}, std::true_type{}, po, PAR - po);
-    abase += astep; wbase += wstep;
-    po = PAR - po;
-  }
-  if (nkt > 1) {
-    ktile(std::false_type{}, std::true_type{}, po, PAR - po);
-    po = PAR - po;
-  }
-  ktile(std::false_type{}, std::false_type{}, po, PAR - po);
-  __builtin_amdgcn_s_setprio(0);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results -> v_accvgpr_read: software wait states
-
-  auto write_tile = [&]() {
-    auto one = [&](auto ii) {
-      constexpr int i = decltype(ii)::value, nb = i >> 3, mb = i & 7;
-      float v[4] = {q4_acc_read<i * 4 + 0>(), q4_acc_read<i * 4 + 1>(), q4_acc_read<i * 4 + 2>(), q4_acc_read<i * 4 + 3>()};
-      if (EPI == OMNI_EPI_BIAS_GELU_TANH) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_tanh_f(v[j]);
-      }
-      u32x2_t o;
-      o[0] = pack_bf16x2(v[0], v[1]);
-      o[1] = pack_bf16x2(v[2], v[3]);
-      char* rowp = smem + (wm * 128 + mb * 16 + l15) * EPI_LDS_STRIDE + (wn * 128 + nb * 16 + g4 * 4) * 2;
-      *reinterpret_cast<u32x2_t*>(rowp) = o;
-    };
-    [&]<int... I>(std::integer_sequence<int, I...>) { (one(q4ic<I>{}), ...); }(std::make_integer_sequence<int, 64>{});
-  };
-  gemm_epilogue_lds_impl<EPI, decltype(write_tile), EpiFromLds, Q4_THREADS>(P, G, m0, n0, smem, tid, write_tile);
-}
-#endif  // OMNI_DEV (V4)
+#include "dev/gemm_family7_v4_vendor_schedule.inc"
+#endif
 
 int gemm_group_m() {
   // dev knob: OMNI_GEMM_GROUP_M = row-tiles per L2 band
@@ -2830,20 +1357,7 @@ bool gemm_persistent() {
 }
 
 #ifdef OMNI_DEV
-// The persistent ping-pong kernel (gemm_bf16_ppp_kernel) takes a launch when every group's output is K32-blocked without a row
-// map (the direct epilogue), the grid is deeper than one round of the CUs, K has at least two K-tiles and the outputs stay
-// below 2 GiB (32-bit descriptor offsets; PPP_DROP must be out of range).
-constexpr int OMNI_PPP_FAMILY = 8;
-bool gemm_persistent_direct(const omni_gemm_params* p, int tiles_m, int tiles_n) {
-  if (gemm_variant(p) != OMNI_PPP_FAMILY || p->fp8 || p->K / PBK < 2) return false;
-  if (tiles_m * tiles_n <= (gemm_num_cus() & ~7) || p->N % 32 != 0) return false;
-  for (int g = 0; g < p->ngroups; ++g) {
-    const omni_gemm_group& G = p->g[g];
-    if (!G.out_k32_rows || G.out_row_map || G.out_k32_rows < G.M) return false;
-    if ((int64_t)(p->N / 32) * G.out_k32_rows * 64 >= (1ll << 31)) return false;
-  }
-  return true;
-}
+#include "dev/gemm_dev_persistent_predicate.inc"
 #endif
 
 // Split-K factor for a launch of the ping-pong kernel, 1 = off.  On when the caller gave a workspace and the grid would leave
@@ -2856,7 +1370,7 @@ int splitk_factor(const omni_gemm_params* p, int tiles_m, int tiles_n) {
   if (knob < 0) {
     knob = omni_dev_env_int("OMNI_GEMM_SPLITK", 1);
   }
-  if (!knob || !p->splitk_ws || p->splitk_ws_floats <= 0 || !OMNI_PP_MFMA16) return 1;
+  if (!knob || !p->splitk_ws || p->splitk_ws_floats <= 0) return 1;
   const int tiles = tiles_m * tiles_n;
   if (tiles > 128 || (tiles_m > 10 && p->kernel_hint != OMNI_GEMM_KERNEL_SPLITK_TALL) || (p->N % 4) != 0 ||
       (reinterpret_cast<uintptr_t>(p->splitk_ws) & 15))
@@ -2878,19 +1392,7 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
 #ifdef OMNI_DEV
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp2_kernel<EPI, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp2_kernel<EPI, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_w4_kernel<EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_q4_kernel<EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_v4_kernel<EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
-      return OMNI_ERR_LAUNCH;
+#include "dev/gemm_dev_launch_attrs.inc"
 #endif
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
@@ -2906,11 +1408,7 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
       return OMNI_ERR_LAUNCH;
 #ifdef OMNI_DEV
-    if constexpr (EPI == OMNI_EPI_BIAS || EPI == OMNI_EPI_BIAS_GELU_TANH) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ppp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              RLDS_BYTES) != hipSuccess)
-        return OMNI_ERR_LAUNCH;
-    }
+#include "dev/gemm_dev_launch_attr_persistent.inc"
 #endif
     attr_set = true;
   }
@@ -2925,55 +1423,13 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
     return OMNI_OK;
   }
 #ifdef OMNI_DEV
-  if (gemm_variant(p) == 0 && p->K % BK == 0) {
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(NTHREADS), LDS_BYTES, s, *p, mt0, tiles_m,
-                       tiles_n, gemm_group_m());
-    OMNI_CHECK_LAUNCH();
-    return OMNI_OK;
-  }
-  if (gemm_variant(p) == 2) {
-    hipLaunchKernelGGL(gemm_bf16_w4_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(W4_THREADS), RLDS_BYTES, s, *p, mt0,
-                       tiles_m, tiles_n, gemm_group_m());
-    OMNI_CHECK_LAUNCH();
-    return OMNI_OK;
-  }
-  if ((gemm_variant(p) == 5 || gemm_variant(p) == 6) && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
-    if (gemm_variant(p) == 5)
-      hipLaunchKernelGGL((gemm_bf16_pp2_kernel<EPI, false>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
-                         tiles_m, tiles_n, gemm_group_m());
-    else
-      hipLaunchKernelGGL((gemm_bf16_pp2_kernel<EPI, true>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0,
-                         tiles_m, tiles_n, gemm_group_m());
-    OMNI_CHECK_LAUNCH();
-    return OMNI_OK;
-  }
+#include "dev/gemm_dev_launch_first_w4_pp2.inc"
 #endif
 #ifdef OMNI_DEV
-  if (gemm_variant(p) == 7 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p) &&
-      splitk_factor(p, tiles_m, tiles_n) == 1) {
-    hipLaunchKernelGGL((gemm_bf16_v4_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(Q4_THREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
-                       tiles_n, gemm_group_m());
-    OMNI_CHECK_LAUNCH();
-    return OMNI_OK;
-  }
-  if (gemm_variant(p) == 4 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p) &&
-      splitk_factor(p, tiles_m, tiles_n) == 1) {
-    hipLaunchKernelGGL((gemm_bf16_q4_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(Q4_THREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
-                       tiles_n, gemm_group_m());
-    OMNI_CHECK_LAUNCH();
-    return OMNI_OK;
-  }
+#include "dev/gemm_dev_launch_q4_v4.inc"
 #endif
 #ifdef OMNI_DEV
-  if constexpr (EPI == OMNI_EPI_BIAS || EPI == OMNI_EPI_BIAS_GELU_TANH) {
-    if (gemm_persistent_direct(p, tiles_m, tiles_n) && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
-      if (omni_dev_env_int("OMNI_PPP_TRACE", 0)) fprintf(stderr, "omni: persistent ping-pong launch, %d tiles\n", tiles_m * tiles_n);
-      hipLaunchKernelGGL((gemm_bf16_ppp_kernel<EPI>), dim3(gemm_num_cus() & ~7), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
-                         tiles_n, gemm_group_m());
-      OMNI_CHECK_LAUNCH();
-      return OMNI_OK;
-    }
-  }
+#include "dev/gemm_dev_launch_persistent.inc"
 #endif
   if (false) {
   }
@@ -3012,56 +1468,15 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
 
 
 #ifdef OMNI_DEV
-// dev-only (NOT part of the C-ABI in include/omni_cdna4.h): time the 2-stage kernel with parts removed.
-extern "C" int omni_dev_gemm_ablate(const omni_gemm_params* p, int mode, omni_stream stream) {
-  const int mt0 = (p->g[0].M + BM - 1) / BM;
-  const int mt1 = p->ngroups > 1 ? (p->g[1].M + BM - 1) / BM : 0;
-  const int tiles_m = mt0 + mt1, tiles_n = (p->N + BN - 1) / BN;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-#define OMNI_ABL(A)                                                                                                \
-  case A:                                                                                                          \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<OMNI_EPI_BIAS, A>),                         \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                                    \
-    hipLaunchKernelGGL((gemm_bf16_kernel<OMNI_EPI_BIAS, A>), dim3(tiles_m * tiles_n), dim3(NTHREADS), LDS_BYTES, s, \
-                       *p, mt0, tiles_m, tiles_n, GROUP_M_DEFAULT);                                                                 \
-    break;
-  switch (mode) {
-    OMNI_ABL(0) OMNI_ABL(1) OMNI_ABL(2) OMNI_ABL(3) OMNI_ABL(4) OMNI_ABL(5)
-    default: return OMNI_ERR_BAD_ARG;
-  }
-#undef OMNI_ABL
-  OMNI_CHECK_LAUNCH();
-  return OMNI_OK;
-}
-
-extern "C" int omni_dev_gemm_ring_ablate(const omni_gemm_params* p, int mode, omni_stream stream) {
-  const int mt0 = (p->g[0].M + BM - 1) / BM;
-  const int tiles_m = mt0, tiles_n = (p->N + BN - 1) / BN;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-#define OMNI_ABL(A)                                                                                                  \
-  case A:                                                                                                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<OMNI_EPI_BIAS, A>),                      \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES);                                     \
-    hipLaunchKernelGGL((gemm_bf16_ring_kernel<OMNI_EPI_BIAS, A>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, \
-                       s, *p, mt0, tiles_m, tiles_n, GROUP_M_DEFAULT);                                               \
-    break;
-  switch (mode) {
-    OMNI_ABL(0) OMNI_ABL(1) OMNI_ABL(3) OMNI_ABL(4)
-    default: return OMNI_ERR_BAD_ARG;
-  }
-#undef OMNI_ABL
-  OMNI_CHECK_LAUNCH();
-  return OMNI_OK;
-}
-
-#endif  // OMNI_DEV
+#include "dev/gemm_dev_entry_points.inc"
+#endif
 
 extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
   if (!p || p->ngroups < 1 || p->ngroups > 2 || p->N <= 0 || p->K <= 0) return OMNI_ERR_BAD_ARG;
   if (p->K % RBK != 0 || p->N % 8 != 0) return OMNI_ERR_UNSUPPORTED;
   if (p->fp8 != 0 && p->fp8 != 1) return OMNI_ERR_BAD_ARG;
   if (p->fp8) {                                      // e4m3 operands: K64-blocked layouts only, whole 128-k tiles, fp32 scales
-    if (p->K % 128 != 0 || p->N % 4 != 0 || !p->w_k32_blocked || !OMNI_PP_MFMA16) return OMNI_ERR_UNSUPPORTED;
+    if (p->K % 128 != 0 || p->N % 4 != 0 || !p->w_k32_blocked) return OMNI_ERR_UNSUPPORTED;
     for (int g = 0; g < p->ngroups; ++g) {
       if (!p->g[g].a_scale || !p->g[g].w_scale) return OMNI_ERR_BAD_ARG;
       if (!p->g[g].a_k32_rows) return OMNI_ERR_UNSUPPORTED;
