@@ -219,3 +219,103 @@ def test_worker_shards_requests_over_sp_groups_on_gloo(world, degree):
     for i, v in enumerate(got):                              # value = seed + 1000 * sum(ranks of the group that ran it)
         g = next(g for g in range(world // degree) if i in res[g * degree][2])
         assert v == pytest.approx(i + 1000.0 * sum(range(g * degree, (g + 1) * degree)), rel=1e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# TeaCache under sequence parallelism (round 5): per-rank slices, ONE all-reduced pair of sums, the single-device decision
+def _toy_modulated_inputs(steps=12, S=32, D=16):
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(S, D, generator=g)
+    seq = []
+    for t in range(steps):                                   # a drifting "modulated input": small and large steps mixed
+        x = x + (0.02 if t % 3 else 0.25) * torch.randn(S, D, generator=g)
+        seq.append(x.bfloat16())
+    return seq
+
+
+def _toy_teacache_forward(rank, P, mod_full, st):
+    """The TeaCache part of `_sp_forward_gen` on this rank's row slice of a given modulated input."""
+    S, D = mod_full.shape
+    mod = mod_full[rank * (S // P):(rank + 1) * (S // P)]
+    if st.cnt > 0 and st.prev_mod is not None:
+        part = torch.stack([(mod - st.prev_mod).abs().float().sum(), st.prev_mod.abs().float().sum()])
+        total = yield ("all_reduce", part)
+        compute = st.decide(total, S * D)
+    else:
+        st.first()
+        compute = True
+    st.prev_mod = mod
+    flags = yield ("all_gather", torch.tensor([1.0 if compute else 0.0]))
+    return flags.reshape(-1)
+
+
+def _reference_rule_decisions(seq, cfg):
+    """The reference's host hook on the FULL tensors (vllm_omni/diffusion/cache/teacache/hook.py:170-217 via our TeaCacheHook)."""
+    from vllm_omni_amd.diffusion.cache.teacache.hook import TeaCacheHook, TeaCacheState
+
+    hook, st, out = TeaCacheHook(cfg), TeaCacheState(), []
+    for m in seq:
+        out.append(hook._should_compute_full_transformer(st, m))
+        st.previous_modulated_input = m
+        st.cnt += 1
+    return out
+
+
+def _tc_rank(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from vllm_omni_amd.diffusion.cache.teacache.config import TeaCacheConfig
+    from vllm_omni_amd.diffusion.cache.teacache.sp_state import TeaCacheSPState
+    from vllm_omni_amd.diffusion.distributed.sp_driver import drive
+
+    dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+    cfg = TeaCacheConfig(rel_l1_thresh=0.3, transformer_type="QwenImageTransformer2DModel")
+    seq = _toy_modulated_inputs()
+    # two items ("CFG branches") pipelined per step, each with its own state
+    sts = [TeaCacheSPState(cfg), TeaCacheSPState(cfg)]
+    seen = []
+    for m in seq:
+        outs = drive([_toy_teacache_forward(rank, world, m, sts[0]), _toy_teacache_forward(rank, world, (m * 1.5).bfloat16(), sts[1])], None)
+        seen.append([o.tolist() for o in outs])
+    q.put((rank, seen, [s.decisions for s in sts], [s.skipped for s in sts]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_teacache_under_sequence_parallelism_takes_the_single_device_decisions_on_gloo(world):
+    from test_host_logic import _free_port
+
+    from vllm_omni_amd.diffusion.cache.teacache.config import TeaCacheConfig
+    from vllm_omni_amd.diffusion.cache.teacache.sp_state import TeaCacheSPState
+    from vllm_omni_amd.diffusion.distributed.sp_driver import drive_in_process
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tc_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, seen, dec, skipped = q.get(timeout=180)
+        res[rank] = (seen, dec, skipped)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = TeaCacheConfig(rel_l1_thresh=0.3, transformer_type="QwenImageTransformer2DModel")
+    seq = _toy_modulated_inputs()
+    want = [_reference_rule_decisions(seq, cfg), _reference_rule_decisions([(m * 1.5).bfloat16() for m in seq], cfg)]
+    assert any(not d for d in want[0][1:]) and any(d for d in want[0][1:])          # the toy sequence both skips and computes
+    for r in range(world):
+        assert res[r][1] == want, (r, res[r][1], want)                              # every rank == the single-device rule
+        assert res[r][2] == [sum(1 for d in w if not d) for w in want]
+        for step, per_item in enumerate(res[r][0]):                                 # and every rank SAW every rank agree
+            for i, flags in enumerate(per_item):
+                assert flags == [1.0 if want[i][step] else 0.0] * world
+    # the in-process exchange used by the one-device GPU tests gives the same decisions
+    sts = [[TeaCacheSPState(cfg)] for _ in range(world)]
+    for m in seq:
+        drive_in_process([[_toy_teacache_forward(r, world, m, sts[r][0])] for r in range(world)])
+    assert all(sts[r][0].decisions == want[0] for r in range(world))

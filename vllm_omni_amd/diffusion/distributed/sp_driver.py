@@ -2,7 +2,8 @@
 
 `QwenImageTransformer2DModel._sp_forward_gen` (reference attention/parallel/ulysses.py:59-135,
 qwen_image_transformer.py:735-742,776-781,800-801) computes up to an exchange point, yields
-`("all_to_all", send[P, ...])` or `("all_gather", x)`, and continues with the received tensor.  This module runs one or
+`("all_to_all", send[P, ...])`, `("all_gather", x)` or `("all_reduce", x)` (sum; TeaCache's two partial sums), and continues
+with the received tensor.  This module runs one or
 SEVERAL such generators over a process group:
 
   * one generator: collective, continue, collective, ... (what the reference does: its all-to-alls sit on the critical path);
@@ -49,6 +50,11 @@ def _launch(msg, group):
         flat = torch.empty((P * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)   # concatenation along dim 0
         work = dist.all_gather_into_tensor(flat, t, group=group, async_op=True)
         out = flat.view((P,) + tuple(t.shape))
+    elif kind == "all_reduce":
+        if P == 1:
+            return _Done(t)
+        out = t.contiguous().clone()
+        work = dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group, async_op=True)
     else:
         raise RuntimeError(f"unknown collective {kind!r}")
 
@@ -80,4 +86,49 @@ def drive(gens: list[Generator], group=None) -> list[Any]:
                 pending[i] = _launch(g.send(got), group)
             except StopIteration as e:
                 results[i], alive[i] = e.value, False
+    return results
+
+
+def drive_in_process(gens_by_rank: list[list[Generator]]) -> list[Any]:
+    """Test harness for ONE device: `gens_by_rank[r][i]` is forward i on virtual rank r.  The P generators of a forward run in
+    lock step and their collectives are performed in process (all-to-all: recv[r][j] = send[j][r]; all-gather: the stack;
+    all-reduce: the sum) — every kernel, reshard and index permutation of the real path runs, only the wire is replaced.
+    Every rank must yield the same collective kind at the same point and end with the same result (checked); returns virtual
+    rank 0's results."""
+    P = len(gens_by_rank)
+    results = []
+    for i in range(len(gens_by_rank[0])):
+        gens = [gens_by_rank[r][i] for r in range(P)]
+        msgs, done = [], []
+        for g in gens:
+            try:
+                msgs.append(next(g))
+            except StopIteration as e:
+                done.append(e.value)
+        while not done:
+            kinds = {m[0] for m in msgs}
+            if len(kinds) != 1:
+                raise RuntimeError(f"virtual ranks disagree on the next collective: {kinds}")
+            kind, sends = kinds.pop(), [m[1] for m in msgs]
+            if kind == "all_to_all":
+                outs = [torch.stack([sends[j][r] for j in range(P)]) for r in range(P)]
+            elif kind == "all_gather":
+                outs = [torch.stack(sends) for _ in range(P)]
+            elif kind == "all_reduce":
+                tot = torch.stack(sends).sum(0)
+                outs = [tot.clone() for _ in range(P)]
+            else:
+                raise RuntimeError(f"unknown collective {kind!r}")
+            msgs = []
+            for g, o in zip(gens, outs):
+                try:
+                    msgs.append(g.send(o))
+                except StopIteration as e:
+                    done.append(e.value)
+        if len(done) != P:
+            raise RuntimeError("virtual ranks finished at different points")
+        for o in done[1:]:
+            if not torch.equal(o, done[0]):
+                raise RuntimeError("virtual ranks ended with different results")
+        results.append(done[0])
     return results

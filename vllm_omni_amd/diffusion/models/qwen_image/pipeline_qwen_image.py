@@ -146,10 +146,8 @@ class QwenImagePipeline(nn.Module):
         sequence of token grids ((1, h, w), (1, h_c, w_c), ...).  `cfg_normalize` = False: true-CFG combination without the norm
         rescale; `t_cond`: the Layered variant's `additional_t_cond` (is_rgb) for every item."""
         tr, dev = self.transformer, self.device
-        if self.sp_degree > 1 or getattr(self, "_force_sp_path", False):
-            if not cfg_normalize or t_cond is not None:
-                raise NotImplementedError("the Layered variant is not built sequence-parallel")
-            return self._denoise_sp(latents, pos, neg, grid, timesteps, dts, cfg_scales, cond)
+        if self.sp_degree > 1 or getattr(self, "_force_sp_path", False) or getattr(self, "_sp_emulate_ranks", 0):
+            return self._denoise_sp(latents, pos, neg, grid, timesteps, dts, cfg_scales, cond, cfg_normalize, t_cond)
         R = len(latents)
         S = latents[0].shape[0]
         S_c = 0 if cond is None else int(cond[0].shape[0])
@@ -274,35 +272,55 @@ class QwenImagePipeline(nn.Module):
         return list(lat.clone().view(R, S, -1).unbind(0))
 
     @torch.no_grad()
-    def _denoise_sp(self, latents, pos, neg, grid, timesteps, dts, cfg_scales, cond=None) -> list[torch.Tensor]:
+    def _denoise_sp(self, latents, pos, neg, grid, timesteps, dts, cfg_scales, cond=None, cfg_normalize: bool = True,
+                    t_cond: int | None = None) -> list[torch.Tensor]:
         """The same loop with every DiT forward SEQUENCE-PARALLEL over `self.sp_group` (reference wiring:
         qwen_image_transformer.py:735-742,776-781,800-801 + attention/parallel/ulysses.py:59-135; end-to-end contract
-        tests/e2e/offline_inference/test_sequence_parallel.py:68-71,128-147): each rank holds S_img / P image rows of an
+        tests/e2e/offline_inference/test_sequence_parallel.py:68-71,128-147): each rank holds S / P image rows of an
         item through the block stack, attention runs on H / P heads over the whole sequence.  The items of a step (requests
         x CFG branches) are independent forwards: they are software-pipelined so that one item's all-to-all flies while the
-        next item's GEMMs run (distributed/sp_driver.py).  Every rank ends with the full latents."""
+        next item's GEMMs run (distributed/sp_driver.py).  Every rank ends with the full latents.
+
+        The strategy is pipeline-agnostic, as the reference's is (its Ulysses layer wraps any DiT forward):
+          * `cond` (Edit / Edit-Plus / Layered): the condition-image rows ride on the sequence axis of every forward — the rows
+            [latents ; condition] are sharded as ONE sequence (the reference chunks `hidden_states` after the pipeline's
+            `torch.cat([latents, image_latents], dim=1)`, pipeline_qwen_image_edit.py:600-632) and the prediction is cut back to
+            the latent rows; `grid` is then the sequence of token grids;
+          * `t_cond` / `cfg_normalize` (Layered): the additional_t_cond rows join the timestep embedding on every rank, the
+            true-CFG combination runs without the norm rescale;
+          * TeaCache: one TeaCacheSPState per item and rank — per-rank residual slices, ONE all-reduced pair of sums per forward
+            for the decision, so every rank takes the single-device decision (cache/teacache/sp_state.py)."""
         tr, dev = self.transformer, self.device
-        if cond is not None:
-            raise NotImplementedError("sequence parallelism with condition images (Edit pipelines) is not built")
-        if getattr(tr, "teacache", None) is not None:
-            raise NotImplementedError("TeaCache with sequence parallelism is not built (per-rank residual slices)")
         do_cfg = neg is not None
         if do_cfg and len(set(cfg_scales)) != 1:
             raise NotImplementedError("step-batched requests must share true_cfg_scale")
         R, S = len(latents), int(latents[0].shape[0])
         lat = torch.stack([x.to(dev, BF16) for x in latents]).contiguous()                  # [R, S, 64]
         pe = [p.to(dev, BF16) for p in pos] + ([n.to(dev, BF16) for n in neg] if do_cfg else [])
+        cv = None if cond is None else [c.to(dev, BF16) for c in cond]                      # [S_c, 64] per request
         sig_in = self.scheduler.model_timestep(timesteps).to(dev)
         dt_dev = dts.to(dev, torch.float32).contiguous()
         tr.do_true_cfg = do_cfg
         flat = lat.view(R * S, -1)
+        n_items = (2 if do_cfg else 1) * R
+        emu = int(getattr(self, "_sp_emulate_ranks", 0) or 0)
+        tcfg = getattr(tr, "teacache", None)
+        tc_states = None
+        if tcfg is not None:
+            from ...cache.teacache.sp_state import TeaCacheSPState, TeaCacheSPStats
+
+            tc_states = ([[TeaCacheSPState(tcfg) for _ in range(n_items)] for _ in range(emu)] if emu
+                         else [TeaCacheSPState(tcfg) for _ in range(n_items)])
+            self.last_teacache_state = TeaCacheSPStats(tc_states[0] if emu else tc_states)
         for i in range(len(timesteps)):
             sg = sig_in[i:i + 1]
-            items = [(lat[r % R], pe[j], sg) for j, r in enumerate(list(range(R)) * (2 if do_cfg else 1))]
-            preds = tr.forward_sp_multi(items, grid, self.sp_group)
+            rows = [lat[r] if cv is None else torch.cat([lat[r], cv[r]]) for r in range(R)]
+            items = [(rows[r % R], pe[j], sg) for j, r in enumerate(list(range(R)) * (2 if do_cfg else 1))]
+            preds = tr.forward_sp_multi(items, grid, self.sp_group, t_cond=t_cond, teacache_states=tc_states, emulate_ranks=emu)
+            preds = [p[:S] for p in preds]                                                  # noise_pred[:, :latents.size(1)]
             p = torch.cat(preds[:R]).contiguous()
             n = torch.cat(preds[R:]).contiguous() if do_cfg else None
-            ops.cfg_euler_step_(flat, p, n, cfg_scales[0], dt_dev[i:i + 1])
+            ops.cfg_euler_step_(flat, p, n, cfg_scales[0], dt_dev[i:i + 1], normalize=cfg_normalize)
         return list(lat.clone().unbind(0))
 
     def _use_graph(self, img_rows: int) -> bool:

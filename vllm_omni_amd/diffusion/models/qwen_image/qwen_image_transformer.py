@@ -647,21 +647,32 @@ class QwenImageTransformer2DModel(nn.Module):
 
     # ------------------------------------------------------------------ Ulysses sequence parallelism
     def _sp_forward_gen(self, rank: int, P: int, latents: torch.Tensor, prompt_embeds: torch.Tensor, sigma: torch.Tensor,
-                        grid: tuple[int, int, int]):
+                        grid, t_cond: int | None = None, teacache=None):
         """One DiT forward of ONE item with its image tokens split over P ranks (reference qwen_image_transformer.py:
         735-742,776-781,800-801 + attention/parallel/ulysses.py:59-135), written as a generator that YIELDS its collectives
-        (`("all_to_all", send[P, ...])` -> recv, `("all_gather", x)` -> [P, ...]) so that the same code is driven by
-        torch.distributed (forward_sp) or, in tests, by an in-process exchange between P generators on one GPU.
+        (`("all_to_all", send[P, ...])` -> recv, `("all_gather", x)` -> [P, ...], `("all_reduce", x)` -> sum) so that the same
+        code is driven by torch.distributed (forward_sp) or, in tests, by an in-process exchange between P generators on one GPU.
 
-        latents [S_img, 64] (full; this rank takes rows [rank*S_img/P, ...)), prompt_embeds [T, joint] (replicated),
-        sigma fp32 [1].  Per block: omni_dit_block_qkv on the local rows -> ONE fused all-to-all of the image q/k/v
-        (sequence <-> heads; the replicated text q/k/v are only head-sliced, no communication — unlike the reference, which
-        sends P copies of the text queries through the all-to-all) -> flash attention over the whole sequence for H/P heads
-        -> ONE all-to-all back (image rows to their owners + the text rows' head slice to everyone) -> omni_dit_block_post."""
+        latents [S, 64] (full; this rank takes rows [rank*S/P, ...)), prompt_embeds [T, joint] (replicated), sigma fp32 [1].
+        `grid`: one (f, h, w) triple, or SEVERAL (the Edit pipelines: target + condition images on one sequence axis, reference
+        pipeline_qwen_image_edit.py:600-632; the Layered variant's explicit frame indices) — S is then the total over all of
+        them and the rows are sharded as ONE sequence, exactly as the reference chunks `hidden_states` after the concatenation.
+        `t_cond`: the Layered variant's additional_t_cond.  Per block: omni_dit_block_qkv on the local rows -> ONE fused
+        all-to-all of the image q/k/v (sequence <-> heads; the replicated text q/k/v are only head-sliced, no communication —
+        unlike the reference, which sends P copies of the text queries through the all-to-all) -> flash attention over the whole
+        sequence for H/P heads -> ONE all-to-all back (image rows to their owners + the text rows' head slice to everyone) ->
+        omni_dit_block_post.
+
+        `teacache`: a cache.teacache.sp_state.TeaCacheSPState of this (rank, item) — TeaCache under sequence parallelism.  The
+        decision input (relative L1 distance of consecutive modulated inputs of block 0, reference hook.py:195-206) is a mean over
+        ALL image rows: every rank sums its slice, ONE all-reduce of two floats makes the sums global, and every rank takes the
+        same decision — the single-device decision.  The cached residual is this rank's row slice."""
         H, d, D = self.num_heads, self.head_dim, self.inner_dim
         S = grid_tokens(grid)
         if S % P or H % P:
-            raise ValueError(f"Ulysses needs S_img ({S}) and heads ({H}) divisible by the degree ({P})")
+            raise ValueError(f"Ulysses needs the image-token count ({S}) and the heads ({H}) divisible by the degree ({P})")
+        if latents.shape[0] != S:
+            raise ValueError(f"{latents.shape[0]} latent rows for a token grid of {S}")
         S_loc, Hh, T = S // P, H // P, prompt_embeds.shape[0]
         dev = self.device
         rb = build_ragged_batch([T], grid, img_rows=(rank * S_loc, S_loc))
@@ -670,55 +681,87 @@ class QwenImageTransformer2DModel(nn.Module):
         stream = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
         hid = self.img_in(latents[rank * S_loc:(rank + 1) * S_loc].to(dev, BF16)).contiguous()          # [S_loc, D]
         enc = self.txt_in(self.txt_norm(prompt_embeds.to(dev, BF16))).contiguous()                      # [T, D]
-        temb = self.time_text_embed(sigma.to(dev), hid).contiguous()                                    # [1, D]
-        cu = torch.tensor([0, T + S], dtype=torch.int32, device=dev)
-        scale = 1.0 / (d ** 0.5)
-        for l in range(len(self.transformer_blocks)):
-            _, w, b = self._descriptor(prepared, S_loc, T)
-            ws_base, ws_t = self._workspace.data_ptr(), self._workspace
-            qp, kp, vp = C.c_void_p(), C.c_void_p(), C.c_void_p()
-            N.check(lib.omni_dit_block_qkv(C.byref(w), l, C.byref(b), hid.data_ptr(), enc.data_ptr(), temb.data_ptr(),
-                                           C.byref(qp), C.byref(kp), C.byref(vp), stream()), "omni_dit_block_qkv")
-            view = lambda p: ws_t[p.value - ws_base: p.value - ws_base + (T + S_loc) * D * 2].view(BF16).view(T + S_loc, H, d)  # noqa: E731
-            q, k, v = view(qp), view(kp), view(vp)                       # joint order: [text ; image chunk]
-            # my head slice of the replicated text rows (copied: the workspace is reused by the next native call)
-            hs = slice(rank * Hh, (rank + 1) * Hh)
-            txt_qkv = torch.stack([q[:T, hs], k[:T, hs], v[:T, hs]]).reshape(3, T, Hh * d).clone()
-            send = torch.stack([q[T:], k[T:], v[T:]]).view(3, S_loc, P, Hh * d).permute(2, 0, 1, 3).contiguous()
-            recv = yield ("all_to_all", send)                            # [P(source = sequence chunk), 3, S_loc, Hh*d]
-            img_qkv = recv.permute(1, 0, 2, 3).reshape(3, S, Hh * d)
-            full = torch.cat([txt_qkv, img_qkv], dim=1).contiguous()     # [3, T + S, Hh*d]
-            o = ops.flash_attn_varlen(full[0], full[1], full[2], cu, Hh, T + S, scale)           # [T + S, Hh*d]
-            send2 = torch.cat([o[T:].view(P, S_loc, Hh * d), o[:T].unsqueeze(0).expand(P, T, Hh * d)], dim=1).contiguous()
-            recv2 = yield ("all_to_all", send2)                          # [P(source = head slice), S_loc + T, Hh*d]
-            loc = recv2.permute(1, 0, 2).reshape(S_loc + T, D)           # heads in source-rank order = original order
-            attn = torch.cat([loc[S_loc:], loc[:S_loc]]).contiguous()    # back to the joint order [text ; image chunk]
-            _, w, b = self._descriptor(prepared, S_loc, T)
-            N.check(lib.omni_dit_block_post(C.byref(w), l, C.byref(b), hid.data_ptr(), enc.data_ptr(), temb.data_ptr(),
-                                            attn.data_ptr(), stream()), "omni_dit_block_post")
+        temb = self.time_text_embed(sigma.to(dev), hid, None if t_cond is None else [t_cond]).contiguous()   # [1, D]
+        compute, hid_in = True, None
+        if teacache is not None:
+            first = self.transformer_blocks[0]
+            img_mod1, _ = first.img_mod(temb).chunk(2, dim=-1)
+            mod, _ = first.img_norm1(hid.view(1, S_loc, D), img_mod1)
+            mod = mod.reshape(S_loc, D).contiguous()
+            if teacache.cnt > 0 and teacache.prev_mod is not None:
+                # the reference subtracts two bf16 tensors (rounded to bf16) before abs().mean() (hook.py:197-201)
+                part = torch.stack([(mod - teacache.prev_mod).abs().float().sum(), teacache.prev_mod.abs().float().sum()])
+                total = yield ("all_reduce", part)
+                compute = teacache.decide(total, S * D)
+            else:
+                teacache.first()
+            teacache.prev_mod = mod
+            if compute or teacache.prev_res is None:
+                compute, hid_in = True, hid.clone()
+            else:
+                hid = (hid + teacache.prev_res).contiguous()
+        if compute:
+            cu = torch.tensor([0, T + S], dtype=torch.int32, device=dev)
+            scale = 1.0 / (d ** 0.5)
+            for l in range(len(self.transformer_blocks)):
+                _, w, b = self._descriptor(prepared, S_loc, T)
+                ws_base, ws_t = self._workspace.data_ptr(), self._workspace
+                qp, kp, vp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+                N.check(lib.omni_dit_block_qkv(C.byref(w), l, C.byref(b), hid.data_ptr(), enc.data_ptr(), temb.data_ptr(),
+                                               C.byref(qp), C.byref(kp), C.byref(vp), stream()), "omni_dit_block_qkv")
+                view = lambda p: ws_t[p.value - ws_base: p.value - ws_base + (T + S_loc) * D * 2].view(BF16).view(T + S_loc, H, d)  # noqa: E731
+                q, k, v = view(qp), view(kp), view(vp)                       # joint order: [text ; image chunk]
+                # my head slice of the replicated text rows (copied: the workspace is reused by the next native call)
+                hs = slice(rank * Hh, (rank + 1) * Hh)
+                txt_qkv = torch.stack([q[:T, hs], k[:T, hs], v[:T, hs]]).reshape(3, T, Hh * d).clone()
+                send = torch.stack([q[T:], k[T:], v[T:]]).view(3, S_loc, P, Hh * d).permute(2, 0, 1, 3).contiguous()
+                recv = yield ("all_to_all", send)                            # [P(source = sequence chunk), 3, S_loc, Hh*d]
+                img_qkv = recv.permute(1, 0, 2, 3).reshape(3, S, Hh * d)
+                full = torch.cat([txt_qkv, img_qkv], dim=1).contiguous()     # [3, T + S, Hh*d]
+                o = ops.flash_attn_varlen(full[0], full[1], full[2], cu, Hh, T + S, scale)           # [T + S, Hh*d]
+                send2 = torch.cat([o[T:].view(P, S_loc, Hh * d), o[:T].unsqueeze(0).expand(P, T, Hh * d)], dim=1).contiguous()
+                recv2 = yield ("all_to_all", send2)                          # [P(source = head slice), S_loc + T, Hh*d]
+                loc = recv2.permute(1, 0, 2).reshape(S_loc + T, D)           # heads in source-rank order = original order
+                attn = torch.cat([loc[S_loc:], loc[:S_loc]]).contiguous()    # back to the joint order [text ; image chunk]
+                _, w, b = self._descriptor(prepared, S_loc, T)
+                N.check(lib.omni_dit_block_post(C.byref(w), l, C.byref(b), hid.data_ptr(), enc.data_ptr(), temb.data_ptr(),
+                                                attn.data_ptr(), stream()), "omni_dit_block_post")
+            if teacache is not None:
+                teacache.prev_res = hid - hid_in                             # this rank's rows of the residual (hook.py:151)
         out_loc = self.proj_out(self.norm_out(hid.view(1, S_loc, D), temb)).view(S_loc, -1)
         gathered = yield ("all_gather", out_loc.contiguous())            # [P, S_loc, 64]
         return gathered.reshape(S, -1)
 
     @torch.no_grad()
     def forward_sp(self, latents: torch.Tensor, prompt_embeds: torch.Tensor, sigma: torch.Tensor,
-                   grid: tuple[int, int, int], group=None) -> torch.Tensor:
+                   grid, group=None) -> torch.Tensor:
         """Ulysses sequence-parallel forward over `group` (RCCL): every rank passes the same full `latents` / prompt and
         receives the full noise prediction [S_img, 64].  240 all-to-alls + 1 all-gather per 60-layer forward."""
         return self.forward_sp_multi([(latents, prompt_embeds, sigma)], grid, group)[0]
 
     @torch.no_grad()
-    def forward_sp_multi(self, items: list[tuple[torch.Tensor, torch.Tensor, torch.Tensor]], grid, group=None) -> list[torch.Tensor]:
+    def forward_sp_multi(self, items: list[tuple[torch.Tensor, torch.Tensor, torch.Tensor]], grid, group=None, *,
+                         t_cond: int | None = None, teacache_states=None, emulate_ranks: int = 0) -> list[torch.Tensor]:
         """Several sequence-parallel forwards over the same grid — the two true-CFG branches of a request, or several
         requests — software-pipelined: while one forward's all-to-all is in flight the next forward's GEMMs run
-        (distributed/sp_driver.py).  items[i] = (latents [S_img, 64], prompt_embeds [T_i, joint], sigma fp32 [1])."""
+        (distributed/sp_driver.py).  items[i] = (latents [S, 64], prompt_embeds [T_i, joint], sigma fp32 [1]).
+        `teacache_states[i]`: the TeaCacheSPState of item i on this rank (None: no TeaCache).
+        `emulate_ranks = P` (tests, one device): P virtual ranks run the same forwards with an in-process exchange
+        (`teacache_states[r][i]` then belongs to virtual rank r); every rank's result is checked to be identical."""
         import torch.distributed as dist
 
-        from ...distributed.sp_driver import drive
+        from ...distributed.sp_driver import drive, drive_in_process
 
+        if emulate_ranks:
+            P = int(emulate_ranks)
+            gens = [[self._sp_forward_gen(r, P, lat, pe, sg, grid, t_cond,
+                                          None if teacache_states is None else teacache_states[r][i])
+                     for i, (lat, pe, sg) in enumerate(items)] for r in range(P)]
+            return drive_in_process(gens)
         P = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
-        gens = [self._sp_forward_gen(rank, P, lat, pe, sg, grid) for lat, pe, sg in items]
+        gens = [self._sp_forward_gen(rank, P, lat, pe, sg, grid, t_cond, None if teacache_states is None else teacache_states[i])
+                for i, (lat, pe, sg) in enumerate(items)]
         return drive(gens, group)
 
     # ------------------------------------------------------------------ reference-shaped forward
