@@ -89,48 +89,88 @@ def cpu_baseline(layers_sample: int = 4) -> dict:
 
 
 def measure_roofline(dev, R: int = 5) -> dict:
+    """HIP-event time of the dominant kernel (MLP-up GEMM + GELU at the step-batch shape, production layouts) measured IN THE
+    KERNEL MIX OF A DiT BLOCK: a launched-alone loop of one kernel settles at its own clock / power point (the part runs at its
+    package power limit), up to 3 % off what the same launch takes between the other kernels of a layer (round-5 first profile:
+    2247 us alone vs 2173 us inside the bench under rocprofv3).  So the timed launch sits in a replica of a block's launch
+    sequence — QKV GEMM, joint attention, out-proj GEMM, [MLP-up: timed], MLP-down GEMM, all at the bench's shapes — and one
+    event pair brackets the MLP-up launch of every iteration, on the stream it is launched on."""
+    import math
+
     from vllm_omni_amd import ops
 
-    D, Mi, Mt = 3072, 2 * R * 4096, 2 * R * T_TXT
+    BF = torch.bfloat16
+    D, H, Mi, Mt = 3072, 24, 2 * R * 4096, 2 * R * T_TXT
     N, K = 4 * D, D
     g = torch.Generator(device=dev).manual_seed(7)
-    xi = torch.randn(Mi, K, device=dev, generator=g).to(torch.bfloat16)
-    xt = torch.randn(Mt, K, device=dev, generator=g).to(torch.bfloat16)
-    blocked = True                                                    # the layout the DiT layers run with
-    wi = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
-    wt = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
-    ablk = True                                                       # A and the GELU output K32-blocked, as in the layers
-    if blocked:
-        wi, wt = ops.w_to_k32_blocked(wi), ops.w_to_k32_blocked(wt)
-    if ablk:
-        xi, xt = ops.w_to_k32_blocked(xi), ops.w_to_k32_blocked(xt)
-    b = torch.zeros(N, device=dev, dtype=torch.bfloat16)
-    oi = torch.empty(Mi, N, device=dev, dtype=torch.bfloat16)
-    ot = torch.empty(Mt, N, device=dev, dtype=torch.bfloat16)
 
-    def launch():
-        ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi, a_k32_blocked=ablk, out_k32_blocked=ablk),
-                  ops.GemmGroupArgs(xt, wt, b, ot, a_k32_blocked=ablk, out_k32_blocked=ablk)], ops.EPI_BIAS_GELU_TANH,
-                 w_k32_blocked=blocked)
+    def rn(rows, cols, s=1.0):
+        return (torch.randn(rows, cols, device=dev, generator=g) * s).to(BF)
 
-    for _ in range(3):
-        launch()
+    blk = ops.w_to_k32_blocked
+    # the timed launch: A, W and the GELU output K32-blocked, as in the layers
+    xi, xt = blk(rn(Mi, K)), blk(rn(Mt, K))
+    wi, wt = blk(rn(N, K, 0.02)), blk(rn(N, K, 0.02))
+    b = torch.zeros(N, device=dev, dtype=BF)
+    oi, ot = torch.empty(Mi, N, device=dev, dtype=BF), torch.empty(Mt, N, device=dev, dtype=BF)
+
+    def mlp_up():
+        ops.gemm([ops.GemmGroupArgs(xi, wi, b, oi, a_k32_blocked=True, out_k32_blocked=True),
+                  ops.GemmGroupArgs(xt, wt, b, ot, a_k32_blocked=True, out_k32_blocked=True)], ops.EPI_BIAS_GELU_TANH,
+                 w_k32_blocked=True)
+
+    # the neighbours of that launch in a block (plain bias epilogues: they only set the mix the timed launch runs in)
+    w_qkv, w_o, w_dn = blk(rn(3 * D, D, 0.02)), blk(rn(D, D, 0.02)), blk(rn(D, 4 * D, 0.02))
+    b3, b1 = torch.zeros(3 * D, device=dev, dtype=BF), torch.zeros(D, device=dev, dtype=BF)
+    qkv = torch.empty(Mi, 3 * D, device=dev, dtype=BF)
+    o1, o2 = torch.empty(Mi, D, device=dev, dtype=BF), torch.empty(Mi, D, device=dev, dtype=BF)
+    q, k, v = rn(Mi + Mt, D), rn(Mi + Mt, D), rn(Mi + Mt, D)
+    S = 4096 + T_TXT
+    cu = (torch.arange(2 * R + 1, dtype=torch.int32) * S).to(dev)
+    att = torch.empty(Mi + Mt, D, device=dev, dtype=BF)
+
+    def neighbours_before():
+        ops.gemm([ops.GemmGroupArgs(xi, w_qkv, b3, qkv, a_k32_blocked=True)], ops.EPI_BIAS, w_k32_blocked=True)
+        ops.flash_attn_varlen(q, k, v, cu, H, S, 1.0 / math.sqrt(128), out=att)
+        ops.gemm([ops.GemmGroupArgs(xi, w_o, b1, o1, a_k32_blocked=True)], ops.EPI_BIAS, w_k32_blocked=True)
+
+    def neighbours_after():
+        ops.gemm([ops.GemmGroupArgs(oi, w_dn, b1, o2, a_k32_blocked=True)], ops.EPI_BIAS, w_k32_blocked=True)
+
+    def block_mix(ev=None):
+        neighbours_before()
+        if ev is not None:
+            ev[0].record(s)
+        mlp_up()
+        if ev is not None:
+            ev[1].record(s)
+        neighbours_after()
+
     s = torch.cuda.current_stream()
+    for _ in range(3):
+        block_mix()
     iters = 30
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for ev in evs:
+        block_mix(ev)
+    torch.cuda.synchronize()
+    times = sorted(e0.elapsed_time(e1) * 1e-3 for e0, e1 in evs)
+    sec = sum(times) / iters
+    # the same launch back to back, alone (what rounds 1-4 reported as `avg_launch_us`)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(s)
     for _ in range(iters):
-        launch()
+        mlp_up()
     e1.record(s)
     torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    sec_alone = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 2.0 * (Mi + Mt) * N * K
     ach = flops / sec / 1e12
     # HBM/fabric bytes per launch of this very kernel + shape: bench.py cannot run rocprofv3 on itself, so it reports the
     # committed PMC measurement (tools/profile_round.sh -> tools/summarize_prof.py; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)
     traffic, traffic_src = None, None
     kname = "gemm_bf16_pp_kernel<OMNI_EPI_BIAS_GELU_TANH>"
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_roofline_traffic_pmc.json")) as fh:
                 j = json.load(fh)
@@ -139,10 +179,14 @@ def measure_roofline(dev, R: int = 5) -> dict:
                 break
         except (OSError, KeyError, ValueError):
             pass
-    return {"bound": "mfma", "kernel": f"{kname} M={Mi}+{Mt} N=12288 K=3072"
-                                      + (" (W" + (", A, out" if ablk else "") + " K32-blocked)" if blocked else ""),
+    return {"bound": "mfma", "kernel": f"{kname} M={Mi}+{Mt} N=12288 K=3072 (W, A, out K32-blocked)",
             "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12),
-            "flop_per_launch": flops, "avg_launch_us": sec * 1e6, "traffic": traffic, "traffic_source": traffic_src,
+            "flop_per_launch": flops, "avg_launch_us": sec * 1e6, "median_launch_us": times[iters // 2] * 1e6,
+            "launches_timed": iters,
+            "timing": "HIP events around the launch inside a replica of a DiT block's kernel sequence (QKV GEMM, attention, "
+                      "out-proj GEMM, [MLP-up], MLP-down GEMM at the bench shapes) on the launch stream",
+            "avg_launch_us_back_to_back_alone": sec_alone * 1e6,
+            "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": 2.0 * ((Mi + Mt) * K + 2 * N * K + (Mi + Mt) * N)}
 
 
