@@ -352,7 +352,7 @@ def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
         return t_loop, time.perf_counter() - t0, bool(torch.isfinite(img.float()).all())
 
     t50, tv, ok = run2048()
-    flop_step = 2 * 423.01e12                       # 423.01 TFLOP per forward at 2048^2, two forwards per step
+    flop_step = 2 * 423.01e12 * layers / LAYERS     # 423.01 TFLOP per forward at 2048^2 (60 layers), two forwards per step
     out["res2048_bf16_ms_per_denoise_step"] = t50 / 50 * 1e3
     out["res2048_bf16_vae_decode_ms"] = tv * 1e3
     out["res2048_bf16_50step_seconds_per_image"] = t50 + tv
@@ -389,7 +389,7 @@ def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
         out["res2048_fp8_50step_images_per_sec"] = 1.0 / (t50f + tvf)
         out["res2048_fp8_finite_outputs"] = okf
         # roofline of the mixed-precision step: GEMM flops against the fp8 peak (5 PF), attention flops against the bf16 peak
-        gemm_flop = 2 * (423.01e12 - 4.0 * 24 * (16384 + T_TXT) ** 2 * 128 * layers)
+        gemm_flop = 2 * (423.01e12 * layers / LAYERS - 4.0 * 24 * (16384 + T_TXT) ** 2 * 128 * layers)
         attn_flop = 2 * 4.0 * 24 * (16384 + T_TXT) ** 2 * 128 * layers
         out["res2048_fp8_roofline_frac"] = (gemm_flop / 5.0e15 + attn_flop / 2.5e15) / (t50f / 50)
         out["res2048_fp8_note"] = ("transformer.enable_fp8(): OCP e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4), bf16 attention / "
