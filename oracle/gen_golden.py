@@ -170,6 +170,34 @@ def run_vae_encode_case():
     print(f"vae_encode_64x96_fp32: mean {tuple(mean.shape)} std {mean.std():.4f}")
 
 
+def run_vae_tiled_case():
+    """The reference's vendored VAE with spatial tiling on (`vae.enable_tiling()`; od_config.vae_use_tiling sets `use_tiling`,
+    registry.py:88-92): tiled_decode (autoencoder_kl_qwenimage.py:971-1031) of a 36 x 40 latent (2 x 2 tiles of 32 x 32 every
+    24, both blends) and tiled_encode (:905-969) of a 288 x 320 image."""
+    import ref_shims_pipeline as RP
+
+    vae = RP.build_reference_vae()
+    Pd, Pe = O.make_vae_params(), O.make_vae_encoder_params()
+    sd = vae.state_dict()
+    for k, v in list(Pd.items()) + list(Pe.items()):
+        assert sd[k].shape == v.shape, k
+        sd[k].copy_(v)
+    vae.enable_tiling()
+    z = torch.randn(1, 16, 1, 36, 40, generator=torch.Generator().manual_seed(13))
+    img_in = torch.rand(1, 3, 1, 288, 320, generator=torch.Generator().manual_seed(14)) * 2 - 1
+    with torch.no_grad():
+        img = vae.decode(z, return_dict=False)[0]
+        mean = vae.encode(img_in, return_dict=False)[0].mode()
+    meta = dict(case=dict(latent=[36, 40], tile_sample_min=256, tile_sample_stride=192, seeds=[13, 14]),
+                params_sha256=params_checksum({**Pd, **Pe}),
+                reference="autoencoder_kl_qwenimage.py:742-770 (enable_tiling), :844-845 -> :971-1031 (tiled_decode, un-clamped), "
+                          ":791-792 -> :905-969 (tiled_encode), :889-903 (blend) via oracle/ref_shims_pipeline.py")
+    np.savez_compressed(os.path.join(OUT, "vae_tiled_36x40_fp32.npz"), z=z.numpy(), image=img.numpy().astype(np.float32),
+                        mean=mean.numpy(), meta=json.dumps(meta))       # the encoder's input image is torch.rand(seed 14) * 2 - 1 (CPU generator)
+    print(f"vae_tiled_36x40_fp32: image {tuple(img.shape)} std {img.std():.4f} |max| {float(img.abs().max()):.3f}; "
+          f"mean {tuple(mean.shape)} std {mean.std():.4f}")
+
+
 def run_edit_case():
     """Reference DiT forward over a TWO-image sequence (target latents + one condition image of another size), the way the
     Edit pipelines call it: img_shapes = [[(1, h, w), (1, h2, w2)]] -> per-image RoPE frame index
@@ -622,6 +650,8 @@ def main():
         run_diffuse_case()
     if only is None or "encode" in only:
         run_vae_encode_case()
+    if only is None or "vaetiled" in only:
+        run_vae_tiled_case()
     if only is None or "edit" in only:
         run_edit_case()
     if only is None or "editplus" in only:

@@ -620,7 +620,7 @@ def vae_upsample(P: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
     return F.conv2d(up, P[pre + ".resample.1.weight"], P[pre + ".resample.1.bias"], padding=1)
 
 
-def vae_decode(P: Params, z: torch.Tensor, cfg: VaeConfig = VaeConfig()) -> torch.Tensor:
+def vae_decode(P: Params, z: torch.Tensor, cfg: VaeConfig = VaeConfig(), clamp: bool = True) -> torch.Tensor:
     """AutoencoderKLQwenImage._decode for one frame — :839-863 + QwenImageDecoder3d.forward :618-664.
 
     z [B, z_dim, 1, h, w] (already de-normalised) -> image [B, 3, 1, 8h, 8w] clamped to [-1, 1].
@@ -642,7 +642,99 @@ def vae_decode(P: Params, z: torch.Tensor, cfg: VaeConfig = VaeConfig()) -> torc
             x = vae_upsample(P, f"decoder.up_blocks.{i}.upsamplers.0", x)
     x = F.silu(vae_rms_norm(x, P["decoder.norm_out.gamma"]))
     x = _conv3d_as_2d(P, "decoder.conv_out", x)
-    return torch.clamp(x, -1.0, 1.0).unsqueeze(2)
+    return (torch.clamp(x, -1.0, 1.0) if clamp else x).unsqueeze(2)
+
+
+# ---- spatial tiling (od_config.vae_use_tiling -> vae.use_tiling, registry.py:88-92) --------------------------------------------
+def vae_blend_v(a: torch.Tensor, b: torch.Tensor, blend_extent: int) -> torch.Tensor:
+    """AutoencoderKLQwenImage.blend_v — :889-895: the top `blend_extent` rows of b become a linear cross-fade from a's bottom
+    rows, IN PLACE on b (the reference's tiles are modified in place, so a tile that serves as `a` later is already blended)."""
+    blend_extent = min(a.shape[-2], b.shape[-2], blend_extent)
+    for y in range(blend_extent):
+        b[:, :, :, y, :] = a[:, :, :, -blend_extent + y, :] * (1 - y / blend_extent) + b[:, :, :, y, :] * (y / blend_extent)
+    return b
+
+
+def vae_blend_h(a: torch.Tensor, b: torch.Tensor, blend_extent: int) -> torch.Tensor:
+    """AutoencoderKLQwenImage.blend_h — :897-903."""
+    blend_extent = min(a.shape[-1], b.shape[-1], blend_extent)
+    for x in range(blend_extent):
+        b[:, :, :, :, x] = a[:, :, :, :, -blend_extent + x] * (1 - x / blend_extent) + b[:, :, :, :, x] * (x / blend_extent)
+    return b
+
+
+def _vae_blend_rows(rows, blend_h: int, blend_w: int, stride_h: int, stride_w: int) -> torch.Tensor:
+    """The stitching loop shared by tiled_encode / tiled_decode — :955-968, :1014-1028: every tile is blended with the
+    (already blended) tile above and the one to its left, cropped to the stride, rows concatenated."""
+    result_rows = []
+    for i, row in enumerate(rows):
+        result_row = []
+        for j, tile in enumerate(row):
+            if i > 0:
+                tile = vae_blend_v(rows[i - 1][j], tile, blend_h)
+            if j > 0:
+                tile = vae_blend_h(row[j - 1], tile, blend_w)
+            result_row.append(tile[:, :, :, :stride_h, :stride_w])
+        result_rows.append(torch.cat(result_row, dim=-1))
+    return torch.cat(result_rows, dim=3)
+
+
+def vae_tiled_decode(P: Params, z: torch.Tensor, cfg: VaeConfig = VaeConfig(), tile_sample_min: int = 256,
+                     tile_sample_stride: int = 192) -> torch.Tensor:
+    """AutoencoderKLQwenImage.tiled_decode for one frame — :971-1031.  Latent tiles of (256/8)^2 every 192/8 positions are decoded
+    independently (post_quant_conv + decoder), overlaps of 64 pixels are cross-faded, every tile contributes its first 192 x 192
+    pixels.  NOTE the reference returns the stitched image UN-CLAMPED: `_decode` leaves for `tiled_decode` before its
+    torch.clamp (:844-845 vs :857), so values outside [-1, 1] survive until the image processor."""
+    _, _, _, height, width = z.shape
+    sr = 8
+    tmin, tstr = tile_sample_min // sr, tile_sample_stride // sr
+    blend = tile_sample_min - tile_sample_stride
+    rows = []
+    for i in range(0, height, tstr):
+        row = []
+        for j in range(0, width, tstr):
+            row.append(vae_decode(P, z[:, :, :, i:i + tmin, j:j + tmin], cfg, clamp=False))
+        rows.append(row)
+    dec = _vae_blend_rows(rows, blend, blend, tile_sample_stride, tile_sample_stride)
+    return dec[:, :, :, : height * sr, : width * sr]
+
+
+def vae_encode_moments(P: Params, image: torch.Tensor, cfg: VaeConfig = VaeConfig()) -> torch.Tensor:
+    """encoder + quant_conv of one frame: all 2 * z_dim channels (mean | logvar) — the tensor tiled_encode blends (:948-949)."""
+    x = _conv3d_as_2d(P, "encoder.conv_in", image[:, :, 0])
+    dims = [cfg.base_dim * u for u in [1] + list(cfg.dim_mult)]
+    k = 0
+    for i in range(len(dims) - 1):
+        for _ in range(cfg.num_res_blocks):
+            x = vae_res_block(P, f"encoder.down_blocks.{k}", x)
+            k += 1
+        if i != len(cfg.dim_mult) - 1:
+            x = vae_downsample(P, f"encoder.down_blocks.{k}", x)
+            k += 1
+    x = vae_res_block(P, "encoder.mid_block.resnets.0", x)
+    x = vae_attn_block(P, "encoder.mid_block.attentions.0", x)
+    x = vae_res_block(P, "encoder.mid_block.resnets.1", x)
+    x = F.silu(vae_rms_norm(x, P["encoder.norm_out.gamma"]))
+    x = _conv3d_as_2d(P, "encoder.conv_out", x)
+    return _conv3d_as_2d(P, "quant_conv", x).unsqueeze(2)
+
+
+def vae_tiled_encode(P: Params, image: torch.Tensor, cfg: VaeConfig = VaeConfig(), tile_sample_min: int = 256,
+                     tile_sample_stride: int = 192) -> torch.Tensor:
+    """AutoencoderKLQwenImage.tiled_encode for one frame + DiagonalGaussianDistribution.mode() — :905-969: image tiles of 256^2
+    every 192 pixels through encoder + quant_conv, 8-latent-row overlaps cross-faded, posterior mean [B, z_dim, 1, H/8, W/8]."""
+    _, _, _, height, width = image.shape
+    sr = 8
+    tmin, tstr = tile_sample_min // sr, tile_sample_stride // sr
+    blend = tmin - tstr
+    rows = []
+    for i in range(0, height, tile_sample_stride):
+        row = []
+        for j in range(0, width, tile_sample_stride):
+            row.append(vae_encode_moments(P, image[:, :, :, i:i + tile_sample_min, j:j + tile_sample_min], cfg))
+        rows.append(row)
+    enc = _vae_blend_rows(rows, blend, blend, tstr, tstr)[:, :, :, : height // sr, : width // sr]
+    return enc[:, : cfg.z_dim]
 
 
 def vae_downsample(P: Params, pre: str, x: torch.Tensor) -> torch.Tensor:

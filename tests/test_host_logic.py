@@ -799,8 +799,19 @@ def test_request_and_config_accept_the_reference_field_names():
     cfg = OmniDiffusionConfig(model="Qwen/Qwen-Image", dit_cpu_offload=False, vae_use_slicing=True, enable_torch_compile=True,
                               host="0.0.0.0", port=8091, log_level="debug", parallel_config={"ulysses_degree": 2})
     assert cfg.num_gpus == 2 and cfg.parallel_config.ulysses_degree == 2
+    # vae_use_slicing / vae_use_tiling reach the pipeline's VAE (reference registry.py:88-92)
+    from vllm_omni_amd.diffusion.registry import apply_vae_memory_flags
+
+    class _V:
+        use_slicing = use_tiling = False
+
+    class _M:
+        vae = _V()
+
+    m = apply_vae_memory_flags(_M(), OmniDiffusionConfig(vae_use_slicing=True, vae_use_tiling=True))
+    assert m.vae.use_slicing and m.vae.use_tiling
     # ... and what would change the results is refused
-    for kw in (dict(lora_path="/adapters/x"), dict(vae_use_tiling=True), dict(VSA_sparsity=0.5), dict(use_fsdp_inference=True),
+    for kw in (dict(lora_path="/adapters/x"), dict(VSA_sparsity=0.5), dict(use_fsdp_inference=True),
                dict(override_transformer_cls_name="Other")):
         with pytest.raises(NotImplementedError):
             OmniDiffusionConfig(**kw)
@@ -835,3 +846,20 @@ def test_small_surface_pieces_a_reference_side_caller_may_touch():
     assert torch.equal(SeqAllToAll4D.forward(None, None, x, 2, 1), x)             # no process group: the identity
     assert torch.equal(SeqAllToAll5D.forward(None, None, x.unsqueeze(2), 3, 1), x.unsqueeze(2))
     assert callable(GPUWorker.generate) and callable(GPUWorker.shutdown)
+
+
+def test_vae_tile_stitching_equals_the_reference_blend_loops():
+    """The product's vectorised cross-fade (`AutoencoderKLQwenImage._blend` / `_stitch`) against the oracle's restatement of the
+    reference's per-row loops (autoencoder_kl_qwenimage.py:889-903, :1014-1028; pinned to a reference run in
+    tests/test_oracle_golden.py): bit-equal in fp32, and in bf16 — the dtype the VAE runs in — where every product and the sum
+    round separately."""
+    import qwen_image_oracle as O
+    from vllm_omni_amd.diffusion.models.qwen_image.autoencoder_kl_qwenimage import AutoencoderKLQwenImage as V
+
+    g = torch.Generator().manual_seed(5)
+    for dtype in (torch.float32, torch.bfloat16):
+        shapes = [[(40, 40), (40, 24)], [(24, 40), (24, 24)]]                 # ragged edge tiles, as the last row / column has them
+        rows = [[torch.randn(2, 3, 1, h, w, generator=g).to(dtype) for h, w in r] for r in shapes]
+        a = V._stitch([[t.clone() for t in r] for r in rows], 8, 8, 32, 32)
+        b = O._vae_blend_rows([[t.clone() for t in r] for r in rows], 8, 8, 32, 32)
+        assert a.shape == b.shape == (2, 3, 1, 56, 56) and torch.equal(a, b), dtype

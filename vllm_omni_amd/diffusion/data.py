@@ -147,7 +147,7 @@ class OmniDiffusionConfig:
     log_level: str = "info"
 
     _REFUSED = {"lora_path": None, "use_fsdp_inference": False, "hsdp_replicate_dim": 1, "hsdp_shard_dim": -1,
-                "mask_strategy_file_path": None, "VSA_sparsity": 0.0, "moba_config_path": None, "vae_use_tiling": False,
+                "mask_strategy_file_path": None, "VSA_sparsity": 0.0, "moba_config_path": None,
                 "override_transformer_cls_name": None, "boundary_ratio": None, "flow_shift": None}
 
     def __post_init__(self):

@@ -141,6 +141,31 @@ class AutoencoderKLQwenImage(nn.Module):
             self._names[name] = key
             self.params[key] = nn.Parameter(torch.empty(shape, device=dev, dtype=dtype), requires_grad=False)
         self._packed: dict[str, torch.Tensor] | None = None
+        # memory savers of the reference's VAE (autoencoder_kl_qwenimage.py:713-730; set from od_config.vae_use_slicing /
+        # vae_use_tiling by the registry, registry.py:88-92)
+        self.use_slicing = False
+        self.use_tiling = False
+        self.tile_sample_min_height = self.tile_sample_min_width = 256
+        self.tile_sample_stride_height = self.tile_sample_stride_width = 192
+        self.spatial_compression_ratio = 8
+
+    # ---- reference switches (:742-773) ------------------------------------------------------------------------------------------
+    def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None, tile_sample_stride_height=None,
+                      tile_sample_stride_width=None) -> None:
+        self.use_tiling = True
+        self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
+        self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
+        self.tile_sample_stride_height = tile_sample_stride_height or self.tile_sample_stride_height
+        self.tile_sample_stride_width = tile_sample_stride_width or self.tile_sample_stride_width
+
+    def disable_tiling(self) -> None:
+        self.use_tiling = False
+
+    def enable_slicing(self) -> None:
+        self.use_slicing = True
+
+    def disable_slicing(self) -> None:
+        self.use_slicing = False
 
     @property
     def dtype(self):
@@ -255,9 +280,107 @@ class AutoencoderKLQwenImage(nn.Module):
 
     @torch.no_grad()
     def encode(self, image: torch.Tensor) -> torch.Tensor:
-        """image [B, 3, 1, H, W] in [-1, 1] -> posterior MEAN [B, z_dim, 1, H/8, W/8] (reference _encode :788-810 for one
-        frame + DiagonalGaussianDistribution.mode(); the Edit pipelines use sample_mode="argmax",
-        pipeline_qwen_image_edit.py:459-467)."""
+        """image [B, 3, 1, H, W] in [-1, 1] -> posterior MEAN [B, z_dim, 1, H/8, W/8] (reference encode :811-835 + _encode
+        :788-810 for one frame + DiagonalGaussianDistribution.mode(); the Edit pipelines use sample_mode="argmax",
+        pipeline_qwen_image_edit.py:459-467).  `use_slicing`: one image at a time (:828-830); `use_tiling`: images larger than
+        the tile go through `tiled_encode` (:791-792)."""
+        if self.use_slicing and image.shape[0] > 1:
+            return torch.cat([self._encode(x) for x in image.split(1)])
+        return self._encode(image)
+
+    def _encode(self, image: torch.Tensor) -> torch.Tensor:
+        if image.dim() == 5 and self.use_tiling and (image.shape[4] > self.tile_sample_min_width or
+                                                     image.shape[3] > self.tile_sample_min_height):
+            return self.tiled_encode(image)
+        return self._encode_plain(image)
+
+    # ---- spatial tiling (reference tiled_encode :905-969, tiled_decode :971-1031, blend_v / blend_h :889-903) ----------------------
+    @staticmethod
+    def _blend(a: torch.Tensor, b: torch.Tensor, extent: int, dim: int) -> torch.Tensor:
+        """The first `extent` rows (dim = -2) / columns (dim = -1) of b become a cross-fade from the last ones of a, IN PLACE on b:
+        b[y] = a[-extent + y] * (1 - y / extent) + b[y] * (y / extent).  The reference runs this loop in the VAE's dtype (bf16)
+        with Python-float weights: each product and the sum are rounded to bf16 — reproduced here in one vectorised step."""
+        extent = min(a.shape[dim], b.shape[dim], extent)
+        if extent <= 0:
+            return b
+        y = torch.arange(extent, dtype=torch.float64)
+        shape = [1] * b.dim()
+        shape[dim] = extent
+        w_b = (y / extent).to(torch.float32).view(shape).to(b.device)
+        w_a = (1 - y / extent).to(torch.float32).view(shape).to(b.device)
+        a_part = a.narrow(dim, a.shape[dim] - extent, extent)
+        b_part = b.narrow(dim, 0, extent)
+        pa = (a_part.float() * w_a).to(b.dtype)
+        pb = (b_part.float() * w_b).to(b.dtype)
+        b_part.copy_((pa.float() + pb.float()).to(b.dtype))
+        return b
+
+    @classmethod
+    def _stitch(cls, rows, blend_h: int, blend_w: int, stride_h: int, stride_w: int) -> torch.Tensor:
+        """(:955-968, :1014-1028) every tile is blended with the already blended tile above and the one to its left, cropped to
+        the stride; rows and columns are concatenated."""
+        out_rows = []
+        for i, row in enumerate(rows):
+            out_row = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = cls._blend(rows[i - 1][j], tile, blend_h, -2)
+                if j > 0:
+                    tile = cls._blend(row[j - 1], tile, blend_w, -1)
+                out_row.append(tile[:, :, :, :stride_h, :stride_w])
+            out_rows.append(torch.cat(out_row, dim=-1))
+        return torch.cat(out_rows, dim=3)
+
+    TILE_BATCH = 16                                   # equal-sized tiles decoded / encoded per call (a 1024^2 image's worth of pixels)
+
+    def _map_tiles(self, x: torch.Tensor, tmin_h: int, tmin_w: int, str_h: int, str_w: int, fn):
+        """Cut x [B, C, 1, H, W] into overlapping tiles, run fn on them — equal-sized tiles batched TILE_BATCH at a time (every
+        kernel of the VAE treats batch entries independently) — and return them as rows[i][j] of [B, C', 1, h', w'] tensors."""
+        B, H, Wd = x.shape[0], x.shape[3], x.shape[4]
+        pos = [(i, j) for i in range(0, H, str_h) for j in range(0, Wd, str_w)]
+        tiles = {p: x[:, :, :, p[0]:p[0] + tmin_h, p[1]:p[1] + tmin_w] for p in pos}
+        done: dict[tuple, torch.Tensor] = {}
+        by_shape: dict[tuple, list] = {}
+        for p in pos:
+            by_shape.setdefault(tuple(tiles[p].shape[3:]), []).append(p)
+        for _shape, ps in by_shape.items():
+            for c0 in range(0, len(ps), max(1, self.TILE_BATCH // B)):
+                part = ps[c0:c0 + max(1, self.TILE_BATCH // B)]
+                out = fn(torch.cat([tiles[p] for p in part]).contiguous())
+                for k, p in enumerate(part):
+                    done[p] = out[k * B:(k + 1) * B].clone()
+        return [[done[(i, j)] for j in range(0, Wd, str_w)] for i in range(0, H, str_h)]
+
+    @torch.no_grad()
+    def tiled_encode(self, image: torch.Tensor) -> torch.Tensor:
+        """(:905-969) image tiles of 256^2 every 192 pixels through the encoder, latent overlaps of 8 cross-faded -> posterior mean
+        [B, z_dim, 1, H/8, W/8].  (The reference blends mean | logvar together; the blend is linear and per channel, so blending
+        the mean half alone is the same.)"""
+        sr = self.spatial_compression_ratio
+        H, Wd = image.shape[3], image.shape[4]
+        tl_h, tl_w = self.tile_sample_min_height // sr, self.tile_sample_min_width // sr
+        ts_h, ts_w = self.tile_sample_stride_height // sr, self.tile_sample_stride_width // sr
+        rows = self._map_tiles(image, self.tile_sample_min_height, self.tile_sample_min_width, self.tile_sample_stride_height,
+                               self.tile_sample_stride_width, self._encode_plain)
+        return self._stitch(rows, tl_h - ts_h, tl_w - ts_w, ts_h, ts_w)[:, :, :, : H // sr, : Wd // sr].contiguous()
+
+    @torch.no_grad()
+    def tiled_decode(self, z: torch.Tensor, return_dict: bool = False):
+        """(:971-1031) latent tiles of 32^2 every 24 positions decoded independently, pixel overlaps of 64 cross-faded, every tile
+        contributes its first 192 x 192 pixels.  As in the reference the stitched image is NOT clamped (`_decode` leaves for
+        `tiled_decode` before its clamp, :844-845 vs :857): values outside [-1, 1] reach the image processor."""
+        sr = self.spatial_compression_ratio
+        h, w = z.shape[3], z.shape[4]
+        tl_h, tl_w = self.tile_sample_min_height // sr, self.tile_sample_min_width // sr
+        ts_h, ts_w = self.tile_sample_stride_height // sr, self.tile_sample_stride_width // sr
+        rows = self._map_tiles(z, tl_h, tl_w, ts_h, ts_w, lambda t: self._decode_plain_or_bordered(t, clamp=None))
+        img = self._stitch(rows, self.tile_sample_min_height - self.tile_sample_stride_height,
+                           self.tile_sample_min_width - self.tile_sample_stride_width, self.tile_sample_stride_height,
+                           self.tile_sample_stride_width)[:, :, :, : h * sr, : w * sr].contiguous()
+        return (img,)
+
+    @torch.no_grad()
+    def _encode_plain(self, image: torch.Tensor) -> torch.Tensor:
         if not self.with_encoder:
             raise RuntimeError("this VAE was built without its encoder (with_encoder=True)")
         if image.dim() != 5 or image.shape[2] != 1 or image.shape[1] != 3:
@@ -315,11 +438,25 @@ class AutoencoderKLQwenImage(nn.Module):
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = False):
-        """z [B, z_dim, 1, h, w] -> [B, 3, 1, 8h, 8w] in [-1, 1] (reference _decode :839-863, one frame)."""
+        """z [B, z_dim, 1, h, w] -> [B, 3, 1, 8h, 8w] (reference decode :865-887 + _decode :839-863, one frame): clamped to
+        [-1, 1] on the plain path; `use_slicing`: one latent at a time (:879-881); `use_tiling`: latents larger than a tile go
+        through `tiled_decode` (:844-845)."""
         if z.dim() != 5 or z.shape[2] != 1:
             raise NotImplementedError("single-frame (image) decode only")
+        if self.use_slicing and z.shape[0] > 1:
+            return (torch.cat([self._decode(zs)[0] for zs in z.split(1)]),)
+        return self._decode(z)
+
+    def _decode(self, z: torch.Tensor):
+        sr = self.spatial_compression_ratio
+        if self.use_tiling and (z.shape[4] > self.tile_sample_min_width // sr or z.shape[3] > self.tile_sample_min_height // sr):
+            return self.tiled_decode(z)
+        return (self._decode_plain_or_bordered(z, clamp=(-1.0, 1.0)),)
+
+    @torch.no_grad()
+    def _decode_plain_or_bordered(self, z: torch.Tensor, clamp=(-1.0, 1.0)) -> torch.Tensor:
         if not self._bordered_ok():
-            return self._decode_plain(z)
+            return self._decode_plain(z, clamp)[0]
         W = self._pack()
         c = self.config
         x = z[:, :, 0].permute(0, 2, 3, 1).contiguous().to(BF16)      # NHWC
@@ -348,12 +485,11 @@ class AutoencoderKLQwenImage(nn.Module):
                 r = ops.vae_conv2d(x, W[name + ".weight"], W[name + ".bias"], upsample2x=True, x_bordered=True,
                                    y_bordered=True, norm_gamma=g)      # the x2 upsample happens in the conv's operand fetch
                 x, xn = r if g is not None else (r, None)
-        x = ops.vae_conv2d(xn, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], clamp=(-1.0, 1.0), x_bordered=True)
-        img = x.permute(0, 3, 1, 2).unsqueeze(2)                       # [B, 3, 1, H, W]
-        return (img,)
+        x = ops.vae_conv2d(xn, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], clamp=clamp, x_bordered=True)
+        return x.permute(0, 3, 1, 2).unsqueeze(2)                      # [B, 3, 1, H, W]
 
     @torch.no_grad()
-    def _decode_plain(self, z: torch.Tensor):
+    def _decode_plain(self, z: torch.Tensor, clamp=(-1.0, 1.0)):
         """The same network over plain NHWC rasters (the gather kernel does the zero padding per tap): channel counts the
         bordered kernel is not built for."""
         W = self._pack()
@@ -372,6 +508,6 @@ class AutoencoderKLQwenImage(nn.Module):
                 u = f"decoder.up_blocks.{i}.upsamplers.0.resample.1"
                 x = ops.vae_conv2d(x, W[u + ".weight"], W[u + ".bias"], upsample2x=True)
         x = ops.vae_rmsnorm_silu(x, W["decoder.norm_out.gamma"])
-        x = ops.vae_conv2d(x, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], clamp=(-1.0, 1.0))
+        x = ops.vae_conv2d(x, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], clamp=clamp)
         img = x.permute(0, 3, 1, 2).unsqueeze(2)                       # [B, 3, 1, H, W]
         return (img,)

@@ -33,9 +33,22 @@ def resolve_model_cls(arch: str):
     return getattr(_module(arch), _DIFFUSION_MODELS[arch][2])
 
 
+def apply_vae_memory_flags(model, od_config: OmniDiffusionConfig):
+    """od_config.vae_use_slicing / vae_use_tiling -> the pipeline's VAE (reference registry.py:88-92)."""
+    vae = getattr(model, "vae", None)
+    if vae is not None:
+        if hasattr(vae, "use_slicing"):
+            vae.use_slicing = bool(getattr(od_config, "vae_use_slicing", False))
+        if hasattr(vae, "use_tiling"):
+            vae.use_tiling = bool(getattr(od_config, "vae_use_tiling", False))
+    return model
+
+
 def initialize_model(od_config: OmniDiffusionConfig, **kw):
-    """Instantiate `od_config.model_class_name` with the registry contract `__init__(*, od_config, prefix="")`."""
-    return resolve_model_cls(od_config.model_class_name or "QwenImagePipeline")(od_config=od_config, **kw)
+    """Instantiate `od_config.model_class_name` with the registry contract `__init__(*, od_config, prefix="")`, then hand the
+    VAE its memory flags."""
+    return apply_vae_memory_flags(resolve_model_cls(od_config.model_class_name or "QwenImagePipeline")(od_config=od_config, **kw),
+                                  od_config)
 
 
 def _load_process_func(od_config: OmniDiffusionConfig, table: dict[str, str]):
