@@ -78,11 +78,11 @@ constexpr int A_O = 0, A_Q = 128, A_K = 192;
 #endif
 #ifndef OMNI_W64_ABL
 #define OMNI_W64_ABL 0          // dev-only timing ablations (WRONG results): 1 no DMA, 2 no end-of-tile wait + barrier, 4 no exp,
-#endif                          // 8 no LDS fragment reads, 16 no row max, 32 no MFMA
+#endif                          // 8 no LDS fragment reads, 16 no row max, 32 no MFMA, 64 no K DMA pieces (V only), 128 no K fragment reads
 
 // LDS issue order of P2 (LDS operations return in order, so a counted lgkmcnt retires exactly the reads a step needs):
 //   VREAD(0) VREAD(1) VREAD(2) | step f: [wait] MFMAs, VREAD(f+3) (2 ops), KREADs of step f (16 / KREAD_STEPS ops, f < KREAD_STEPS)
-constexpr int kreads_at(int f) { return f < OMNI_W64_KREAD_STEPS ? 16 / OMNI_W64_KREAD_STEPS : 0; }
+constexpr int kreads_at(int f) { return (OMNI_W64_ABL & 128) ? 0 : f < OMNI_W64_KREAD_STEPS ? 16 / OMNI_W64_KREAD_STEPS : 0; }
 constexpr int lds_ops_allowed_at(int f) {   // operations issued after VREAD(f) and before step f's wait
   int issued = 6, after_vf = f < 3 ? 2 * (f + 1) : 0;
   for (int s = 0; s < f; ++s) {
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
     };
     auto kreads_of = [&](auto ff) {                 // K(t+2) (zeros past the last tile: unused)
       constexpr int f = decltype(ff)::value, n = kreads_at(f);
-      if constexpr (!(OMNI_W64_ABL & 8))
+      if constexpr (!(OMNI_W64_ABL & (8 | 128)) && n > 0)
         [&]<int... J>(std::integer_sequence<int, J...>) { (kread_one(ic<f * n + J>{}, ka), ...); }(std::make_integer_sequence<int, n>{});
     };
     auto p2_step = [&](auto ff) {
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
           if constexpr (pc < 4) issue_V_piece(t + 2, s2, ic<pc>{});
           else issue_K_piece(t + 4, s1, ic<pc - 4>{});
         } else if constexpr (pc < 4) dma16_at<pc * 4096, pc * 64>(v_srd, v_src, v_soff, v_lds);
-        else dma16_at<(pc - 4) * 4096>(k_srd, k_src, k_soff, kps[pc - 4], k_lds);
+        else if constexpr (!(OMNI_W64_ABL & 64)) dma16_at<(pc - 4) * 4096>(k_srd, k_src, k_soff, kps[pc - 4], k_lds);
       }
       if constexpr (f + 3 < 16) vread(ic<f + 3>{});
       kreads_of(ff);
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
     }
     if constexpr (!(OMNI_W64_ABL & 2)) {
       // everything but this iteration's 8 pieces has landed: K(t+3), V(t+1) (issued one iteration ago); K(t+2) is in AGPRs
-      asm volatile("s_waitcnt vmcnt(%c0)\n\ts_waitcnt lgkmcnt(0)" ::"i"((OMNI_W64_ABL & 1) ? 0 : 8) : "memory");
+      asm volatile("s_waitcnt vmcnt(%c0)\n\ts_waitcnt lgkmcnt(0)" ::"i"((OMNI_W64_ABL & 1) ? 0 : (OMNI_W64_ABL & 64) ? 4 : 8) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
     }
