@@ -11,7 +11,16 @@ its (k+1)-th; actions of different waves in the same epoch are concurrent.  Grou
 flight (vmcnt retires in order).  `READ (t, h)`: fragment reads, complete at the `lgkmcnt(0)` that follows the NEXT barrier.
   RAW: a READ in epoch kr needs, for every wave group, a covering WAIT in an epoch kw < kr (own pieces: earlier in the program).
   WAR: an ISSUE in epoch ki into the slot of X needs every other wave's reads of X issued in epochs kr <= ki - 2 (own: kr < ki).
-The schedules below restate the kernel's loops (what is sent / read in which phase); if a loop changes, this table changes with it."""
+The schedules below restate the kernel's loops (what is sent / read in which phase); if a loop changes, this table changes with it.
+
+Round-5 hardware result, and the limit of this model.  The two-big-phase schedule (`two_big_phases` below, round 4's
+`-DOMNI_PP_SCHED=9`) PASSES this model and was run on the GPU in round 5: same speed as the product loop, but its output differed
+from the product's on 16 of 17 shape classes while the probe build of the same schedule (slower phases) was bit-identical
+(profiles/r05_gemm_sched9_two_big_phases_run.log) — a timing-dependent hazard.  The model checks ORDER (a covering counted wait and
+a barrier precede every read); it does not model when an LDS-DMA write whose `vmcnt` has retired in the SENDING wave becomes
+visible to ANOTHER wave's `ds_read` — the product schedule leaves six phases between the two, the big-phase one two epochs.  The
+schedule was rejected (no speed to gain) and its kernel code removed; the function stays here as the design record, and the
+product's four-phase schedule is the one both the model and the hardware agree on."""
 import pytest
 
 
