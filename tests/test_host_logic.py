@@ -330,22 +330,26 @@ def _dp_worker(rank, world, port, q, fail_rank=-1, mixed=False, decode_fail_rank
     torch.distributed.destroy_process_group()
 
 
-def test_dp_worker_two_ranks_gloo():
+@pytest.mark.parametrize("world", [2, 8])
+def test_dp_worker_two_ranks_gloo(world):
+    """(world = 8: the width of the node the scaling run uses — five requests over eight ranks leaves three ranks without work,
+    which must still join the gather with zero rows.)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict()
-    for _ in range(2):
-        rank, err, vals = q.get(timeout=120)
+    for _ in range(world):
+        rank, err, vals = q.get(timeout=180)
         res[rank] = (err, vals)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0] == (None, [0.0, 1.0, 2.0, 3.0, 4.0])     # request order restored on the output rank
-    assert res[1] == (None, None)
+    for r in range(1, world):
+        assert res[r] == (None, None)
 
 
 def test_dp_worker_mixed_resolutions_and_decodes_dealt_over_the_ranks():
