@@ -306,6 +306,7 @@ class QwenImagePipeline(nn.Module):
         emu = int(getattr(self, "_sp_emulate_ranks", 0) or 0)
         tcfg = getattr(tr, "teacache", None)
         tc_states = None
+        self.last_teacache_state = None
         if tcfg is not None:
             from ...cache.teacache.sp_state import TeaCacheSPState, TeaCacheSPStats
 
