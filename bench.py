@@ -492,7 +492,7 @@ def main():
         imgs = [pipe.decode_latents(lat, HEIGHT, WIDTH)]                               # each rank decodes its own R images, one VAE call
         ev[3].record()
         marks.append(ev)
-        return gathered, imgs[-1]
+        return gathered, imgs[-1], lat
 
     for i in range(args.warmup):
         one_step(100 + i)
@@ -502,7 +502,7 @@ def main():
     marks.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        gathered, img = one_step(42 + rank * 1000 + i)
+        gathered, img, sent_lat = one_step(42 + rank * 1000 + i)
     torch.cuda.synchronize()
     mine = time.perf_counter() - t0                      # this rank's own seconds (before it waits for the others)
     if world > 1:
@@ -534,7 +534,7 @@ def main():
             w = (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 65521) + 1
             return int(((v * w).sum() % ((1 << 61) - 1)).item())
 
-        sent = digest(gathered[rank * R:(rank + 1) * R])   # == this rank's own `lat` of the last step (checked below via slot `rank`)
+        sent = digest(sent_lat)                            # what THIS rank handed to the collective in the last step
         got = [digest(gathered[r * R:(r + 1) * R]) for r in range(world)]
         mine_t = torch.tensor([sent] + got, dtype=torch.int64)
         alld = [torch.zeros_like(mine_t) for _ in range(world)]
