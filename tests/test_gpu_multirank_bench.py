@@ -44,6 +44,26 @@ def test_bench_two_ranks_on_one_device_over_gloo():
         assert w["steps"] > 0 and 0 < w["busy_frac"] <= 1.0 + 1e-6 and 1.0 <= w["mean_batch"] <= 2.0
 
 
+def test_bench_two_ranks_under_torch_distributed_run():
+    """The launcher the DRIVER uses for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (ranks, local ranks and the rendezvous come from its environment, not from bench.py's own
+    self-launch) — on one device over gloo."""
+    from test_host_logic import _free_port
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--layers", "1", "--steps", "1",
+           "--warmup", "1", "--requests", "1", "--no-cpu-baseline", "--no-engine", "--dist-backend", "gloo", "--share-device"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["finite_outputs"]
+    assert j["collective"]["world"] == 2 and j["collective"]["gathered_checksum_matches_all_ranks"]
+    assert [r["rank"] for r in j["per_rank"]] == [0, 1]
+
+
 def test_bench_eight_ranks_on_one_device_over_gloo():
     """The REAL width of the driver's scaling run (8 ranks: ports, spawn, NUMA pinning, the 8-way gather and its checksum proof,
     max-over-ranks timing) on one device with one layer; the serving line is skipped (eight worker processes x their own weights
