@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5 closing pass 2/2: the bench as the driver runs it, then rocprofv3 --kernel-trace --stats of the bench command and the PMC
+# Closing pass of a round 2/2 (first used in round 5): the bench as the driver runs it, then rocprofv3 --kernel-trace --stats of the bench command and the PMC
 # passes (separate runs) of the roofline launch and the attention launch, all on the library that ships.
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5 closing pass 1/2: the full GPU suite + smoke on the library that ships (flags: vllm_omni_amd/csrc/build.py FLAGS).
+# Closing pass of a round 1/2 (first used in round 5): the full GPU suite + smoke on the library that ships (flags: vllm_omni_amd/csrc/build.py FLAGS).
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
