@@ -241,6 +241,35 @@ int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, const omni_bf
                         int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
                         int32_t out_k32_rows, omni_stream stream);
 
+/* ABI v11 — the attention of the WHOLE plug-in point: everything `SDPAImpl.forward` hands to
+ * F.scaled_dot_product_attention (vllm_omni/diffusion/attention/backends/sdpa.py:46-66; the backend selector is process-global,
+ * attention/selector.py:49-77, so a registered backend also serves the other in-tree DiTs) beyond the self-attention above:
+ * separate query / key sequences (cross-attention, wan2_2_transformer.py:243,340), head size 64 or 128 (sd3_transformer.py:108),
+ * an attention mask, is_causal, grouped K / V heads.
+ *   q, out: [total_q_rows, H * dh]; k, v: [total_k_rows, H_kv * dh]; item b owns query rows [cu_seqlens_q[b], cu_seqlens_q[b+1])
+ *   and key rows [cu_seqlens_k[b], cu_seqlens_k[b+1]) (DEVICE int32 arrays of B + 1 entries; the two may be the same array).
+ *   mask (nullable, mask_type 0): element (b, h, i, j) at mask[b * mask_stride_b + h * mask_stride_h + i * mask_stride_q +
+ *   j * mask_stride_k] with strides in ELEMENTS, 0 = broadcast (what `mask.expand(B, H, S_q, S_k).stride()` returns);
+ *   mask_type 1: one byte per element, non-zero = attend (torch.bool); 2: bf16 added to the scaled scores; 3: fp32 added.
+ *   causal = 1: key j takes part in query i only if j <= i (torch's is_causal: aligned to the top-left corner).
+ *   out = softmax(scale * q k^T + mask) v per (item, head), fp32 softmax; rows with no key to attend to produce zeros.
+ * head_dim 64 or 128 (OMNI_ERR_UNSUPPORTED otherwise); H % H_kv == 0. */
+typedef struct {
+  const omni_bf16 *q, *k, *v;
+  omni_bf16* out;
+  int64_t ldq, ldk, ldv, ldo;          /* row strides in elements (multiples of 8; ldo of 4) */
+  const int32_t* cu_seqlens_q;
+  const int32_t* cu_seqlens_k;
+  int32_t B, H, H_kv, head_dim;
+  int32_t max_seqlen_q, max_seqlen_k;  /* bounds of the per-item lengths (max_seqlen_q sizes the grid) */
+  float softmax_scale;
+  int32_t causal;
+  const void* mask;
+  int32_t mask_type;                   /* 0 none, 1 bool bytes, 2 bf16 additive, 3 fp32 additive */
+  int64_t mask_stride_b, mask_stride_h, mask_stride_q, mask_stride_k;
+} omni_attn_params;
+int omni_flash_attn_general(const omni_attn_params* p, omni_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Small-batch weight-streaming linear:  y[b, n] = act_out( sum_k act_in(x[b, k]) * W[n, k] + bias[n] ).
  * Replaces the GEMVs at qwen_image_transformer.py:51-52 (TimestepEmbedding), :552,557

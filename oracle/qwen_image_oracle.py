@@ -105,6 +105,28 @@ def sdpa_nhd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) ->
     return (p @ v).permute(0, 2, 1, 3)
 
 
+def sdpa_nhd_general(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, attn_mask: torch.Tensor | None = None,
+                     is_causal: bool = False) -> torch.Tensor:
+    """SDPAImpl.forward with everything it forwards to F.scaled_dot_product_attention — diffusion/attention/backends/sdpa.py:46-66:
+    `attn_mask=attn_metadata.attn_mask`, `is_causal=self.causal`, `scale=self.softmax_scale`, q [B,Sq,H,dh], k / v [B,Sk,Hkv,dh]
+    (grouped K / V heads are repeated, as torch's enable_gqa does).  Spelled out (the documented semantics of the torch op, no
+    fused kernel): bool mask True = attend, float mask added to the scaled scores, is_causal = lower triangle aligned top-left.
+    A row without any attendable key yields zeros here (torch's math path: NaN; its fused paths: zeros)."""
+    B, Sq, H, dh = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    q, k, v = (t.permute(0, 2, 1, 3).float() for t in (q, k, v))
+    if Hkv != H:
+        k, v = k.repeat_interleave(H // Hkv, dim=1), v.repeat_interleave(H // Hkv, dim=1)
+    s = (q @ k.transpose(-1, -2)) * scale
+    if is_causal:
+        s = s.masked_fill(~torch.ones(Sq, Sk, dtype=torch.bool, device=s.device).tril(), float("-inf"))
+    if attn_mask is not None:
+        s = s.masked_fill(~attn_mask, float("-inf")) if attn_mask.dtype == torch.bool else s + attn_mask.float()
+    dead = torch.isinf(s).all(dim=-1, keepdim=True)
+    p = torch.softmax(s.masked_fill(dead, 0.0), dim=-1).masked_fill(dead, 0.0)
+    return (p @ v).permute(0, 2, 1, 3)
+
+
 def feed_forward(P: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
     """diffusers FeedForward('gelu-approximate') = Linear -> GELU(tanh) -> Linear (call :491,501,591,596)."""
     h = F.gelu(F.linear(x, P[pre + ".net.0.proj.weight"], P[pre + ".net.0.proj.bias"]), approximate="tanh")

@@ -102,6 +102,23 @@ def test_attention_entry_points_reject_bad_arguments(lib):
         (11, 64, UNSUPPORTED),                           # the kernels are built for head_dim 128 (get_supported_head_sizes)
         (1, P8, ALIGN), (3, P + 4, ALIGN), (4, 3076, ALIGN), (7, 3074, ALIGN)])
     _mutations(lib, "omni_flash_attn_fwd_ex", base[:14] + [0, None], [(14, -1, BAD_ARG), (11, 256, UNSUPPORTED)])
+    # omni_flash_attn_general(params, stream) — ABI v11: the whole SDPA plug-in point (cross-attention, masks, causal, dh 64 / 128)
+    from vllm_omni_amd import _native as N
+
+    def general(**kw):
+        a = N.AttnParams(q=P, k=P, v=P, out=P, ldq=1536, ldk=1536, ldv=1536, ldo=1536, cu_seqlens_q=P, cu_seqlens_k=P, B=2, H=24,
+                         H_kv=24, head_dim=64, max_seqlen_q=1024, max_seqlen_k=77, softmax_scale=0.125, causal=0)
+        for k_, v_ in kw.items():
+            setattr(a, k_, v_)
+        return lib.omni_flash_attn_general(C.byref(a), None)
+
+    assert lib.omni_flash_attn_general(None, None) == BAD_ARG
+    for bad in (dict(q=None), dict(out=None), dict(cu_seqlens_k=None), dict(B=0), dict(H_kv=0), dict(H_kv=5), dict(max_seqlen_q=0),
+                dict(causal=2), dict(mask_type=1), dict(mask=P, mask_type=0), dict(mask=P, mask_type=4)):
+        assert general(**bad) == BAD_ARG, bad
+    assert general(head_dim=96) == UNSUPPORTED and general(head_dim=256) == UNSUPPORTED
+    for bad in (dict(k=P8), dict(out=P + 4), dict(ldq=1540), dict(ldo=1538), dict(mask=P + 1, mask_type=2), dict(mask=P2, mask_type=3)):
+        assert general(**bad) == ALIGN, bad
     # omni_vae_attention(q, k, v, out, B, tokens, C, ldq, ldk, ldv, ldo, scale, stream)
     va = [P, P, P, P, 1, 16384, 384, 1152, 1152, 1152, 384, 0.051, None]
     _mutations(lib, "omni_vae_attention", va, [

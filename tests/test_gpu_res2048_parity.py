@@ -112,3 +112,77 @@ def test_vae_decode_at_2048px():
     d = (img.float() - ref).abs()
     print(f"vae decode {8 * hw}px: rel_l2 {r:.3e} mean|err| {float(d.mean()):.3e} max|err| {float(d.max()):.3e}")
     assert r <= 3e-2 and float(d.mean()) <= 2e-2 and float(d.max()) <= 2e-1
+
+
+def _oracle_loop(P, lat, pos, neg, steps, cfg, dtype):
+    """reference diffuse() (pipeline_qwen_image.py:530-586) over the oracle DiT in `dtype`; latents kept in bf16 (:585).
+    Returns (final latent, first positive-branch prediction, per-step latents)."""
+    ts, sig = O.flow_match_sigmas(steps, lat.shape[1])
+    x, first, traj = lat.float(), None, []
+    for i, t in enumerate(ts):
+        s_in = (t.bfloat16() / 1000).bfloat16().float().expand(1).to(lat.device)
+        p = O.dit_forward(P, x.to(dtype), pos.to(dtype), s_in, GRID, num_heads=24).float()
+        n = O.dit_forward(P, x.to(dtype), neg.to(dtype), s_in, GRID, num_heads=24).float()
+        if first is None:
+            first = p.clone()
+        x = O.euler_step(x, O.cfg_combine(p, n, cfg), float(sig[i]), float(sig[i + 1])).bfloat16().float()
+        traj.append(x.clone())
+        del p, n
+    return x, first, traj
+
+
+def test_config5_geometry_at_real_depth_60_layers_bf16_and_fp8_accurate():
+    """Round-5 verdict item 1(a): BASELINE config 5's geometry AT DEPTH — 60 full-width layers, ONE 2048x2048 request
+    (16384 image + 64 / 48 text rows per CFG branch: 129 row tiles per forward, 258 key tiles per attention query block) — one
+    forward and a 4-step true-CFG loop (reference pipeline_qwen_image.py:530-586) of the product in bf16 and with the ACCURATE
+    fp8 recipe, against the fp32 oracle on the GPU (8 oracle forwards of 423 TFLOP each), with the same oracle in bf16 (the
+    reference's algorithm in the reference's dtype) as the calibration.  Memory: 41 GB product weights + 82 GB fp32 oracle
+    weights + 3 x 26 GB of fp32 score temporaries.
+
+    FIXED bars (BASELINE.md 3): forward rel_l2 <= 2.5e-2, cos >= 0.9996; 4-step final latent rel_l2 <= 6e-2, cos >= 0.998;
+    and never further from fp32 than 1.1 x the bf16-eager reference algorithm.  fp8-accurate: <= 2 x the bf16 path's distance."""
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    steps = 4
+    m = _model(60, seed=1234)
+    g = torch.Generator(device=DEV).manual_seed(42)
+    lat = torch.randn(1, S, 64, device=DEV, generator=g).to(BF16)
+    pos = torch.randn(1, 64, 3584, device=DEV, generator=g).to(BF16)
+    neg = torch.randn(1, 48, 3584, device=DEV, generator=g).to(BF16)
+    with torch.no_grad():
+        P32 = {n: p.detach().float() for n, p in m.named_parameters()}
+        ref, ref_first, t32 = _oracle_loop(P32, lat, pos, neg, steps, 4.0, torch.float32)
+        del P32
+        torch.cuda.empty_cache()
+        Pb = {n: p.detach().clone() for n, p in m.named_parameters()}
+        eager, eager_first, tb = _oracle_loop(Pb, lat, pos, neg, steps, 4.0, BF16)
+        del Pb
+        torch.cuda.empty_cache()
+    pipe = QwenImagePipeline(od_config=OmniDiffusionConfig(use_hip_graph=False), device=DEV, transformer=m)
+    sig0 = pipe.scheduler.model_timestep(pipe.scheduler.set_timesteps(steps, S))[:1].to(DEV)
+    kw = dict(hidden_states=lat, encoder_hidden_states=pos, timestep=sig0, img_shapes=[[GRID]], txt_seq_lens=[64], return_dict=False)
+    req = OmniDiffusionRequest(height=2048, width=2048, num_inference_steps=steps, true_cfg_scale=4.0, latents=lat,
+                               prompt_embeds=pos, negative_prompt_embeds=neg, output_type="latent")
+    res = {}
+    for tag, classes in (("bf16", False), ("fp8_accurate", m.FP8_RECIPE_ACCURATE)):
+        m.enable_fp8(classes)
+        fwd = m(**kw)[0].clone()
+        out = pipe.generate([req], output_type="latent")[0].output.clone()
+        torch.cuda.synchronize()
+        res[tag] = (rel_l2(fwd, ref_first), cosine(fwd, ref_first), rel_l2(out, ref), cosine(out, ref))
+        assert torch.isfinite(out.float()).all() and torch.isfinite(fwd.float()).all()
+    m.enable_fp8(False)
+    e_f, e_l = rel_l2(eager_first, ref_first), rel_l2(eager, ref)
+    print(f"60 layers @ 2048^2 (16384+64 rows): bf16-eager reference algorithm vs fp32 oracle: forward {e_f:.3e}, {steps}-step loop {e_l:.3e}")
+    for i in range(steps):
+        print(f"   step {i + 1}/{steps}: bf16-eager drift {rel_l2(tb[i], t32[i]):.3e}")
+    for tag, (rf, cf, rl, cl) in res.items():
+        print(f"   {tag:13s}: forward {rf:.3e} (cos {cf:.6f}); {steps}-step true-CFG final latent {rl:.3e} (cos {cl:.6f})")
+    rf, cf, rl, cl = res["bf16"]
+    assert rf <= 2.5e-2 and cf >= 0.9996 and rf <= 1.1 * e_f
+    assert rl <= 6e-2 and cl >= 0.998 and rl <= 1.1 * e_l
+    rf8, cf8, rl8, cl8 = res["fp8_accurate"]
+    assert rf8 <= 2.0 * rf and rl8 <= 2.0 * rl and cl8 >= 0.995

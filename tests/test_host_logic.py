@@ -96,6 +96,8 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(omni_gemm_group, tile_skip), offsetof(omni_gemm_params, g),
          offsetof(omni_dit_weights, layers), offsetof(omni_dit_batch, teacache), offsetof(omni_teacache, prev_mod),
          offsetof(omni_dit_batch, rope_cos));
+  printf("%zu %zu %zu %zu\\n", sizeof(omni_attn_params), offsetof(omni_attn_params, cu_seqlens_q),
+         offsetof(omni_attn_params, mask), offsetof(omni_attn_params, mask_stride_k));
   return 0;
 }
 ''')
@@ -106,7 +108,9 @@ int main(void) {
                                         N.DitBatch, N.TeaCache)]
     offs = [N.GemmGroup.tile_skip.offset, N.GemmParams.g.offset, N.DitWeights.layers.offset, N.DitBatch.teacache.offset,
             N.TeaCache.prev_mod.offset, N.DitBatch.rope_cos.offset]
-    assert [int(x) for x in out] == sizes + offs
+    attn = [ctypes.sizeof(N.AttnParams), N.AttnParams.cu_seqlens_q.offset, N.AttnParams.mask.offset,       # ABI v11
+            N.AttnParams.mask_stride_k.offset]
+    assert [int(x) for x in out] == sizes + offs + attn
 
 
 def test_product_path_fails_loudly_without_gpu():
@@ -845,7 +849,7 @@ def test_small_surface_pieces_a_reference_side_caller_may_touch():
     assert get_cache_backend(cache_backend="none", cache_config={}) is None and get_cache_backend(None, None) is None
     assert type(get_cache_backend(cache_backend="tea_cache", cache_config={"rel_l1_thresh": 0.2})).__name__ == "TeaCacheBackend"
     assert isinstance(NoParallelAttention(), ParallelAttentionStrategy) and isinstance(UlyssesParallelAttention(), ParallelAttentionStrategy)
-    assert CDNA4FlashBackend.get_builder_cls() is None and CDNA4FlashBackend.get_supported_head_sizes() == [128]
+    assert CDNA4FlashBackend.get_builder_cls() is None and CDNA4FlashBackend.get_supported_head_sizes() == [64, 128]
     x = torch.arange(24.0).reshape(1, 2, 3, 4)
     assert torch.equal(SeqAllToAll4D.forward(None, None, x, 2, 1), x)             # no process group: the identity
     assert torch.equal(SeqAllToAll5D.forward(None, None, x.unsqueeze(2), 3, 1), x.unsqueeze(2))

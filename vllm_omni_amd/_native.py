@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomni_cdna4.so")   # fixed: dev sweeps assign this attribute (tools/devlib.py)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_bf16_p = C.c_void_p  # device pointer to uint16_t bf16 bits
 c_i32_p = C.c_void_p
@@ -46,6 +46,20 @@ class GemmParams(C.Structure):
         ("split_n", C.c_int32), ("w_k32_blocked", C.c_int32), ("g", GemmGroup * 2),
         ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_int64),          # ABI v4
         ("kernel_hint", C.c_int32), ("fp8", C.c_int32),                      # ABI v6: kernel_hint; v7: fp8 operands
+    ]
+
+
+class AttnParams(C.Structure):
+    """omni_attn_params (ABI v11): the general attention of the SDPA plug-in point — cross-attention, masks, causal, dh 64 / 128."""
+    _fields_ = [
+        ("q", c_bf16_p), ("k", c_bf16_p), ("v", c_bf16_p), ("out", c_bf16_p),
+        ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldo", C.c_int64),
+        ("cu_seqlens_q", c_i32_p), ("cu_seqlens_k", c_i32_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("H_kv", C.c_int32), ("head_dim", C.c_int32),
+        ("max_seqlen_q", C.c_int32), ("max_seqlen_k", C.c_int32),
+        ("softmax_scale", C.c_float), ("causal", C.c_int32),
+        ("mask", C.c_void_p), ("mask_type", C.c_int32),
+        ("mask_stride_b", C.c_int64), ("mask_stride_h", C.c_int64), ("mask_stride_q", C.c_int64), ("mask_stride_k", C.c_int64),
     ]
 
 
@@ -149,6 +163,7 @@ PROTOTYPES = {
     "omni_flash_attn_fwd_ex": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_int64, c_i32_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                          C.c_int32, C.c_void_p]),
+    "omni_flash_attn_general": (C.c_int, [C.POINTER(AttnParams), C.c_void_p]),                      # ABI v11
     "omni_linear_smallbatch": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, c_bf16_p, c_bf16_p, C.c_int64, C.c_int32,
                                          c_bf16_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "omni_timestep_sinusoid": (C.c_int, [c_f32_p, C.c_int32, C.c_int32, C.c_float, c_bf16_p, C.c_void_p]),

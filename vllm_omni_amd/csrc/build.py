@@ -17,7 +17,7 @@ import sys
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "attention.hip", "attention_w64.hip", "elementwise.hip", "vae.hip", "dit_forward.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "attention_w64.hip", "attention_general.hip", "elementwise.hip", "vae.hip", "dit_forward.hip"]
 LIB = os.path.join(os.path.dirname(HERE), "libomni_cdna4.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden", "-Wno-unused-result"]

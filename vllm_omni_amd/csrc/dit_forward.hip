@@ -313,7 +313,7 @@ int prepare_positions(const omni_dit_batch* b, const Workspace& ws, omni_stream 
 }
 }  // namespace
 
-extern "C" int omni_abi_version(void) { return 10; }
+extern "C" int omni_abi_version(void) { return 11; }
 extern "C" const char* omni_build_arch(void) { return "gfx950"; }
 extern "C" const char* omni_status_string(int status) {
   switch (status) {

@@ -228,6 +228,37 @@ def flash_attn_varlen(q, k, v, cu_seqlens, num_heads: int, max_seqlen: int, soft
     return o
 
 
+_MASK_TYPES = {torch.bool: 1, torch.uint8: 1, torch.bfloat16: 2, torch.float32: 3}
+
+
+def flash_attn_general(q, k, v, cu_seqlens_q, cu_seqlens_k, num_heads: int, num_kv_heads: int, max_seqlen_q: int,
+                       max_seqlen_k: int, softmax_scale: float, causal: bool = False, mask: torch.Tensor | None = None,
+                       mask_strides: tuple[int, int, int, int] | None = None, out=None):
+    """omni_flash_attn_general (ABI v11): q / out [rows_q, H * dh], k / v [rows_k, H_kv * dh], dh 64 or 128; per-item row ranges
+    from the two int32 prefix-sum vectors.  `mask`: bool / uint8 (True = attend), bf16 or fp32 (additive) DEVICE tensor whose
+    element (b, h, i, j) sits `mask_strides` (in elements, 0 = broadcast) apart — `mask.expand(B, H, Sq, Sk).stride()`."""
+    rows, HD, ldq = _rows2d(q, "q")
+    o = torch.empty(rows, HD, dtype=BF16, device=q.device) if out is None else out
+    p = N.AttnParams()
+    p.q, p.k, p.v, p.out = _p(q, name="q"), _p(k, name="k"), _p(v, name="v"), _p(o, name="out")
+    p.ldq, p.ldk, p.ldv, p.ldo = ldq, k.stride(0), v.stride(0), o.stride(0)
+    p.cu_seqlens_q, p.cu_seqlens_k = _p(cu_seqlens_q, torch.int32, "cu_seqlens_q"), _p(cu_seqlens_k, torch.int32, "cu_seqlens_k")
+    p.B, p.H, p.H_kv, p.head_dim = cu_seqlens_q.numel() - 1, num_heads, num_kv_heads, HD // num_heads
+    p.max_seqlen_q, p.max_seqlen_k = max_seqlen_q, max_seqlen_k
+    p.softmax_scale, p.causal = softmax_scale, int(bool(causal))
+    if mask is not None:
+        if mask.dtype not in _MASK_TYPES:
+            raise N.OmniNativeError(f"attention mask must be bool, uint8, bfloat16 or float32, got {mask.dtype}")
+        if not mask.is_cuda:
+            raise N.OmniNativeError("attention mask must live on the GPU")
+        if mask_strides is None or len(mask_strides) != 4:
+            raise N.OmniNativeError("mask_strides = the four element strides of the mask over (B, H, S_q, S_k)")
+        p.mask, p.mask_type = mask.data_ptr(), _MASK_TYPES[mask.dtype]
+        p.mask_stride_b, p.mask_stride_h, p.mask_stride_q, p.mask_stride_k = (int(x) for x in mask_strides)
+    N.check(N.lib().omni_flash_attn_general(C.byref(p), _stream()), "omni_flash_attn_general")
+    return o
+
+
 def linear_smallbatch(x, w, bias=None, act_in: int = 0, act_out: int = 0, out=None):
     B, K, ldx = _rows2d(x, "x")
     Nn = w.shape[0]
