@@ -156,6 +156,15 @@ typedef struct {
  * and its shards take the same decision; a caller that passes this vouches that nothing compares the result across batch
  * compositions bit for bit. */
 #define OMNI_GEMM_KERNEL_SPLITK_TALL 2
+/* ABI v11 — TAIL SPLIT (automatic with a split-K workspace, this hint turns it off).  A launch of more than one round of 256x256
+ * tiles whose last round is thin (tiles % CUs at most a quarter of the CUs: 1548 tiles on 256 CUs = 6 rounds + 12 tiles, the
+ * N = 3072 GEMMs of one 2048x2048 request) runs the tiles of the full rounds unsplit — bit-identical to a launch without workspace — and splits the K
+ * loop of the remaining tiles s ways (s = 4 or 8: 12 / 24 K-tiles per piece; fp32 partials splitk_ws[tail tile][s][256][256] as far
+ * as splitk_ws_floats allows — up to 64 x 8 x 65536 floats — a small second kernel runs their epilogue), so the partial round
+ * costs its share of the work instead of a whole tile time.  The tail tiles then agree with the unsplit
+ * kernel to fp32 summation order; WHICH tiles are tail tiles depends on the launch's tile count, i.e. on the batch composition —
+ * a caller that compares results bit for bit across batch compositions passes OMNI_GEMM_KERNEL_NO_TAIL_SPLIT (or no workspace). */
+#define OMNI_GEMM_KERNEL_NO_TAIL_SPLIT 3
 
 int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream);
 
@@ -240,6 +249,18 @@ int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, const omni_bf
                         int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,
                         int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
                         int32_t out_k32_rows, omni_stream stream);
+
+/* ABI v11 — the same with an optional caller-owned fp32 DEVICE workspace (16-byte aligned, omni_flash_attn_workspace_bytes(B, H)
+ * bytes; NULL = omni_flash_attn_fwd_ex).  With it, a grid whose per-item LAST 256-query block is short (<= 64 rows: 4160 = 16 x 256 +
+ * 64 joint rows at 1024^2, 16448 = 64 x 256 + 64 at 2048^2) and would open a thin extra round of workgroups (one 2048^2 request:
+ * 48 x 65 = 3120 workgroups = 12 rounds of 256 CUs + 48) splits that block's KEY range over s workgroups (s <= 8, picked from a
+ * makespan model), which leave un-normalised fp32 partials (O, running max, row sum) in the workspace; a second small kernel merges
+ * them (flash-decoding style).  Results agree with the unsplit kernel to fp32 summation order on those rows, bit for bit elsewhere. */
+size_t omni_flash_attn_workspace_bytes(int32_t B, int32_t H);
+int omni_flash_attn_fwd_ws(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
+                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,
+                           int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
+                           int32_t out_k32_rows, void* workspace, size_t workspace_bytes, omni_stream stream);
 
 /* ABI v11 — the attention of the WHOLE plug-in point: everything `SDPAImpl.forward` hands to
  * F.scaled_dot_product_attention (vllm_omni/diffusion/attention/backends/sdpa.py:46-66; the backend selector is process-global,

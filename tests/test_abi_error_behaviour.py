@@ -102,6 +102,11 @@ def test_attention_entry_points_reject_bad_arguments(lib):
         (11, 64, UNSUPPORTED),                           # the kernels are built for head_dim 128 (get_supported_head_sizes)
         (1, P8, ALIGN), (3, P + 4, ALIGN), (4, 3076, ALIGN), (7, 3074, ALIGN)])
     _mutations(lib, "omni_flash_attn_fwd_ex", base[:14] + [0, None], [(14, -1, BAD_ARG), (11, 256, UNSUPPORTED)])
+    # omni_flash_attn_fwd_ws(..., out_k32_rows, workspace, workspace_bytes, stream) — ABI v11; the workspace query is host arithmetic
+    wb = lib.omni_flash_attn_workspace_bytes(2, 24)
+    assert wb == 2 * 24 * 8 * 64 * 130 * 4 and lib.omni_flash_attn_workspace_bytes(0, 24) == 0
+    _mutations(lib, "omni_flash_attn_fwd_ws", base[:14] + [0, P, wb, None], [
+        (0, None, BAD_ARG), (9, 0, BAD_ARG), (11, 64, UNSUPPORTED), (15, P + 4, ALIGN), (2, P8, ALIGN)])
     # omni_flash_attn_general(params, stream) — ABI v11: the whole SDPA plug-in point (cross-attention, masks, causal, dh 64 / 128)
     from vllm_omni_amd import _native as N
 

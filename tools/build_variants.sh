@@ -13,7 +13,7 @@ while [ $# -ge 2 ]; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -fno-gpu-rdc -fvisibility=hidden -DOMNI_DEV -Iinclude -Ivllm_omni_amd/csrc $f \
       -c vllm_omni_amd/csrc/$tu.hip -o $B/abl/${tu}_$n.o 2>/dev/null
   objs=""
-  for t in gemm attention attention_w64 elementwise vae dit_forward; do
+  for t in gemm attention attention_w64 attention_general elementwise vae dit_forward; do
     if [ $t = $tu ]; then objs="$objs $B/abl/${tu}_$n.o"; else objs="$objs $B/$t.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $B/abl/libomni_$n.so

@@ -163,6 +163,10 @@ PROTOTYPES = {
     "omni_flash_attn_fwd_ex": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_int64, c_i32_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                          C.c_int32, C.c_void_p]),
+    "omni_flash_attn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),                         # ABI v11
+    "omni_flash_attn_fwd_ws": (C.c_int, [c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p, C.c_int64, C.c_int64, C.c_int64,
+                                         C.c_int64, c_i32_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                         C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),         # ABI v11
     "omni_flash_attn_general": (C.c_int, [C.POINTER(AttnParams), C.c_void_p]),                      # ABI v11
     "omni_linear_smallbatch": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, c_bf16_p, c_bf16_p, C.c_int64, C.c_int32,
                                          c_bf16_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

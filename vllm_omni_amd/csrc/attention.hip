@@ -658,13 +658,11 @@ template <int NW, int NQ = 1, int PP = 0>
 int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq, int64_t ldk,
                 int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H, int32_t max_seqlen,
                 float softmax_scale, int out_k32_rows, hipStream_t s, const int32_t* item_skip = nullptr, int q_prescaled = 0) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe_kernel<NW, NQ, PP>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return OMNI_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};     // per device (common.h omni_once_per_device)
+  OMNI_TRY_STATUS(omni_once_per_device(attr_done, [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_pipe_kernel<NW, NQ, PP>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+  }));
   const int qblocks = (max_seqlen + 32 * NW * NQ - 1) / (32 * NW * NQ);
   const int nh = B * H;
   hipLaunchKernelGGL((flash_attn_fwd_pipe_kernel<NW, NQ, PP>), dim3(nh * qblocks), dim3(NW * 64), LDS_BYTES, s, q, k, v, out, ldq,
@@ -686,7 +684,7 @@ int launch_pipe(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni
 int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq,
                              int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H,
                              int32_t head_dim, int32_t max_seqlen, float softmax_scale, int32_t out_k32_rows,
-                             const int32_t* item_skip, int32_t q_prescaled, void* stream) {
+                             const int32_t* item_skip, int32_t q_prescaled, void* part_ws, size_t part_ws_bytes, void* stream) {
   if (!q || !k || !v || !out || !cu_seqlens || B <= 0 || H <= 0 || max_seqlen <= 0 || out_k32_rows < 0)
     return OMNI_ERR_BAD_ARG;
   if (head_dim != DH) return OMNI_ERR_UNSUPPORTED;
@@ -700,7 +698,7 @@ int omni_internal_flash_attn(const omni_bf16* q, const omni_bf16* k, const omni_
   if ((long)B * H * ((max_seqlen + 255) / 256) >= 512 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
       (out_k32_rows || ldo % 8 == 0))                       // its epilogue stores whole 16-byte pieces
     return omni_internal_flash_attn_w64(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, max_seqlen, softmax_scale,
-                                        out_k32_rows, item_skip, q_prescaled, stream);
+                                        out_k32_rows, item_skip, q_prescaled, part_ws, part_ws_bytes, stream);
 #endif
 #ifdef OMNI_DEV
 #include "dev/attention_dev_dispatch.inc"
@@ -717,7 +715,21 @@ extern "C" int omni_flash_attn_fwd_ex(const omni_bf16* q, const omni_bf16* k, co
                                       int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
                                       int32_t out_k32_rows, omni_stream stream) {
   return omni_internal_flash_attn(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, head_dim, max_seqlen, softmax_scale,
-                                  out_k32_rows, nullptr, 0, stream);
+                                  out_k32_rows, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" size_t omni_flash_attn_workspace_bytes(int32_t B, int32_t H) {
+  if (B <= 0 || H <= 0) return 0;
+  return omni_internal_flash_attn_w64_ws_bytes(B, H);
+}
+
+extern "C" int omni_flash_attn_fwd_ws(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,
+                                      int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens,
+                                      int32_t B, int32_t H, int32_t head_dim, int32_t max_seqlen, float softmax_scale,
+                                      int32_t out_k32_rows, void* workspace, size_t workspace_bytes, omni_stream stream) {
+  if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) return OMNI_ERR_ALIGN;
+  return omni_internal_flash_attn(q, k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, B, H, head_dim, max_seqlen, softmax_scale,
+                                  out_k32_rows, nullptr, 0, workspace, workspace ? workspace_bytes : 0, stream);
 }
 
 extern "C" int omni_flash_attn_fwd(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out,

@@ -29,6 +29,7 @@
 //        slot takes V(j+3) in P2 of iteration j+1.
 // The slot of a tile is a run-time value (a period of 3 against the S ping-pong's period of 2 would need a 6-fold unroll):
 // the nine fragment base addresses are re-based once per tile (9 VALU).
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -213,11 +214,18 @@ OMNI_DEVINL u32x4_t make_srd(const void* base, uint32_t bytes) {
 template <int N>
 using ic = std::integral_constant<int, N>;
 
+// Split mode (nsplit > 1; host: omni_internal_flash_attn_w64): the grid lists the FULL 256-query blocks first (qfull per (item,
+// head), XCD-aware order as before) and behind them, for the item's short LAST block (<= 64 query rows: 4160 = 16 x 256 + 64, 16448 =
+// 64 x 256 + 64 — one wave of four has rows), nsplit workgroups per (item, head) that each visit 1 / nsplit of the key tiles and
+// leave an UN-normalised partial (O, running max, row sum: fp32) in `part_o` / `part_ml`; attn_split_combine_kernel merges them.
+// The short block otherwise costs a whole workgroup-time with three idle waves, dispatched last: at 2 x 24 heads x 65 blocks
+// (one 2048^2 request) the 13th round of the grid holds 48 workgroups on 256 CUs.
 __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     uint16_t* __restrict__ out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
     const int32_t* __restrict__ cu_seqlens, int n_heads_total, int H, float scale_log2e, int out_k32_rows,
-    const int32_t* __restrict__ item_skip, int q_prescaled) {
+    const int32_t* __restrict__ item_skip, int q_prescaled, int qfull, int nsplit, float* __restrict__ part_o,
+    float* __restrict__ part_ml) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -226,13 +234,20 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
 
   // XCD-aware head-major block order (attention.hip): block b runs on XCD b % 8; every XCD gets a contiguous range of the
   // (item*head, q-block) list, so the workgroups resident on an XCD stream the same few heads' K / V through its L2
-  int hb, qb;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x, qblocks = nwg / n_heads_total;
+  int hb, qb, sp = 0;
+  const int nfull = n_heads_total * qfull;          // == gridDim.x without split mode
+  const bool split = (int)blockIdx.x >= nfull;
+  if (!split) {
+    const int nwg = nfull, bid = blockIdx.x, qblocks = qfull;
     const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
     hb = lid / qblocks;
     qb = lid - hb * qblocks;
+  } else {
+    const int r = (int)blockIdx.x - nfull;
+    hb = r / nsplit;
+    sp = r - hb * nsplit;
+    qb = qfull;
   }
   const int b = hb / H, h = hb - b * H;
   if (item_skip && item_skip[b]) return;
@@ -243,15 +258,29 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
   asm volatile(OMNI_OWNS_AGPRS ::: OMNI_ALL_AGPRS);   // allocate a[0:255]
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const int ntiles = (seq_len + KVBLK - 1) / KVBLK;
+  // key tiles of this workgroup: all of them, or (split mode) the sp-th of nsplit contiguous ranges.  Everything below indexes
+  // tiles and keys RELATIVE to the range: the buffer descriptors start at its first key and end at its last.
+  const int ntiles_all = (seq_len + KVBLK - 1) / KVBLK;
+  const int t_first = split ? (int)((long)sp * ntiles_all / nsplit) : 0;
+  const int t_last = split ? (int)((long)(sp + 1) * ntiles_all / nsplit) : ntiles_all;
+  const int ntiles = t_last - t_first;
+  const int kv_row0 = t_first * KVBLK;
+  const int kv_rows = min(seq_len, t_last * KVBLK) - kv_row0;     // keys of the range (the last range ends with the sequence)
+  if (ntiles <= 0) {                                // fewer tiles than splits: an empty partial (l = 0; the combine skips it)
+    if (wave == 0 && lane < 64) {
+      float* ml = part_ml + ((int64_t)(hb * nsplit + sp) * 64 + lane) * 2;
+      ml[0] = -INFINITY; ml[1] = 0.0f;
+    }
+    return;
+  }
 
   // ---- LDS-DMA sources.  Piece P = wave + 4i (1 KiB of a tile image), lane L -> byte 16 L of the piece.
   //  K piece P: key = 4P + (L>>4) = [4 wave + (L>>4)] + 16 i; LDS chunk L&15 holds logical chunk (L&15) ^ (key&15) — the same
   //             for every i, so the four pieces differ by a uniform 16-row stride in soffset;
   //  V piece P = (dblk = i, key group = wave): key = 16 wave + 4 (L>>4) + ((L>>2)&3), logical chunk 4i + (L&3): the four
   //             pieces differ by 64 B in soffset.
-  const u32x4_t k_srd = make_srd(k + (int64_t)seq_start * ldk + h * DH, (uint32_t)((int64_t)(seq_len - 1) * ldk * 2 + DH * 2));
-  const u32x4_t v_srd = make_srd(v + (int64_t)seq_start * ldv + h * DH, (uint32_t)((int64_t)(seq_len - 1) * ldv * 2 + DH * 2));
+  const u32x4_t k_srd = make_srd(k + (int64_t)(seq_start + kv_row0) * ldk + h * DH, (uint32_t)((int64_t)(kv_rows - 1) * ldk * 2 + DH * 2));
+  const u32x4_t v_srd = make_srd(v + (int64_t)(seq_start + kv_row0) * ldv + h * DH, (uint32_t)((int64_t)(kv_rows - 1) * ldv * 2 + DH * 2));
   const int k_key0 = 4 * wave + (lane >> 4);
   const int v_key = 16 * wave + 4 * (lane >> 4) + ((lane >> 2) & 3);
   const uint32_t k_src = (uint32_t)(k_key0 * ldk * 2) + (uint32_t)(((lane & 15) ^ (k_key0 & 15)) * 16);
@@ -374,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (key >= seq_len) { S[0][j][r] = -INFINITY; S[1][j][r] = -INFINITY; }
+        if (key >= kv_rows) { S[0][j][r] = -INFINITY; S[1][j][r] = -INFINITY; }
       }
   };
   auto row_max = [&](f32x16_t (&S)[2][2], float (&mx)[2]) {
@@ -404,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
   __builtin_amdgcn_sched_barrier(0);
   kread_all(1);
   mfma_drain_s(sA);                                 // S(0) is read by VALU right away here (in the loop it is not)
-  if (KVBLK > seq_len) mask_tail(sA, 0);
+  if (KVBLK > kv_rows) mask_tail(sA, 0);
   row_max(sA, mxA);
   // tile 0 opened its chains with C = 0: its row max becomes the first running max here (O = l = 0: nothing to rescale), also
   // when every score of the tile is far below zero; the loop then sees a tile whose max is exactly at the reference point
@@ -528,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
     __builtin_amdgcn_s_setprio(1);
     [&]<int... I>(std::integer_sequence<int, I...>) { (p1_step(ic<I>{}), ...); }(std::make_integer_sequence<int, 32>{});
     if constexpr (!OMNI_W64_FINP2) { exp_finish(ic<30>{}); exp_finish(ic<31>{}); }
-    if (HAS_NEXT && (t + 2) * KVBLK > seq_len) { mfma_drain_s(SN); mask_tail(SN, (t + 1) * KVBLK); }
+    if (HAS_NEXT && (t + 2) * KVBLK > kv_rows) { mfma_drain_s(SN); mask_tail(SN, (t + 1) * KVBLK); }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- P2: O^T += V(t)^T P(t)^T.  PV step f = 0..15 <-> (j = f >> 3, half = (f >> 2) & 1, d = f & 3): ONE V^T fragment
@@ -638,6 +667,33 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
 
   // ---- epilogue: O / l -> out.  o[bq][d][4 qd + j] = O[q][d*32 + qd*8 + hi*4 + j]
   mfma_drain();
+  if (split) {
+    // un-normalised partial of this key range: O (relative to the running max m~ of the range, exp2 domain), m~ and the row sum.
+    // The short block has at most 64 rows: they all belong to wave 0 (the host enables split mode only then).
+    if (wave == 0) {
+#pragma unroll
+      for (int bq = 0; bq < 2; ++bq) {
+        const float l = xhalf_sum(lsum[bq][0] + lsum[bq][1]);
+        float o[64];
+        if (bq == 0) [&]<int... I>(std::integer_sequence<int, I...>) { ((o[I] = agpr_read<A_O + I>()), ...); }(std::make_integer_sequence<int, 64>{});
+        else [&]<int... I>(std::integer_sequence<int, I...>) { ((o[I] = agpr_read<A_O + 64 + I>()), ...); }(std::make_integer_sequence<int, 64>{});
+        const int64_t prow = (int64_t)(hb * nsplit + sp) * 64 + bq * 32 + l31;
+        float* po = part_o + prow * DH + hi * 4;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const f32x4_t w = {o[d * 16 + qd * 4 + 0], o[d * 16 + qd * 4 + 1], o[d * 16 + qd * 4 + 2], o[d * 16 + qd * 4 + 3]};
+            *reinterpret_cast<f32x4_t*>(po + d * 32 + qd * 8) = w;
+          }
+        if (hi == 0) {
+          part_ml[prow * 2 + 0] = -negm16[bq][0];
+          part_ml[prow * 2 + 1] = l;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int bq = 0; bq < 2; ++bq) {
     const float inv = 1.0f / xhalf_sum(lsum[bq][0] + lsum[bq][1]);
@@ -668,25 +724,118 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fwd_w64_kernel(
   }
 }
 
+// Merge of the split-mode partials: out[row] = sum_s 2^(m_s - M) O_s[row] / sum_s 2^(m_s - M) l_s, M = max_s m_s.  One workgroup per
+// (item, head), a thread = 32 channels (one 64-byte piece of the output row, row-major or K32-blocked) of one of the <= 64 rows.
+__global__ __launch_bounds__(256) void attn_split_combine_kernel(uint16_t* __restrict__ out, int64_t ldo, int out_k32_rows,
+                                                                 const int32_t* __restrict__ cu_seqlens, int H, int qfull, int nsplit,
+                                                                 const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                                 const int32_t* __restrict__ item_skip) {
+  const int hb = blockIdx.x, b = hb / H, h = hb - b * H;
+  if (item_skip && item_skip[b]) return;
+  const int seq_start = cu_seqlens[b], seq_len = cu_seqlens[b + 1] - seq_start;
+  const int row = threadIdx.x >> 2, cg = threadIdx.x & 3;
+  const int qrow = qfull * QBLK + row;
+  if (qrow >= seq_len) return;
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* ml = part_ml + ((int64_t)(hb * nsplit + s) * 64 + row) * 2;
+    if (ml[1] > 0.0f) M = fmaxf(M, ml[0]);
+  }
+  float acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
+  float L = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+    const int64_t prow = (int64_t)(hb * nsplit + s) * 64 + row;
+    const float l = part_ml[prow * 2 + 1];
+    if (!(l > 0.0f)) continue;                      // an empty range
+    const float w = __builtin_amdgcn_exp2f(part_ml[prow * 2] - M);
+    L += w * l;
+    const f32x4_t* po = reinterpret_cast<const f32x4_t*>(part_o + prow * DH + cg * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4_t x = po[i];
+      acc[4 * i + 0] += w * x[0]; acc[4 * i + 1] += w * x[1]; acc[4 * i + 2] += w * x[2]; acc[4 * i + 3] += w * x[3];
+    }
+  }
+  const float inv = 1.0f / L;
+  uint16_t* op = out_k32_rows ? out + ((int64_t)(h * 4 + cg) * out_k32_rows + seq_start + qrow) * 32
+                              : out + (int64_t)(seq_start + qrow) * ldo + h * DH + cg * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u32x4_t w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(acc[8 * i + 2 * e] * inv, acc[8 * i + 2 * e + 1] * inv);
+    *reinterpret_cast<u32x4_t*>(op + 8 * i) = w;
+  }
+}
+
+// Split factor of the short last q-block (1 = off) from a makespan model in units of one full workgroup: `nfullwg` full blocks
+// on `cus` CUs, then nh * ns pieces of 1 / ns that the dispatcher hands to whichever CU frees up.
+int w64_split_factor(int nh, int qfull, int max_seqlen, int cus, size_t ws_bytes) {
+  static const int knob = omni_dev_env_int("OMNI_ATTN_SPLIT", 1);        // dev knob (-DOMNI_DEV builds only)
+  const int rem = max_seqlen % QBLK;
+  if (!knob || rem == 0 || rem > 64 || qfull < 4) return 1;
+  const long nfullwg = (long)nh * qfull, fr = nfullwg / cus, r = nfullwg % cus;
+  auto makespan = [&](int ns) {
+    const long small = (long)nh * ns;
+    if (r > 0) {
+      const long cap = (cus - r) * ns;
+      return small <= cap ? (double)(fr + 1) : fr + 1 + (double)((small - cap + cus - 1) / cus) / ns;
+    }
+    return fr + (double)((small + cus - 1) / cus) / ns;
+  };
+  const int ntiles = (max_seqlen + KVBLK - 1) / KVBLK;
+  int best = 1;
+  double tbest = makespan(1) - 0.12;                // a split must save more than the partial round trip + the combine launch cost
+  for (int ns = 2; ns <= 8; ++ns) {
+    if (ntiles / ns < 8 || (size_t)nh * ns * 64 * (DH + 2) * sizeof(float) > ws_bytes) break;
+    const double t = makespan(ns);
+    if (t < tbest - 1e-9) { tbest = t; best = ns; }
+  }
+  return best;
+}
+
 }  // namespace
 
-// internal: the 64-queries-per-wave kernel (same contract as omni_internal_flash_attn; picked by it for large grids)
+size_t omni_internal_flash_attn_w64_ws_bytes(int32_t B, int32_t H) {
+  // room for the largest split the factor rule can pick (8 ranges) — 33 KB per (item, head) and range
+  return (size_t)B * H * 8 * 64 * (DH + 2) * sizeof(float);
+}
+
+// internal: the 64-queries-per-wave kernel (same contract as omni_internal_flash_attn; picked by it for large grids).
+// `part_ws` (nullable, fp32-aligned DEVICE memory of part_ws_bytes): enables split mode for the short last q-block.
 int omni_internal_flash_attn_w64(const omni_bf16* q, const omni_bf16* k, const omni_bf16* v, omni_bf16* out, int64_t ldq,
                                  int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* cu_seqlens, int32_t B, int32_t H,
                                  int32_t max_seqlen, float softmax_scale, int32_t out_k32_rows, const int32_t* item_skip,
-                                 int32_t q_prescaled, void* stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_w64_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return OMNI_ERR_LAUNCH;
-    attr_set = true;
-  }
+                                 int32_t q_prescaled, void* part_ws, size_t part_ws_bytes, void* stream) {
+  static std::atomic<uint64_t> attr_done{0};
+  OMNI_TRY_STATUS(omni_once_per_device(attr_done, [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_w64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               LDS_BYTES) == hipSuccess;
+  }));
   const int qblocks = (max_seqlen + QBLK - 1) / QBLK;
   const int nh = B * H;
-  hipLaunchKernelGGL(flash_attn_fwd_w64_kernel, dim3(nh * qblocks), dim3(256), LDS_BYTES, static_cast<hipStream_t>(stream), q,
-                     k, v, out, ldq, ldk, ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows,
-                     item_skip, q_prescaled);
+  int nsplit = 1;
+  if (part_ws && (reinterpret_cast<uintptr_t>(part_ws) & 15) == 0)
+    nsplit = w64_split_factor(nh, max_seqlen / QBLK, max_seqlen, omni_num_cus(), part_ws_bytes);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (nsplit > 1) {
+    const int qfull = max_seqlen / QBLK;
+    float* part_o = static_cast<float*>(part_ws);
+    float* part_ml = part_o + (size_t)nh * nsplit * 64 * DH;
+    hipLaunchKernelGGL(flash_attn_fwd_w64_kernel, dim3(nh * qfull + nh * nsplit), dim3(256), LDS_BYTES, s, q, k, v, out, ldq, ldk,
+                       ldv, ldo, cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows, item_skip, q_prescaled, qfull,
+                       nsplit, part_o, part_ml);
+    OMNI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_split_combine_kernel, dim3(nh), dim3(256), 0, s, out, ldo, out_k32_rows, cu_seqlens, H, qfull, nsplit,
+                       part_o, part_ml, item_skip);
+    OMNI_CHECK_LAUNCH();
+    return OMNI_OK;
+  }
+  hipLaunchKernelGGL(flash_attn_fwd_w64_kernel, dim3(nh * qblocks), dim3(256), LDS_BYTES, s, q, k, v, out, ldq, ldk, ldv, ldo,
+                     cu_seqlens, nh, H, softmax_scale * 1.4426950408889634f, out_k32_rows, item_skip, q_prescaled, qblocks, 1,
+                     nullptr, nullptr);
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }

@@ -87,6 +87,8 @@ def mfma_loop_lane_spills(asm_lines) -> dict[str, int]:
                 bm = re.search(r"\bs_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
                 if bm and labels.get(bm.group(1), j) < j:          # backward branch = a loop
                     loop = body[labels[bm.group(1)]:j]
+                    if any("s_endpgm" in x for x in loop):          # an out-of-line block behind the kernel's end that jumps back
+                        continue                                   # into it (see mfma_loops): a backward branch, not a loop
                     if any("v_mfma" in x for x in loop):
                         worst = max(worst, sum(1 for x in loop if re.search(r"\bv_(write|read)lane_b32", x)))
             out[fn] = worst

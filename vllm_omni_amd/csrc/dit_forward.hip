@@ -18,8 +18,10 @@ struct Workspace {
   omni_bf16 *tproj, *th, *temb, *mod_img, *mod_txt, *emb_out;
   omni_bf16 *hidden_img, *hidden_txt, *xn, *txt_normed, *q, *k, *v, *attn, *mlp_h, *h_in;
   int32_t *img_pos, *txt_pos;   // RoPE table row of every image / text stream row (joint_pos gathered through the joint-row maps)
-  float* splitk;                // fp32 partial tiles of the split-K GEMMs (small batches only; include/omni_cdna4.h splitk_ws)
-  int64_t splitk_floats;
+  float* splitk;                // fp32 partial tiles of the split-K GEMMs (small batches: whole-launch split-K; larger ones: the
+  int64_t splitk_floats;        // tail split of a thin last round — include/omni_cdna4.h splitk_ws, OMNI_GEMM_KERNEL_NO_TAIL_SPLIT)
+  void* attn_part;              // fp32 partials of the attention's split short last q-block (attention_w64.hip)
+  size_t attn_part_bytes;
   uint8_t* x8;                  // fp8 mode: the e4m3 copy of the NEXT block GEMM's input ([K/64][rows][64]; image rows, then text rows)
   float* x8_scale;              // fp8 mode: its per-row scales [n_joint_rows]
   size_t total;
@@ -58,9 +60,12 @@ Workspace carve(void* base, const omni_dit_weights* w, int64_t Ri, int64_t Rt, i
   ws.txt_pos = reinterpret_cast<int32_t*>(take(Rt * 2));
   // split-K workspace of the GEMMs whose grid would leave half of the chip idle (include/omni_cdna4.h splitk_ws): up to 8
   // splits x rows x D fp32 for a batch of at most four row tiles (63 MB for a CFG pair of 256x256 images), 2 splits up to ten
-  // row tiles (a CFG pair at 512x512: 53 MB); larger batches fill the chip without it
-  ws.splitk_floats = Rj <= 4 * 256 ? 8 * Rj * D : (Rj <= 10 * 256 ? 2 * Rj * D : 0);
+  // row tiles (a CFG pair at 512x512: 53 MB); larger batches fill the chip without it, but their LAST round of tiles may be thin
+  // (1548 tiles = 6 rounds + 12 at one 2048^2 request): the tail split takes up to 64 tail tiles x 8 pieces of 256 KiB (134 MB)
+  ws.splitk_floats = Rj <= 4 * 256 ? 8 * Rj * D : (Rj <= 10 * 256 ? 2 * Rj * D : (int64_t)512 * 256 * 256);
   ws.splitk = reinterpret_cast<float*>(take(ws.splitk_floats * 2));
+  ws.attn_part_bytes = (size_t)512 * 64 * (128 + 2) * sizeof(float);      // up to 512 (item, head, key range) partials of 64 rows
+  ws.attn_part = take((int64_t)(ws.attn_part_bytes / 2));
   ws.x8 = nullptr; ws.x8_scale = nullptr;
   if (w->fp8_layers) {
     ws.x8 = reinterpret_cast<uint8_t*>(take(Rj * 2 * D));             // Rj x 4D bytes (the MLP-down input is the widest)
@@ -220,7 +225,8 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   if (phase == BLOCK_QKV) return OMNI_OK;
   // joint attention (reference :437-443 -> attention/backends/sdpa.py:46-66)
   OMNI_TRY(omni_internal_flash_attn(ws.q, ws.k, ws.v, ws.attn, D, D, D, D, b->cu_seqlens, b->n_items, w->num_heads,
-                                    w->head_dim, b->max_seqlen, sm_scale, bRj, pr.item, q_prescale ? 1 : 0, stream));
+                                    w->head_dim, b->max_seqlen, sm_scale, bRj, pr.item, q_prescale ? 1 : 0, ws.attn_part,
+                                    ws.attn_part_bytes, stream));
   }  // phase != BLOCK_POST
   const omni_bf16* attn_src = phase == BLOCK_POST ? attn_in : ws.attn;
   const int32_t attn_k32 = phase == BLOCK_POST ? 0 : bRj;       // a caller-provided attention output is row-major

@@ -253,11 +253,13 @@ struct EpiFromLds {};
 // split-K finish (gemm_splitk_finish_kernel): phase 2 forms C = sum over the K-splits of the fp32 partial tiles (in split
 // order: deterministic) + bias (+ GELU), rounded to bf16 exactly where the fused kernel rounds (acc + bias -> bf16 in LDS)
 struct EpiFromPartials {
-  const float* ws;          // [nsplit][Mtot][N] fp32
-  int64_t split_stride;     // Mtot * N
-  int64_t row_base;         // first row of this group inside the Mtot rows
+  const float* ws;          // whole-launch split-K: [nsplit][Mtot][N] fp32;  tail split: this tile's [nsplit][256][256]
+  int64_t split_stride;     // Mtot * N                                       |  256 * 256
+  int64_t row_base;         // first row of this group inside the Mtot rows   |  0
   int nsplit;
   int b_begin, b_end;       // row batches (64 rows each) of the tile this workgroup finishes
+  int64_t row_stride;       // N                                              |  256
+  int row0, col0;           // 0, 0                                           |  m0, n0 of the tile (partials are tile-local)
 };
 
 template <int EPI, typename WriteTile, typename CSrc = EpiFromLds, int NT = NTHREADS>
@@ -343,8 +345,8 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
         d.r[j] = *reinterpret_cast<const u32x4_t*>(G.res + (int64_t)x.ro[j] * G.ldres + n);
       }
       if constexpr (FROM_PARTIALS) {
-        const int64_t row = csrc.row_base + min(m0 + (b * BATCH + j) * RS + rsub, M - 1);
-        const float* src = csrc.ws + row * N + n;
+        const int64_t row = csrc.row_base + min(m0 + (b * BATCH + j) * RS + rsub, M - 1) - csrc.row0;
+        const float* src = csrc.ws + row * csrc.row_stride + (n - csrc.col0);
         f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
         for (int sp = 0; sp < csrc.nsplit; ++sp) {
           lo += *reinterpret_cast<const f32x4_t*>(src + sp * csrc.split_stride);
@@ -929,16 +931,24 @@ constexpr int PLDS_BYTES = 8 * PSLOT_BYTES;   // 128 KiB ring
 // tile b / nsplit with split = b % nsplit and stores its fp32 accumulators to P.splitk_ws[split][row][col]; the epilogue runs
 // in gemm_splitk_finish_kernel.  A DiT forward over one or two 256x256 images has 36 workgroups in its N = 3072 GEMMs, each
 // streaming its 256 x K weight panel at the pace of one CU's k-loop (~1.2 us per K-tile): the weights arrive at ~1 TB/s.
+// SPLITK == 2 (host: tail_split_factor()): TAIL split.  A launch of more than one round of workgroups whose LAST round is thin —
+// 1548 tiles on 256 CUs are 6 rounds + 12 tiles, the N = 3072 GEMMs of one 2048^2 request — runs its first `tail_first` tiles
+// exactly as the unsplit kernel does (same code path, same bits) and the remaining tiles `nsplit` ways along K: blocks
+// tail_first + (tile - tail_first) * nsplit + split, dispatched last, fp32 partials in a tile-compact workspace
+// splitk_ws[tile - tail_first][split][256][256], epilogue in gemm_tail_finish_kernel.  The thin round then costs ~1 / nsplit of a
+// tile time instead of a whole one.
 template <int EPI, int SPLITK = 0, int FP8 = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
-                                                                     int tiles_n, int GROUP_M, int nsplit) {
+                                                                     int tiles_n, int GROUP_M, int nsplit, int tail_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = tiles_m * tiles_n;
-  const int split = SPLITK ? (int)blockIdx.x % nsplit : 0;
-  const int bid = SPLITK ? (int)blockIdx.x / nsplit : (int)blockIdx.x;
+  const bool tail = SPLITK == 2 && (int)blockIdx.x >= tail_first;          // uniform over the workgroup
+  const int split = SPLITK == 1 ? (int)blockIdx.x % nsplit : (tail ? ((int)blockIdx.x - tail_first) % nsplit : 0);
+  const int bid = SPLITK == 1 ? (int)blockIdx.x / nsplit : (tail ? tail_first + ((int)blockIdx.x - tail_first) / nsplit : (int)blockIdx.x);
+  const bool partial = SPLITK == 1 || tail;                                // this workgroup leaves an fp32 partial tile
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   const int band_sz = GROUP_M * tiles_n;
@@ -978,9 +988,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   const int64_t astep = G.a_k32_rows ? (int64_t)G.a_k32_rows * 128 : 128;
   const int64_t wstep = P.w_k32_blocked ? (int64_t)N * 128 : 128;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const int nkt = SPLITK ? K / PBK / nsplit : K / PBK;             // K-tiles of this workgroup
-  const char* const Ab = reinterpret_cast<const char*>(G.A) + (SPLITK ? (int64_t)split * nkt * astep : 0);
-  const char* const Wb = reinterpret_cast<const char*>(G.W) + (SPLITK ? (int64_t)split * nkt * wstep : 0);
+  // K-tiles of this workgroup: all of them; an nsplit-th (whole-launch split-K: nsplit divides the count); tail split: the
+  // split-th of nsplit near-equal contiguous ranges
+  const int nkt_all = K / PBK;
+  const int kt0 = SPLITK == 1 ? split * (nkt_all / nsplit) : (tail ? (int)((long)split * nkt_all / nsplit) : 0);
+  const int nkt = SPLITK == 1 ? nkt_all / nsplit : (tail ? (int)((long)(split + 1) * nkt_all / nsplit) - kt0 : nkt_all);
+  const char* const Ab = reinterpret_cast<const char*>(G.A) + (SPLITK ? (int64_t)kt0 * astep : 0);
+  const char* const Wb = reinterpret_cast<const char*>(G.W) + (SPLITK ? (int64_t)kt0 * wstep : 0);
   // piece i (0 / 1) of half-tile h (compile time) of K-tile `tile`
 #define OMNI_PP_ISSUE_PIECE(h, tile, i)                                                                     \
   do {                                                                                                      \
@@ -1018,10 +1032,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   for (int nb = 0; nb < 4; ++nb) {
     const int n = n0 + wn * 64 + nb * 16 + g4 * 4;
     u32x2_t b = {0u, 0u};
-    if (!SPLITK && !FP8 && G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);   // split-K: the finish adds the bias; fp8: the epilogue does (after the scales)
+    if (!partial && !FP8 && G.bias && n < N) b = *reinterpret_cast<const u32x2_t*>(G.bias + n);   // split-K: the finish adds the bias; fp8: the epilogue does (after the scales)
     const f32x4_t bini = {bf16_lo(b[0]), bf16_hi(b[0]), bf16_lo(b[1]), bf16_hi(b[1])};
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = bini;
+  }
+  // tail split: everything the partial store needs, formed HERE as per-lane values (a pointer pair and two small counts in
+  // VGPRs) so that bid / split / nsplit / tail_first are dead across the K-loop — kept as scalars they pushed the QKV instance
+  // into SGPR spills inside the loop
+  float* tail_wsp = nullptr;
+  int tail_rows = 0, tail_cols = 0;
+  if (SPLITK == 2 && tail) {
+    const int rl = wm * 128 + l15, cl = wn * 64 + g4 * 4;
+    tail_wsp = P.splitk_ws + ((int64_t)(bid - tail_first) * nsplit + split) * (BM * BN) + rl * BN + cl;
+    tail_rows = M - m0 - rl;                       // block mb exists iff tail_rows > 16 mb
+    tail_cols = N - n0 - cl;                       // block nb exists iff tail_cols > 16 nb
+    asm volatile("" : "+v"(tail_wsp), "+v"(tail_rows), "+v"(tail_cols));
   }
   if (nkt > 1) {
     asm volatile(OMNI_PP_VMCNT ::: "memory");
@@ -1104,7 +1130,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   // per phase, M0 = one s_add of a per-wave constant and an immediate: 0.25 scalar instructions per MFMA (1.17 in the general
   // loop; the vendor kernel: 0.33), load section 246 -> 154 cycles per phase by the phase probe.  The fp8
   // instance runs the same loop since round 5 (its clusters are half as long: the scalar stream weighed twice as much).
-  if constexpr (!SPLITK) {
+  if constexpr (SPLITK != 1) {
     const uint32_t lds_w = lds0 + (uint32_t)(wave * 2048);           // this wave's two pieces inside a half-tile slot
     const char* a_nx = Ab + astep;                                  // K-tile t + 1 of either operand (t = 0)
     const char* w_nx = Wb + wstep;
@@ -1183,7 +1209,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   OMNI_PP_PROBE_WRITE();
 #endif
 
-  if (SPLITK) {
+  if (SPLITK == 2 && tail) {
+    // tail split: tile-compact fp32 partial [256][256] of (tile, split); rows / columns past M / N are never read back
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      if (tail_rows <= mb * 16) continue;             // rows of this lane's 16-row blocks that exist (m0 + rl < M)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+        if (tail_cols > nb * 16) *reinterpret_cast<f32x4_t*>(tail_wsp + mb * 16 * BN + nb * 16) = acc[nb][mb];
+    }
+    return;
+  }
+  if (SPLITK == 1) {
     // fp32 partial tile: lane (l15, g4) holds C[mb*16 + l15][nb*16 + 4*g4 .. +4]: 16-B stores, 64 contiguous bytes per row
     float* const wsp = P.splitk_ws + ((int64_t)split * (P.g[0].M + (P.ngroups > 1 ? P.g[1].M : 0)) + (gi ? P.g[0].M : 0)) * N;
 #pragma unroll
@@ -1250,7 +1287,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm_splitk_finish_kernel(const omni
   if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;
   if (m0 + quarter * 64 >= G.M) return;
   const int64_t mtot = P.g[0].M + (P.ngroups > 1 ? P.g[1].M : 0);
-  const EpiFromPartials src = {P.splitk_ws, mtot * P.N, gi ? (int64_t)P.g[0].M : 0, nsplit, quarter, quarter + 1};
+  const EpiFromPartials src = {P.splitk_ws, mtot * P.N, gi ? (int64_t)P.g[0].M : 0, nsplit, quarter, quarter + 1, P.N, 0, 0};
+  gemm_epilogue_lds_impl<EPI>(P, G, m0, n0, nullptr, (int)threadIdx.x, []() {}, src);
+}
+
+// Tail-split finish: the same epilogue over the tail tiles only (four workgroups of 64 rows per tile), C = the sum of the tile's
+// nsplit compact partials in split order.
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_tail_finish_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
+                                                                     int tiles_n, int GROUP_M, int nsplit, int tail_first) {
+  const int tl = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+  const int bid = tail_first + tl;
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int band_sz = GROUP_M * tiles_n;
+  const int band = lid / band_sz, in_band = lid - band * band_sz;
+  const int first_m = band * GROUP_M;
+  const int gm = min(GROUP_M, tiles_m - first_m);
+  const int mt = first_m + in_band % gm;
+  const int nt = in_band / gm;
+  const int gi = (mt >= mtiles0) ? 1 : 0;
+  const omni_gemm_group G = pick_group(P, gi);
+  const int m0 = (gi ? mt - mtiles0 : mt) * BM;
+  const int n0 = nt * BN;
+  if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;
+  if (m0 + quarter * 64 >= G.M) return;
+  const EpiFromPartials src = {P.splitk_ws + (int64_t)tl * nsplit * (BM * BN), BM * BN, 0, nsplit, quarter, quarter + 1, BN, m0, n0};
   gemm_epilogue_lds_impl<EPI>(P, G, m0, n0, nullptr, (int)threadIdx.x, []() {}, src);
 }
 
@@ -1315,17 +1378,7 @@ bool epilogue_rows_coalescable(const omni_gemm_params* p) {
   return true;
 }
 
-int gemm_num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8)
-      v = 256;
-    n = v;
-  }
-  return n;
-}
+int gemm_num_cus() { return omni_num_cus(); }
 // SADDR-form DMA needs every byte offset of both operands to fit 32 bits (dev knob OMNI_GEMM_SADDR=0 disables it)
 bool ring_saddr_ok(const omni_gemm_params* p) {
   static int knob = -1;
@@ -1384,13 +1437,45 @@ int splitk_factor(const omni_gemm_params* p, int tiles_m, int tiles_n) {
   return 1;
 }
 
+// Tail split of a launch of `tiles` 256x256 tiles (see the kernel comment): returns the split factor of the tiles of its last,
+// partial round (1 = off) and *tail_first = the number of tiles that run unsplit.  The rule is MEASURED, not modelled:
+//   * only a THIN tail is split (at most a quarter round of tiles): 12 K-tiles per piece at K = 3072 (factor 4), 24 at K = 12288
+//     (factor 8).  Whole 60-layer forwards, same box (profiles/r06_ab_splits_*.log): two 1024^2 requests (780 / 2340 / 3120
+//     tiles = 3 / 9 / 12 rounds + 12 / 36 / 48) -4.4 %, one 2048^2 request (6 / 18 / 24 rounds + 12 / 36 / 48) -1.0 %;
+//   * a BIG tail (140 .. 236 tiles: one, three or five 1024^2 requests) is left alone.  Launched alone, every factor >= 4 gains
+//     1 .. 12 % there too (profiles/r06_tail_split_sweep.log) — the 35 .. 60 MB of fp32 partials stay in the 256 MB Infinity Cache —
+//     but inside a forward the same launches cost +2.5 .. +8 % of the step: 150 .. 250 MB of partials per GEMM evict the
+//     activations the next kernel reads.  (Factors 2 and 3 on a big tail are slower even alone: two nearly synchronous
+//     sub-rounds of long pieces.)
+// Like splitk_factor() it looks at tile counts only; unlike it, it changes the fp32 summation order of SOME tiles of a launch, so
+// results agree with the unsplit kernel to that order on the tail tiles and bit for bit elsewhere (tests/test_gpu_tail_split.py).
+int tail_split_factor(const omni_gemm_params* p, int tiles, int* tail_first) {
+  static const int knob = omni_dev_env_int("OMNI_GEMM_TAILSPLIT", 1);     // dev knob (-DOMNI_DEV builds only)
+  if (!knob || !p->splitk_ws || p->splitk_ws_floats <= 0 || p->kernel_hint == OMNI_GEMM_KERNEL_NO_TAIL_SPLIT) return 1;
+  if ((reinterpret_cast<uintptr_t>(p->splitk_ws) & 15) || (p->N % 4) != 0) return 1;
+  const int cus = gemm_num_cus();
+  const int tt = tiles % cus;
+  if (tiles <= cus || tt == 0) return 1;
+  const int nkt = p->K / PBK;
+  *tail_first = tiles - tt;
+  const int force = omni_dev_env_int("OMNI_GEMM_TAIL_NS", 0);            // dev knob, read per call: a fixed factor (sweeps)
+  if (force > 0) {
+    const long blocks = (long)tt * force;
+    return (force == 1 || nkt / force < 2 || blocks * (long)(BM * BN) > p->splitk_ws_floats) ? 1 : force;
+  }
+  if (tt * 4 > cus) return 1;                                            // a big tail: see above
+  int ns = nkt >= 96 ? 8 : 4;
+  while (ns > 1 && (nkt / ns < 8 || (long)tt * ns * (long)(BM * BN) > p->splitk_ws_floats)) ns >>= 1;
+  return ns;
+}
+
 template <int EPI>
 int launch(const omni_gemm_params* p, hipStream_t s) {
   const int mt0 = (p->g[0].M + BM - 1) / BM;
   const int mt1 = p->ngroups > 1 ? (p->g[1].M + BM - 1) / BM : 0;
   const int tiles_m = mt0 + mt1, tiles_n = (p->N + BN - 1) / BN;
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};     // per device and per epilogue instance (common.h omni_once_per_device)
+  auto set_attrs = []() -> bool {
 #ifdef OMNI_DEV
 #include "dev/gemm_dev_launch_attrs.inc"
 #endif
@@ -1404,21 +1489,24 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI, 0, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
-      return OMNI_ERR_LAUNCH;
+      return false;
 #ifdef OMNI_DEV
 #include "dev/gemm_dev_launch_attr_persistent.inc"
 #endif
-    attr_set = true;
-  }
+    return true;
+  };
+  OMNI_TRY_STATUS(omni_once_per_device(attr_done, set_attrs));
   if (p->fp8) {
     // the fp8 operands are, byte for byte, K32-blocked bf16 matrices with K / 2 columns: the kernel runs on that view
     omni_gemm_params q = *p;
     q.K = p->K / 2;
     if (!epilogue_rows_coalescable(&q) || !ring_saddr_ok(&q)) return OMNI_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, 0, 1>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, q, mt0, tiles_m,
-                       tiles_n, gemm_group_m(), 1);
+                       tiles_n, gemm_group_m(), 1, 0);
     OMNI_CHECK_LAUNCH();
     return OMNI_OK;
   }
@@ -1435,15 +1523,24 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
   }
   else if (gemm_variant(p) >= 3 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p)) {
     const int nsplit = splitk_factor(p, tiles_m, tiles_n);
+    int tail_first = 0;
+    const int tail_ns = nsplit > 1 ? 1 : tail_split_factor(p, tiles_m * tiles_n, &tail_first);
     if (nsplit > 1) {
       hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, 1>), dim3(tiles_m * tiles_n * nsplit), dim3(NTHREADS), RLDS_BYTES, s, *p,
-                         mt0, tiles_m, tiles_n, gemm_group_m(), nsplit);
+                         mt0, tiles_m, tiles_n, gemm_group_m(), nsplit, 0);
       OMNI_CHECK_LAUNCH();
       hipLaunchKernelGGL((gemm_splitk_finish_kernel<EPI>), dim3(tiles_m * tiles_n * 4), dim3(NTHREADS), 0, s, *p, mt0,
                          tiles_m, tiles_n, gemm_group_m(), nsplit);
+    } else if (tail_ns > 1) {
+      const int tt = tiles_m * tiles_n - tail_first;
+      hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, 2>), dim3(tail_first + tt * tail_ns), dim3(NTHREADS), RLDS_BYTES, s, *p,
+                         mt0, tiles_m, tiles_n, gemm_group_m(), tail_ns, tail_first);
+      OMNI_CHECK_LAUNCH();
+      hipLaunchKernelGGL((gemm_tail_finish_kernel<EPI>), dim3(tt * 4), dim3(NTHREADS), 0, s, *p, mt0, tiles_m, tiles_n,
+                         gemm_group_m(), tail_ns, tail_first);
     } else {
       hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
-                         tiles_n, gemm_group_m(), 1);
+                         tiles_n, gemm_group_m(), 1, 0);
     }
   }
   else if (epilogue_rows_coalescable(p)) {

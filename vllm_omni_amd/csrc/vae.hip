@@ -1137,13 +1137,11 @@ extern "C" int omni_vae_conv2d(const omni_conv_params* p, omni_stream stream) {
     if (npix * p->Cin * 2 >= (1ll << 32) - (1 << 24) || p->B > 65535) return OMNI_ERR_UNSUPPORTED;   // 32-bit DMA offsets per image
     auto launch = [&]<int WM, int WN, int PB, int KC, int NS, bool FUSE, bool UP>() -> int {
       constexpr int lds = conv_lds_bytes<WM, WN, PB, KC, NS>(), MT = 32 * PB * WM, NT = 96 * WN;
-      static bool attr_set = false;
-      if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bordered_kernel<WM, WN, PB, KC, NS, FUSE, UP>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-          return OMNI_ERR_LAUNCH;
-        attr_set = true;
-      }
+      static std::atomic<uint64_t> attr_done{0};     // per device and per template instance (common.h omni_once_per_device)
+      OMNI_TRY_STATUS(omni_once_per_device(attr_done, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bordered_kernel<WM, WN, PB, KC, NS, FUSE, UP>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+      }));
       const int64_t chunk = (conv_tiles_of(&q, MT, 32 * PB) + 7) / 8;   // tiles per XCD (see the kernel's blockIdx mapping)
       hipLaunchKernelGGL((conv_bordered_kernel<WM, WN, PB, KC, NS, FUSE, UP>), dim3((unsigned)(8 * chunk * ((q.Cout + NT - 1) / NT)), 1, q.B),
                          dim3(64 * WM * WN), lds, s, q, conv_run_len(&q, MT, 32 * PB));
@@ -1223,13 +1221,11 @@ extern "C" int omni_vae_attention(const omni_bf16* q, const omni_bf16* k, const 
       (ldk % 8) || (ldv % 8) || (ldo % 4))
     return OMNI_ERR_ALIGN;
   if ((int64_t)tokens * ldk * 2 >= (1ll << 32) || (int64_t)tokens * ldv * 2 >= (1ll << 32)) return OMNI_ERR_UNSUPPORTED;   // 32-bit offsets
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(vae_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, VA_LDS) !=
-        hipSuccess)
-      return OMNI_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  OMNI_TRY_STATUS(omni_once_per_device(attr_done, [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(vae_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, VA_LDS) ==
+           hipSuccess;
+  }));
   hipLaunchKernelGGL(vae_attn_fwd_kernel, dim3((unsigned)((tokens + 32 * VA_NW - 1) / (32 * VA_NW)), B), dim3(VA_NW * 64), VA_LDS,
                      static_cast<hipStream_t>(stream), q, k, v, out, ldq, ldk, ldv, ldo, tokens, scale * 1.4426950408889634f);
   OMNI_CHECK_LAUNCH();

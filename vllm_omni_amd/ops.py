@@ -57,7 +57,7 @@ class GemmGroupArgs:
         self.tile_skip = tile_skip                                # int32 [ceil(M / 256)] device flags: non-zero = that row tile is skipped
 
 
-GEMM_KERNEL_AUTO, GEMM_KERNEL_RING, GEMM_KERNEL_SPLITK_TALL = 0, 1, 2      # omni_gemm_params.kernel_hint
+GEMM_KERNEL_AUTO, GEMM_KERNEL_RING, GEMM_KERNEL_SPLITK_TALL, GEMM_KERNEL_NO_TAIL_SPLIT = 0, 1, 2, 3      # omni_gemm_params.kernel_hint
 
 
 def w_to_k32_blocked(w: torch.Tensor) -> torch.Tensor:
@@ -214,18 +214,25 @@ def rope_interleaved(x, cos_tab, sin_tab, out=None):
 
 
 def flash_attn_varlen(q, k, v, cu_seqlens, num_heads: int, max_seqlen: int, softmax_scale: float, out=None,
-                      out_k32_blocked: bool = False):
+                      out_k32_blocked: bool = False, workspace: torch.Tensor | None = None):
     """q,k,v [rows, H*128] (row strides free), cu_seqlens int32 [B+1] on device.  out_k32_blocked: out (same shape)
-    holds the K32-blocked order [H*128/32][rows][32] (omni_flash_attn_fwd_ex)."""
+    holds the K32-blocked order [H*128/32][rows][32] (omni_flash_attn_fwd_ex).  `workspace`: optional fp32 device tensor of
+    `flash_attn_workspace_floats(B, H)` elements — lets the kernel split the key range of a short last q-block
+    (omni_flash_attn_fwd_ws, ABI v11)."""
     rows, HD, ldq = _rows2d(q, "q")
     o = torch.empty(rows, HD, dtype=BF16, device=q.device) if out is None else out
-    N.check(N.lib().omni_flash_attn_fwd_ex(_p(q, name="q"), _p(k, name="k"), _p(v, name="v"), _p(o, name="out"), ldq,
+    wsp, wsb = (None, 0) if workspace is None else (_p(workspace, torch.float32, "workspace"), workspace.numel() * 4)
+    N.check(N.lib().omni_flash_attn_fwd_ws(_p(q, name="q"), _p(k, name="k"), _p(v, name="v"), _p(o, name="out"), ldq,
                                            k.stride(0), v.stride(0), o.stride(0),
                                            _p(cu_seqlens, torch.int32, "cu_seqlens"), cu_seqlens.numel() - 1, num_heads,
                                            HD // num_heads, max_seqlen, softmax_scale,
-                                           o.shape[0] if out_k32_blocked else 0, _stream()),
-            "omni_flash_attn_fwd_ex")
+                                           o.shape[0] if out_k32_blocked else 0, wsp, wsb, _stream()),
+            "omni_flash_attn_fwd_ws")
     return o
+
+
+def flash_attn_workspace_floats(B: int, H: int) -> int:
+    return int(N.lib().omni_flash_attn_workspace_bytes(B, H)) // 4
 
 
 _MASK_TYPES = {torch.bool: 1, torch.uint8: 1, torch.bfloat16: 2, torch.float32: 3}
