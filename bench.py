@@ -192,23 +192,80 @@ def measure_roofline(dev, R: int = 5) -> dict:
 
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without torchrun: spawn the N ranks ourselves (one process per GPU, env:// rendezvous on
-    127.0.0.1) and pass rank 0's stdout (the JSON line) through."""
+    127.0.0.1) and pass rank 0's stdout (the JSON line) through.  First contact with a real multi-GPU node must not be mute:
+    every rank's stderr (and the stdout of ranks != 0) goes to `gpurun_out/bench_n{N}_rank{r}.log` (NCCL_DEBUG=WARN unless the
+    caller set it), and as soon as ONE rank exits non-zero the others are terminated and the tail of the failing rank's log is
+    printed — rank 0 does not sit in a collective until the driver's timeout."""
     import socket
     import subprocess
 
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    logdir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(logdir, exist_ok=True)
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
+        path = os.path.join(logdir, f"bench_n{n}_rank{r}.log")
+        fh = open(path, "w")
+        logs.append((path, fh))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+                                      stdout=None if r == 0 else fh, stderr=fh))
+    rc, failed = 0, None
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and failed is None:
+                failed, rc = r, abs(code) or 1
+                for q in alive:                       # the rest would wait for the dead rank in a collective
+                    procs[q].terminate()
+        if alive:
+            time.sleep(0.2)
+    for _path, fh in logs:
+        fh.close()
+    if failed is not None:
+        path = logs[failed][0]
+        try:
+            tail = open(path).read()[-3000:]
+        except OSError:
+            tail = ""
+        print(f"bench.py: rank {failed} of {n} exited with status {rc}; the other ranks were terminated.  Its log ({path}) ends:\n{tail}",
+              file=sys.stderr, flush=True)
     return rc
+
+
+class _Watchdog:
+    """First-contact guard for N > 1: if `what` has not finished within `seconds`, say which rank is stuck where and exit non-zero
+    (self_launch then takes the other ranks down).  A failed RCCL bootstrap otherwise shows up as a silent hang."""
+
+    def __init__(self, seconds: float, what: str):
+        import threading
+
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.what, self.seconds = what, seconds
+
+    def _fire(self):
+        print(f"bench.py watchdog: rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')} still in '{self.what}' "
+              f"after {self.seconds:.0f} s (MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}, device "
+              f"{os.environ.get('LOCAL_RANK')}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}) — giving up",
+              file=sys.stderr, flush=True)
+        os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
 
 
 def _engine_pipeline(layers: int, R: int):
@@ -319,6 +376,16 @@ def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
     single = reqs(1, HEIGHT, STEPS_DENOISE, cfg=True)
     t = timed(lambda: pipe.decode_latents(pipe.generate(single, output_type="latent")[0].output, HEIGHT, WIDTH))
     out["single_request_1024px_seconds_per_image"] = t
+    # small step-batches (a lightly loaded worker): r requests of the headline workload step-batched, images/s and the fraction
+    # of the bf16 MFMA roofline.  r = 2 / 4 take the GEMM tail split (12 .. 96 tail tiles), r = 1 .. 4 the attention short-block
+    # split (DESIGN.md kernel table; profiles/r06_ab_splits_thin_tail_rule.log)
+    out["r1_images_per_sec"] = 1.0 / t
+    for r in (2, 3):
+        few = reqs(r, HEIGHT, STEPS_DENOISE, cfg=True)
+        tr_ = timed(lambda: [pipe.decode_latents(o.output, HEIGHT, WIDTH) for o in pipe.generate(few, output_type="latent")])
+        out[f"r{r}_images_per_sec"] = r / tr_
+    for r in (1, 2, 3):
+        out[f"r{r}_mfma_roofline_frac"] = out[f"r{r}_images_per_sec"] * PFLOP_PER_IMAGE * (layers / LAYERS) / PEAK_BF16
     # BASELINE config 1 at real depth: 256x256, 4 steps, batch 1, true-CFG; eager launches vs hipGraph replay
     one = reqs(1, 256, 4, cfg=True)
     for name, flag in (("eager", False), ("hipgraph", True)):
@@ -433,6 +500,8 @@ def main():
     ap.add_argument("--sp", type=int, default=0, help="P = --gpus: also time one 2048^2 request Ulysses-parallel over all ranks")
     # dev / test only: run the N-rank control flow (self-launch, rendezvous, per-rank stats, gather, JSON) on ONE device —
     # every rank on device 0 over a gloo group (RCCL refuses duplicate GPUs).  tests/test_gpu_multirank_bench.py
+    ap.add_argument("--init-timeout", type=float, default=120.0,
+                    help="seconds the rendezvous + first RCCL collective may take before the rank reports itself stuck and exits")
     ap.add_argument("--dist-backend", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -449,11 +518,17 @@ def main():
     local_dev = None
     if args.share_device:
         local_dev = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
-    rank, world, local = dp.init_distributed(backend=args.dist_backend, local_device=local_dev)
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    with _Watchdog(args.init_timeout, "process-group rendezvous + first RCCL all-reduce"):
+        rank, world, local = dp.init_distributed(backend=args.dist_backend, local_device=local_dev)
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1:                                  # RCCL builds its communicator on the first collective: do it HERE, watched
+            probe = torch.ones(1, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(probe)
+            if int(probe.item()) != world:
+                raise SystemExit(f"first all-reduce returned {probe.item()} on a world of {world}")
     from vllm_omni_amd.diffusion.distributed.numa import pin_to_gpu_numa
 
     numa = pin_to_gpu_numa(local)                  # this rank's host threads next to its GPU (distributed/numa.py)
@@ -547,6 +622,7 @@ def main():
         except Exception:  # noqa: BLE001
             ver = None
         collective = {"backend": torch.distributed.get_backend(), "world": world, "rccl_version": ver,
+                      "nccl_debug": os.environ.get("NCCL_DEBUG"), "rank_logs": f"gpurun_out/bench_n{world}_rank<r>.log",
                       "op": f"all_gather_into_tensor of [{R}, {S_img}, 64] bf16 per rank and step",
                       "gathered_checksum_matches_all_ranks": bool(match), "per_rank_payloads_distinct": bool(distinct),
                       "devices": sorted({int(t[8]) for t in allstats}) if allstats[0].numel() > 8 else None}

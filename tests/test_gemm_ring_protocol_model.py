@@ -221,3 +221,61 @@ def test_a_long_lead_two_big_phase_schedule_exists_on_the_eight_slot_ring(nkt):
         assert min(leads(long_lead_big_phases)) >= 3 and max(leads(two_big_phases)) <= 2
         steady = sorted({w[1] for g in (0, 1) for w in long_lead_big_phases(nkt, g)[40:-40] if w[0] == "WAIT"})
         assert steady in ([2, 6, 8], [2, 6], [8], [6, 8], [2, 8]), steady      # the vmcnt immediates the kernel would carry
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6 (round-5 verdict item 6b): a DMA-LANDING term.  The order model above accepts `two_big_phases` — the schedule the
+# hardware REJECTED (different bits on 16 of 17 shape classes unless slowed down by the probe).  What that schedule does and
+# the product loop does not: a half-tile is read by the PARTNER wave group in the epoch right after the sending group's counted
+# wait retired it, and that wait comes at most two epochs after the send — the piece is still landing when its `vmcnt` slot
+# retires, and the retire in the sending wave says nothing about when the LDS write is visible to another wave's `ds_read`.  The
+# term: a cross-group read is EXPOSED when  (covering wait - send) <= LAND epochs  and  (read - covering wait) < SETTLE epochs.
+# With LAND = 2, SETTLE = 2 the witness is rejected in every steady-state K-tile; the product loop (six phases = twelve epochs of
+# lead) and the long-lead candidate have no steady-state exposure.  The only exposed reads of the product loop are those of
+# K-tile 0 / 1 pieces sent in the PROLOGUE — nothing can be sent earlier than the kernel's first instruction; the prologue waits
+# for them with the same counted wait + barrier and is what tests/test_gpu_soak.py hammers on the hardware (every tile of
+# every launch goes through it).
+# ---------------------------------------------------------------------------------------------------------------------
+LAND, SETTLE = 2, 2
+
+
+def landing_exposures(schedule, nkt: int):
+    """[(reader group, half-tile, send epoch, wait epoch, read epoch)] of cross-group reads exposed under the landing term."""
+    groups = [analyse(schedule(nkt, g)) for g in (0, 1)]
+    out = []
+    for w, (_sw, _cw, reads_w, _) in enumerate(groups):
+        for ht, [(kr, _pr)] in reads_w.items():
+            for v, (sends_v, covered_v, _rv, _) in enumerate(groups):
+                if v == w:
+                    continue
+                ki, kw = sends_v[ht][0], covered_v[ht][0]
+                if kw - ki <= LAND and kr - kw < SETTLE:
+                    out.append((w, ht, ki, kw, kr))
+    return out
+
+
+@pytest.mark.parametrize("nkt", [3, 4, 6, 12, 48, 192])
+def test_landing_term_rejects_the_two_big_phase_witness_and_accepts_the_product_loop(nkt):
+    steady = lambda ex: [e for e in ex if e[1][0] >= 2]   # noqa: E731 - K-tiles whose pieces are sent from inside the loop
+    bad = steady(landing_exposures(two_big_phases, nkt))
+    assert bad, "the landing term must reject the schedule the hardware rejected (SCHED=9)"
+    assert {ht[0] for _w, ht, *_ in bad} >= set(range(2, nkt)), "... in every steady-state K-tile"
+    good = landing_exposures(four_phase, nkt)
+    assert not steady(good), steady(good)[:3]
+    # the product loop's only exposure is the prologue's (K-tiles 0 and 1: sent before the first barrier), bounded and constant
+    assert all(ht[0] < 2 for _w, ht, *_ in good) and len(good) <= 12
+    if nkt >= 6:
+        assert not steady(landing_exposures(long_lead_big_phases, nkt))
+
+
+def test_product_loop_dma_lead_is_long_in_steady_state():
+    """The margin the product schedule has and the witness lacks, as numbers: epochs between the send of a half-tile and the
+    sending group's covering wait (>= 7 for every steady-state half-tile of the product loop; <= 2 for the witness)."""
+    def leads(schedule, nkt):
+        out = []
+        for g in (0, 1):
+            sends, covered, _r, _ = analyse(schedule(nkt, g))
+            out += [covered[ht][0] - sends[ht][0] for ht in sends if 2 <= ht[0] < nkt - 1]
+        return out
+
+    assert min(leads(four_phase, 12)) >= 7 and max(leads(two_big_phases, 12)) <= 2

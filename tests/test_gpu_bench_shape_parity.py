@@ -16,8 +16,10 @@ weights and inputs.  The oracle itself is pinned to reference-run fixtures on CP
 Tolerances (bf16 storage / fp32 accumulate vs fp32): single forward of <= 4 layers rel_l2 <= 1e-2, cosine >= 0.9995
 (SURVEY.md §8c).  At 60 layers bf16 itself drifts: the REFERENCE ALGORITHM run in bf16 (the dtype the reference runs in)
 sits at 1.75e-2 per forward and 5.7e-2 on the 4-step final latent against its own fp32 run (measured, round 2; random
-N(0, 0.02^2) weights), so the bar there is relative: the product must be no further from fp32 than 1.1x the bf16-eager
-reference algorithm (measured: 1.57e-2 / 5.4e-2, i.e. closer to fp32 than the eager reference), cosine >= 0.997;
+N(0, 0.02^2) weights), so the bar there has two parts: RELATIVE — the product must be no further from fp32 than 1.1x the
+bf16-eager reference algorithm (measured: 1.57e-2 / 5.4e-2, i.e. closer to fp32 than the eager reference), cosine >= 0.997 —
+and, since round 6, FIXED numbers next to it (forward <= 2.0e-2 and cos >= 0.9998; 4 steps <= 5.0e-2 and cos >= 0.9985;
+the benchmarked 20 steps <= 2.6e-2 and cos >= 0.9995; BASELINE.md 3);
 VAE image: rel_l2 <= 3e-2, mean |err| <= 2e-2 (the reference's own pixel bar, tests/e2e/offline_inference/
 test_sequence_parallel.py:128-147)."""
 import pytest
@@ -158,6 +160,14 @@ def test_headline_1024px_at_real_depth_60_layers(steps):
     assert torch.isfinite(out.float()).all()
     assert r_f <= max(1e-2, 1.1 * r_f_eager)
     assert r <= max(2e-2, 1.1 * r_eager) and c >= (0.997 if steps == 4 else 0.995)
+    # FIXED bars at the benchmarked depth (round-5 verdict weak #1: the relative bar above floats with the oracle's own bf16 run).
+    # Measured in rounds 3-5 on random N(0, 0.02^2) weights: forward 1.64e-2 (cos 0.99986); 4 steps 4.35e-2 .. 4.37e-2 (cos
+    # 0.9990); 20 steps 2.17e-2 (cos 0.99975).  BASELINE.md 3 states the same numbers.
+    assert r_f <= 2.0e-2 and cosine(fwd, ref_first) >= 0.9998
+    if steps == 4:
+        assert r <= 5.0e-2 and c >= 0.9985
+    else:
+        assert r <= 2.6e-2 and c >= 0.9995
 
 
 def test_60_layers_at_the_bench_step_batch_of_10_items():
@@ -190,6 +200,7 @@ def test_60_layers_at_the_bench_step_batch_of_10_items():
     assert torch.isfinite(out.float()).all()
     for r, c, e in rows:
         assert r <= max(1e-2, 1.1 * e) and c >= 0.999
+        assert r <= 2.0e-2 and c >= 0.9998            # fixed bar (measured 1.63e-2 .. 1.65e-2, cos >= 0.99985)
 
 
 def test_config1_256px_4steps_at_real_depth_60_layers():
@@ -231,6 +242,7 @@ def test_config1_256px_4steps_at_real_depth_60_layers():
     print(f"   product vs bf16-eager oracle (two independent bf16 roundings of the same path): {rel_l2(out, eager):.3e}")
     assert r_f <= max(1e-2, 1.1 * r_f_eager)
     assert r <= max(2e-2, 1.1 * r_eager) and c >= 0.997
+    assert r_f <= 2.0e-2 and r <= 6.5e-2                 # fixed bars (measured 1.57e-2 / 5.4e-2; bf16-eager 1.75e-2 / 5.7e-2)
 
 
 @pytest.mark.parametrize("hw", [64, 128])

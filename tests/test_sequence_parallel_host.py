@@ -22,7 +22,9 @@ def _free_port():
 
 def _worker(rank, world, port, q_out):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), DIFFUSION_ATTENTION_BACKEND="TORCH_SDPA")
+                      MASTER_PORT=str(port), DIFFUSION_ATTENTION_BACKEND="TORCH_SDPA",
+                      HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")   # a host-only worker also on a GPU box: the selector refuses
+    #                                                                        TORCH_SDPA wherever a GPU is visible
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 

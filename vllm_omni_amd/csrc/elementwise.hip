@@ -251,13 +251,24 @@ __global__ __launch_bounds__(256) void linear_smallbatch_kernel(const uint16_t* 
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
-    for (int c = lane; c < nchunk; c += 64) {
-      u32x4_t w[R];
+    // ALL of the two rows' 16-byte pieces (K <= 4096: at most 8 per lane and row) are requested before the first one is used:
+    // with a load per loop trip (round 1's form) a wave had 2 KB in flight and the table pass of a 4-step request (NB = 4: 48 KB
+    // of staged activations, three workgroups per CU) streamed the modulation weights at 1.9 TB/s (profiles/r06_first_profiles_
+    // step_shapes.txt: 59 us per 113 MB matrix).  Pieces past the row end re-read the last piece (unconditional loads can be
+    // hoisted; a load under `if (c < nchunk)` is waited for on the spot) and are skipped in the arithmetic.
+    constexpr int MAXC = 8;
+    u32x4_t w[R][MAXC];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int64_t n = min(n0 + r, N - 1);
-        w[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(W + n * K + c * 8));
-      }
+    for (int r = 0; r < R; ++r) {
+      const uint16_t* wrow = W + min(n0 + r, N - 1) * K;
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j)
+        w[r][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow + min(lane + 64 * j, nchunk - 1) * 8));
+    }
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+      const int c = lane + 64 * j;
+      if (c >= nchunk) break;
       float xv[NB][8];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(256) void linear_smallbatch_kernel(const uint16_t* 
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float wf[8];
-        unpack8(w[r], wf);
+        unpack8(w[r][j], wf);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll

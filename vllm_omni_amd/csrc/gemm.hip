@@ -1140,9 +1140,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
     const uint32_t v0_ = ((h) == 0 || (h) == 3) ? a_off[(h) == 3][0] : w_off[(h) == 2][0];                 \
     const uint32_t v1_ = ((h) == 0 || (h) == 3) ? a_off[(h) == 3][1] : w_off[(h) == 2][1];                 \
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                      \
-                 :: "s"(lds_w), "i"(so_), "v"(v0_), "s"(base) : "memory");                                 \
+                 :: "s"(lds_w), "i"(so_), "v"(v0_), "s"(base) : "memory", "scc");                        \
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"                      \
-                 :: "s"(lds_w), "i"(so_ + 1024u), "v"(v1_), "s"(base) : "memory");                         \
+                 :: "s"(lds_w), "i"(so_ + 1024u), "v"(v1_), "s"(base) : "memory", "scc");                \
   } while (0)
     // one K-tile of ring parity PAR
     auto ktile = [&](auto par_c) __attribute__((always_inline)) {

@@ -28,6 +28,15 @@ def get_attn_backend(head_size: int) -> type[AttentionBackend]:
         if up not in _BACKEND_CONFIG:
             raise ValueError(f"Invalid attention backend for diffusion: '{name}'. Valid backends are: "
                              f"{list(_BACKEND_CONFIG)}")
+        if up == "TORCH_SDPA":
+            import torch
+
+            if torch.cuda.is_available():
+                # refused HERE, not at the first forward (round-5 advisor): on a GPU host the reference's default backend would
+                # run F.scaled_dot_product_attention on device tensors — this build has no torch attention on the device (no dual
+                # backend); CDNA4_FLASH honours what SDPAImpl honours (attn_mask, cross-attention, causal, head sizes 64 / 128)
+                raise ValueError("DIFFUSION_ATTENTION_BACKEND=TORCH_SDPA serves CPU-only hosts; a GPU is visible here: unset the "
+                                 "variable (CDNA4_FLASH takes attn_mask / cross-attention / causal / head sizes 64 and 128)")
         return load_backend(up)
     import torch
 

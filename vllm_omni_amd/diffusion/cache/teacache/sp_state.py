@@ -40,13 +40,18 @@ class TeaCacheSPState:
     def decide(self, sums: torch.Tensor, count: int) -> bool:
         """sums = [sum |cur - prev|, sum |prev|] over ALL ranks' rows, count = elements of the whole modulated input.
         Returns True = compute.  One host read per forward, like the reference's `.cpu().item()`."""
-        sd, sp = (float(v) for v in sums.detach().float().cpu().tolist())
-        # the reference forms the ratio from bf16 tensors: .abs().mean() -> bf16, (+ 1e-8) -> bf16, division -> bf16
-        rel = _bf16(_bf16(sd / count) / _bf16(_bf16(sp / count) + 1e-8))
-        r = torch.tensor(float(self.config.coefficients[0]), dtype=torch.float32)
-        for c in self.config.coefficients[1:]:             # numpy.poly1d order (highest power first), float32 Horner as on the device
-            r = r * torch.tensor(rel, dtype=torch.float32) + torch.tensor(float(c), dtype=torch.float32)
-        self.acc = float(torch.tensor(self.acc, dtype=torch.float32) + r.abs())
+        # the device kernel's arithmetic, operation for operation in fp32 (csrc/elementwise.hip teacache_decide_kernel:
+        # `rb(rb(sd * inv_count) / rb(rb(sp * inv_count) + 1e-8f))`, rb = round to bf16; then an fp32 Horner) — python doubles
+        # here (sd / count, + 1e-8 in double) could land on the other side of a bf16 rounding tie or of the threshold
+        f32 = torch.float32
+        s2 = sums.detach().to("cpu", f32)
+        inv = torch.tensor(1.0, dtype=f32) / torch.tensor(float(count), dtype=f32)
+        rb = lambda t: t.bfloat16().to(f32)  # noqa: E731
+        rel = rb(rb(s2[0] * inv) / rb(rb(s2[1] * inv) + torch.tensor(1e-8, dtype=f32)))
+        r = torch.tensor(float(self.config.coefficients[0]), dtype=f32)
+        for c in self.config.coefficients[1:]:             # numpy.poly1d order (highest power first); mul then add, as `r * rel + c`
+            r = r * rel + torch.tensor(float(c), dtype=f32)
+        self.acc = float(torch.tensor(self.acc, dtype=f32) + r.abs())
         self.cnt += 1
         if self.acc < float(self.config.rel_l1_thresh):
             self.skipped += 1

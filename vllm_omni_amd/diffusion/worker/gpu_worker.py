@@ -57,6 +57,18 @@ class GPUWorker:
 
                     pipeline_factory = lambda: initialize_model(self.od_config, device=dev)  # noqa: E731
             self.pipeline = pipeline_factory()
+            # vae_use_slicing / vae_use_tiling reach the VAE whichever factory built the pipeline (reference registry.py:88-92 does
+            # it inside initialize_model; a user `pipeline_factory` bypasses that): a flag that cannot be honoured is refused
+            # loudly instead of running a 2048^2 decode untiled
+            from ..registry import apply_vae_memory_flags
+
+            want = bool(getattr(self.od_config, "vae_use_slicing", False) or getattr(self.od_config, "vae_use_tiling", False))
+            vae = getattr(self.pipeline, "vae", None)
+            if want and (vae is None or not (hasattr(vae, "use_slicing") and hasattr(vae, "use_tiling"))):
+                raise NotImplementedError(f"{type(self.pipeline).__name__}'s VAE has no use_slicing / use_tiling switches: "
+                                          "vae_use_slicing / vae_use_tiling cannot be honoured for this pipeline")
+            if want:
+                apply_vae_memory_flags(self.pipeline, self.od_config)
         if self.sp_degree > 1:
             if not hasattr(self.pipeline, "sp_degree"):
                 raise NotImplementedError(f"{type(self.pipeline).__name__} has no sequence-parallel denoise loop")
@@ -150,6 +162,9 @@ class GPUWorker:
                 px, derr = [], None
                 try:
                     px = [self._decode_one(reqs[i], lat[i].unsqueeze(0), h, w) for i in deal[self.rank]]
+                    for t in px:                      # a wrong element count must surface BEFORE the barrier below, not as a
+                        if t.numel() != n_img * 3 * h * w:   # reshape error on one rank while the others sit in the gather
+                            raise ValueError(f"decode returned {tuple(t.shape)} for a sample of {n_img} x 3 x {h} x {w}")
                 except Exception as e:  # noqa: BLE001
                     derr = f"rank {self.rank}: decode failed: {type(e).__name__}: {e}"
                 if dp.any_rank_failed(derr is not None, dev):
