@@ -170,7 +170,7 @@ def measure_roofline(dev, R: int = 5) -> dict:
     # committed PMC measurement (tools/profile_round.sh -> tools/summarize_prof.py; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)
     traffic, traffic_src = None, None
     kname = "gemm_bf16_pp_kernel<OMNI_EPI_BIAS_GELU_TANH>"
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_roofline_traffic_pmc.json")) as fh:
                 j = json.load(fh)

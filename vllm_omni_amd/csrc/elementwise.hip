@@ -233,11 +233,31 @@ __global__ __launch_bounds__(256) void linear_smallbatch_kernel(const uint16_t* 
                                                                 int act_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xs = reinterpret_cast<float*>(smem);  // [NB][K]
-  for (int i = threadIdx.x; i < NB * K; i += 256) {
-    const int b = i / K, kk = i - b * K;
-    float v = bf16_bits_to_f32(x[(int64_t)b * ldx + kk]);
-    if (act_in == 1) v = silu_f(v);
-    xs[i] = v;
+  // staging: 16-byte pieces (8 activations) per thread and trip when the rows allow it.  The scalar form (one bf16 per thread
+  // and trip: 48 dependent trips at NB = 4, K = 3072) cost as much as streaming the block's weight rows — the block count is
+  // now sized so that a block streams at least three times the bytes it stages (host side).
+  if ((ldx % 8) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const int nch = K / 8;
+    for (int i = threadIdx.x; i < NB * nch; i += 256) {
+      const int b = i / nch, c = i - b * nch;
+      const u32x4_t w = *reinterpret_cast<const u32x4_t*>(x + (int64_t)b * ldx + c * 8);
+      float f[8];
+      unpack8(w, f);
+      if (act_in == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+      }
+      float* dst = xs + b * K + c * 8;
+      *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{f[0], f[1], f[2], f[3]};
+      *reinterpret_cast<f32x4_t*>(dst + 4) = f32x4_t{f[4], f[5], f[6], f[7]};
+    }
+  } else {
+    for (int i = threadIdx.x; i < NB * K; i += 256) {
+      const int b = i / K, kk = i - b * K;
+      float v = bf16_bits_to_f32(x[(int64_t)b * ldx + kk]);
+      if (act_in == 1) v = silu_f(v);
+      xs[i] = v;
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -685,9 +705,16 @@ extern "C" int omni_linear_smallbatch(const omni_bf16* x, int64_t ldx, int32_t B
   if (B > 8 || K % 8 || K > 4096) return OMNI_ERR_UNSUPPORTED;
   if (!omni_aligned16(W)) return OMNI_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // 2 weight rows per wave-iteration, 4 waves per block; cap the grid at 8 blocks/CU and grid-stride the rest
+  // 2 weight rows per wave-iteration, 4 waves per block.  Grid: as many blocks as fit on the chip AT ONCE (the staged activations
+  // take B * K * 4 bytes of LDS per block: 8 blocks per CU at B = 1, 3 at B = 4, 1 at B = 8), grid-striding over the rows — every
+  // block stages its activations once, so more blocks than resident slots only repeat the staging (round 6: the 4-row table pass
+  // ran 2048 blocks of 8 weight rows each, staging 48 KB to stream 48 KB: 1.9 TB/s)
+  const int cus = omni_num_cus();
+  const size_t lds_need = (size_t)B * K * sizeof(float);
+  int per_cu = (int)((160 * 1024) / (lds_need + 512));
+  per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
   int64_t blocks = (N + 7) / 8;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;
   const dim3 grid((unsigned)blocks), block(256);
 #define OMNI_LSB(NB)                                                                                              \
   do {                                                                                                            \

@@ -257,7 +257,7 @@ struct EpiFromPartials {
   int64_t split_stride;     // Mtot * N                                       |  256 * 256
   int64_t row_base;         // first row of this group inside the Mtot rows   |  0
   int nsplit;
-  int b_begin, b_end;       // row batches (64 rows each) of the tile this workgroup finishes
+  int b_begin, b_end;       // row batches (4 rows per thread x NT / 32 rows in flight: 64 rows at 512 threads, 32 at 256) this workgroup finishes
   int64_t row_stride;       // N                                              |  256
   int row0, col0;           // 0, 0                                           |  m0, n0 of the tile (partials are tile-local)
 };
@@ -347,10 +347,22 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
       if constexpr (FROM_PARTIALS) {
         const int64_t row = csrc.row_base + min(m0 + (b * BATCH + j) * RS + rsub, M - 1) - csrc.row0;
         const float* src = csrc.ws + row * csrc.row_stride + (n - csrc.col0);
+        // All of a row's partials (up to 8 splits x 32 B) are requested before the first add: one load per loop trip (round 2's
+        // form) left a thread with 32 B in flight, and the finish of a 6-way split at 640 rows x 3072 columns ran at 3.2 TB/s
+        // (14.6 us, profiles/r06_first_profiles_step_shapes.txt).  Splits past nsplit re-read the last one (unconditional loads
+        // can be hoisted) and are skipped in the sum; the order of the adds stays the split order (deterministic, as before).
         f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
-        for (int sp = 0; sp < csrc.nsplit; ++sp) {
-          lo += *reinterpret_cast<const f32x4_t*>(src + sp * csrc.split_stride);
-          hi += *reinterpret_cast<const f32x4_t*>(src + sp * csrc.split_stride + 4);
+        for (int sp0 = 0; sp0 < csrc.nsplit; sp0 += 8) {
+          f32x4_t pl[8], ph[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float* q = src + (int64_t)min(sp0 + u, csrc.nsplit - 1) * csrc.split_stride;
+            pl[u] = *reinterpret_cast<const f32x4_t*>(q);
+            ph[u] = *reinterpret_cast<const f32x4_t*>(q + 4);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (sp0 + u < csrc.nsplit) { lo += pl[u]; hi += ph[u]; }
         }
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         if (G.bias) {
@@ -1267,10 +1279,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 
 // Split-K finish: one workgroup per output tile (the same workgroup -> tile map as the ping-pong kernel), phase 2 of the
 // row-coalesced epilogue with C taken from the fp32 partials.
+// Round 6: EIGHT workgroups of 256 threads per tile (32 rows each) instead of four of 512: a 36-tile launch (one 256^2 CFG pair)
+// finishes on 288 workgroups instead of 144 — the finish is a latency-bound stream of fp32 partials and the chip has 256 CUs.
+constexpr int FIN_THREADS = 256, FIN_PER_TILE = 8;                // 8 rows in flight per pass x 4 per thread = 32 rows per workgroup
 template <int EPI>
-__global__ __launch_bounds__(NTHREADS) void gemm_splitk_finish_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
+__global__ __launch_bounds__(FIN_THREADS) void gemm_splitk_finish_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
                                                                        int tiles_n, int GROUP_M, int nsplit) {
-  const int bid = blockIdx.x >> 2, quarter = blockIdx.x & 3;      // four workgroups per tile: 64 rows (one row batch) each
+  const int bid = blockIdx.x / FIN_PER_TILE, quarter = blockIdx.x % FIN_PER_TILE;      // (`quarter`: the tile's 32-row slice)
   const int nwg = tiles_m * tiles_n;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
@@ -1285,18 +1300,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_splitk_finish_kernel(const omni
   const int m0 = (gi ? mt - mtiles0 : mt) * BM;
   const int n0 = nt * BN;
   if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;
-  if (m0 + quarter * 64 >= G.M) return;
+  if (m0 + quarter * (BM / FIN_PER_TILE) >= G.M) return;
   const int64_t mtot = P.g[0].M + (P.ngroups > 1 ? P.g[1].M : 0);
   const EpiFromPartials src = {P.splitk_ws, mtot * P.N, gi ? (int64_t)P.g[0].M : 0, nsplit, quarter, quarter + 1, P.N, 0, 0};
-  gemm_epilogue_lds_impl<EPI>(P, G, m0, n0, nullptr, (int)threadIdx.x, []() {}, src);
+  auto nothing = []() {};
+  gemm_epilogue_lds_impl<EPI, decltype(nothing), EpiFromPartials, FIN_THREADS>(P, G, m0, n0, nullptr, (int)threadIdx.x, nothing, src);
 }
 
 // Tail-split finish: the same epilogue over the tail tiles only (four workgroups of 64 rows per tile), C = the sum of the tile's
 // nsplit compact partials in split order.
 template <int EPI>
-__global__ __launch_bounds__(NTHREADS) void gemm_tail_finish_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
+__global__ __launch_bounds__(FIN_THREADS) void gemm_tail_finish_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
                                                                      int tiles_n, int GROUP_M, int nsplit, int tail_first) {
-  const int tl = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+  const int tl = blockIdx.x / FIN_PER_TILE, quarter = blockIdx.x % FIN_PER_TILE;
   const int bid = tail_first + tl;
   const int nwg = tiles_m * tiles_n;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
@@ -1312,9 +1328,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tail_finish_kernel(const omni_g
   const int m0 = (gi ? mt - mtiles0 : mt) * BM;
   const int n0 = nt * BN;
   if (G.tile_skip && G.tile_skip[gi ? mt - mtiles0 : mt]) return;
-  if (m0 + quarter * 64 >= G.M) return;
+  if (m0 + quarter * (BM / FIN_PER_TILE) >= G.M) return;
   const EpiFromPartials src = {P.splitk_ws + (int64_t)tl * nsplit * (BM * BN), BM * BN, 0, nsplit, quarter, quarter + 1, BN, m0, n0};
-  gemm_epilogue_lds_impl<EPI>(P, G, m0, n0, nullptr, (int)threadIdx.x, []() {}, src);
+  auto nothing = []() {};
+  gemm_epilogue_lds_impl<EPI, decltype(nothing), EpiFromPartials, FIN_THREADS>(P, G, m0, n0, nullptr, (int)threadIdx.x, nothing, src);
 }
 
 #ifdef OMNI_DEV
@@ -1529,14 +1546,14 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
       hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, 1>), dim3(tiles_m * tiles_n * nsplit), dim3(NTHREADS), RLDS_BYTES, s, *p,
                          mt0, tiles_m, tiles_n, gemm_group_m(), nsplit, 0);
       OMNI_CHECK_LAUNCH();
-      hipLaunchKernelGGL((gemm_splitk_finish_kernel<EPI>), dim3(tiles_m * tiles_n * 4), dim3(NTHREADS), 0, s, *p, mt0,
+      hipLaunchKernelGGL((gemm_splitk_finish_kernel<EPI>), dim3(tiles_m * tiles_n * FIN_PER_TILE), dim3(FIN_THREADS), 0, s, *p, mt0,
                          tiles_m, tiles_n, gemm_group_m(), nsplit);
     } else if (tail_ns > 1) {
       const int tt = tiles_m * tiles_n - tail_first;
       hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, 2>), dim3(tail_first + tt * tail_ns), dim3(NTHREADS), RLDS_BYTES, s, *p,
                          mt0, tiles_m, tiles_n, gemm_group_m(), tail_ns, tail_first);
       OMNI_CHECK_LAUNCH();
-      hipLaunchKernelGGL((gemm_tail_finish_kernel<EPI>), dim3(tt * 4), dim3(NTHREADS), 0, s, *p, mt0, tiles_m, tiles_n,
+      hipLaunchKernelGGL((gemm_tail_finish_kernel<EPI>), dim3(tt * FIN_PER_TILE), dim3(FIN_THREADS), 0, s, *p, mt0, tiles_m, tiles_n,
                          gemm_group_m(), tail_ns, tail_first);
     } else {
       hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), RLDS_BYTES, s, *p, mt0, tiles_m,
