@@ -500,7 +500,7 @@ def main():
     ap.add_argument("--sp", type=int, default=0, help="P = --gpus: also time one 2048^2 request Ulysses-parallel over all ranks")
     # dev / test only: run the N-rank control flow (self-launch, rendezvous, per-rank stats, gather, JSON) on ONE device —
     # every rank on device 0 over a gloo group (RCCL refuses duplicate GPUs).  tests/test_gpu_multirank_bench.py
-    ap.add_argument("--init-timeout", type=float, default=120.0,
+    ap.add_argument("--init-timeout", type=float, default=300.0,
                     help="seconds the rendezvous + first RCCL collective may take before the rank reports itself stuck and exits")
     ap.add_argument("--dist-backend", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)

@@ -953,3 +953,16 @@ def test_round5_advisor_fixes_host_side(monkeypatch):
     selector.get_attn_backend.cache_clear()
     assert selector.get_attn_backend(128).get_name() == "TORCH_SDPA"
     selector.get_attn_backend.cache_clear()
+
+
+def test_product_build_defines_no_tuning_macros():
+    """Round-5 verdict nit 14: the product translation units keep `#ifndef OMNI_*` tuning knobs for -DOMNI_DEV variant builds
+    (tools/build_variants.sh).  Their production values are the in-source defaults BY CONSTRUCTION: the product build passes no
+    -D flag at all (csrc/build.py FLAGS), and attention_w64.hip additionally static_asserts its eleven knobs in non-dev builds."""
+    from vllm_omni_amd.csrc import build as B
+
+    assert not [f for f in B.FLAGS if f.startswith("-D")], B.FLAGS
+    src = open(os.path.join(ROOT, "vllm_omni_amd", "csrc", "attention_w64.hip")).read()
+    knobs = set(re.findall(r"#ifndef (OMNI_W64_\w+)", src))
+    guard = src[src.index("#ifndef OMNI_DEV\n// The knobs above"):src.index("#endif", src.index("#ifndef OMNI_DEV\n// The knobs above"))]
+    assert knobs and all(k in guard for k in knobs), sorted(k for k in knobs if k not in guard)

@@ -22,5 +22,9 @@ for spec in "2048 1" "1024 1" "1024 2"; do
 done
 timeout 600 rocprofv3 --kernel-trace --stats -T -d $OUT/prof_${TAG}_final_config1 -o p -- python tools/run_config1.py 5 > /dev/null 2>&1
 python tools/time_config1.py 2>&1 | tail -1 > $OUT/${TAG}_config1_ms.txt
+OMNI_PROFILES_DIR=$OUT python tools/summarize_prof.py $OUT $TAG > $OUT/${TAG}_rocprof_summary_final.txt 2>&1
+# gpurun merges at most 64 MiB back: the counter and step databases are summarised above; only the bench trace travels
+rm -rf $OUT/pmc_${TAG}_* $OUT/prof_${TAG}_final_* 
+find $OUT -name "*.db" -size +45M -delete
 sha256sum vllm_omni_amd/libomni_cdna4.so | cut -c1-16 > $OUT/${TAG}_library_sha.txt
 tail -5 $OUT/${TAG}_pytest_gpu_full.log; head -c 1200 $OUT/${TAG}_bench_n1_default.json; echo; cat $OUT/${TAG}_step_table_2048px_R1.txt $OUT/${TAG}_config1_ms.txt

@@ -61,6 +61,7 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
            "note": "fabric-side bytes per launch = 2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE; "
                    "Infinity-Cache hits are included, so this bounds HBM traffic from above",
            "tcc_hit": vals.get("TCC_HIT_sum"), "tcc_miss": vals.get("TCC_MISS_sum")}
-    with open(f"profiles/{tag}_roofline_traffic_pmc.json", "w") as fh:
+    dst = os.path.join(os.environ.get("OMNI_PROFILES_DIR", "profiles"), f"{tag}_roofline_traffic_pmc.json")
+    with open(dst, "w") as fh:
         json.dump(out, fh, indent=1)
-    print("wrote", f"profiles/{tag}_roofline_traffic_pmc.json", out["traffic_bytes"] / 1e6, "MB")
+    print("wrote", dst, out["traffic_bytes"] / 1e6, "MB")

@@ -148,28 +148,69 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void flash_attn_general_kernel(const
     }
     // ---- scale, mask, online softmax.  register r of sub-block j <-> key t*64 + 32 j + (r & 3) + 8 (r >> 2) + 4 hi
     const int kv0 = t * GKV;
-    const bool edge = kv0 + GKV > k_len || P.causal || P.mask_type;
+    // which tiles need per-element work: the ragged last tile; with `causal` only the tiles that reach past this WAVE's smallest
+    // query index (everything before the diagonal is attended as it is); with a mask every tile
+    const bool tail = kv0 + GKV > k_len;
+    const bool diag = P.causal && kv0 + GKV - 1 > q0 + wave * 32;
     float mx = -INFINITY;
+    if (!(tail || diag || P.mask_type)) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float x = s[j][r] * sl2;
-        if (edge) {
-          const int key = kv0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          bool ok = key < k_len;
-          if (P.causal) ok = ok && key <= qi;
-          if (P.mask_type && key < k_len) {
-            const char* mp = mrow + (int64_t)key * P.mask_stride_k * msz;
-            if (P.mask_type == 1) ok = ok && *reinterpret_cast<const uint8_t*>(mp) != 0;
-            else if (P.mask_type == 2) x += bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(mp)) * 1.4426950408889634f;
-            else x += *reinterpret_cast<const float*>(mp) * 1.4426950408889634f;
-          }
-          if (!ok) x = -INFINITY;
+        for (int r = 0; r < 16; ++r) {
+          s[j][r] *= sl2;
+          mx = fmaxf(mx, s[j][r]);
         }
-        s[j][r] = x;
-        mx = fmaxf(mx, x);
-      }
+    } else {
+      // mask values of a lane's four CONSECUTIVE keys (r & 3) come in one load when the mask is contiguous along the keys and
+      // the address allows it (the usual cases: a [B, 1, 1, S_k] padding mask, a dense [.., S_q, S_k] bias); else one by one
+      const bool vec = P.mask_type && P.mask_stride_k == 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int kb = kv0 + j * 32 + 8 * rq + 4 * hi;                 // first of this lane's four consecutive keys
+          float add[4] = {0.f, 0.f, 0.f, 0.f};
+          bool ok[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ok[e] = kb + e < k_len && (!P.causal || kb + e <= qi);
+          if (P.mask_type && kb < k_len) {
+            const char* mp = mrow + (int64_t)kb * P.mask_stride_k * msz;
+            const bool whole = vec && kb + 3 < k_len && (reinterpret_cast<uintptr_t>(mp) & (4 * msz - 1)) == 0;
+            if (P.mask_type == 1) {
+              uint32_t w = 0;
+              if (whole) w = *reinterpret_cast<const uint32_t*>(mp);
+              else
+                for (int e = 0; e < 4; ++e)
+                  if (kb + e < k_len) w |= (uint32_t)(*reinterpret_cast<const uint8_t*>(mp + (int64_t)e * P.mask_stride_k) != 0) << (8 * e);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ok[e] = ok[e] && ((w >> (8 * e)) & 0xffu) != 0;
+            } else if (P.mask_type == 2) {
+              if (whole) {
+                const u32x2_t w = *reinterpret_cast<const u32x2_t*>(mp);
+                add[0] = bf16_lo(w[0]); add[1] = bf16_hi(w[0]); add[2] = bf16_lo(w[1]); add[3] = bf16_hi(w[1]);
+              } else {
+                for (int e = 0; e < 4; ++e)
+                  if (kb + e < k_len) add[e] = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(mp + (int64_t)e * P.mask_stride_k * 2));
+              }
+            } else {
+              if (whole) {
+                const f32x4_t w = *reinterpret_cast<const f32x4_t*>(mp);
+                add[0] = w[0]; add[1] = w[1]; add[2] = w[2]; add[3] = w[3];
+              } else {
+                for (int e = 0; e < 4; ++e)
+                  if (kb + e < k_len) add[e] = *reinterpret_cast<const float*>(mp + (int64_t)e * P.mask_stride_k * 4);
+              }
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = ok[e] ? s[j][rq * 4 + e] * sl2 + add[e] * 1.4426950408889634f : -INFINITY;
+            s[j][rq * 4 + e] = x;
+            mx = fmaxf(mx, x);
+          }
+        }
+    }
     mx = g_xhalf_max(mx);
     const float m_new = fmaxf(m_run, mx);
     const float m_use = m_new == -INFINITY ? 0.0f : m_new;   // nothing attendable so far: every p below is exp2(-inf) = 0

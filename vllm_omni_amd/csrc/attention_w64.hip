@@ -80,6 +80,14 @@ constexpr int A_O = 0, A_Q = 128, A_K = 192;
 #ifndef OMNI_W64_ABL
 #define OMNI_W64_ABL 0          // dev-only timing ablations (WRONG results): 1 no DMA, 2 no end-of-tile wait + barrier, 4 no exp,
 #endif                          // 8 no LDS fragment reads, 16 no row max, 32 no MFMA, 64 no K DMA pieces (V only), 128 no K fragment reads
+#ifndef OMNI_DEV
+// The knobs above exist for -DOMNI_DEV variant builds (tools/build_variants.sh).  A PRODUCT build must carry the measured
+// production values: anything else on the command line is a build error, not a silently different kernel (round-5 verdict nit 14).
+static_assert(OMNI_W64_P2SPLIT == 1 && OMNI_W64_KREAD_STEPS == 8 && OMNI_W64_DMA_STEP0 == 0 && OMNI_W64_HOISTV == 1 &&
+                  OMNI_W64_NEWDMA == 1 && OMNI_W64_FUSEDMAX == 1 && OMNI_W64_FINP2 == 1 && OMNI_W64_EARLYDEC == 1 &&
+                  OMNI_W64_XHALF_IN_P2 == 1 && OMNI_W64_IDLE_WAVES == 1 && OMNI_W64_ABL == 0,
+              "attention_w64.hip: tuning knobs differ from their production values in a product (non -DOMNI_DEV) build");
+#endif
 
 // LDS issue order of P2 (LDS operations return in order, so a counted lgkmcnt retires exactly the reads a step needs):
 //   VREAD(0) VREAD(1) VREAD(2) | step f: [wait] MFMAs, VREAD(f+3) (2 ops), KREADs of step f (16 / KREAD_STEPS ops, f < KREAD_STEPS)
