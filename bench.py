@@ -394,6 +394,14 @@ def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
         out[f"config1_256px_4step_{name}_ms_per_image"] = t * 1e3
     pipe.od_config.use_hip_graph = None
     out["config1_note"] = f"256x256, 4 steps, true-CFG (8 forwards of {layers} layers), batch 1, + VAE decode"
+    # BASELINE config 1 is weight-bandwidth bound on paper: its roofline is HBM.  Algorithmic bytes per image = the
+    # DiT weights once per RAGGED forward (the CFG pair shares one weight stream: 4 forwards x 40.86 GB at 60 layers, of which the
+    # 13.6 GB of modulation weights are read once per request by the table pass instead) — at 640 rows the layer is in fact as
+    # MFMA-bound as HBM-bound: the fraction below is against the HBM peak only.
+    gb = (4 * (40.86 - 13.6) + 13.6) * layers / LAYERS
+    t1 = out["config1_256px_4step_eager_ms_per_image"] * 1e-3
+    out["config1_hbm_roofline"] = {"bound": "hbm", "achieved": gb / t1, "peak": 8000.0, "unit": "GB/s", "frac": gb / t1 / 8000.0,
+                                   "algorithmic_gb_per_image": gb}
     # the same small requests step-batched: one weight stream (41 GB per forward) serves 16 requests
     many = reqs(16, 256, 4, cfg=True)
     pipe.od_config.max_step_batch = 16
