@@ -337,6 +337,45 @@ def engine_line(R: int, layers: int, static_images_per_sec: float, n_workers: in
         eng.close()
 
 
+def engine_line_guarded(R: int, layers: int, static_images_per_sec: float, n_workers: int, devices, dist_backend,
+                        timeout_s: float) -> dict:
+    """`engine_line` in a child interpreter of its own session, with a deadline.  The serving topology (one worker process per
+    GPU, their own process group) is first-contact code on a multi-GPU node: whatever it does — a hung rendezvous, a crashed
+    worker — must not take the headline line with it.  The child gets the torchrun / rank environment removed (it spawns its own
+    workers on a fresh port), prints the engine dict as one JSON line, and is killed with its whole process group (the workers)
+    when the deadline passes; its stderr goes to gpurun_out/bench_engine_n<N>.log."""
+    import signal
+    import subprocess
+
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+            "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE")
+    env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_")}
+    spec = json.dumps({"R": R, "layers": layers, "static": static_images_per_sec, "n_workers": n_workers, "devices": devices,
+                       "dist_backend": dist_backend})
+    logdir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(logdir, exist_ok=True)
+    path = os.path.join(logdir, f"bench_engine_n{n_workers}.log")
+    with open(path, "w") as fh:
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--engine-child", spec], env=env, stdout=subprocess.PIPE,
+                             stderr=fh, start_new_session=True, text=True)
+        try:
+            out, _ = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            p.wait()
+            return {"engine_error": f"no result within {timeout_s:.0f} s: the engine process group was killed ({path})"}
+    for ln in reversed(out.splitlines()):
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                break
+    return {"engine_error": f"engine child exited with status {p.returncode} and no result line ({path})"}
+
+
 def secondary_lines(pipe, dev, R: int, layers: int) -> dict:
     """SURVEY.md §8d secondary measurements on one GPU (rank 0, N = 1): no-CFG line and BASELINE config 1 eager vs graph."""
     from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
@@ -510,6 +549,9 @@ def main():
     # every rank on device 0 over a gloo group (RCCL refuses duplicate GPUs).  tests/test_gpu_multirank_bench.py
     ap.add_argument("--init-timeout", type=float, default=300.0,
                     help="seconds the rendezvous + first RCCL collective may take before the rank reports itself stuck and exits")
+    ap.add_argument("--engine-timeout", type=float, default=900.0,
+                    help="seconds the serving-path line (a child process group) may take before it is killed and reported as an error")
+    ap.add_argument("--engine-child", default=None, help=argparse.SUPPRESS)       # internal: engine_line_guarded's child
     ap.add_argument("--dist-backend", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -519,6 +561,15 @@ def main():
     from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
     from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
 
+    if args.engine_child:
+        spec = json.loads(args.engine_child)
+        try:
+            res = engine_line(spec["R"], spec["layers"], spec["static"], n_workers=spec["n_workers"], devices=spec["devices"],
+                              dist_backend=spec["dist_backend"])
+        except Exception as e:  # noqa: BLE001
+            res = {"engine_error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(res), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
     if not torch.cuda.is_available():
@@ -703,11 +754,8 @@ def main():
     if rank == 0:
         if run_engine:
             devices = [r % torch.cuda.device_count() for r in range(world)] if args.share_device else None
-            try:
-                line.setdefault("secondary", {}).update(engine_line(R, args.layers, value, n_workers=world, devices=devices,
-                                                                    dist_backend=args.dist_backend))
-            except Exception as e:  # noqa: BLE001
-                line.setdefault("secondary", {})["engine_error"] = f"{type(e).__name__}: {e}"
+            line.setdefault("secondary", {}).update(engine_line_guarded(R, args.layers, value, world, devices, args.dist_backend,
+                                                                        args.engine_timeout))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

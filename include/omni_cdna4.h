@@ -132,7 +132,8 @@ typedef struct {
    * few tiles that at least half of the CUs would idle (<= 128 tiles in <= 10 row tiles: a forward over one or two small images
    * streams its N = 3072 weight panels through 36 workgroups), the K loop is split s ways (s <= 8), the fp32 partial tiles go to
    * splitk_ws[s][M0 + M1][N] and a second kernel sums them in split order and runs the epilogue.  Needs
-   * s * (M0 + M1) * N <= splitk_ws_floats; results agree with the unsplit kernel to fp32 summation order. */
+   * s * (M0 + M1) * N <= splitk_ws_floats; results agree with the unsplit kernel to fp32 summation order
+   * (ABI v12: OMNI_GEMM_KERNEL_SPLITK_IN_LAUNCH below moves the reduction into the launch.) */
   float* splitk_ws;
   int64_t splitk_ws_floats;
   /* ABI v6 — kernel choice, normally 0 = automatic (the ping-pong kernel where its preconditions hold, else the ring kernel).
@@ -165,6 +166,16 @@ typedef struct {
  * kernel to fp32 summation order; WHICH tiles are tail tiles depends on the launch's tile count, i.e. on the batch composition —
  * a caller that compares results bit for bit across batch compositions passes OMNI_GEMM_KERNEL_NO_TAIL_SPLIT (or no workspace). */
 #define OMNI_GEMM_KERNEL_NO_TAIL_SPLIT 3
+/* ABI v12 — split-K (the ABI v4 rule) with the reduction INSIDE the launch, opt-in: needs 512 floats behind the partials
+ * (s * (M0 + M1) * N + 512 <= splitk_ws_floats) and the grid 8 * ceil(tiles / 8) * s within one round of the CUs, else the
+ * two-kernel path runs.  The s workgroups of a tile (all resident at once, placed on one XCD) publish their fp32 partials
+ * write-through, meet at an arrival counter and each runs the epilogue for its share of the tile's rows — no second kernel, the
+ * same bits (the sum is formed in split order by the same code).  The last 512 words of the workspace hold the counters: the
+ * call zeroes them on the stream before its launch and the launch leaves them zero; a wait that cannot complete (a device
+ * whose usable CUs are fewer than it reports) gives up after about a second, sets word 256 and returns wrong rows rather than
+ * hanging the device.  Measured on MI355X it pays only for 2-way splits on grids that nearly fill the chip (+1.1 .. 1.3 % per
+ * forward) and loses for deep splits: not the default. */
+#define OMNI_GEMM_KERNEL_SPLITK_IN_LAUNCH 4
 
 int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream);
 
@@ -206,6 +217,28 @@ int omni_adaln_modulate_fp8(const omni_bf16* x, int64_t ldx, int32_t rows, int32
                             const omni_bf16* shift, int64_t mod_item_stride, const int32_t* row_item_map,
                             int32_t rows_per_item, float eps, omni_bf16* y, int32_t y_k32_rows, uint8_t* y8,
                             int32_t y8_rows, float* y8_scale, omni_stream stream);
+
+/* ABI v12 — AdaLN-modulate of TWO row groups in ONE launch: the image stream's rows and the text stream's rows of a DiT block
+ * (reference qwen_image_transformer.py:564-567 and :590,:595 run `img_norm1` / `txt_norm1`, `img_norm2` / `txt_norm2` back to
+ * back).  Each group is what omni_adaln_modulate_ex / omni_adaln_modulate_fp8 take for one call — x row-major [rows, D] with
+ * row stride D; y (nullable when y8 is given) row-major with row stride D, or K32-blocked with y_k32_rows rows; y8 / y8_scale
+ * (nullable pair) the fp8 copy, K64-blocked with y8_rows rows — and gets the same bits; D, eps and the modulation stride are
+ * shared.  At small batches (one 256x256 CFG pair: 512 + 128 rows) the two launches are latency, not bandwidth. */
+typedef struct omni_adaln_stream {
+  const omni_bf16* x;
+  omni_bf16* y;
+  int32_t rows;
+  const omni_bf16* scale;
+  const omni_bf16* shift;
+  const int32_t* row_item_map;
+  int32_t rows_per_item;
+  int32_t y_k32_rows;
+  uint8_t* y8;
+  int32_t y8_rows;
+  float* y8_scale;
+} omni_adaln_stream;
+int omni_adaln_modulate_pair(const omni_adaln_stream* a, const omni_adaln_stream* b, int32_t D, int64_t mod_item_stride,
+                             float eps, omni_stream stream);
 
 /* RMSNorm over the last dim with learned weight: y = x * rsqrt(mean(x^2) + eps) * w.
  * Replaces vllm RMSNorm at qwen_image_transformer.py:758 (txt_norm, D = 3584).  D % 8 == 0, D <= 8192. */

@@ -69,6 +69,33 @@ def test_elementwise_entry_points_reject_bad_arguments(lib):
     args = list(f8)
     args[10], args[11] = P, 0                            # the optional bf16 copy must come with its blocked row count
     assert _call(lib, "omni_adaln_modulate_fp8", args) == BAD_ARG
+    # omni_adaln_modulate_pair(a, b, D, mod_item_stride, eps, stream) — ABI v12: two row groups (image / text stream) in one launch
+    from vllm_omni_amd import _native as N
+
+    def stream_rec(**kw):
+        r = N.AdalnStream(x=P, y=P, rows=128, scale=P, shift=P, row_item_map=P, rows_per_item=0, y_k32_rows=0, y8=None, y8_rows=0,
+                          y8_scale=None)
+        for k, v in kw.items():
+            setattr(r, k, v)
+        return r
+
+    def pair(a=None, b=None, D=3072, stride=6 * 3072):
+        a = stream_rec() if a is None else a
+        b = stream_rec(rows=64) if b is None else b
+        return lib.omni_adaln_modulate_pair(C.byref(a), C.byref(b), D, stride, 1e-6, None)
+
+    assert lib.omni_adaln_modulate_pair(None, C.byref(stream_rec()), 3072, 6 * 3072, 1e-6, None) == BAD_ARG
+    assert pair(D=0) == BAD_ARG and pair(a=stream_rec(x=None)) == BAD_ARG and pair(b=stream_rec(scale=None)) == BAD_ARG
+    assert pair(b=stream_rec(y=None)) == BAD_ARG                              # neither a bf16 nor an fp8 output
+    assert pair(a=stream_rec(row_item_map=None)) == BAD_ARG                  # rows cannot be attributed to items
+    assert pair(a=stream_rec(y_k32_rows=64)) == BAD_ARG                      # blocked rows < rows
+    assert pair(b=stream_rec(y8=P8, y8_rows=128)) == BAD_ARG                 # an fp8 copy without its scales
+    assert pair(b=stream_rec(y8=P8, y8_rows=128, y8_scale=P)) == BAD_ARG     # the bf16 copy beside an fp8 copy is K32-blocked
+    assert pair(D=3076) == UNSUPPORTED and pair(D=8200) == UNSUPPORTED
+    assert pair(a=stream_rec(y_k32_rows=128), D=3080) == UNSUPPORTED         # K32-blocked output: D % 32
+    assert pair(b=stream_rec(y=None, y8=P8, y8_rows=128, y8_scale=P), D=3104) == UNSUPPORTED   # fp8: D % 64
+    assert pair(a=stream_rec(x=P2)) == ALIGN and pair(b=stream_rec(shift=P8)) == ALIGN and pair(stride=6 * 3072 + 4) == ALIGN
+    assert pair(a=stream_rec(x=None), b=stream_rec(x=P2)) == BAD_ARG        # BAD_ARG of either group before ALIGN of the other
     # omni_rmsnorm(x, ldx, y, ldy, rows, D, weight, eps, stream)
     _mutations(lib, "omni_rmsnorm", [P, 3584, P, 3584, 64, 3584, P, 1e-6, None], [
         (6, None, BAD_ARG), (4, -1, BAD_ARG), (5, 3588, UNSUPPORTED), (6, P8, ALIGN), (3, 3585, ALIGN)])

@@ -98,6 +98,8 @@ int main(void) {
          offsetof(omni_dit_batch, rope_cos));
   printf("%zu %zu %zu %zu\\n", sizeof(omni_attn_params), offsetof(omni_attn_params, cu_seqlens_q),
          offsetof(omni_attn_params, mask), offsetof(omni_attn_params, mask_stride_k));
+  printf("%zu %zu %zu %zu\\n", sizeof(omni_adaln_stream), offsetof(omni_adaln_stream, scale),
+         offsetof(omni_adaln_stream, y8), offsetof(omni_adaln_stream, y8_scale));
   return 0;
 }
 ''')
@@ -110,7 +112,9 @@ int main(void) {
             N.TeaCache.prev_mod.offset, N.DitBatch.rope_cos.offset]
     attn = [ctypes.sizeof(N.AttnParams), N.AttnParams.cu_seqlens_q.offset, N.AttnParams.mask.offset,       # ABI v11
             N.AttnParams.mask_stride_k.offset]
-    assert [int(x) for x in out] == sizes + offs + attn
+    adaln = [ctypes.sizeof(N.AdalnStream), N.AdalnStream.scale.offset, N.AdalnStream.y8.offset,            # ABI v12
+             N.AdalnStream.y8_scale.offset]
+    assert [int(x) for x in out] == sizes + offs + attn + adaln
 
 
 def test_product_path_fails_loudly_without_gpu():
@@ -892,6 +896,31 @@ def test_bench_self_launch_reports_a_failing_rank_instead_of_hanging(tmp_path):
             "with bench._Watchdog(0.3, 'a test phase'):\n    time.sleep(5)\n" % ROOT)
     w = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert w.returncode == 3 and "still in 'a test phase'" in w.stderr
+
+
+def test_bench_engine_line_runs_in_a_guarded_child_process_group():
+    """The serving-path secondary line of bench.py runs in a child interpreter of its own session: a failure inside it comes back
+    as `engine_error` (here: no GPU, the worker refuses to start), a hang is cut at the deadline with the whole process group
+    killed — either way the caller gets a dict and goes on to print the headline line (first contact at N > 1)."""
+    import sys
+    import time
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    env0 = dict(os.environ)
+    os.environ.update(CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", RANK="0", WORLD_SIZE="2", MASTER_PORT="1")   # torchrun leftovers must not reach the child
+    try:
+        t0 = time.time()
+        got = bench.engine_line_guarded(1, 1, 1.0, 1, None, "gloo", timeout_s=240.0)
+        assert "engine_error" in got and "no result within" not in got["engine_error"], got
+        assert time.time() - t0 < 240
+        cut = bench.engine_line_guarded(1, 1, 1.0, 1, None, "gloo", timeout_s=0.05)
+        assert "no result within" in cut["engine_error"] and "killed" in cut["engine_error"]
+    finally:
+        os.environ.clear()
+        os.environ.update(env0)
+    assert os.path.exists(os.path.join(ROOT, "gpurun_out", "bench_engine_n1.log"))
 
 
 def test_round5_advisor_fixes_host_side(monkeypatch):

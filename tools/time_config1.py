@@ -7,6 +7,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools.devlib  # noqa: E402,F401
 from vllm_omni_amd.diffusion.data import OmniDiffusionConfig  # noqa: E402
 from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline  # noqa: E402
 from vllm_omni_amd.diffusion.request import OmniDiffusionRequest  # noqa: E402
@@ -29,4 +30,4 @@ t0 = time.perf_counter()
 for _ in range(5):
     f()
 torch.cuda.synchronize()
-print(f"{hw}x{hw}, 4 steps, true-CFG, batch 1: {(time.perf_counter() - t0) / 5 * 1e3:.1f} ms/image (OMNI_GEMM_SPLITK={os.environ.get('OMNI_GEMM_SPLITK', '1')})")
+print(f"{hw}x{hw}, 4 steps, true-CFG, batch 1: {(time.perf_counter() - t0) / 5 * 1e3:.1f} ms/image (OMNI_GEMM_SPLITK={os.environ.get('OMNI_GEMM_SPLITK', '1')} SPLITK_INLAUNCH={os.environ.get('OMNI_GEMM_SPLITK_INLAUNCH', '1')} ADALN_PAIR={os.environ.get('OMNI_DIT_ADALN_PAIR', '1')})")

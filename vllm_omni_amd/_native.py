@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomni_cdna4.so")   # fixed: dev sweeps assign this attribute (tools/devlib.py)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_bf16_p = C.c_void_p  # device pointer to uint16_t bf16 bits
 c_i32_p = C.c_void_p
@@ -46,6 +46,15 @@ class GemmParams(C.Structure):
         ("split_n", C.c_int32), ("w_k32_blocked", C.c_int32), ("g", GemmGroup * 2),
         ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_int64),          # ABI v4
         ("kernel_hint", C.c_int32), ("fp8", C.c_int32),                      # ABI v6: kernel_hint; v7: fp8 operands
+    ]
+
+
+class AdalnStream(C.Structure):
+    """omni_adaln_stream (ABI v12): one row group of omni_adaln_modulate_pair."""
+    _fields_ = [
+        ("x", c_bf16_p), ("y", c_bf16_p), ("rows", C.c_int32), ("scale", c_bf16_p), ("shift", c_bf16_p),
+        ("row_item_map", c_i32_p), ("rows_per_item", C.c_int32), ("y_k32_rows", C.c_int32),
+        ("y8", C.c_void_p), ("y8_rows", C.c_int32), ("y8_scale", C.c_void_p),
     ]
 
 
@@ -151,6 +160,8 @@ PROTOTYPES = {
     "omni_adaln_modulate_fp8": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, c_bf16_p, C.c_int64, c_i32_p,
                                           C.c_int32, C.c_float, c_bf16_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                           C.c_void_p]),
+    "omni_adaln_modulate_pair": (C.c_int, [C.POINTER(AdalnStream), C.POINTER(AdalnStream), C.c_int32, C.c_int64, C.c_float,
+                                           C.c_void_p]),                                                        # ABI v12
     "omni_rmsnorm": (C.c_int, [c_bf16_p, C.c_int64, c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, C.c_float,
                                C.c_void_p]),
     "omni_qk_norm_rope": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p,

@@ -121,6 +121,22 @@ enum BlockPhase { BLOCK_ALL = 0, BLOCK_QKV = 1, BLOCK_POST = 2 };
 // q/k/v buffers of the workspace, then stop; BLOCK_POST = from the output projections on, reading the attention output from
 // `attn_in` (ROW-MAJOR [n_joint_rows, D]) — the two halves a sequence-parallel caller runs around its all-to-alls
 // (reference attention/parallel/ulysses.py:59-135).  BLOCK_POST recomputes the block's modulation vectors (two GEMVs).
+// AdaLN of the two streams of a block: ONE launch (round 6, omni_adaln_modulate_pair).  A -DOMNI_DEV build can fall back to one
+// launch per stream (OMNI_DIT_ADALN_PAIR=0) for same-box A/B runs; the product has no switch.
+int adaln_streams(const omni_adaln_stream& si, const omni_adaln_stream& st, int32_t D, float eps, omni_stream stream) {
+  static const int pair = omni_dev_env_int("OMNI_DIT_ADALN_PAIR", 1);
+  if (pair) return omni_adaln_modulate_pair(&si, &st, D, 6 * (int64_t)D, eps, stream);
+  for (const omni_adaln_stream* g : {&si, &st}) {
+    if (g->y8)
+      OMNI_TRY(omni_adaln_modulate_fp8(g->x, D, g->rows, D, g->scale, g->shift, 6 * (int64_t)D, g->row_item_map, g->rows_per_item, eps,
+                                       g->y, g->y_k32_rows, g->y8, g->y8_rows, g->y8_scale, stream));
+    else
+      OMNI_TRY(omni_adaln_modulate_ex(g->x, D, g->y, D, g->rows, D, g->scale, g->shift, 6 * (int64_t)D, g->row_item_map,
+                                      g->rows_per_item, eps, g->y_k32_rows, stream));
+  }
+  return OMNI_OK;
+}
+
 template <typename Hook>
 int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const Workspace& ws, omni_bf16* hidden_img,
               omni_bf16* hidden_txt, const omni_bf16* temb, const BlockPred& pr, Hook&& after_img_norm1, omni_stream stream,
@@ -173,20 +189,21 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   if (phase != BLOCK_POST) {
   // norm1 + modulate (reference :564-567).  fp8 mode: the e4m3 copy + per-token scale come out of the same pass (the bf16
   // result is still written for the image stream when TeaCache reads it)
+  // Both streams in ONE launch (round 6, elementwise.hip rownorm_kernel PAIR; the TeaCache hook reads the image stream's
+  // result behind it).
   const bool fused_q = f_qkv && blk;
   if (fused_q) {
-    OMNI_TRY(omni_adaln_modulate_fp8(hidden_img, D, Ri, D, mod_img + D, mod_img, 6 * D, b->img_item, 0, eps,
-                                     b->teacache ? xn_img : nullptr, bRi, ws.x8, Ri, ws.x8_scale, stream));
-    OMNI_TRY(after_img_norm1(xn_img));
-    OMNI_TRY(omni_adaln_modulate_fp8(hidden_txt, D, Rt, D, mod_txt + D, mod_txt, 6 * D, b->txt_item, 0, eps, nullptr, 0,
-                                     ws.x8 + (int64_t)Ri * D, Rt, ws.x8_scale + Ri, stream));
+    const omni_adaln_stream si = {hidden_img, b->teacache ? xn_img : nullptr, Ri, mod_img + D, mod_img, b->img_item, 0,
+                                  b->teacache ? bRi : 0, ws.x8, Ri, ws.x8_scale};
+    const omni_adaln_stream st = {hidden_txt, nullptr, Rt, mod_txt + D, mod_txt, b->txt_item, 0, 0, ws.x8 + (int64_t)Ri * D,
+                                  Rt, ws.x8_scale + Ri};
+    OMNI_TRY(adaln_streams(si, st, D, eps, stream));
   } else {
-  OMNI_TRY(omni_adaln_modulate_ex(hidden_img, D, xn_img, D, Ri, D, mod_img + D, mod_img, 6 * D, b->img_item,
-                                  0, eps, bRi, stream));
-  OMNI_TRY(after_img_norm1(xn_img));
-  OMNI_TRY(omni_adaln_modulate_ex(hidden_txt, D, xn_txt, D, Rt, D, mod_txt + D, mod_txt, 6 * D, b->txt_item,
-                                  0, eps, bRt, stream));
+    const omni_adaln_stream si = {hidden_img, xn_img, Ri, mod_img + D, mod_img, b->img_item, 0, bRi, nullptr, 0, nullptr};
+    const omni_adaln_stream st = {hidden_txt, xn_txt, Rt, mod_txt + D, mod_txt, b->txt_item, 0, bRt, nullptr, 0, nullptr};
+    OMNI_TRY(adaln_streams(si, st, D, eps, stream));
   }
+  OMNI_TRY(after_img_norm1(xn_img));
   // fused QKV projections of both streams, scattered into the joint q/k/v (reference :380-394, :414-416)
   {
     omni_gemm_params p = {};
@@ -260,15 +277,17 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   // norm2 + modulate (reference :590, :595)
   const bool fused_q2 = f_up && blk;
   if (fused_q2) {
-    OMNI_TRY(omni_adaln_modulate_fp8(hidden_img, D, Ri, D, mod_img + 4 * D, mod_img + 3 * D, 6 * D, b->img_item, 0, eps,
-                                     nullptr, 0, ws.x8, Ri, ws.x8_scale, stream));
-    OMNI_TRY(omni_adaln_modulate_fp8(hidden_txt, D, Rt, D, mod_txt + 4 * D, mod_txt + 3 * D, 6 * D, b->txt_item, 0, eps,
-                                     nullptr, 0, ws.x8 + (int64_t)Ri * D, Rt, ws.x8_scale + Ri, stream));
+    const omni_adaln_stream si = {hidden_img, nullptr, Ri, mod_img + 4 * D, mod_img + 3 * D, b->img_item, 0, 0, ws.x8, Ri,
+                                  ws.x8_scale};
+    const omni_adaln_stream st = {hidden_txt, nullptr, Rt, mod_txt + 4 * D, mod_txt + 3 * D, b->txt_item, 0, 0,
+                                  ws.x8 + (int64_t)Ri * D, Rt, ws.x8_scale + Ri};
+    OMNI_TRY(adaln_streams(si, st, D, eps, stream));
   } else {
-  OMNI_TRY(omni_adaln_modulate_ex(hidden_img, D, xn_img, D, Ri, D, mod_img + 4 * D, mod_img + 3 * D, 6 * D,
-                                  b->img_item, 0, eps, bRi, stream));
-  OMNI_TRY(omni_adaln_modulate_ex(hidden_txt, D, xn_txt, D, Rt, D, mod_txt + 4 * D, mod_txt + 3 * D, 6 * D,
-                                  b->txt_item, 0, eps, bRt, stream));
+    const omni_adaln_stream si = {hidden_img, xn_img, Ri, mod_img + 4 * D, mod_img + 3 * D, b->img_item, 0, bRi, nullptr, 0,
+                                  nullptr};
+    const omni_adaln_stream st = {hidden_txt, xn_txt, Rt, mod_txt + 4 * D, mod_txt + 3 * D, b->txt_item, 0, bRt, nullptr, 0,
+                                  nullptr};
+    OMNI_TRY(adaln_streams(si, st, D, eps, stream));
   }
   // MLP up + GELU-tanh (reference :591, :596 -> diffusers FeedForward)
   {
@@ -319,7 +338,7 @@ int prepare_positions(const omni_dit_batch* b, const Workspace& ws, omni_stream 
 }
 }  // namespace
 
-extern "C" int omni_abi_version(void) { return 11; }
+extern "C" int omni_abi_version(void) { return 12; }
 extern "C" const char* omni_build_arch(void) { return "gfx950"; }
 extern "C" const char* omni_status_string(int status) {
   switch (status) {

@@ -31,16 +31,33 @@ OMNI_DEVINL uint32_t cvt_pk_fp8x4(float a, float b, float c, float d) {
 // bytes/row = 2*D (read) + 2*D (write) + modulation vectors (L2-resident).
 // MODE 0: y = LN(x)*(1+scale)+shift    MODE 1: y = x*rsqrt(mean(x^2)+eps)*w
 // ------------------------------------------------------------------------------------------------
-template <int NCH, int MODE>
+// PAIR (round 6): ONE launch over two row groups that share D / ld / eps / the modulation stride — the image stream's rows and,
+// behind them, the text stream's (`g2`).  A DiT block runs AdaLN on both streams back to back; at small batches (one 256^2 CFG
+// pair: 512 + 128 rows) each launch is ~5 us of latency plus its boundary, four times per block.  One wave still owns one row:
+// the group is a wave-uniform select of the pointers.
+struct RowNormGroup {
+  const uint16_t* x; uint16_t* y; const uint16_t* scale; const uint16_t* shift; const int32_t* row_item_map;
+  uint8_t* y8; float* y8_scale; int rows, rows_per_item, y_k32_rows, y8_rows;
+};
+template <int NCH, int MODE, bool PAIR = false>
 __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                       uint16_t* __restrict__ y, int64_t ldy, int rows, int D,
                                                       const uint16_t* __restrict__ scale_or_w,
                                                       const uint16_t* __restrict__ shift, int64_t item_stride,
                                                       const int32_t* __restrict__ row_item_map, int rows_per_item,
-                                                      float eps, int y_k32_rows, uint8_t* __restrict__ y8 = nullptr,
-                                                      int y8_rows = 0, float* __restrict__ y8_scale = nullptr) {
+                                                      float eps, int y_k32_rows, uint8_t* __restrict__ y8,
+                                                      int y8_rows, float* __restrict__ y8_scale, const RowNormGroup g2) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if constexpr (PAIR) {
+    row = __builtin_amdgcn_readfirstlane(row);
+    if (row >= rows) {                                 // a row of the second group (uniform over the wave)
+      row -= rows;
+      x = g2.x; y = g2.y; scale_or_w = g2.scale; shift = g2.shift; row_item_map = g2.row_item_map;
+      y8 = g2.y8; y8_scale = g2.y8_scale; rows = g2.rows; rows_per_item = g2.rows_per_item; y_k32_rows = g2.y_k32_rows;
+      y8_rows = g2.y8_rows;
+    }
+  }
   if (row >= rows) return;
   const uint16_t* xr = x + (int64_t)row * ldx;
   // ALL of the row's loads are issued before the first value is used (round 4: with the load inside `if (e < D) { load; use }`
@@ -153,7 +170,28 @@ int launch_rownorm(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, i
   const dim3 grid((rows + 3) / 4), block(256);
 #define OMNI_RN(N)                                                                                            \
   hipLaunchKernelGGL((rownorm_kernel<N, MODE>), grid, block, 0, s, x, ldx, y, ldy, rows, D, a, b, stride, map, \
-                     rpi, eps, y_k32_rows, y8, y8_rows, y8_scale)
+                     rpi, eps, y_k32_rows, y8, y8_rows, y8_scale, RowNormGroup{})
+  if (nch <= 1) OMNI_RN(1);
+  else if (nch <= 2) OMNI_RN(2);
+  else if (nch <= 4) OMNI_RN(4);
+  else if (nch <= 6) OMNI_RN(6);
+  else if (nch <= 8) OMNI_RN(8);
+  else if (nch <= 16) OMNI_RN(16);
+  else return OMNI_ERR_UNSUPPORTED;
+#undef OMNI_RN
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+// AdaLN over two row groups in one launch (see rownorm_kernel PAIR)
+int launch_adaln_pair(const omni_adaln_stream& a, const omni_adaln_stream& b, int D, int64_t stride, float eps, hipStream_t s) {
+  const int nch = (D + 511) / 512;
+  const dim3 grid((a.rows + b.rows + 3) / 4), block(256);
+  const RowNormGroup g2 = {b.x, b.y, b.scale, b.shift, b.row_item_map, b.y8, b.y8_scale, b.rows, b.rows_per_item,
+                           b.y_k32_rows, b.y8_rows};
+#define OMNI_RN(N)                                                                                                      \
+  hipLaunchKernelGGL((rownorm_kernel<N, 0, true>), grid, block, 0, s, a.x, (int64_t)D, a.y, (int64_t)D, a.rows, D, a.scale,   \
+                     a.shift, stride, a.row_item_map, a.rows_per_item, eps, a.y_k32_rows, a.y8, a.y8_rows, a.y8_scale, g2)
   if (nch <= 1) OMNI_RN(1);
   else if (nch <= 2) OMNI_RN(2);
   else if (nch <= 4) OMNI_RN(4);
@@ -656,6 +694,27 @@ extern "C" int omni_adaln_modulate(const omni_bf16* x, int64_t ldx, omni_bf16* y
                                    float eps, omni_stream stream) {
   return omni_adaln_modulate_ex(x, ldx, y, ldy, rows, D, scale, shift, mod_item_stride, row_item_map, rows_per_item,
                                 eps, 0, stream);
+}
+
+// AdaLN of the image stream and the text stream in ONE launch (ABI v12).  Both streams are row-major [rows, D] (ld = D) with
+// the same modulation stride; per stream the bf16 result (row-major or K32-blocked) and / or the fp8 copy + per-row scales,
+// exactly as omni_adaln_modulate_ex / omni_adaln_modulate_fp8 produce them (same kernel body, same bits).
+extern "C" int omni_adaln_modulate_pair(const omni_adaln_stream* a, const omni_adaln_stream* b, int32_t D, int64_t mod_item_stride,
+                                        float eps, omni_stream stream) {
+  if (!a || !b || D <= 0) return OMNI_ERR_BAD_ARG;
+  for (const omni_adaln_stream* g : {a, b}) {
+    if (!g->x || (!g->y && !g->y8) || !g->scale || !g->shift || g->rows <= 0) return OMNI_ERR_BAD_ARG;
+    if (!g->row_item_map && g->rows_per_item <= 0) return OMNI_ERR_BAD_ARG;
+    if (g->y_k32_rows < 0 || (g->y_k32_rows > 0 && g->y_k32_rows < g->rows)) return OMNI_ERR_BAD_ARG;
+    if (g->y8 && (!g->y8_scale || g->y8_rows < g->rows || (g->y && g->y_k32_rows <= 0))) return OMNI_ERR_BAD_ARG;
+  }
+  for (const omni_adaln_stream* g : {a, b})
+    if (D % 8 || D > 8192 || (g->y_k32_rows && D % 32) || (g->y8 && D % 64)) return OMNI_ERR_UNSUPPORTED;
+  for (const omni_adaln_stream* g : {a, b})
+    if (!omni_aligned16(g->x) || (g->y && !omni_aligned16(g->y)) || !omni_aligned16(g->scale) || !omni_aligned16(g->shift) ||
+        (g->y8 && (reinterpret_cast<uintptr_t>(g->y8) & 7)) || (mod_item_stride % 8))
+      return OMNI_ERR_ALIGN;
+  return launch_adaln_pair(*a, *b, D, mod_item_stride, eps, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int omni_rmsnorm(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows, int32_t D,

@@ -262,7 +262,7 @@ struct EpiFromPartials {
   int row0, col0;           // 0, 0                                           |  m0, n0 of the tile (partials are tile-local)
 };
 
-template <int EPI, typename WriteTile, typename CSrc = EpiFromLds, int NT = NTHREADS>
+template <int EPI, typename WriteTile, typename CSrc = EpiFromLds, int NT = NTHREADS, int BATCH_ = 4>
 OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_gemm_group& G, int m0, int n0, char* smem,
                                         int tid, WriteTile write_tile, CSrc csrc = CSrc{}) {
   constexpr bool FROM_PARTIALS = std::is_same<CSrc, EpiFromPartials>::value;
@@ -272,7 +272,7 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
   // in a ROLLED loop: fully unrolled, hipcc hoists all 16 rows' 64-bit addresses and predicates above phase 1, where
   // they are live together with the 128 accumulator registers and spill.
   constexpr int RS = NT / 32;              // rows in flight per pass: a row is written by 32 threads (16 B each)
-  constexpr int BATCH = 4, NBATCH = BM / RS / BATCH;
+  constexpr int BATCH = BATCH_, NBATCH = BM / RS / BATCH;
   constexpr bool SPLIT = EPI == OMNI_EPI_BIAS_SPLIT3 || EPI == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE;
   constexpr bool QKROPE = EPI == OMNI_EPI_BIAS_SPLIT3_QKNORM_ROPE;
   struct RowIdx { int ro[BATCH], im[BATCH], ps[BATCH]; };
@@ -949,6 +949,19 @@ constexpr int PLDS_BYTES = 8 * PSLOT_BYTES;   // 128 KiB ring
 // tail_first + (tile - tail_first) * nsplit + split, dispatched last, fp32 partials in a tile-compact workspace
 // splitk_ws[tile - tail_first][split][256][256], epilogue in gemm_tail_finish_kernel.  The thin round then costs ~1 / nsplit of a
 // tile time instead of a whole one.
+// SPLITK == 3 (round 6): whole-launch split-K as SPLITK == 1, reduced INSIDE the launch (no finish kernel, no second pass of
+// the partials through a launch boundary).  Every workgroup of the grid is resident at once (host: grid <= CUs, one workgroup
+// per CU), so the nsplit workgroups of a tile can wait for each other: each stores its fp32 partial WRITE-THROUGH (sc1: the
+// bytes leave the XCD's L2 at once, no release fence — cdna_hip_programming.md 6 Guideline 16 "publish-large"), drains its stores,
+// takes a ticket on the tile's arrival counter (relaxed, agent scope), polls it (one lane, relaxed) until all nsplit
+// tickets are drawn, takes ONE agent-scope acquire and then runs the usual epilogue from the partials over ITS share of the
+// tile's rows — a reduce-scatter: nobody reads more than one tile's worth of partials, and the sum is formed in split order by
+// the same code as the finish kernel's (bit-identical results).  The nsplit workgroups of a tile are placed on ONE XCD (block
+// b runs on XCD b % 8): b -> (xcd = b & 7, j = b >> 3), tile = (j / nsplit) * 8 + xcd, split = j % nsplit; the grid is padded to
+// 8 * ceil(tiles / 8) * nsplit blocks and the pad blocks return at once.  Counters: two int32 per tile (arrivals, departures) at
+// the end of the workspace, zero before the launch and zero after it (the last workgroup to leave a tile resets both).
+constexpr int SPLITK_CNT_INTS = 512;              // [0,128) arrivals, [128,256) departures, [256] sticky "a wait timed out" flag
+constexpr int SPLITK_FBATCH = 2;                  // rows per thread and pipeline stage of the in-launch finish: 8 batches of 32 rows per tile
 template <int EPI, int SPLITK = 0, int FP8 = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
                                                                      int tiles_n, int GROUP_M, int nsplit, int tail_first) {
@@ -957,10 +970,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = tiles_m * tiles_n;
+  constexpr bool WHOLE = SPLITK == 1 || SPLITK == 3;                         // every tile of the launch is split
   const bool tail = SPLITK == 2 && (int)blockIdx.x >= tail_first;          // uniform over the workgroup
-  const int split = SPLITK == 1 ? (int)blockIdx.x % nsplit : (tail ? ((int)blockIdx.x - tail_first) % nsplit : 0);
-  const int bid = SPLITK == 1 ? (int)blockIdx.x / nsplit : (tail ? tail_first + ((int)blockIdx.x - tail_first) / nsplit : (int)blockIdx.x);
-  const bool partial = SPLITK == 1 || tail;                                // this workgroup leaves an fp32 partial tile
+  const int split = SPLITK == 1 ? (int)blockIdx.x % nsplit
+                    : SPLITK == 3 ? ((int)blockIdx.x >> 3) % nsplit
+                                  : (tail ? ((int)blockIdx.x - tail_first) % nsplit : 0);
+  const int bid = SPLITK == 1 ? (int)blockIdx.x / nsplit
+                  : SPLITK == 3 ? (((int)blockIdx.x >> 3) / nsplit) * 8 + ((int)blockIdx.x & 7)
+                                : (tail ? tail_first + ((int)blockIdx.x - tail_first) / nsplit : (int)blockIdx.x);
+  if (SPLITK == 3 && bid >= nwg) return;                                   // a pad block of the XCD-aligned grid
+  const bool partial = WHOLE || tail;                                      // this workgroup leaves an fp32 partial tile
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   const int band_sz = GROUP_M * tiles_n;
@@ -1003,8 +1022,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   // K-tiles of this workgroup: all of them; an nsplit-th (whole-launch split-K: nsplit divides the count); tail split: the
   // split-th of nsplit near-equal contiguous ranges
   const int nkt_all = K / PBK;
-  const int kt0 = SPLITK == 1 ? split * (nkt_all / nsplit) : (tail ? (int)((long)split * nkt_all / nsplit) : 0);
-  const int nkt = SPLITK == 1 ? nkt_all / nsplit : (tail ? (int)((long)(split + 1) * nkt_all / nsplit) - kt0 : nkt_all);
+  const int kt0 = WHOLE ? split * (nkt_all / nsplit) : (tail ? (int)((long)split * nkt_all / nsplit) : 0);
+  const int nkt = WHOLE ? nkt_all / nsplit : (tail ? (int)((long)(split + 1) * nkt_all / nsplit) - kt0 : nkt_all);
   const char* const Ab = reinterpret_cast<const char*>(G.A) + (SPLITK ? (int64_t)kt0 * astep : 0);
   const char* const Wb = reinterpret_cast<const char*>(G.W) + (SPLITK ? (int64_t)kt0 * wstep : 0);
   // piece i (0 / 1) of half-tile h (compile time) of K-tile `tile`
@@ -1229,6 +1248,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
         if (tail_cols > nb * 16) *reinterpret_cast<f32x4_t*>(tail_wsp + mb * 16 * BN + nb * 16) = acc[nb][mb];
+    }
+    return;
+  }
+  if constexpr (SPLITK == 3) {
+    const int64_t mtot = P.g[0].M + (P.ngroups > 1 ? P.g[1].M : 0);
+    float* const wsp = P.splitk_ws + ((int64_t)split * mtot + (gi ? P.g[0].M : 0)) * N;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const int row = m0 + wm * 128 + mb * 16 + l15;
+      if (row >= M) continue;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int col = n0 + wn * 64 + nb * 16 + g4 * 4;
+        float* dst = wsp + (int64_t)row * N + col;
+        if (col < N) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(acc[nb][mb]) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave drains its write-through stores
+    __syncthreads();
+    int* const cnt = reinterpret_cast<int*>(P.splitk_ws + P.splitk_ws_floats) - SPLITK_CNT_INTS;
+    if (tid == 0) __hip_atomic_fetch_add(cnt + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // this workgroup's share of the tile's LIVE 32-row batches (a text tile may hold fewer than 256 rows)
+    constexpr int RS3 = NTHREADS / 32 * SPLITK_FBATCH;          // 32 rows per batch
+    const int live = (min(BM, M - m0) + RS3 - 1) / RS3;
+    const int b0 = split * live / nsplit, b1 = (split + 1) * live / nsplit;
+    if (b1 > b0) {
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(cnt + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsplit) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1 << 22)) {                            // ~ a second: never on a healthy launch; do not hang the device
+            __hip_atomic_store(cnt + 256, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE acquire (drops this CU's stale L1 lines), then plain loads
+      }
+      __syncthreads();
+      const EpiFromPartials src = {P.splitk_ws, mtot * N, gi ? (int64_t)P.g[0].M : 0, nsplit, b0, b1, N, 0, 0};
+      auto nothing = []() {};
+      gemm_epilogue_lds_impl<EPI, decltype(nothing), EpiFromPartials, NTHREADS, SPLITK_FBATCH>(P, G, m0, n0, nullptr, tid, nothing, src);
+    }
+    if (tid == 0) {                                             // (behind this workgroup's own wait, if it had one)
+      const int d = __hip_atomic_fetch_add(cnt + 128 + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == nsplit - 1) {                                    // the last to leave: everyone is past the poll
+        __hip_atomic_store(cnt + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + 128 + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     return;
   }
@@ -1486,6 +1553,26 @@ int tail_split_factor(const omni_gemm_params* p, int tiles, int* tail_first) {
   return ns;
 }
 
+// In-launch reduce of a whole-launch split-K (gemm_bf16_pp_kernel SPLITK == 3): OPT-IN (omni_gemm_params.kernel_hint =
+// OMNI_GEMM_KERNEL_SPLITK_IN_LAUNCH).  Needs the XCD-aligned grid within one round of the CUs (all of a tile's workgroups resident
+// together), at most 128 tiles and room for the counters behind the partials; otherwise the two-kernel path runs.
+// MEASURED, same box, whole 60-layer forwards (profiles/r06b_ab_inlaunch_by_factor.log, r06b_ab_smallm.log): it is NOT the
+// default because it does not pay where the split is deep — one 256^2 CFG pair (36 tiles x 6: +2.5 .. +3.8 % per forward,
+// config 1 +3 %): a workgroup exchanges partials with its peers at the per-block rate of the fabric (~65 GB/s, 256 .. 393 KB
+// each way), which takes as long as the 288-workgroup finish kernel it replaces, and the early finishers idle.  Where the
+// split is 2-way and the grid nearly fills the chip it gains 1.1 .. 1.3 % (one 512^2 request, four 256^2 requests: 120 tiles x
+// 2); at 60 tiles x 2 (two 256^2 requests) it loses 3.5 % (120 workgroups finishing 128 rows each against 480 finish
+// workgroups).
+bool splitk_in_launch_ok(const omni_gemm_params* p, int tiles, int nsplit) {
+  if (p->kernel_hint != OMNI_GEMM_KERNEL_SPLITK_IN_LAUNCH &&
+      omni_dev_env_int("OMNI_GEMM_SPLITK_INLAUNCH", 0) < nsplit)           // dev knob (-DOMNI_DEV builds only): largest nsplit taken
+    return false;
+  if (tiles > 128) return false;
+  const int64_t mtot = p->g[0].M + (p->ngroups > 1 ? p->g[1].M : 0);
+  if ((int64_t)nsplit * mtot * p->N + SPLITK_CNT_INTS > p->splitk_ws_floats) return false;
+  return ((tiles + 7) / 8) * 8 * nsplit <= gemm_num_cus();
+}
+
 template <int EPI>
 int launch(const omni_gemm_params* p, hipStream_t s) {
   const int mt0 = (p->g[0].M + BM - 1) / BM;
@@ -1507,6 +1594,8 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI, 3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp_kernel<EPI, 0, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess)
@@ -1542,7 +1631,13 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
     const int nsplit = splitk_factor(p, tiles_m, tiles_n);
     int tail_first = 0;
     const int tail_ns = nsplit > 1 ? 1 : tail_split_factor(p, tiles_m * tiles_n, &tail_first);
-    if (nsplit > 1) {
+    if (nsplit > 1 && splitk_in_launch_ok(p, tiles_m * tiles_n, nsplit)) {
+      // counters: zeroed on the stream before the launch (a memset node under capture), left zero by the launch
+      int* cnt = reinterpret_cast<int*>(p->splitk_ws + p->splitk_ws_floats) - SPLITK_CNT_INTS;
+      if (hipMemsetAsync(cnt, 0, SPLITK_CNT_INTS * sizeof(int), s) != hipSuccess) return OMNI_ERR_LAUNCH;
+      hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, 3>), dim3(((tiles_m * tiles_n + 7) / 8) * 8 * nsplit), dim3(NTHREADS),
+                         RLDS_BYTES, s, *p, mt0, tiles_m, tiles_n, gemm_group_m(), nsplit, 0);
+    } else if (nsplit > 1) {
       hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, 1>), dim3(tiles_m * tiles_n * nsplit), dim3(NTHREADS), RLDS_BYTES, s, *p,
                          mt0, tiles_m, tiles_n, gemm_group_m(), nsplit, 0);
       OMNI_CHECK_LAUNCH();

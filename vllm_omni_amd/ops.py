@@ -58,6 +58,7 @@ class GemmGroupArgs:
 
 
 GEMM_KERNEL_AUTO, GEMM_KERNEL_RING, GEMM_KERNEL_SPLITK_TALL, GEMM_KERNEL_NO_TAIL_SPLIT = 0, 1, 2, 3      # omni_gemm_params.kernel_hint
+GEMM_KERNEL_SPLITK_IN_LAUNCH = 4                                                                      # ABI v12
 
 
 def w_to_k32_blocked(w: torch.Tensor) -> torch.Tensor:
@@ -182,6 +183,36 @@ def adaln_modulate(x, scale, shift, *, mod_item_stride: int, row_item_map=None, 
                                            y.shape[0] if out_k32_blocked else 0, _stream()),
             "omni_adaln_modulate_ex")
     return y
+
+
+def adaln_modulate_pair(streams, *, mod_item_stride: int, eps: float = 1e-6, out_k32_blocked: bool = False, fp8: bool = False,
+                        want_bf16: bool = True):
+    """omni_adaln_modulate_pair (ABI v12): AdaLN-modulate of TWO row groups (the image and the text stream of a DiT block) in one
+    launch.  `streams` = two (x [rows, D] contiguous, scale, shift, row_item_map) tuples.  Returns per stream what the single
+    calls return: y (row-major, or K32-blocked with `out_k32_blocked`); with `fp8` (y8, scale, y-or-None: the bf16 copy is
+    K32-blocked) as `adaln_modulate_fp8`."""
+    assert len(streams) == 2
+    recs, outs = (N.AdalnStream * 2)(), []
+    D = streams[0][0].shape[1]
+    for i, (x, scale, shift, item_map) in enumerate(streams):
+        rows, d, ldx = _rows2d(x, "x")
+        if d != D or ldx != D:
+            raise N.OmniNativeError("adaln_modulate_pair: both streams are contiguous [rows, D] with one D")
+        g = recs[i]
+        g.x, g.rows, g.scale, g.shift = _p(x, name="x"), rows, _p(scale, name="scale"), _p(shift, name="shift")
+        g.row_item_map, g.rows_per_item = _p(item_map, torch.int32, "row_item_map"), 0
+        y = torch.empty(rows, D, dtype=BF16, device=x.device) if (want_bf16 or not fp8) else None
+        g.y, g.y_k32_rows = _p(y, name="y"), rows if (y is not None and (out_k32_blocked or fp8)) else 0
+        if fp8:
+            y8 = torch.empty(rows, D, dtype=torch.uint8, device=x.device)
+            sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+            g.y8, g.y8_rows, g.y8_scale = _p(y8, torch.uint8, "y8"), rows, _p(sc, torch.float32, "scale_out")
+            outs.append((y8, sc, y))
+        else:
+            outs.append(y)
+    N.check(N.lib().omni_adaln_modulate_pair(C.byref(recs[0]), C.byref(recs[1]), D, mod_item_stride, eps, _stream()),
+            "omni_adaln_modulate_pair")
+    return outs
 
 
 def rmsnorm(x, weight, eps: float = 1e-6, out=None):
