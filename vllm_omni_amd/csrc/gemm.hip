@@ -935,6 +935,12 @@ OMNI_DEVINL void pp_mfma_fp8(f32x4_t& acc, const bf16x8_t& a_lo, const bf16x8_t&
 #define OMNI_PP_STAMP(v) ((void)0)
 #define OMNI_PP_PROBE_ACCUM(nq, mq) ((void)0)
 #endif
+// The whole-launch split-K instance (SPLITK == 1) runs the steady-state K-loop too when its piece has at least this many K-tiles
+// (round 6: bit-identical; same box, 60-layer forwards: one 384^2 request -2.7 %, one 512^2 -2.2 %, two / four 256^2 requests
+// -1.9 %; the 8-K-tile pieces of one 256^2 CFG pair's out-projection gain nothing — profiles/r06b_ab_splitk_steady_loop.log)
+#ifndef OMNI_SPLITK_STEADY_MIN_KT
+#define OMNI_SPLITK_STEADY_MIN_KT 12
+#endif
 constexpr int PBK = 64;
 constexpr int PSLOT_BYTES = 128 * PBK * 2;    // 16 KiB per half-tile
 constexpr int PLDS_BYTES = 8 * PSLOT_BYTES;   // 128 KiB ring
@@ -1155,13 +1161,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
   OMNI_PP_PROBE_DECLS();
 #endif
   int t_first = 0;
-  // STEADY STATE (every K-tile whose successors t + 1 and t + 2 both exist; not the split-K instance): everything the scalar unit
+  // STEADY STATE (every K-tile whose successors t + 1 and t + 2 both exist; split-K pieces of >= 12 K-tiles): everything the scalar unit
   // decides per phase in the general loop below is compile-time here — the loop runs two K-tiles per trip (ring parity = a
   // constant), `t + 1 < nkt` / `t + 2 < nkt` hold by construction, one running pointer per operand instead of `base + t * step`
   // per phase, M0 = one s_add of a per-wave constant and an immediate: 0.25 scalar instructions per MFMA (1.17 in the general
   // loop; the vendor kernel: 0.33), load section 246 -> 154 cycles per phase by the phase probe.  The fp8
   // instance runs the same loop since round 5 (its clusters are half as long: the scalar stream weighed twice as much).
-  if constexpr (SPLITK != 1) {
+  if (SPLITK != 1 || nkt >= OMNI_SPLITK_STEADY_MIN_KT) {
     const uint32_t lds_w = lds0 + (uint32_t)(wave * 2048);           // this wave's two pieces inside a half-tile slot
     const char* a_nx = Ab + astep;                                  // K-tile t + 1 of either operand (t = 0)
     const char* w_nx = Wb + wstep;
