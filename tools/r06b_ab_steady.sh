@@ -1,6 +1,8 @@
 #!/bin/bash
 # Same-box A/B: the whole-launch split-K instance on the general K-loop (0) vs the steady-state K-loop (1); the product library
-# first re-runs the round-6b tests (opt-in in-launch reduce, paired AdaLN).
+# first re-runs the round-6b tests (opt-in in-launch reduce, paired AdaLN).  Variant libraries:
+#   tools/build_variants.sh gemm steady0 "-DOMNI_SPLITK_STEADY_MIN_KT=1000000" steady1 "-DOMNI_SPLITK_STEADY_MIN_KT=1"
+# (the product: 12 — pieces of at least 12 K-tiles take the steady-state loop)
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT

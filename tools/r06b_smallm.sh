@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round 6, second session: the small-batch launch savers (in-launch split-K reduce, paired AdaLN) — new GPU tests, then a same-box
 # A/B of whole 60-layer forwards / config-1 images through a -DOMNI_DEV build whose knobs read the environment (the product has
-# none), then the per-kernel trace of the config-1 step with the product library.
+# none), then the per-kernel trace of the config-1 step with the product library.  The dev library = gemm.hip + dit_forward.hip compiled
+# with -DOMNI_DEV (tools/build_variants.sh, both objects linked into libomni_devknobs2.so); OMNI_GEMM_SPLITK_INLAUNCH = the largest
+# split factor reduced in the launch (0 = never, 8 = always), OMNI_DIT_ADALN_PAIR = 0 / 1.
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
@@ -11,7 +13,7 @@ tail -5 $OUT/${TAG}_new_tests.log
 L=$OUT/${TAG}_ab_smallm.log; : > $L
 export OMNI_DEV_LIB=$PWD/vllm_omni_amd/csrc/build/abl/libomni_devknobs2.so
 for rep in 1 2 3; do
-  for mode in "0 0" "1 0" "0 1" "1 1"; do
+  for mode in "0 0" "8 0" "0 1" "8 1"; do
     set -- $mode
     for spec in "256 1" "512 1" "256 4"; do
       set -- $mode $spec
