@@ -124,6 +124,8 @@ def test_product_path_fails_loudly_without_gpu():
     x = torch.zeros(4, 64, dtype=torch.bfloat16)
     with pytest.raises(OmniNativeError):
         ops.linear(x, x)          # CPU tensors must raise, never fall back
+    with pytest.raises(OmniNativeError):
+        ops.adaln_modulate_pair([(x, x, x, None), (x, x, x, None)], mod_item_stride=64)
 
 
 def test_ragged_batch_maps():

@@ -44,6 +44,9 @@ constexpr int GROUP_M_DEFAULT = 4;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+#ifndef OMNI_FIN_REORDER
+#define OMNI_FIN_REORDER 0        // finish kernels: 1 = a row's partial loads are issued before its map-dependent gate / residual loads
+#endif
 #ifndef OMNI_GLDS_AUX
 #define OMNI_GLDS_AUX 0   // cache-policy bits of the DMA loads: 1 = sc0, 2 = nt, 16 = sc1
 #endif
@@ -336,11 +339,13 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
     ncol_out = n - which * P.split_n;
   }
   const char* lds_row = FROM_PARTIALS ? nullptr : smem + rsub * EPI_LDS_STRIDE + chunk * 16;
+  u32x4_t bias8 = {0u, 0u, 0u, 0u};                  // finish kernels: this thread's 8 bias values, loaded ONCE (not per row)
+  if (FROM_PARTIALS && G.bias) bias8 = *reinterpret_cast<const u32x4_t*>(G.bias + n);
   auto load_data = [&](int b, const RowIdx& x, RowData& d) {
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
       d.ro[j] = x.ro[j];
-      if (EPI == OMNI_EPI_BIAS_GATE_RES) {
+      if (EPI == OMNI_EPI_BIAS_GATE_RES && !(FROM_PARTIALS && OMNI_FIN_REORDER)) {
         d.g[j] = *reinterpret_cast<const u32x4_t*>(G.gate + (int64_t)x.im[j] * G.gate_item_stride + n);
         d.r[j] = *reinterpret_cast<const u32x4_t*>(G.res + (int64_t)x.ro[j] * G.ldres + n);
       }
@@ -366,9 +371,8 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
         }
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         if (G.bias) {
-          const u32x4_t bb = *reinterpret_cast<const u32x4_t*>(G.bias + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_lo(bb[e]); v[2 * e + 1] += bf16_hi(bb[e]); }
+          for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_lo(bias8[e]); v[2 * e + 1] += bf16_hi(bias8[e]); }
         }
         if (EPI == OMNI_EPI_BIAS_GELU_TANH) {
 #pragma unroll
@@ -376,6 +380,10 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) d.c[j][e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+        if (EPI == OMNI_EPI_BIAS_GATE_RES && OMNI_FIN_REORDER) {
+          d.g[j] = *reinterpret_cast<const u32x4_t*>(G.gate + (int64_t)x.im[j] * G.gate_item_stride + n);
+          d.r[j] = *reinterpret_cast<const u32x4_t*>(G.res + (int64_t)x.ro[j] * G.ldres + n);
+        }
       } else {
         d.c[j] = *reinterpret_cast<const u32x4_t*>(lds_row + (b * BATCH + j) * RS * EPI_LDS_STRIDE);
       }
@@ -1354,7 +1362,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 // row-coalesced epilogue with C taken from the fp32 partials.
 // Round 6: EIGHT workgroups of 256 threads per tile (32 rows each) instead of four of 512: a 36-tile launch (one 256^2 CFG pair)
 // finishes on 288 workgroups instead of 144 — the finish is a latency-bound stream of fp32 partials and the chip has 256 CUs.
-constexpr int FIN_THREADS = 256, FIN_PER_TILE = 8;                // 8 rows in flight per pass x 4 per thread = 32 rows per workgroup
+#ifndef OMNI_FIN_BATCH
+#define OMNI_FIN_BATCH 4          // rows per thread of a finish workgroup (dev A/B: 1, 2, 4)
+#endif
+constexpr int FIN_THREADS = 256, FIN_BATCH = OMNI_FIN_BATCH, FIN_PER_TILE = BM / (FIN_THREADS / 32 * FIN_BATCH);   // 8 rows in flight per pass x FIN_BATCH per thread = the workgroup's rows
 template <int EPI>
 __global__ __launch_bounds__(FIN_THREADS) void gemm_splitk_finish_kernel(const omni_gemm_params P, int mtiles0, int tiles_m,
                                                                        int tiles_n, int GROUP_M, int nsplit) {
@@ -1377,7 +1388,7 @@ __global__ __launch_bounds__(FIN_THREADS) void gemm_splitk_finish_kernel(const o
   const int64_t mtot = P.g[0].M + (P.ngroups > 1 ? P.g[1].M : 0);
   const EpiFromPartials src = {P.splitk_ws, mtot * P.N, gi ? (int64_t)P.g[0].M : 0, nsplit, quarter, quarter + 1, P.N, 0, 0};
   auto nothing = []() {};
-  gemm_epilogue_lds_impl<EPI, decltype(nothing), EpiFromPartials, FIN_THREADS>(P, G, m0, n0, nullptr, (int)threadIdx.x, nothing, src);
+  gemm_epilogue_lds_impl<EPI, decltype(nothing), EpiFromPartials, FIN_THREADS, FIN_BATCH>(P, G, m0, n0, nullptr, (int)threadIdx.x, nothing, src);
 }
 
 // Tail-split finish: the same epilogue over the tail tiles only (four workgroups of 64 rows per tile), C = the sum of the tile's
@@ -1404,7 +1415,7 @@ __global__ __launch_bounds__(FIN_THREADS) void gemm_tail_finish_kernel(const omn
   if (m0 + quarter * (BM / FIN_PER_TILE) >= G.M) return;
   const EpiFromPartials src = {P.splitk_ws + (int64_t)tl * nsplit * (BM * BN), BM * BN, 0, nsplit, quarter, quarter + 1, BN, m0, n0};
   auto nothing = []() {};
-  gemm_epilogue_lds_impl<EPI, decltype(nothing), EpiFromPartials, FIN_THREADS>(P, G, m0, n0, nullptr, (int)threadIdx.x, nothing, src);
+  gemm_epilogue_lds_impl<EPI, decltype(nothing), EpiFromPartials, FIN_THREADS, FIN_BATCH>(P, G, m0, n0, nullptr, (int)threadIdx.x, nothing, src);
 }
 
 #ifdef OMNI_DEV
