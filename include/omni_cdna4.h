@@ -176,8 +176,18 @@ typedef struct {
  * hanging the device.  Measured on MI355X it pays only for 2-way splits on grids that nearly fill the chip (+1.1 .. 1.3 % per
  * forward) and loses for deep splits: not the default. */
 #define OMNI_GEMM_KERNEL_SPLITK_IN_LAUNCH 4
+/* ABI v13 — split-K (the ABI v4 rule) WITHOUT its finish kernel: the call launches only the K-split main kernel and leaves the
+ * fp32 partials splitk_ws[s][M0 + M1][N] (group 1's rows behind group 0's; no bias, no epilogue applied) for a consumer that
+ * folds the reduction into its own pass — omni_splitk_finish_adaln_pair below for OMNI_EPI_BIAS_GATE_RES.  The caller asks
+ * omni_gemm_splitk_factor first: the hint is valid only for a call whose factor is > 1 (anything else returns
+ * OMNI_ERR_UNSUPPORTED — the library never silently runs a different path).  The output / residual / gate / bias fields of the
+ * groups are not touched by such a call. */
+#define OMNI_GEMM_KERNEL_SPLITK_DEFER_FINISH 5
 
 int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream);
+/* ABI v13 — the whole-launch split-K factor omni_gemm_bf16 would use for `p` on the current device (a function of the tile counts,
+ * K and the workspace size only): 1 = the call does not split, 0 = `p` is not a valid call. */
+int omni_gemm_splitk_factor(const omni_gemm_params* p);
 
 /* ABI v7 — dynamic per-row fp8 (OCP e4m3) quantisation of a bf16 matrix for omni_gemm_params.fp8:
  *   scale[r] = max(amax_k |x[r, k]|, tiny) / 448;   y8[r, k] = e4m3_rn(x[r, k] / scale[r])
@@ -239,6 +249,35 @@ typedef struct omni_adaln_stream {
 } omni_adaln_stream;
 int omni_adaln_modulate_pair(const omni_adaln_stream* a, const omni_adaln_stream* b, int32_t D, int64_t mod_item_stride,
                              float eps, omni_stream stream);
+
+/* ABI v13 — the finish of a DEFERRED split-K GEMM with the gated-residual epilogue (omni_gemm_bf16 with
+ * OMNI_GEMM_KERNEL_SPLITK_DEFER_FINISH, epilogue OMNI_EPI_BIAS_GATE_RES, N = D) fused with the AdaLN-modulate that follows it in a
+ * DiT block: the attention output projection -> norm2 (qwen_image_transformer.py:586-590,595) and the MLP down projection -> the
+ * NEXT block's norm1 (:592,597 -> :564-567).  One wave per row, both streams of the block in ONE launch:
+ *   c      = bf16(sum_s partial[s][row] + bias)                  (split order, the finish kernel's arithmetic)
+ *   hidden = bf16(hidden + gate[item(row)] * c)                  (written back in place: the residual stream)
+ *   y      = bf16(LN(hidden) * (1 + scale[item]) + shift[item])   (omni_adaln_modulate_ex's arithmetic on the rounded row)
+ * — the same bits as the finish kernel followed by omni_adaln_modulate_pair, without the second pass over the residual stream,
+ * two of the three launches and their boundaries (at one 256x256 CFG pair the three are latency, not bandwidth).
+ * Per stream: `rows` rows, `ws_row0` = its first row inside the partials' M0 + M1 rows; hidden row-major [rows, D] (row stride D);
+ * y row-major (row stride D) or K32-blocked with y_k32_rows rows; gate / scale / shift rows of mod_item_stride elements indexed by
+ * row_item_map[row] (or row / rows_per_item).  nsplit in {2, 3, 4, 6, 8}; D % 8 == 0, D <= 4096. */
+typedef struct omni_finish_adaln_stream {
+  int32_t rows;
+  int32_t ws_row0;
+  const omni_bf16* bias; /* [D], nullable */
+  omni_bf16* hidden;
+  const omni_bf16* gate;
+  const omni_bf16* scale;
+  const omni_bf16* shift;
+  const int32_t* row_item_map;
+  int32_t rows_per_item;
+  omni_bf16* y;
+  int32_t y_k32_rows;
+} omni_finish_adaln_stream;
+int omni_splitk_finish_adaln_pair(const float* splitk_ws, int32_t nsplit, int64_t ws_rows, const omni_finish_adaln_stream* a,
+                                  const omni_finish_adaln_stream* b, int32_t D, int64_t mod_item_stride, float eps,
+                                  omni_stream stream);
 
 /* RMSNorm over the last dim with learned weight: y = x * rsqrt(mean(x^2) + eps) * w.
  * Replaces vllm RMSNorm at qwen_image_transformer.py:758 (txt_norm, D = 3584).  D % 8 == 0, D <= 8192. */

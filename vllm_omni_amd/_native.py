@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomni_cdna4.so")   # fixed: dev sweeps assign this attribute (tools/devlib.py)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_bf16_p = C.c_void_p  # device pointer to uint16_t bf16 bits
 c_i32_p = C.c_void_p
@@ -55,6 +55,15 @@ class AdalnStream(C.Structure):
         ("x", c_bf16_p), ("y", c_bf16_p), ("rows", C.c_int32), ("scale", c_bf16_p), ("shift", c_bf16_p),
         ("row_item_map", c_i32_p), ("rows_per_item", C.c_int32), ("y_k32_rows", C.c_int32),
         ("y8", C.c_void_p), ("y8_rows", C.c_int32), ("y8_scale", C.c_void_p),
+    ]
+
+
+class FinishAdalnStream(C.Structure):
+    """omni_finish_adaln_stream (ABI v13): one row group of omni_splitk_finish_adaln_pair."""
+    _fields_ = [
+        ("rows", C.c_int32), ("ws_row0", C.c_int32), ("bias", c_bf16_p), ("hidden", c_bf16_p), ("gate", c_bf16_p),
+        ("scale", c_bf16_p), ("shift", c_bf16_p), ("row_item_map", c_i32_p), ("rows_per_item", C.c_int32),
+        ("y", c_bf16_p), ("y_k32_rows", C.c_int32),
     ]
 
 
@@ -162,6 +171,9 @@ PROTOTYPES = {
                                           C.c_void_p]),
     "omni_adaln_modulate_pair": (C.c_int, [C.POINTER(AdalnStream), C.POINTER(AdalnStream), C.c_int32, C.c_int64, C.c_float,
                                            C.c_void_p]),                                                        # ABI v12
+    "omni_gemm_splitk_factor": (C.c_int, [C.POINTER(GemmParams)]),                                              # ABI v13
+    "omni_splitk_finish_adaln_pair": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(FinishAdalnStream),
+                                                C.POINTER(FinishAdalnStream), C.c_int32, C.c_int64, C.c_float, C.c_void_p]),  # ABI v13
     "omni_rmsnorm": (C.c_int, [c_bf16_p, C.c_int64, c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, C.c_float,
                                C.c_void_p]),
     "omni_qk_norm_rope": (C.c_int, [c_bf16_p, C.c_int64, C.c_int32, C.c_int32, c_bf16_p, c_bf16_p, c_bf16_p, c_bf16_p,

@@ -112,6 +112,21 @@ int linear_rows(const omni_bf16* x, int64_t ldx, int32_t B, const omni_bf16* W, 
 
 struct BlockPred { const int32_t *tile_img, *tile_txt, *item; };
 
+// Split-K finish folded into the AdaLN behind it (ABI v13, omni_splitk_finish_adaln_pair): when the out-projection / the MLP
+// down-projection of a block runs K-split (a forward over one or two small images), its finish kernel is not launched — the
+// AdaLN that follows (norm2 of the same block / norm1 of the NEXT block) sums the partials, applies bias + gate + residual,
+// writes the residual stream and normalises the row in the same pass.  Same bits as the three-kernel sequence.  -DOMNI_DEV
+// builds: OMNI_DIT_FUSE_FINISH = 0 off, 1 out-projection only, 2 MLP-down only, 3 both (the product: 3, no switch).
+int dit_fuse_finish() {
+  static const int v = omni_dev_env_int("OMNI_DIT_FUSE_FINISH", 3);
+  return v;
+}
+// an MLP down-projection whose finish is still pending when its block returns (the next block's norm1 performs it)
+struct PendingFinish {
+  int nsplit = 0;
+  const omni_bf16 *bias_img = nullptr, *bias_txt = nullptr, *gate_img = nullptr, *gate_txt = nullptr;
+};
+
 // One dual-stream block (reference QwenImageTransformerBlock.forward, qwen_image_transformer.py:541-605) on the residual
 // streams hidden_img / hidden_txt (in place).  `after_img_norm1` (nullable) runs right after the image stream's first AdaLN:
 // omni_dit_forward hooks the TeaCache decision there (the "modulated input" of extractors.py:189-194).
@@ -140,7 +155,8 @@ int adaln_streams(const omni_adaln_stream& si, const omni_adaln_stream& st, int3
 template <typename Hook>
 int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const Workspace& ws, omni_bf16* hidden_img,
               omni_bf16* hidden_txt, const omni_bf16* temb, const BlockPred& pr, Hook&& after_img_norm1, omni_stream stream,
-              BlockPhase phase = BLOCK_ALL, const omni_bf16* attn_in = nullptr) {
+              BlockPhase phase = BLOCK_ALL, const omni_bf16* attn_in = nullptr, PendingFinish* pend = nullptr,
+              bool may_defer_down = false) {
   const omni_dit_layer_weights& L = w->layers[l];
   const int32_t Ri = b->n_img_rows, Rt = b->n_txt_rows, nT = b->n_temb;
   const int32_t D = w->num_heads * w->head_dim;
@@ -192,7 +208,15 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   // Both streams in ONE launch (round 6, elementwise.hip rownorm_kernel PAIR; the TeaCache hook reads the image stream's
   // result behind it).
   const bool fused_q = f_qkv && blk;
-  if (fused_q) {
+  if (pend && pend->nsplit > 1) {
+    // the previous block's MLP down-projection left its K-split partials: finish + gated residual + this block's norm1 in one pass
+    const omni_finish_adaln_stream fi = {Ri, 0, pend->bias_img, hidden_img, pend->gate_img, mod_img + D, mod_img, b->img_item, 0,
+                                         xn_img, bRi};
+    const omni_finish_adaln_stream ft = {Rt, Ri, pend->bias_txt, hidden_txt, pend->gate_txt, mod_txt + D, mod_txt, b->txt_item, 0,
+                                         xn_txt, bRt};
+    OMNI_TRY(omni_splitk_finish_adaln_pair(ws.splitk, pend->nsplit, (int64_t)Ri + Rt, &fi, &ft, D, 6 * (int64_t)D, eps, stream));
+    pend->nsplit = 0;
+  } else if (fused_q) {
     const omni_adaln_stream si = {hidden_img, b->teacache ? xn_img : nullptr, Ri, mod_img + D, mod_img, b->img_item, 0,
                                   b->teacache ? bRi : 0, ws.x8, Ri, ws.x8_scale};
     const omni_adaln_stream st = {hidden_txt, nullptr, Rt, mod_txt + D, mod_txt, b->txt_item, 0, 0, ws.x8 + (int64_t)Ri * D,
@@ -247,6 +271,10 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   }  // phase != BLOCK_POST
   const omni_bf16* attn_src = phase == BLOCK_POST ? attn_in : ws.attn;
   const int32_t attn_k32 = phase == BLOCK_POST ? 0 : bRj;       // a caller-provided attention output is row-major
+  // split-K finishes folded into the following AdaLN: bf16 blocks without TeaCache predicates (a skipped tile leaves no partials)
+  // and a width the fused kernel takes
+  const bool fuse_ok = !F && !pr.tile_img && !pr.tile_txt && D % 8 == 0 && D <= 4096;
+  bool norm2_done = false;
   // output projections + gated residual (reference :448-456, :586-587)
   {
     omni_gemm_params p = {};
@@ -272,11 +300,25 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
       p.g[0].W = reinterpret_cast<const omni_bf16*>(F->to_out_w8); p.g[0].w_scale = F->to_out_s;
       p.g[1].W = reinterpret_cast<const omni_bf16*>(F->to_add_out_w8); p.g[1].w_scale = F->to_add_out_s;
     }
-    OMNI_TRY(omni_gemm_bf16(&p, stream));
+    // K-split launch (small batches): leave the partials to norm2's pass instead of a finish kernel
+    const int ns = (fuse_ok && (dit_fuse_finish() & 1)) ? omni_gemm_splitk_factor(&p) : 1;
+    if (ns > 1) {
+      p.kernel_hint = OMNI_GEMM_KERNEL_SPLITK_DEFER_FINISH;
+      OMNI_TRY(omni_gemm_bf16(&p, stream));
+      const omni_finish_adaln_stream fi = {Ri, 0, L.to_out_b, hidden_img, mod_img + 2 * D, mod_img + 4 * D, mod_img + 3 * D,
+                                           b->img_item, 0, xn_img, bRi};
+      const omni_finish_adaln_stream ft = {Rt, Ri, L.to_add_out_b, hidden_txt, mod_txt + 2 * D, mod_txt + 4 * D, mod_txt + 3 * D,
+                                           b->txt_item, 0, xn_txt, bRt};
+      OMNI_TRY(omni_splitk_finish_adaln_pair(ws.splitk, ns, (int64_t)Ri + Rt, &fi, &ft, D, 6 * (int64_t)D, eps, stream));
+      norm2_done = true;
+    } else {
+      OMNI_TRY(omni_gemm_bf16(&p, stream));
+    }
   }
   // norm2 + modulate (reference :590, :595)
   const bool fused_q2 = f_up && blk;
-  if (fused_q2) {
+  if (norm2_done) {
+  } else if (fused_q2) {
     const omni_adaln_stream si = {hidden_img, nullptr, Ri, mod_img + 4 * D, mod_img + 3 * D, b->img_item, 0, 0, ws.x8, Ri,
                                   ws.x8_scale};
     const omni_adaln_stream st = {hidden_txt, nullptr, Rt, mod_txt + 4 * D, mod_txt + 3 * D, b->txt_item, 0, 0,
@@ -322,7 +364,16 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
       OMNI_TRY(quant_streams(h_img, bRi, h_txt, bRt, 4 * D));
       fp8_streams(p, 4 * D, F->img_mlp_w2_8, F->img_mlp_w2_s, F->txt_mlp_w2_8, F->txt_mlp_w2_s);
     }
-    OMNI_TRY(omni_gemm_bf16(&p, stream));
+    // K-split launch inside omni_dit_forward's block loop, modulation rows from the request's table (the gate must outlive this
+    // block): the NEXT block's norm1 finishes it
+    const int ns = (pend && may_defer_down && fuse_ok && b->mod_table && (dit_fuse_finish() & 2)) ? omni_gemm_splitk_factor(&p) : 1;
+    if (ns > 1) {
+      p.kernel_hint = OMNI_GEMM_KERNEL_SPLITK_DEFER_FINISH;
+      OMNI_TRY(omni_gemm_bf16(&p, stream));
+      *pend = PendingFinish{ns, L.img_mlp_b2, L.txt_mlp_b2, mod_img + 5 * D, mod_txt + 5 * D};
+    } else {
+      OMNI_TRY(omni_gemm_bf16(&p, stream));
+    }
   }
   return OMNI_OK;
 }
@@ -338,7 +389,7 @@ int prepare_positions(const omni_dit_batch* b, const Workspace& ws, omni_stream 
 }
 }  // namespace
 
-extern "C" int omni_abi_version(void) { return 12; }
+extern "C" int omni_abi_version(void) { return 13; }
 extern "C" const char* omni_build_arch(void) { return "gfx950"; }
 extern "C" const char* omni_status_string(int status) {
   switch (status) {
@@ -405,18 +456,21 @@ extern "C" int omni_dit_forward(const omni_dit_weights* w, const omni_dit_batch*
   }
   const BlockPred pred = tc ? BlockPred{tc->tile_skip_img, tc->tile_skip_txt, tc->skip} : BlockPred{nullptr, nullptr, nullptr};
   const int32_t blocked = (dit_act_blocked() && (D % 32 == 0)) ? 1 : 0;
+  PendingFinish pend;                                   // block l's MLP-down finish, performed by block l + 1's norm1
   for (int l = 0; l < w->num_layers; ++l) {
+    const bool more = l + 1 < w->num_layers;
     if (l == 0 && tc) {
       // decision on the first block's modulated input, BEFORE anything of the block stack that could be skipped; the
       // predicates it writes gate every GEMM row tile / attention block of skipped items from here on
       auto hook = [&](omni_bf16* xn_img) {
         return omni_internal_teacache_decide(tc, xn_img, b->n_items, rows_per_item, Ri, Rt, D, blocked, stream);
       };
-      OMNI_TRY(run_block(w, l, b, ws, ws.hidden_img, ws.hidden_txt, ws.temb, pred, hook, stream));
+      OMNI_TRY(run_block(w, l, b, ws, ws.hidden_img, ws.hidden_txt, ws.temb, pred, hook, stream, BLOCK_ALL, nullptr, &pend, more));
     } else {
-      OMNI_TRY(run_block(w, l, b, ws, ws.hidden_img, ws.hidden_txt, ws.temb, pred, NoHook{}, stream));
+      OMNI_TRY(run_block(w, l, b, ws, ws.hidden_img, ws.hidden_txt, ws.temb, pred, NoHook{}, stream, BLOCK_ALL, nullptr, &pend, more));
     }
   }
+  if (pend.nsplit > 1) return OMNI_ERR_LAUNCH;          // (cannot happen: the last block never defers)
   if (tc) OMNI_TRY(omni_internal_teacache_post(tc, ws.hidden_img, ws.h_in, Ri, rows_per_item, D, stream));
 
   omni_bf16* xn_img = ws.xn;

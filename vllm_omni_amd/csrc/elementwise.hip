@@ -205,6 +205,179 @@ int launch_adaln_pair(const omni_adaln_stream& a, const omni_adaln_stream& b, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-K finish + gated residual + AdaLN in one pass (ABI v13, omni_splitk_finish_adaln_pair).  At one 256^2 CFG pair (512 + 128
+// rows) the out-projection and the MLP down-projection run 6-way K-split; their finish kernel (47 MB of fp32 partials -> the
+// residual stream, ~15 us) is followed at once by the AdaLN of that stream (~5 us): three launches, each latency-bound, and the
+// residual row written only to be read back.  Here ONE wave owns one row of either stream:
+//   c = bf16(sum_s partial[s][row][:] + bias)   the sum in split order from 0.0f, exactly gemm_epilogue_lds_impl<FROM_PARTIALS>
+//   h = bf16(fma(gate, c, res))                 (hipcc contracts the epilogue's `res + gate * c` to an fma: the same bits)
+//   y = AdaLN(h)                                rownorm_kernel<MODE 0>'s arithmetic on the ROUNDED row, operation for operation:
+//                                               sequential sums, IEEE divisions, var += d * d as a mul and an add (hipcc does not
+//                                               contract that one: the products are formed pairwise, v_pk_mul_f32), the output as
+//                                               fma((v - mean) * rstd, 1 + scale, shift)
+// with implicit contraction OFF in this function, so that what is an fma is written as one — tests/test_gpu_finish_adaln.py
+// asserts bit equality with the two-kernel path for both streams, row-major and K32-blocked.
+// Loads: the partials of chunk c + 2 (NS x 32 B per lane), its residual, gate and bias pieces are requested while chunk c is
+// reduced (two chunks in flight: 24 x 16 B per lane at NS = 6 — 640 waves x 64 lanes x 384 B = 15.7 MB in flight).
+// ------------------------------------------------------------------------------------------------
+struct FinishGroup {
+  const float* ws;             // partials of this group's first row in split 0
+  const uint16_t* bias;        // nullable
+  uint16_t* hidden;            // [rows, D], read (residual) and written (result) in place
+  const uint16_t* gate; const uint16_t* scale; const uint16_t* shift;
+  const int32_t* row_item_map;
+  uint16_t* y;
+  int rows, rows_per_item, y_k32_rows;
+};
+template <int NCH, int NS>
+__global__ __launch_bounds__(64) void splitk_finish_adaln_kernel(const FinishGroup g1, const FinishGroup g2, int64_t split_stride,
+                                                                 int D, int64_t item_stride, float eps) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x;
+  int row = blockIdx.x;                                // one wave = one workgroup = one row (uniform)
+  const float* ws = g1.ws; const uint16_t* bias = g1.bias; uint16_t* hidden = g1.hidden;
+  const uint16_t *gate = g1.gate, *scale = g1.scale, *shift = g1.shift;
+  const int32_t* row_item_map = g1.row_item_map; uint16_t* y = g1.y;
+  int rows = g1.rows, rows_per_item = g1.rows_per_item, y_k32_rows = g1.y_k32_rows;
+  if (row >= g1.rows) {                                // a row of the second group: field-wise (a struct select goes to scratch)
+    row -= g1.rows;
+    ws = g2.ws; bias = g2.bias; hidden = g2.hidden; gate = g2.gate; scale = g2.scale; shift = g2.shift;
+    row_item_map = g2.row_item_map; y = g2.y; rows = g2.rows; rows_per_item = g2.rows_per_item; y_k32_rows = g2.y_k32_rows;
+  }
+  if (row >= rows) return;
+  const int item = row_item_map ? row_item_map[row] : row / rows_per_item;    // requested first: only the gate / scale / shift
+  const float* wr = ws + (int64_t)row * D;                                    // loads wait for it
+  uint16_t* hr = hidden + (int64_t)row * D;
+  f32x4_t pl[2][NS], ph[2][NS];
+  u32x4_t rr[2], bb[2], gg[2];
+  auto issue_partials = [&](int c, int buf) {
+    const int e = min((c * 64 + lane) * 8, D - 8);     // chunks past D read a clamped address and are masked afterwards
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float* q = wr + (int64_t)s * split_stride + e;
+      pl[buf][s] = *reinterpret_cast<const f32x4_t*>(q);
+      ph[buf][s] = *reinterpret_cast<const f32x4_t*>(q + 4);
+    }
+    rr[buf] = *reinterpret_cast<const u32x4_t*>(hr + e);
+    bb[buf] = u32x4_t{0u, 0u, 0u, 0u};
+    if (bias) bb[buf] = *reinterpret_cast<const u32x4_t*>(bias + e);
+  };
+  issue_partials(0, 0);
+  if (NCH > 1) issue_partials(1, 1);
+  __builtin_amdgcn_sched_barrier(0);                   // keep the first USE of `item` (and its wait) behind those loads
+  const int64_t moff = (int64_t)item * item_stride;
+  auto issue_gate = [&](int c, int buf) {
+    gg[buf] = *reinterpret_cast<const u32x4_t*>(gate + moff + min((c * 64 + lane) * 8, D - 8));
+  };
+  issue_gate(0, 0);
+  if (NCH > 1) issue_gate(1, 1);
+  u32x4_t rsc[NCH], rsh[NCH];                          // the AdaLN vectors of the row's item (L2-resident)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e = min((c * 64 + lane) * 8, D - 8);
+    rsc[c] = *reinterpret_cast<const u32x4_t*>(scale + moff + e);
+    rsh[c] = *reinterpret_cast<const u32x4_t*>(shift + moff + e);
+  }
+  u32x4_t raw[NCH];                                    // the new residual row, PACKED (as rownorm_kernel keeps it)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int buf = c & 1;
+    f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { lo += pl[buf][s]; hi += ph[buf][s]; }
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[2 * i] += bf16_lo(bb[buf][i]); v[2 * i + 1] += bf16_hi(bb[buf][i]); }
+    }
+    u32x4_t o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t cw = pack_bf16x2(v[2 * i], v[2 * i + 1]);       // the GEMM output, rounded where the fused epilogue rounds it
+      o[i] = pack_bf16x2(__builtin_fmaf(bf16_lo(gg[buf][i]), bf16_lo(cw), bf16_lo(rr[buf][i])),
+                         __builtin_fmaf(bf16_hi(gg[buf][i]), bf16_hi(cw), bf16_hi(rr[buf][i])));
+    }
+    raw[c] = o;
+    if ((c * 64 + lane) * 8 < D) *reinterpret_cast<u32x4_t*>(hr + (c * 64 + lane) * 8) = o;
+    if (c + 2 < NCH) { issue_partials(c + 2, buf); issue_gate(c + 2, buf); }
+  }
+  // ---- AdaLN of the row: rownorm_kernel<NCH, 0>'s passes
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if ((c * 64 + lane) * 8 < D) {
+      float v[8];
+      unpack8(raw[c], v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += v[i];
+    }
+  }
+  sum = wave_sum<64>(sum);
+  const float mean = sum / D;
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if ((c * 64 + lane) * 8 < D) {
+      float v[8];
+      unpack8(raw[c], v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = v[i] - mean;
+        const float dd = d * d;
+        var += dd;
+      }
+    }
+  }
+  var = wave_sum<64>(var) / D;
+  const float rstd = rsqrtf(var + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e = (c * 64 + lane) * 8;
+    if (e < D) {
+      float v[8], sc[8], sh[8], o[8];
+      unpack8(raw[c], v);
+      unpack8(rsc[c], sc);
+      unpack8(rsh[c], sh);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf((v[i] - mean) * rstd, 1.0f + sc[i], sh[i]);
+      uint16_t* dst = y_k32_rows ? y + ((int64_t)(e >> 5) * y_k32_rows + row) * 32 + (e & 31) : y + (int64_t)row * D + e;
+      *reinterpret_cast<u32x4_t*>(dst) = pack8(o);
+    }
+  }
+}
+
+int launch_finish_adaln(const float* ws, int nsplit, int64_t ws_rows, const omni_finish_adaln_stream& a,
+                        const omni_finish_adaln_stream& b, int D, int64_t stride, float eps, hipStream_t s) {
+  auto grp = [&](const omni_finish_adaln_stream& g) {
+    return FinishGroup{ws + (int64_t)g.ws_row0 * D, g.bias, g.hidden, g.gate, g.scale, g.shift, g.row_item_map, g.y,
+                       g.rows, g.rows_per_item, g.y_k32_rows};
+  };
+  const FinishGroup g1 = grp(a), g2 = grp(b);
+  const dim3 grid(a.rows + b.rows), block(64);
+  const int64_t split_stride = ws_rows * D;
+  const int nch = (D + 511) / 512;
+#define OMNI_FA(N, S) hipLaunchKernelGGL((splitk_finish_adaln_kernel<N, S>), grid, block, 0, s, g1, g2, split_stride, D, stride, eps)
+#define OMNI_FA_NS(N)                    \
+  switch (nsplit) {                      \
+    case 2: OMNI_FA(N, 2); break;        \
+    case 3: OMNI_FA(N, 3); break;        \
+    case 4: OMNI_FA(N, 4); break;        \
+    case 6: OMNI_FA(N, 6); break;        \
+    case 8: OMNI_FA(N, 8); break;        \
+    default: return OMNI_ERR_UNSUPPORTED; \
+  }
+  if (nch <= 2) { OMNI_FA_NS(2) }
+  else if (nch <= 4) { OMNI_FA_NS(4) }
+  else if (nch <= 6) { OMNI_FA_NS(6) }
+  else if (nch <= 8) { OMNI_FA_NS(8) }
+  else return OMNI_ERR_UNSUPPORTED;
+#undef OMNI_FA_NS
+#undef OMNI_FA
+  OMNI_CHECK_LAUNCH();
+  return OMNI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-head RMSNorm(128) + interleaved RoPE, in place.  16 lanes x 8 elements = one (row, head);
 // a wave handles 4 (row, head) pairs per instruction.  bytes = 2 * rows*H*128*2 (read + write).
 // ------------------------------------------------------------------------------------------------
@@ -715,6 +888,30 @@ extern "C" int omni_adaln_modulate_pair(const omni_adaln_stream* a, const omni_a
         (g->y8 && (reinterpret_cast<uintptr_t>(g->y8) & 7)) || (mod_item_stride % 8))
       return OMNI_ERR_ALIGN;
   return launch_adaln_pair(*a, *b, D, mod_item_stride, eps, static_cast<hipStream_t>(stream));
+}
+
+// The finish of a deferred split-K GEMM (gated-residual epilogue) + the AdaLN behind it, both streams in one launch (ABI v13; see
+// splitk_finish_adaln_kernel).
+extern "C" int omni_splitk_finish_adaln_pair(const float* splitk_ws, int32_t nsplit, int64_t ws_rows,
+                                             const omni_finish_adaln_stream* a, const omni_finish_adaln_stream* b, int32_t D,
+                                             int64_t mod_item_stride, float eps, omni_stream stream) {
+  if (!splitk_ws || !a || !b || D <= 0 || ws_rows <= 0) return OMNI_ERR_BAD_ARG;
+  for (const omni_finish_adaln_stream* g : {a, b}) {
+    if (!g->hidden || !g->gate || !g->scale || !g->shift || !g->y || g->rows <= 0) return OMNI_ERR_BAD_ARG;
+    if (!g->row_item_map && g->rows_per_item <= 0) return OMNI_ERR_BAD_ARG;
+    if (g->ws_row0 < 0 || (int64_t)g->ws_row0 + g->rows > ws_rows) return OMNI_ERR_BAD_ARG;
+    if (g->y_k32_rows < 0 || (g->y_k32_rows > 0 && g->y_k32_rows < g->rows)) return OMNI_ERR_BAD_ARG;
+  }
+  if (nsplit != 2 && nsplit != 3 && nsplit != 4 && nsplit != 6 && nsplit != 8) return OMNI_ERR_UNSUPPORTED;
+  if (D % 8 || D > 4096) return OMNI_ERR_UNSUPPORTED;
+  for (const omni_finish_adaln_stream* g : {a, b}) {
+    if (g->y_k32_rows && D % 32) return OMNI_ERR_UNSUPPORTED;
+    if (!omni_aligned16(g->hidden) || !omni_aligned16(g->gate) || !omni_aligned16(g->scale) || !omni_aligned16(g->shift) ||
+        !omni_aligned16(g->y) || (g->bias && !omni_aligned16(g->bias)))
+      return OMNI_ERR_ALIGN;
+  }
+  if (!omni_aligned16(splitk_ws) || (mod_item_stride % 8)) return OMNI_ERR_ALIGN;
+  return launch_finish_adaln(splitk_ws, nsplit, ws_rows, *a, *b, D, mod_item_stride, eps, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int omni_rmsnorm(const omni_bf16* x, int64_t ldx, omni_bf16* y, int64_t ldy, int32_t rows, int32_t D,

@@ -45,8 +45,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 #ifndef OMNI_FIN_REORDER
-#define OMNI_FIN_REORDER 0        // finish kernels: 1 = a row's partial loads are issued before its map-dependent gate / residual loads
-#endif
+#define OMNI_FIN_REORDER 1        // finish kernels: 1 = a row's partial loads are issued before its map-dependent gate / residual loads
+#endif                            // (with OMNI_FIN_BATCH below: same-box A/B, profiles/r06c_ab_finish_variants.log)
 #ifndef OMNI_GLDS_AUX
 #define OMNI_GLDS_AUX 0   // cache-policy bits of the DMA loads: 1 = sc0, 2 = nt, 16 = sc1
 #endif
@@ -1362,8 +1362,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(const omni_ge
 // row-coalesced epilogue with C taken from the fp32 partials.
 // Round 6: EIGHT workgroups of 256 threads per tile (32 rows each) instead of four of 512: a 36-tile launch (one 256^2 CFG pair)
 // finishes on 288 workgroups instead of 144 — the finish is a latency-bound stream of fp32 partials and the chip has 256 CUs.
+// Round 6, third session: ONE row per thread — 32 workgroups of 8 rows per tile — and the partial loads of a row in front of its
+// map-dependent loads: 60-layer forwards, same box, -0.7 % (two 256^2 requests), -1.3 % (one 384^2 request, config 1) against four
+// rows per thread (profiles/r06c_ab_finish_variants.log); same bits (the order of the adds is the split order either way).
 #ifndef OMNI_FIN_BATCH
-#define OMNI_FIN_BATCH 4          // rows per thread of a finish workgroup (dev A/B: 1, 2, 4)
+#define OMNI_FIN_BATCH 1          // rows per thread of a finish workgroup (dev A/B: 1, 2, 4)
 #endif
 constexpr int FIN_THREADS = 256, FIN_BATCH = OMNI_FIN_BATCH, FIN_PER_TILE = BM / (FIN_THREADS / 32 * FIN_BATCH);   // 8 rows in flight per pass x FIN_BATCH per thread = the workgroup's rows
 template <int EPI>
@@ -1532,8 +1535,9 @@ int splitk_factor(const omni_gemm_params* p, int tiles_m, int tiles_n) {
   const int nkt = p->K / PBK;
   const int64_t mtot = p->g[0].M + (p->ngroups > 1 ? p->g[1].M : 0);
   const int cus = gemm_num_cus();
+  const int min_kt = omni_dev_env_int("OMNI_GEMM_SPLITK_MIN_KT", 4);      // dev knob (-DOMNI_DEV builds only): K-tiles per piece
   for (int s : {8, 6, 4, 3, 2}) {
-    if (nkt % s == 0 && nkt / s >= 4 && tiles * s <= cus && (int64_t)s * mtot * p->N <= p->splitk_ws_floats) return s;
+    if (nkt % s == 0 && nkt / s >= min_kt && tiles * s <= cus && (int64_t)s * mtot * p->N <= p->splitk_ws_floats) return s;
   }
   return 1;
 }
@@ -1624,6 +1628,7 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
   };
   OMNI_TRY_STATUS(omni_once_per_device(attr_done, set_attrs));
   if (p->fp8) {
+    if (p->kernel_hint == OMNI_GEMM_KERNEL_SPLITK_DEFER_FINISH) return OMNI_ERR_UNSUPPORTED;       // fp8: no split-K
     // the fp8 operands are, byte for byte, K32-blocked bf16 matrices with K / 2 columns: the kernel runs on that view
     omni_gemm_params q = *p;
     q.K = p->K / 2;
@@ -1648,7 +1653,12 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
     const int nsplit = splitk_factor(p, tiles_m, tiles_n);
     int tail_first = 0;
     const int tail_ns = nsplit > 1 ? 1 : tail_split_factor(p, tiles_m * tiles_n, &tail_first);
-    if (nsplit > 1 && splitk_in_launch_ok(p, tiles_m * tiles_n, nsplit)) {
+    if (p->kernel_hint == OMNI_GEMM_KERNEL_SPLITK_DEFER_FINISH) {
+      // ABI v13: the K-split main kernel only; the caller's consumer (omni_splitk_finish_adaln_pair) reduces the partials
+      if (nsplit <= 1) return OMNI_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, 1>), dim3(tiles_m * tiles_n * nsplit), dim3(NTHREADS), RLDS_BYTES, s, *p,
+                         mt0, tiles_m, tiles_n, gemm_group_m(), nsplit, 0);
+    } else if (nsplit > 1 && splitk_in_launch_ok(p, tiles_m * tiles_n, nsplit)) {
       // counters: zeroed on the stream before the launch (a memset node under capture), left zero by the launch
       int* cnt = reinterpret_cast<int*>(p->splitk_ws + p->splitk_ws_floats) - SPLITK_CNT_INTS;
       if (hipMemsetAsync(cnt, 0, SPLITK_CNT_INTS * sizeof(int), s) != hipSuccess) return OMNI_ERR_LAUNCH;
@@ -1672,6 +1682,7 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
                          tiles_n, gemm_group_m(), 1, 0);
     }
   }
+  else if (p->kernel_hint == OMNI_GEMM_KERNEL_SPLITK_DEFER_FINISH) return OMNI_ERR_UNSUPPORTED;   // no split-K outside the ping-pong kernel
   else if (epilogue_rows_coalescable(p)) {
     int grid = tiles_m * tiles_n;
     if (gemm_persistent() && grid > gemm_num_cus()) grid = gemm_num_cus() & ~7;
@@ -1697,7 +1708,8 @@ int launch(const omni_gemm_params* p, hipStream_t s) {
 #include "dev/gemm_dev_entry_points.inc"
 #endif
 
-extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
+namespace {
+int gemm_validate(const omni_gemm_params* p) {
   if (!p || p->ngroups < 1 || p->ngroups > 2 || p->N <= 0 || p->K <= 0) return OMNI_ERR_BAD_ARG;
   if (p->K % RBK != 0 || p->N % 8 != 0) return OMNI_ERR_UNSUPPORTED;
   if (p->fp8 != 0 && p->fp8 != 1) return OMNI_ERR_BAD_ARG;
@@ -1747,6 +1759,24 @@ extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
   }
   if (p->w_k32_blocked != 0 && p->w_k32_blocked != 1) return OMNI_ERR_BAD_ARG;
   if (p->w_k32_blocked && !gemm_variant_blocked_ok(p)) return OMNI_ERR_UNSUPPORTED;   // only the ring / ping-pong kernels read that layout
+  return OMNI_OK;
+}
+}  // namespace
+
+// ABI v13: the whole-launch split-K factor the call would use (launch()'s rule, evaluated without launching)
+extern "C" int omni_gemm_splitk_factor(const omni_gemm_params* p) {
+  if (gemm_validate(p) != OMNI_OK) return 0;
+  if (p->fp8) return 1;
+  if (!(gemm_variant(p) >= 3 && p->K % PBK == 0 && epilogue_rows_coalescable(p) && ring_saddr_ok(p))) return 1;
+  const int mt0 = (p->g[0].M + BM - 1) / BM;
+  const int mt1 = p->ngroups > 1 ? (p->g[1].M + BM - 1) / BM : 0;
+  return splitk_factor(p, mt0 + mt1, (p->N + BN - 1) / BN);
+}
+
+extern "C" int omni_gemm_bf16(const omni_gemm_params* p, omni_stream stream) {
+  OMNI_TRY_STATUS(gemm_validate(p));
+  // a deferred finish exists only for a call that splits: refused here, before anything touches the device
+  if (p->kernel_hint == OMNI_GEMM_KERNEL_SPLITK_DEFER_FINISH && omni_gemm_splitk_factor(p) <= 1) return OMNI_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (p->epilogue) {
     case OMNI_EPI_BIAS: return launch<OMNI_EPI_BIAS>(p, s);

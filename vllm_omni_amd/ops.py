@@ -59,6 +59,7 @@ class GemmGroupArgs:
 
 GEMM_KERNEL_AUTO, GEMM_KERNEL_RING, GEMM_KERNEL_SPLITK_TALL, GEMM_KERNEL_NO_TAIL_SPLIT = 0, 1, 2, 3      # omni_gemm_params.kernel_hint
 GEMM_KERNEL_SPLITK_IN_LAUNCH = 4                                                                      # ABI v12
+GEMM_KERNEL_SPLITK_DEFER_FINISH = 5                                                                   # ABI v13
 
 
 def w_to_k32_blocked(w: torch.Tensor) -> torch.Tensor:
@@ -72,6 +73,24 @@ def w_to_k32_blocked(w: torch.Tensor) -> torch.Tensor:
 
 def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0, m_override: list[int] | None = None,
          w_k32_blocked: bool = False, splitk_ws: torch.Tensor | None = None, kernel_hint: int = 0, fp8: bool = False):
+    p = _gemm_params(groups, epilogue, split_n, m_override, w_k32_blocked, splitk_ws, kernel_hint, fp8)
+    N.check(N.lib().omni_gemm_bf16(C.byref(p), _stream()), "omni_gemm_bf16")
+
+
+def gemm_splitk_factor(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0, m_override: list[int] | None = None,
+                       w_k32_blocked: bool = False, splitk_ws: torch.Tensor | None = None, kernel_hint: int = 0,
+                       fp8: bool = False) -> int:
+    """omni_gemm_splitk_factor (ABI v13): the whole-launch split-K factor `gemm` would use for these arguments (1 = no split).
+    A caller that wants the partials left for `splitk_finish_adaln_pair` asks this first and then calls `gemm` with
+    kernel_hint = GEMM_KERNEL_SPLITK_DEFER_FINISH."""
+    p = _gemm_params(groups, epilogue, split_n, m_override, w_k32_blocked, splitk_ws, kernel_hint, fp8)
+    s = int(N.lib().omni_gemm_splitk_factor(C.byref(p)))
+    if s <= 0:
+        raise N.OmniNativeError("omni_gemm_splitk_factor: not a valid GEMM call")
+    return s
+
+
+def _gemm_params(groups, epilogue, split_n, m_override, w_k32_blocked, splitk_ws, kernel_hint, fp8):
     """Y_g = epilogue(A_g @ W_g.T + bias_g) for up to two groups sharing N, K (omni_gemm_bf16).  `splitk_ws`: optional fp32
     device workspace; with it, launches of at most 128 tiles in at most 10 row tiles split their K loop (ABI v4).
     `kernel_hint`: 0 = automatic, GEMM_KERNEL_RING = force the fallback (ring) kernel (ABI v6; cross-checks),
@@ -120,7 +139,7 @@ def gemm(groups: list[GemmGroupArgs], epilogue: int = EPI_BIAS, split_n: int = 0
         G.a_k32_rows = g.a.shape[0] if g.a_k32_blocked else 0       # blocked tensors keep their [rows, K] shape
         G.out_k32_rows = g.out.shape[0] if g.out_k32_blocked else 0
         G.tile_skip = _p(g.tile_skip, torch.int32, "tile_skip")
-    N.check(N.lib().omni_gemm_bf16(C.byref(p), _stream()), "omni_gemm_bf16")
+    return p
 
 
 def quantize_fp8_rows(x: torch.Tensor, *, x_k32_blocked: bool = False, out: torch.Tensor | None = None,
@@ -212,6 +231,32 @@ def adaln_modulate_pair(streams, *, mod_item_stride: int, eps: float = 1e-6, out
             outs.append(y)
     N.check(N.lib().omni_adaln_modulate_pair(C.byref(recs[0]), C.byref(recs[1]), D, mod_item_stride, eps, _stream()),
             "omni_adaln_modulate_pair")
+    return outs
+
+
+def splitk_finish_adaln_pair(splitk_ws: torch.Tensor, nsplit: int, ws_rows: int, streams, *, mod_item_stride: int,
+                             eps: float = 1e-6, out_k32_blocked: bool = False):
+    """omni_splitk_finish_adaln_pair (ABI v13): the finish of a DEFERRED split-K GEMM with the gated-residual epilogue + the AdaLN
+    that follows it, both streams of a DiT block in one launch.  `splitk_ws` = the fp32 partials [nsplit][ws_rows][D] the GEMM left;
+    `streams` = two (ws_row0, bias-or-None, hidden [rows, D] contiguous, gate, scale, shift, row_item_map) tuples.  `hidden` is
+    updated IN PLACE (hidden + gate * (sum of partials + bias)); returns the two AdaLN outputs (row-major, or K32-blocked)."""
+    assert len(streams) == 2
+    recs, outs = (N.FinishAdalnStream * 2)(), []
+    D = streams[0][2].shape[1]
+    for i, (row0, bias, hidden, gate, scale, shift, item_map) in enumerate(streams):
+        rows, d, ld = _rows2d(hidden, "hidden")
+        if d != D or ld != D:
+            raise N.OmniNativeError("splitk_finish_adaln_pair: both streams are contiguous [rows, D] with one D")
+        g = recs[i]
+        g.rows, g.ws_row0, g.bias, g.hidden = rows, int(row0), _p(bias, name="bias"), _p(hidden, name="hidden")
+        g.gate, g.scale, g.shift = _p(gate, name="gate"), _p(scale, name="scale"), _p(shift, name="shift")
+        g.row_item_map, g.rows_per_item = _p(item_map, torch.int32, "row_item_map"), 0
+        y = torch.empty(rows, D, dtype=BF16, device=hidden.device)
+        g.y, g.y_k32_rows = _p(y, name="y"), rows if out_k32_blocked else 0
+        outs.append(y)
+    N.check(N.lib().omni_splitk_finish_adaln_pair(_p(splitk_ws, torch.float32, "splitk_ws"), int(nsplit), int(ws_rows),
+                                                  C.byref(recs[0]), C.byref(recs[1]), D, mod_item_stride, eps, _stream()),
+            "omni_splitk_finish_adaln_pair")
     return outs
 
 
