@@ -133,3 +133,57 @@ def test_modulation_table_equals_the_per_forward_gemvs():
             assert torch.equal(again, outs[pre, graph])
     assert torch.equal(outs[True, False], outs[True, True]) and torch.equal(outs[False, False], outs[False, True])
     assert rel_l2(outs[True, False], outs[False, False]) <= 2e-2      # 10 steps of true-CFG 4.0: SiLU rounded to bf16 in the table's GEMM path
+
+
+def test_modulation_table_is_kept_per_schedule_and_dropped_with_the_weights():
+    """od_config.cache_modulation_tables (QwenImageTransformer2DModel.modulation_table_for_schedule): the table is a function of the
+    weights and the schedule's sigmas only, so a later request with the same (resolution, step count) reuses it — no second pass
+    over the modulation weights — and gets the same bits as with the cache off; another step count is another entry; new weights
+    drop every entry; the byte cap evicts the oldest."""
+    from vllm_omni_amd.diffusion.data import OmniDiffusionConfig
+    from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenImagePipeline
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+    from vllm_omni_amd.diffusion.request import OmniDiffusionRequest
+
+    heads, joint, layers = 2, 128, 2
+    P = O.make_dit_params(layers, seed=77, bias_std=0.02, norm_jitter=0.1, num_heads=heads, joint_dim=joint)
+    m = QwenImageTransformer2DModel(num_layers=layers, num_attention_heads=heads, joint_attention_dim=joint, device=DEV)
+    m.load_weights(P.items())
+    calls = []
+    plain = m.modulation_table
+    m.modulation_table = lambda *a, **k: (calls.append(1), plain(*a, **k))[1]
+
+    def req(steps, seed):
+        g = torch.Generator().manual_seed(seed)
+        return OmniDiffusionRequest(height=128, width=128, num_inference_steps=steps, true_cfg_scale=4.0, output_type="latent",
+                                    latents=torch.randn(1, 64, 64, generator=g).to(BF16),
+                                    prompt_embeds=torch.randn(1, 9, joint, generator=g).to(BF16),
+                                    negative_prompt_embeds=torch.randn(1, 5, joint, generator=g).to(BF16))
+
+    def run(pipe, r):
+        return pipe.generate([r], output_type="latent")[0].output.float().cpu()
+
+    cold = QwenImagePipeline(od_config=OmniDiffusionConfig(cache_modulation_tables=False), device=DEV, transformer=m)
+    warm = QwenImagePipeline(od_config=OmniDiffusionConfig(), device=DEV, transformer=m)
+    ref_a, ref_b = run(cold, req(6, 1)), run(cold, req(6, 2))
+    assert len(calls) == 2 and not m._mod_tables                     # cache off: one pass per generation, nothing kept
+    got_a = run(warm, req(6, 1))
+    assert len(calls) == 3 and len(m._mod_tables) == 1
+    got_b = run(warm, req(6, 2))                                       # another prompt / seed, the same schedule: a hit
+    assert len(calls) == 3
+    assert torch.equal(got_a, ref_a) and torch.equal(got_b, ref_b)
+    run(warm, req(4, 1))                                               # another step count: another schedule
+    assert len(calls) == 4 and len(m._mod_tables) == 2
+    assert torch.equal(run(warm, req(6, 1)), ref_a) and len(calls) == 4
+    # the byte cap: room for one table only -> the older entry goes
+    one_table = next(iter(m._mod_tables.values())).numel() * 2
+    m.MOD_TABLE_CACHE_BYTES = one_table
+    run(warm, req(4, 1))
+    assert len(m._mod_tables) == 1 and len(calls) == 4
+    del m.MOD_TABLE_CACHE_BYTES
+    # new weights: the generation moves, every entry is stale
+    P2 = O.make_dit_params(layers, seed=78, bias_std=0.02, norm_jitter=0.1, num_heads=heads, joint_dim=joint)
+    m.load_weights(P2.items())
+    fresh = run(warm, req(4, 1))
+    assert len(calls) == 5 and len(m._mod_tables) == 1
+    assert torch.equal(fresh, run(cold, req(4, 1)))

@@ -21,7 +21,10 @@ for spec in "2048 1" "1024 1" "1024 2"; do
   tail -1 $OUT/prof_${TAG}_final_step_$1px_R$2.log | grep -v amdgpu >> $OUT/${TAG}_step_table_$1px_R$2.txt
 done
 timeout 600 rocprofv3 --kernel-trace --stats -T -d $OUT/prof_${TAG}_final_config1 -o p -- python tools/run_config1.py 5 > /dev/null 2>&1
-python tools/time_config1.py 2>&1 | tail -1 > $OUT/${TAG}_config1_ms.txt
+python tools/time_config1.py cold 2>&1 | tail -1 > $OUT/${TAG}_config1_ms.txt
+python tools/time_config1.py warm 2>&1 | tail -1 >> $OUT/${TAG}_config1_ms.txt
+timeout 600 rocprofv3 --kernel-trace --stats -T -d $OUT/prof_${TAG}_final_step_256px_R1 -o p -- python tools/time_step.py 256 60 5 1 > $OUT/prof_${TAG}_final_step_256px_R1.log 2>&1
+python tools/step_profile_table.py $OUT/prof_${TAG}_final_step_256px_R1/*.db 256 1 > $OUT/${TAG}_step_table_256px_R1.txt 2>&1
 OMNI_PROFILES_DIR=$OUT python tools/summarize_prof.py $OUT $TAG > $OUT/${TAG}_rocprof_summary_final.txt 2>&1
 # gpurun merges at most 64 MiB back: the counter and step databases are summarised above; only the bench trace travels
 rm -rf $OUT/pmc_${TAG}_* $OUT/prof_${TAG}_final_* 

@@ -13,7 +13,9 @@ from vllm_omni_amd.diffusion.models.qwen_image.pipeline_qwen_image import QwenIm
 from vllm_omni_amd.diffusion.request import OmniDiffusionRequest  # noqa: E402
 
 dev = torch.device("cuda:0")
-pipe = QwenImagePipeline(od_config=OmniDiffusionConfig(model="x"), device=dev)
+cold = "cold" in sys.argv[1:]          # every image pays its own modulation-table pass (od_config.cache_modulation_tables = False)
+sys.argv = [a for a in sys.argv if a not in ("cold", "warm")]
+pipe = QwenImagePipeline(od_config=OmniDiffusionConfig(model="x", cache_modulation_tables=not cold), device=dev)
 pipe.transformer.init_random_(seed=1234)
 pipe.vae.init_random_(seed=4321)
 g = torch.Generator().manual_seed(3)
@@ -30,4 +32,4 @@ t0 = time.perf_counter()
 for _ in range(5):
     f()
 torch.cuda.synchronize()
-print(f"{hw}x{hw}, 4 steps, true-CFG, batch 1: {(time.perf_counter() - t0) / 5 * 1e3:.1f} ms/image (OMNI_GEMM_SPLITK={os.environ.get('OMNI_GEMM_SPLITK', '1')} SPLITK_INLAUNCH={os.environ.get('OMNI_GEMM_SPLITK_INLAUNCH', '1')} ADALN_PAIR={os.environ.get('OMNI_DIT_ADALN_PAIR', '1')})")
+print(f"{hw}x{hw}, 4 steps, true-CFG, batch 1: {(time.perf_counter() - t0) / 5 * 1e3:.1f} ms/image ({'cold' if cold else 'warm'} schedule table; OMNI_GEMM_SPLITK={os.environ.get('OMNI_GEMM_SPLITK', '1')} SPLITK_INLAUNCH={os.environ.get('OMNI_GEMM_SPLITK_INLAUNCH', '1')} ADALN_PAIR={os.environ.get('OMNI_DIT_ADALN_PAIR', '1')})")

@@ -436,7 +436,9 @@ __global__ __launch_bounds__(256) void rope_kernel(const uint16_t* __restrict__ 
 // (16 B per lane per load, ROWS_PER_ITER rows in flight) and reduces across the wave.
 // bytes = N*K*2 (W, read once) — the 13.6 GB/forward modulation stream of the DiT.
 // ------------------------------------------------------------------------------------------------
-template <int NB>
+// MAXC = 16-byte pieces per lane and weight row (K <= 512 * MAXC): a template parameter since round 6's third session — with the
+// fixed 8 a K = 3072 row (6 pieces) issued two more loads of its last piece per row, a quarter of the kernel's load instructions.
+template <int NB, int MAXC>
 __global__ __launch_bounds__(256) void linear_smallbatch_kernel(const uint16_t* __restrict__ x, int64_t ldx,
                                                                 const uint16_t* __restrict__ W,
                                                                 const uint16_t* __restrict__ bias, int64_t N, int K,
@@ -487,7 +489,6 @@ __global__ __launch_bounds__(256) void linear_smallbatch_kernel(const uint16_t* 
     // of staged activations, three workgroups per CU) streamed the modulation weights at 1.9 TB/s (profiles/r06_first_profiles_
     // step_shapes.txt: 59 us per 113 MB matrix).  Pieces past the row end re-read the last piece (unconditional loads can be
     // hoisted; a load under `if (c < nchunk)` is waited for on the spot) and are skipped in the arithmetic.
-    constexpr int MAXC = 8;
     u32x4_t w[R][MAXC];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -972,16 +973,25 @@ extern "C" int omni_linear_smallbatch(const omni_bf16* x, int64_t ldx, int32_t B
   int64_t blocks = (N + 7) / 8;
   if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;
   const dim3 grid((unsigned)blocks), block(256);
-#define OMNI_LSB(NB)                                                                                              \
+  const int pieces = (K / 8 + 63) / 64;            // 16-byte pieces per lane and row: 6 at K = 3072
+#define OMNI_LSB_C(NB, MC)                                                                                        \
   do {                                                                                                            \
     const size_t lds = (size_t)NB * K * sizeof(float);                                                            \
     if (lds > 65536) {                                                                                            \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_smallbatch_kernel<NB>),                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_smallbatch_kernel<NB, MC>),                    \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
         return OMNI_ERR_LAUNCH;                                                                                   \
     }                                                                                                             \
-    hipLaunchKernelGGL(linear_smallbatch_kernel<NB>, grid, block, lds, s, x, ldx, W, bias, N, K, y, ldy, act_in,  \
-                       act_out);                                                                                  \
+    hipLaunchKernelGGL((linear_smallbatch_kernel<NB, MC>), grid, block, lds, s, x, ldx, W, bias, N, K, y, ldy,    \
+                       act_in, act_out);                                                                          \
+  } while (0)
+#define OMNI_LSB(NB)                                                                                              \
+  do {                                                                                                            \
+    if (pieces <= 1) OMNI_LSB_C(NB, 1);                                                                           \
+    else if (pieces <= 2) OMNI_LSB_C(NB, 2);                                                                      \
+    else if (pieces <= 4) OMNI_LSB_C(NB, 4);                                                                      \
+    else if (pieces <= 6) OMNI_LSB_C(NB, 6);                                                                      \
+    else OMNI_LSB_C(NB, 8);                                                                                       \
   } while (0)
   if (B == 1) OMNI_LSB(1);
   else if (B == 2) OMNI_LSB(2);
@@ -993,6 +1003,7 @@ extern "C" int omni_linear_smallbatch(const omni_bf16* x, int64_t ldx, int32_t B
     if (B == 7) OMNI_LSB(7); else OMNI_LSB(8);
   }
 #undef OMNI_LSB
+#undef OMNI_LSB_C
   OMNI_CHECK_LAUNCH();
   return OMNI_OK;
 }

@@ -101,6 +101,9 @@ class OmniDiffusionConfig:
     precompute_modulation: bool = True  # NEW: compute every block's modulation vectors for ALL steps of a request in one pass
                                      # over the modulation weights (omni_dit_modulation_table) instead of re-streaming 13.6 GB
                                      # of weights in every forward
+    cache_modulation_tables: bool = True  # NEW: keep a schedule's modulation table for later requests with the same sigmas
+                                     # (the same resolution and step count): a function of weights + schedule only, never of
+                                     # a request's prompt / latents / seed (QwenImageTransformer2DModel.modulation_table_for_schedule)
     max_steps_in_flight: int = 2     # NEW: how many denoising steps a worker's host may enqueue ahead of the device
                                      # (step_batcher.py: bounded run-ahead, so that a newcomer joins within this many steps)
     # ---- the reference's remaining fields (data.py:255-360), so that a config written for it constructs here unchanged.

@@ -161,7 +161,8 @@ class QwenImagePipeline(nn.Module):
         rb = build_ragged_batch(lens, grid, temb_rows=[0] * len(lens))
         prepared = tr.prepare_batch(rb)
         n_items = (2 if do_cfg else 1) * R
-        sig_in = self.scheduler.model_timestep(timesteps).to(dev)                   # bf16-rounded t/1000, fp32 [N]
+        sig_host = self.scheduler.model_timestep(timesteps)                         # bf16-rounded t/1000, fp32 [N]
+        sig_in = sig_host.to(dev)
         dt_dev = dts.to(dev, torch.float32).contiguous()
         graph_on = self._use_graph(n_items * S)
         tcfg = getattr(tr, "teacache", None)
@@ -212,7 +213,9 @@ class QwenImagePipeline(nn.Module):
         # modulation vectors of every step of this schedule, computed once (all requests of a static step-batch share it)
         mod_tab = None
         if getattr(self.od_config, "precompute_modulation", True):
-            mod_tab = tr.modulation_table(sig_in, None if t_cond is None else [t_cond] * len(timesteps))  # [L, 2, N, 6D]
+            mod_tab = tr.modulation_table_for_schedule(sig_in, None if t_cond is None else [t_cond] * len(timesteps),
+                                                       cache=bool(getattr(self.od_config, "cache_modulation_tables", True)),
+                                                       sigma_host=sig_host)                                # [L, 2, N, 6D]
             if st.get("mod") is None:
                 st["mod"] = torch.empty(mod_tab.shape[0], 2, 1, mod_tab.shape[3], dtype=BF16, device=dev)  # static: graphs bake it
         mod_now = st.get("mod") if mod_tab is not None else None
@@ -528,10 +531,11 @@ class QwenImagePipeline(nn.Module):
         a.n_steps = len(ts)
         if a.n_steps >= self.SERVE_MAX_STEPS:
             raise NotImplementedError(f"{a.n_steps} denoising steps: the step batcher's schedule tables hold {self.SERVE_MAX_STEPS - 1}")
-        sig_d = sch.model_timestep(ts).float().to(self.device)
+        sig_h = sch.model_timestep(ts).float()
+        sig_d = sig_h.to(self.device)
         # mod_tab: this sample's modulation table [L, 2, n_steps, 6D] (88 MB at 20 steps) — built when the sample first takes
         # a slot of a running batch, not at admission: a long queue of waiting requests must not hold one each
-        a.state = dict(sig_d=sig_d, dt_d=sch.dt().float().to(self.device), mod_tab=None,
+        a.state = dict(sig_d=sig_d, sig_h=sig_h, dt_d=sch.dt().float().to(self.device), mod_tab=None,
                        lat=sm["lat"].to(self.device, BF16).clone(), pos=sm["pos"].to(self.device, BF16),
                        neg=None if sm["neg"] is None else sm["neg"].to(self.device, BF16),
                        cond=None if sm.get("cond") is None else sm["cond"].to(self.device, BF16),
@@ -684,7 +688,9 @@ class QwenImagePipeline(nn.Module):
             if st["mod"] is not None:
                 if a.state.get("mod_tab") is None:
                     tc_ = a.sample.get("t_cond")
-                    a.state["mod_tab"] = tr.modulation_table(a.state["sig_d"], None if tc_ is None else [tc_] * a.n_steps)
+                    a.state["mod_tab"] = tr.modulation_table_for_schedule(
+                        a.state["sig_d"], None if tc_ is None else [tc_] * a.n_steps,
+                        cache=bool(getattr(self.od_config, "cache_modulation_tables", True)), sigma_host=a.state.get("sig_h"))
                 # sample r's modulation rows for ITS step (`a.step`: the host's count of the steps enqueued for it — equal to
                 # the device-side counter when this copy executes, and the source table is never written again)
                 st["mod"][:, :, r].copy_(a.state["mod_tab"][:, :, min(a.step, a.n_steps - 1)])

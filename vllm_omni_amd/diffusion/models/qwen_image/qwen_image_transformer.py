@@ -338,6 +338,7 @@ class QwenImageTransformer2DModel(nn.Module):
         self._fp8_classes = frozenset()
         self._workspace = None
         self._batch_cache: dict = {}
+        self._mod_tables: dict = {}   # modulation_table_for_schedule(): (weights generation, sigmas, t_cond) -> table, newest last
 
     # ------------------------------------------------------------------ weights
     @property
@@ -626,6 +627,37 @@ class QwenImageTransformer2DModel(nn.Module):
         N.check(lib.omni_dit_modulation_table(C.byref(w), temb.data_ptr(), M, table.data_ptr(), ws.data_ptr(), need,
                                               torch.cuda.current_stream().cuda_stream), "omni_dit_modulation_table")
         return table
+
+    MOD_TABLE_CACHE_BYTES = 1 << 30        # tables kept for later requests (a 50-step table is 221 MB; 288 GB of HBM)
+
+    @torch.no_grad()
+    def modulation_table_for_schedule(self, sigma: torch.Tensor, additional_t_cond=None, cache: bool = True,
+                                      sigma_host: torch.Tensor | None = None) -> torch.Tensor:
+        """`modulation_table`, remembered per SCHEDULE.  The table is a function of the weights and of the conditioning rows alone
+        (the sigmas of the schedule, the Layered variant's additional_t_cond) — not of the prompt, the latents or the seed — and a
+        server sees the same (resolution, step count) again and again: requests that share a schedule share the table, and the
+        pass over the 13.6 GB of modulation weights (3.4 ms: 5 % of a 256x256 / 4-step image) is paid by the first of them
+        only.  The reference streams these weights in every forward (qwen_image_transformer.py:552-561).  Keyed by the weights
+        generation (a weight load / re-layout / fp8 switch drops every entry), the exact fp32 sigmas and t_cond; newest-first
+        eviction beyond MOD_TABLE_CACHE_BYTES.  The returned table is shared: callers must not write to it.  `sigma_host`: the
+        same values on the host (the key is formed from them: reading a device tensor back would wait for the stream)."""
+        if not cache:
+            return self.modulation_table(sigma, additional_t_cond)
+        sig = (sigma if sigma_host is None else sigma_host).detach().to("cpu", torch.float32).reshape(-1)
+        self._native_weights()                                   # (re)build the pointer table first: the generation is then current
+        key = (self._native_gen, sig.numpy().tobytes(), None if additional_t_cond is None else tuple(int(t) for t in additional_t_cond))
+        hit = self._mod_tables.pop(key, None)
+        if hit is None:
+            for k in [k for k in self._mod_tables if k[0] != self._native_gen]:
+                del self._mod_tables[k]                          # tables of weights that no longer exist
+            hit = self.modulation_table(sigma, additional_t_cond)
+        self._mod_tables[key] = hit                              # newest last
+        total = sum(t.numel() * 2 for t in self._mod_tables.values())
+        for k in list(self._mod_tables):
+            if total <= self.MOD_TABLE_CACHE_BYTES or k == key:
+                break
+            total -= self._mod_tables.pop(k).numel() * 2
+        return hit
 
     def _run_block(self, layer: int, hidden_states, encoder_hidden_states, temb, image_rotary_emb):
         """Module-surface entry of ONE block (QwenImageTransformerBlock.forward): [B,S,D], [B,T,D], temb [B,D] -> (enc, hid)."""
