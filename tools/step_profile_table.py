@@ -62,13 +62,14 @@ if att:
     print(f"{'joint attention (+ split combine)':44s} {n:8d} {avg / 1e3:9.1f} {min(r[4] for r in att) / 1e3:9.1f} {100 * (tot + ctot) / total:10.1f} "
           f"{flop / 1e12:13.3f} {flop / (avg * 1e-9) / 2.5e15:12.3f}  grid {att[0][1] // 256} workgroups" + (f", combine {ctot / max(1, sum(r[2] for r in comb)) / 1e3:.1f} us" if comb else ""))
 for key, label in (("rownorm_kernel", "AdaLN / RMSNorm (rownorm_kernel)"), ("gemm_tail_finish", "GEMM tail-split finish"),
-                   ("gemm_splitk_finish", "GEMM split-K finish"), ("linear_smallbatch", "modulation / timestep GEMVs")):
+                   ("gemm_splitk_finish", "GEMM split-K finish"), ("splitk_finish_adaln", "split-K finish + AdaLN (fused, ABI v13)"),
+                   ("linear_smallbatch", "modulation / timestep GEMVs")):
     rs = [r for r in rows if key in r[0]]
     if rs:
         n, tot = sum(r[2] for r in rs), sum(r[5] for r in rs)
         print(f"{label:44s} {n:8d} {tot / n / 1e3:9.1f} {min(r[4] for r in rs) / 1e3:9.1f} {100 * tot / total:10.1f}")
 other = [r for r in rows if not any(k in r[0] for k in ("gemm_bf16_pp_kernel", "flash_attn_fwd", "attn_split_combine", "rownorm_kernel",
-                                                          "gemm_tail_finish", "gemm_splitk_finish", "linear_smallbatch"))]
+                                                          "gemm_tail_finish", "gemm_splitk_finish", "splitk_finish_adaln", "linear_smallbatch"))]
 small = [r for r in rows if "gemm_bf16_pp_kernel" in r[0] and id(r) not in seen]
 print(f"{'other GEMM launches (img_in, txt_in, proj_out)':44s} {sum(r[2] for r in small):8d} {'':9s} {'':9s} {100 * sum(r[5] for r in small) / total:10.1f}")
 print(f"{'everything else (torch init / RNG, gathers)':44s} {sum(r[2] for r in other):8d} {'':9s} {'':9s} {100 * sum(r[5] for r in other) / total:10.1f}")

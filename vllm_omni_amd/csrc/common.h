@@ -74,6 +74,16 @@ OMNI_DEVINL float row16_sum(float v) {
   return v;
 }
 
+// Sum over the whole wave, VALU only, result in LANE 63: the four row sums (row16_sum) are folded by the two wave-level DPP
+// broadcasts of gfx9 — row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: total = (r3 + r2) + (r1 + r0).  wave_sum<64>
+// (six __shfl_xor = six ds_bpermute round trips through the LDS pipe) is the form for callers that need the sum in every lane.
+OMNI_DEVINL float wave_sum_to_lane63(float v) {
+  v = row16_sum(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));   // row_bcast:15
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));   // row_bcast:31
+  return v;
+}
+
 // Per-head RMSNorm(128) + interleaved RoPE on the 8 consecutive columns one lane holds (16 lanes = one head).  ONE
 // definition with explicit fma / no implicit contraction, shared by qk_norm_rope_kernel and the fused QKV-GEMM epilogue, so
 // that the two paths produce identical bits (left to the compiler, `a*c - b*s` contracts differently in the two contexts).

@@ -522,11 +522,13 @@ __global__ __launch_bounds__(256) void linear_smallbatch_kernel(const uint16_t* 
           for (int i = 0; i < 8; ++i) acc[r][b] += wf[i] * xv[b][i];
       }
     }
+    // R x NB wave reductions per iteration: VALU-only (DPP), the total lands in lane 63 (round 6, third session: the butterfly form
+    // was 48 ds_bpermute round trips per iteration at NB = 4, in the LDS pipe that also serves the activation reads)
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int b = 0; b < NB; ++b) acc[r][b] = wave_sum<64>(acc[r][b]);
-    if (lane == 0) {
+      for (int b = 0; b < NB; ++b) acc[r][b] = wave_sum_to_lane63(acc[r][b]);
+    if (lane == 63) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int64_t n = n0 + r;
