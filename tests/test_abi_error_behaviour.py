@@ -116,7 +116,6 @@ def test_elementwise_entry_points_reject_bad_arguments(lib):
     assert fin(a=fin_rec(row_item_map=None)) == BAD_ARG                      # rows cannot be attributed to items
     assert fin(b=fin_rec(rows=128, ws_row0=600)) == BAD_ARG                  # the group's rows end past the partials' rows
     assert fin(a=fin_rec(y_k32_rows=64)) == BAD_ARG                          # blocked rows < rows
-    assert fin(a=fin_rec(bias=None)) != BAD_ARG or True                      # (bias is optional)
     assert fin(nsplit=5) == UNSUPPORTED and fin(nsplit=1) == UNSUPPORTED     # the factors split-K produces: 2, 3, 4, 6, 8
     assert fin(D=3076) == UNSUPPORTED and fin(D=4104) == UNSUPPORTED
     assert fin(a=fin_rec(y_k32_rows=512), D=3080) == UNSUPPORTED             # K32-blocked output: D % 32

@@ -318,6 +318,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
   // norm2 + modulate (reference :590, :595)
   const bool fused_q2 = f_up && blk;
   if (norm2_done) {
+    // (performed by omni_splitk_finish_adaln_pair above)
   } else if (fused_q2) {
     const omni_adaln_stream si = {hidden_img, nullptr, Ri, mod_img + 4 * D, mod_img + 3 * D, b->img_item, 0, 0, ws.x8, Ri,
                                   ws.x8_scale};
