@@ -505,7 +505,13 @@ extern "C" int omni_dit_modulation_table(const omni_dit_weights* w, const omni_b
   if (workspace_bytes < omni_dit_modulation_table_workspace_bytes(w, M)) return OMNI_ERR_BAD_ARG;
   if (M <= 8) {
     // a handful of rows (BASELINE config 1: 4 steps): the weight-streaming GEMV, one launch per matrix at HBM speed (the GEMM
-    // kernel below needs two launches per matrix and is paced by one CU's k-loop per 256-column panel: 2.5x slower at M = 4)
+    // kernel below needs two launches per matrix and is paced by one CU's k-loop per 256-column panel).  Measured, 60 layers
+    // (profiles/r06e_table_pass.txt): GEMV 2.5 / 3.0 / 3.0 / 3.4 / 4.3 / 4.2 ms at M = 1 .. 6 (5.4 .. 3.3 TB/s), 7.1 / 7.9 ms at
+    // M = 7 / 8 (8 staged fp32 rows are 96 KB of LDS: one block per CU); the GEMM path: 4.3 .. 4.9 ms at M = 7 .. 50.  M = 7 / 8
+    // stay on the GEMV nevertheless: the two paths round SiLU differently (fp32 inside the GEMV, bf16 in front of the GEMM as the
+    // reference's eager Sequential does), and a table must agree with the per-forward GEMVs of the module-level plug-in path
+    // (TeaCache's host hook walks that one) to the GEMV's own bits wherever both exist — tests/test_gpu_teacache.py; a schedule's
+    // table is computed once and kept (modulation_table_for_schedule), so the 3 ms are paid once per schedule
     for (int l = 0; l < w->num_layers; ++l) {
       const omni_dit_layer_weights& L = w->layers[l];
       OMNI_TRY(omni_linear_smallbatch(temb, D, M, L.img_mod_w, L.img_mod_b, 6 * D, (int32_t)D,
