@@ -478,7 +478,29 @@ __global__ __launch_bounds__(256) void linear_smallbatch_kernel(const uint16_t* 
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const int nchunk = K / 8;  // 16-B chunks per row
   constexpr int R = 2;       // weight rows in flight per wave
+  // Round 6, third session: with FIVE or more staged rows (96 KB of LDS at 8: one workgroup per CU, four waves) the NEXT trip's
+  // weight rows are requested before this trip's arithmetic — the table pass of 8 rows: 7.9 -> 5.2 ms, 6 rows 4.2 -> 3.8.  Up to four
+  // rows (three workgroups per CU) the same change costs 12 .. 18 % (2.5 -> 3.0 ms at one row): the second row pair's registers buy
+  // nothing there, the loads of twelve resident waves already cover each other (profiles/r06e_table_pass.txt).
+  constexpr bool AHEAD = NB >= 5;
+  u32x4_t w[R][MAXC], wn[R][AHEAD ? MAXC : 1];
+  auto load_rows = [&](int64_t n0, auto& dst) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint16_t* wrow = W + min(n0 + r, N - 1) * K;
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j)
+        dst[r][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow + min(lane + 64 * j, nchunk - 1) * 8));
+    }
+  };
+  if (AHEAD && wave_global * R < N) load_rows(wave_global * R, w);
   for (int64_t n0 = wave_global * R; n0 < N; n0 += nwaves * R) {
+    const bool more = AHEAD && n0 + nwaves * R < N;      // uniform over the wave
+    if constexpr (AHEAD) {
+      if (more) load_rows(n0 + nwaves * R, wn);
+    } else {
+      load_rows(n0, w);
+    }
     float acc[R][NB];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -489,14 +511,6 @@ __global__ __launch_bounds__(256) void linear_smallbatch_kernel(const uint16_t* 
     // of staged activations, three workgroups per CU) streamed the modulation weights at 1.9 TB/s (profiles/r06_first_profiles_
     // step_shapes.txt: 59 us per 113 MB matrix).  Pieces past the row end re-read the last piece (unconditional loads can be
     // hoisted; a load under `if (c < nchunk)` is waited for on the spot) and are skipped in the arithmetic.
-    u32x4_t w[R][MAXC];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint16_t* wrow = W + min(n0 + r, N - 1) * K;
-#pragma unroll
-      for (int j = 0; j < MAXC; ++j)
-        w[r][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow + min(lane + 64 * j, nchunk - 1) * 8));
-    }
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
       const int c = lane + 64 * j;
@@ -541,6 +555,14 @@ __global__ __launch_bounds__(256) void linear_smallbatch_kernel(const uint16_t* 
             y[(int64_t)b * ldy + n] = f32_to_bf16_bits(v);
           }
         }
+      }
+    }
+    if constexpr (AHEAD) {
+      if (more) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int j = 0; j < MAXC; ++j) w[r][j] = wn[r][j];
       }
     }
   }
