@@ -356,18 +356,31 @@ OMNI_DEVINL void gemm_epilogue_lds_impl(const omni_gemm_params& P, const omni_ge
         // form) left a thread with 32 B in flight, and the finish of a 6-way split at 640 rows x 3072 columns ran at 3.2 TB/s
         // (14.6 us, profiles/r06_first_profiles_step_shapes.txt).  Splits past nsplit re-read the last one (unconditional loads
         // can be hoisted) and are skipped in the sum; the order of the adds stays the split order (deterministic, as before).
+        // Round 6, third session: the request width follows the split factor (2, 3, 4, 6 exactly; else 8 at a time) — with the fixed
+        // 8 the finish of a 2-way split (QKV of one 256^2 CFG pair) issued four loads for every one it needed and ran 18.5 us
+        // against 14.3 us for the same bytes 6-way.  Same adds, same order.
         f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
-        for (int sp0 = 0; sp0 < csrc.nsplit; sp0 += 8) {
-          f32x4_t pl[8], ph[8];
+        auto sum_splits = [&](auto wc) {
+          constexpr int W = decltype(wc)::value;
+          for (int sp0 = 0; sp0 < csrc.nsplit; sp0 += W) {
+            f32x4_t pl[W], ph[W];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const float* q = src + (int64_t)min(sp0 + u, csrc.nsplit - 1) * csrc.split_stride;
-            pl[u] = *reinterpret_cast<const f32x4_t*>(q);
-            ph[u] = *reinterpret_cast<const f32x4_t*>(q + 4);
+            for (int u = 0; u < W; ++u) {
+              const float* q = src + (int64_t)min(sp0 + u, csrc.nsplit - 1) * csrc.split_stride;
+              pl[u] = *reinterpret_cast<const f32x4_t*>(q);
+              ph[u] = *reinterpret_cast<const f32x4_t*>(q + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < W; ++u)
+              if (sp0 + u < csrc.nsplit) { lo += pl[u]; hi += ph[u]; }
           }
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (sp0 + u < csrc.nsplit) { lo += pl[u]; hi += ph[u]; }
+        };
+        switch (csrc.nsplit) {                          // uniform over the launch
+          case 2: sum_splits(std::integral_constant<int, 2>{}); break;
+          case 3: sum_splits(std::integral_constant<int, 3>{}); break;
+          case 4: sum_splits(std::integral_constant<int, 4>{}); break;
+          case 6: sum_splits(std::integral_constant<int, 6>{}); break;
+          default: sum_splits(std::integral_constant<int, 8>{}); break;
         }
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         if (G.bias) {
