@@ -141,3 +141,35 @@ def test_attention_short_last_block_split_matches_unsplit_and_oracle(lens, H, bl
         o += n
     ref = _attn_ref(q, k, v, lens, H)
     assert rel_l2(split, ref) <= 4e-3 and (split.float().cpu() - ref).abs().max() <= 2e-2
+
+
+def test_forward_at_one_round_plus_thin_tail_mlp_up():
+    """omni_dit_forward hands MLP-up (N = 4 D, 48 column tiles) the split-K workspace when a thin tail follows one to three full
+    rounds (csrc/dit_forward.hip mlp_up_tail_split): one 384x384 CFG pair = 1152 + 128 rows = 6 row tiles x 48 = 288 tiles = one
+    round + 32, whose 32 tail tiles then run 4-way K-split.  Two full-width layers against the fp32 oracle at the usual forward
+    bar, determinism, and — the rule looks at tile counts — a 256x256 pair (240 tiles: no tail) for contrast at the same bar."""
+    from vllm_omni_amd.diffusion.models.qwen_image.qwen_image_transformer import QwenImageTransformer2DModel
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    if _cus() != 256:
+        pytest.skip("the shapes below are chosen for 256 CUs")
+    m = QwenImageTransformer2DModel(num_layers=2, device=DEV)
+    m.init_random_(seed=91)
+    P = {n: p.detach().float() for n, p in m.named_parameters()}          # before the first forward (row-major layout)
+    for hw in (24, 16):                                                    # 384^2 (the tail-split shape), 256^2
+        B, S, T = 2, hw * hw, 64
+        g = torch.Generator(device=DEV).manual_seed(hw)
+        lat = torch.randn(B, S, 64, device=DEV, generator=g).to(BF16)
+        txt = torch.randn(B, T, 3584, device=DEV, generator=g).to(BF16)
+        sig = torch.full((B,), 0.6015625, device=DEV)
+        kw = dict(hidden_states=lat, encoder_hidden_states=txt, timestep=sig, img_shapes=[[(1, hw, hw)]] * B, txt_seq_lens=[T] * B,
+                  return_dict=False)
+        out = m(**kw)[0].clone()
+        again = m(**kw)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(out, again)
+        with torch.no_grad():
+            for i in range(B):
+                ref = O.dit_forward(P, lat[i:i + 1].float(), txt[i:i + 1].float(), sig[i:i + 1], (1, hw, hw), num_heads=24)
+                r = rel_l2(out[i:i + 1], ref)
+                assert r <= 1e-2, (hw, i, r)

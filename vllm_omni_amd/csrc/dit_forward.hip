@@ -20,6 +20,7 @@ struct Workspace {
   int32_t *img_pos, *txt_pos;   // RoPE table row of every image / text stream row (joint_pos gathered through the joint-row maps)
   float* splitk;                // fp32 partial tiles of the split-K GEMMs (small batches: whole-launch split-K; larger ones: the
   int64_t splitk_floats;        // tail split of a thin last round — include/omni_cdna4.h splitk_ws, OMNI_GEMM_KERNEL_NO_TAIL_SPLIT)
+  int64_t splitk_tail_floats;   // the buffer's whole size (>= splitk_floats): what MLP-up's thin-tail split may use
   void* attn_part;              // fp32 partials of the attention's split short last q-block (attention_w64.hip)
   size_t attn_part_bytes;
   uint8_t* x8;                  // fp8 mode: the e4m3 copy of the NEXT block GEMM's input ([K/64][rows][64]; image rows, then text rows)
@@ -63,7 +64,10 @@ Workspace carve(void* base, const omni_dit_weights* w, int64_t Ri, int64_t Rt, i
   // row tiles (a CFG pair at 512x512: 53 MB); larger batches fill the chip without it, but their LAST round of tiles may be thin
   // (1548 tiles = 6 rounds + 12 at one 2048^2 request): the tail split takes up to 64 tail tiles x 8 pieces of 256 KiB (134 MB)
   ws.splitk_floats = Rj <= 4 * 256 ? 8 * Rj * D : (Rj <= 10 * 256 ? 2 * Rj * D : (int64_t)512 * 256 * 256);
-  ws.splitk = reinterpret_cast<float*>(take(ws.splitk_floats * 2));
+  // (the size handed to the N = 3072 GEMMs also CAPS their split factor — 2-way up to ten row tiles — so MLP-up's thin-tail split,
+  // run_block / mlp_up_tail_split, gets its own figure over the same buffer: a 64-tile tail x 4 pieces of 256 KiB = 67 MB)
+  ws.splitk_tail_floats = ws.splitk_floats < (int64_t)256 * 256 * 256 ? (int64_t)256 * 256 * 256 : ws.splitk_floats;
+  ws.splitk = reinterpret_cast<float*>(take(ws.splitk_tail_floats * 2));
   ws.attn_part_bytes = (size_t)512 * 64 * (128 + 2) * sizeof(float);      // up to 512 (item, head, key range) partials of 64 rows
   ws.attn_part = take((int64_t)(ws.attn_part_bytes / 2));
   ws.x8 = nullptr; ws.x8_scale = nullptr;
@@ -120,6 +124,21 @@ struct BlockPred { const int32_t *tile_img, *tile_txt, *item; };
 int dit_fuse_finish() {
   static const int v = omni_dev_env_int("OMNI_DIT_FUSE_FINISH", 3);
   return v;
+}
+// MLP-up (N = 4 D: the launch with the most tiles) gets the split-K workspace — i.e. the GEMM's TAIL SPLIT — only when a thin tail
+// (<= a quarter round) follows ONE to THREE full rounds of the CUs.  One 384^2 CFG pair (1152 + 128 rows: 6 x 48 = 288 tiles = 1
+// round + 32) spent HALF of the launch on a round that is an eighth full: 27.4 -> 26.3 ms per 60-layer forward (-4.2 %); 2 rounds + 64
+// (one 576^2 request) -0.8 %, 3 + 48 (704^2) -0.5 % (profiles/r06l_ab_mlpup_tail_rounds.log).  With six or more full rounds in
+// front of it the same split gains nothing inside a forward (profiles/r06b_ab_mlp_up_tail_split_rejected.log), and at <= 128 tiles
+// the workspace would switch the whole launch to split-K with N = 4 D wide partials.  The tail tiles then carry the tail split's
+// summation order (include/omni_cdna4.h, ABI v11).  -DOMNI_DEV builds: OMNI_DIT_MLPUP_TAIL = the largest number of rounds, 0 off.
+bool mlp_up_tail_split(int32_t Ri, int32_t Rt, int64_t N) {
+  static const int knob = omni_dev_env_int("OMNI_DIT_MLPUP_TAIL", 3);
+  if (!knob) return false;
+  const int64_t tiles = ((int64_t)(Ri + 255) / 256 + (Rt + 255) / 256) * ((N + 255) / 256);
+  const int cus = omni_num_cus();
+  const int64_t rounds = tiles / cus, tail = tiles % cus;
+  return rounds >= 1 && rounds <= knob && tail > 0 && tail <= cus / 4;
 }
 // an MLP down-projection whose finish is still pending when its block returns (the next block's norm1 performs it)
 struct PendingFinish {
@@ -342,6 +361,7 @@ int run_block(const omni_dit_weights* w, int l, const omni_dit_batch* b, const W
     p.g[1].A = xn_txt; p.g[1].lda = D; p.g[1].M = Rt; p.g[1].W = L.txt_mlp_w1; p.g[1].bias = L.txt_mlp_b1;
     p.g[1].out = h_txt; p.g[1].ldo = 4 * D;
     p.g[0].tile_skip = pr.tile_img; p.g[1].tile_skip = pr.tile_txt;
+    if (mlp_up_tail_split(Ri, Rt, 4 * D)) { p.splitk_ws = ws.splitk; p.splitk_ws_floats = ws.splitk_tail_floats; }
     if (f_up) {
       if (!fused_q2) OMNI_TRY(quant_streams(xn_img, bRi, xn_txt, bRt, D));
       fp8_streams(p, D, F->img_mlp_w1_8, F->img_mlp_w1_s, F->txt_mlp_w1_8, F->txt_mlp_w1_s);
